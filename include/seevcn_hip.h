@@ -1,0 +1,72 @@
+/* seevcn_hip.h — C ABI of libseevcn_hip.so (hand-written HIP kernels for gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the SEE-VCN hot path: every entry point below is what the
+ * reference's Python would bind (ctypes / pybind) in place of the CUDA extension or third-party
+ * call named in its comment (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - every entry takes the HIP stream it must enqueue on (`void* stream` = hipStream_t; NULL = null stream)
+ *     — the reference launches on the legacy default stream (e.g. pointnet2_stack/src/ball_query_gpu.cu:83);
+ *   - entries never allocate, never synchronise and never exit(): they return 0 or an SV_ERR_* code and
+ *     sv_last_error() gives the message (the reference prints and calls exit(-1), ball_query_gpu.cu:85-89);
+ *   - counts that are only known on the device are written to caller-provided device int32 slots; callers
+ *     pass capacities. Scratch/workspace sizes come from the matching *_bytes() query;
+ *   - "persistent" workspaces must be zero-filled once by the caller (hipMemset) and are returned zeroed
+ *     by every entry that uses them (entries clean exactly the cells they touched).
+ *   - float = IEEE fp32, indices = int32, linear cell keys = int64.
+ */
+#ifndef SEEVCN_HIP_H
+#define SEEVCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SV_OK 0
+#define SV_ERR_ARG 1
+#define SV_ERR_HIP 2
+
+#define SV_ABI_VERSION 1
+
+int sv_abi_version(void);
+const char* sv_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Coordinate index (persistent workspace shared by voxelisation and rulebook builds)
+ * ---------------------------------------------------------------------------------------------- */
+/* bytes of persistent (zero-initialised) workspace indexing `ncells` grid cells */
+size_t sv_index_persistent_bytes(int64_t ncells);
+/* bytes of per-call scratch used by the chunk scan for `ncells` cells */
+size_t sv_index_scratch_bytes(int64_t ncells);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dynamic voxelisation + mean VFE
+ *   replaces DynamicMeanVFE.forward (detector3d/pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:38-76):
+ *   floor((xyz-min)/voxel) -> in-range mask -> key=b*XYZ+x*YZ+y*Z+z -> torch.unique(sorted) -> scatter_mean.
+ *   points: (P, point_stride) fp32 rows [batch_idx, x, y, z, extra...]; the first `num_features`
+ *   columns after batch_idx are averaged.  Outputs are ordered by ascending key (same as torch.unique):
+ *   voxel_coords (cap,4) int32 [b,z,y,x], voxel_features (cap,num_features), point_to_voxel (P) int32
+ *   (row of the voxel each point fell in, -1 if out of range; may be NULL), *num_voxels (device int32).
+ *   index_ws: sv_index_persistent_bytes(batch*X*Y*Z); scratch: sv_voxelize_dynamic_scratch_bytes().
+ * ---------------------------------------------------------------------------------------------- */
+size_t sv_voxelize_dynamic_scratch_bytes(int64_t num_points, int64_t ncells, int64_t capacity);
+int sv_voxelize_dynamic(const float* points, int64_t num_points, int point_stride, int num_features,
+                        const float* pc_range_host /*6*/, const float* voxel_size_host /*3*/,
+                        const int32_t* grid_size_host /*3: X,Y,Z*/, int batch_size,
+                        void* index_ws, void* scratch,
+                        int32_t* voxel_coords, float* voxel_features, int32_t* point_to_voxel,
+                        int64_t capacity, int32_t* num_voxels, void* stream);
+
+/* MeanVFE.forward (backbones_3d/vfe/mean_vfe.py:14-31): sum over the point axis / clamp_min(count,1).
+ * voxels (V, max_points, C) fp32, num_points (V) int32 -> out (V, C). */
+int sv_mean_vfe(const float* voxels, const int32_t* num_points, int64_t num_voxels, int max_points,
+                int num_features, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEEVCN_HIP_H */

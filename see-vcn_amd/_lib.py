@@ -1,0 +1,115 @@
+"""ctypes binding of libseevcn_hip.so (the C-ABI in include/seevcn_hip.h).
+
+There is no CPU fallback: if the library is missing or a symbol is absent, import of any op fails loudly.
+Tensors are passed as raw device pointers plus the current torch HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libseevcn_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "seevcn_hip.h")
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/seevcn_hip.h declares
+SIGNATURES = {
+    "sv_abi_version": (c_i, []),
+    "sv_last_error": (ctypes.c_char_p, []),
+    "sv_index_persistent_bytes": (c_sz, [c_i64]),
+    "sv_index_scratch_bytes": (c_sz, [c_i64]),
+    "sv_voxelize_dynamic_scratch_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "sv_voxelize_dynamic": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
+    "sv_mean_vfe": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p, c_p]),
+}
+
+_lib = None
+
+
+class SeevcnHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and attach signatures. Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SeevcnHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C see-vcn_amd/csrc`). seevcn_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().sv_last_error().decode(errors="replace")
+        raise SeevcnHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "seevcn_amd ops need contiguous tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SeevcnHipError("seevcn_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def host_array(ctype, values):
+    return (ctype * len(values))(*values)
+
+
+class Workspace:
+    """Grow-only device byte buffers, one set per device.
+
+    `persistent(name, nbytes)` returns a zero-initialised buffer that the kernels keep zeroed between calls
+    (coordinate-index bitmaps); `scratch(name, nbytes)` returns uninitialised bytes.
+    """
+
+    def __init__(self):
+        self._bufs = {}
+
+    def _get(self, kind, name, nbytes, device, zero):
+        key = (kind, name, device.index)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            n = int(nbytes * 1.25) + 256 if buf is not None else int(nbytes)
+            n = max(n, 256)
+            buf = (torch.zeros if zero else torch.empty)(n, dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf
+
+    def persistent(self, name, nbytes, device):
+        return self._get("p", name, nbytes, device, True)
+
+    def scratch(self, name, nbytes, device):
+        return self._get("s", name, nbytes, device, False)
+
+    def reset(self):
+        self._bufs.clear()
+
+
+workspace = Workspace()

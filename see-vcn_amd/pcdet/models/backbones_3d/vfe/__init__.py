@@ -1,0 +1,10 @@
+from .dynamic_mean_vfe import DynamicMeanVFE
+from .mean_vfe import MeanVFE
+from .vfe_template import VFETemplate
+
+# same registry shape as the reference (backbones_3d/vfe/__init__.py:8-15): name -> class
+__all__ = {
+    'VFETemplate': VFETemplate,
+    'MeanVFE': MeanVFE,
+    'DynMeanVFE': DynamicMeanVFE,
+}

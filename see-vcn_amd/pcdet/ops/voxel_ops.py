@@ -1,0 +1,61 @@
+"""Host wrappers over the voxelisation entry points of libseevcn_hip.so."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ... import _lib
+
+
+def _geom(pc_range, voxel_size, grid_size):
+    r = _lib.host_array(ctypes.c_float, [float(np.float32(v)) for v in pc_range])
+    v = _lib.host_array(ctypes.c_float, [float(np.float32(x)) for x in voxel_size])
+    g = _lib.host_array(ctypes.c_int32, [int(x) for x in grid_size])
+    return r, v, g
+
+
+def voxelize_dynamic(points, pc_range, voxel_size, grid_size, batch_size, num_features=None,
+                     capacity=None, return_point_to_voxel=False, sync=True):
+    """Dynamic voxelisation + per-voxel mean (replaces dynamic_mean_vfe.py:38-76).
+
+    points: (P, 1+C) fp32 cuda [b, x, y, z, ...].  Returns (voxel_features (V,C), voxel_coords (V,4) int32
+    [b,z,y,x], point_to_voxel or None).  With sync=False the outputs keep `capacity` rows and a device
+    int32 count is returned as a 4th value instead of narrowing (no host sync; graph-capturable).
+    """
+    lib = _lib.load()
+    _lib.require_cuda(points)
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] >= 4
+    points = points.contiguous()
+    P, stride = points.shape
+    C = stride - 1 if num_features is None else int(num_features)
+    cap = int(P if capacity is None else capacity)
+    dev = points.device
+    ncells = int(batch_size) * int(grid_size[0]) * int(grid_size[1]) * int(grid_size[2])
+    ws = _lib.workspace.persistent("vox_index", lib.sv_index_persistent_bytes(ncells), dev)
+    scratch = _lib.workspace.scratch("vox_scratch", lib.sv_voxelize_dynamic_scratch_bytes(P, ncells, cap), dev)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    feats = torch.empty((cap, C), dtype=torch.float32, device=dev)
+    p2v = torch.empty((P,), dtype=torch.int32, device=dev) if return_point_to_voxel else None
+    nvox = torch.empty((1,), dtype=torch.int32, device=dev)
+    r, v, g = _geom(pc_range, voxel_size, grid_size)
+    rc = lib.sv_voxelize_dynamic(_lib.ptr(points), P, stride, C, r, v, g, int(batch_size), _lib.ptr(ws),
+                                 _lib.ptr(scratch), _lib.ptr(coords), _lib.ptr(feats), _lib.ptr(p2v), cap,
+                                 _lib.ptr(nvox), _lib.stream())
+    _lib.check(rc, "sv_voxelize_dynamic")
+    if not sync:
+        return feats, coords, p2v, nvox
+    n = int(nvox.item())
+    return feats[:n], coords[:n], p2v
+
+
+def mean_vfe(voxels, voxel_num_points):
+    """MeanVFE arithmetic (mean_vfe.py:25-29) on (V, max_points, C) hard voxels."""
+    lib = _lib.load()
+    _lib.require_cuda(voxels, voxel_num_points)
+    voxels = voxels.contiguous().float()
+    nump = voxel_num_points.contiguous().to(torch.int32)
+    V, mp, C = voxels.shape
+    out = torch.empty((V, C), dtype=torch.float32, device=voxels.device)
+    rc = lib.sv_mean_vfe(_lib.ptr(voxels), _lib.ptr(nump), V, mp, C, _lib.ptr(out), _lib.stream())
+    _lib.check(rc, "sv_mean_vfe")
+    return out
