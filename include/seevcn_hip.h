@@ -66,6 +66,40 @@ int sv_voxelize_dynamic(const float* points, int64_t num_points, int point_strid
 int sv_mean_vfe(const float* voxels, const int32_t* num_points, int64_t num_voxels, int max_points,
                 int num_features, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * VCN surface completion (see/surface_completion/models/vcn/models/VCN_VC.py:178-214, VCN_CN.py:142-156)
+ *   Activations are channel-last (M = B*n points, C) fp32; weights keep PyTorch's (C_out, C_in) layout.
+ * ---------------------------------------------------------------------------------------------- */
+#define SV_ACT_NONE 0
+#define SV_ACT_RELU 1
+#define SV_ACT_LRELU 2
+
+int sv_fill_f32(float* dst, int64_t n, float value, void* stream);
+
+/* C[M,N] = act(A[M,K] @ W[N,K]^T + bias[N] + group_bias[row / rows_per_group][N])  on the fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32: exact fp32).  Replaces the Conv1d(k=1)(+BN folded)(+ReLU/LeakyReLU) layers of
+ * pose_encoder / FeatureEncoder (VCN_VC.py:81-106,116-123) and the Linear layers (:124-131).
+ * C may be NULL (no store); group_max (M/rows_per_group, N), pre-filled with -inf, receives the max over each
+ * group of rows (torch.max(feature, dim=2), VCN_VC.py:100,104 and AdaptiveMaxPool1d :122).  K % 32 == 0. */
+int sv_gemm_bias_act(const float* A, int lda, const float* W, int ldw, const float* bias,
+                     const float* group_bias, int rows_per_group, float* C, int ldc, float* group_max,
+                     int M, int N, int K, int act, float slope, void* stream);
+
+/* out[m][c] = act(weight[c][0..2] . xyz[m] + bias[c])   (the Conv1d(3, C, 1) first layers; C % 4 == 0) */
+int sv_pointwise_conv3(const float* xyz, const float* weight, const float* bias, float* out, int64_t M,
+                       int C, int act, float slope, void* stream);
+
+/* VCN_VC.py:185-190: frustum angle, rotation to the frustum view, mean-centering.
+ * input (B,n,3) -> fview (B,n,3), centred (B,n,3), state (B,32) [angle, mean xyz, centre xyz, rot 3x3]. */
+int sv_vcn_vc_prep(const float* input, int batch, int n, float* fview, float* centred, float* state, void* stream);
+/* VCN_VC.py:195-200: rel_pose (B,9) -> centre, rot (ortho6d, :36-49) into state; pc_cn = (fview-centre) @ rot^T */
+int sv_vcn_vc_pose(const float* fview, int batch, int n, const float* rel_pose, float* state, float* pc_cn, void* stream);
+/* VCN_VC.py:205-212: coarse_cn (B,nc,3) -> coarse (B,nc,3) in the sensor view, reg_rot (B,3,3), reg_centre (B,3) */
+int sv_vcn_vc_finish(const float* coarse_cn, int batch, int num_coarse, const float* state, float* coarse,
+                     float* reg_rot, float* reg_centre, void* stream);
+/* VCN_CN.py:146-154 with utils/transform.py:91-160: inverse=0: vc_to_cn + normalize_scale; 1: restore_scale + cn_to_vc */
+int sv_vcn_cn_transform(const float* in, int batch, int n, const float* gt_boxes, int inverse, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

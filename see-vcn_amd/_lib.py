@@ -27,6 +27,13 @@ SIGNATURES = {
     "sv_voxelize_dynamic_scratch_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "sv_voxelize_dynamic": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "sv_mean_vfe": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p, c_p]),
+    "sv_fill_f32": (c_i, [c_p, c_i64, c_f, c_p]),
+    "sv_gemm_bias_act": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "sv_pointwise_conv3": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p]),
+    "sv_vcn_vc_prep": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "sv_vcn_vc_pose": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "sv_vcn_vc_finish": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sv_vcn_cn_transform": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p]),
 }
 
 _lib = None

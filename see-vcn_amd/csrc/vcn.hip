@@ -1,0 +1,405 @@
+// VCN surface-completion network kernels (see/surface_completion/models/vcn/models/VCN_VC.py:178-214).
+//
+// The network is a chain of per-point 1x1 convolutions (= GEMMs over M = B*n points) with max-pools over
+// the n points of each object, plus a few per-object 3x3 transforms.  It is the one MFMA-bound stage of
+// the hot path: 0.99 GMAC/object in exact fp32.  gfx950 has an fp32-input MFMA (v_mfma_f32_32x32x2_f32,
+// 64 FLOP/clk/SIMD = the fp32 vector peak, 157 TFLOP/s) whose result is bit-for-bit an fmaf chain, so the
+// GEMMs run on the matrix cores in fp32 and the VALU stays free for the epilogues.
+//
+// Layout: activations are channel-last (M, C) fp32 (the reference's (B,C,n) Conv1d layout transposed),
+// weights keep PyTorch's (C_out, C_in) layout, so both GEMM operands are K-contiguous.
+#include <math.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ACT_RELU = SV_ACT_RELU, ACT_LRELU = SV_ACT_LRELU;
+constexpr int EPI_STORE = 1, EPI_MAX = 2;
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_LRELU) return v >= 0.f ? v : v * slope;
+  return v;
+}
+
+// order-independent float max through integer atomics; *addr must start at -inf
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.f)
+    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else
+    atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+// ------------------------------------------------------------------------------------------------
+// C[M,N] = act(A[M,K] * W[N,K]^T + bias[N] + group_bias[row / rows_per_group][N])
+//   EPI_STORE: write C;  EPI_MAX: column max over each group of rows_per_group rows -> gmax[group][N]
+// 128x128 tile, BK=32, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles, double-buffered LDS with
+// 36-float row pitch (conflict-free ds_read_b128), register-staged global loads.
+// K order inside an 8-group is permuted identically for A and W (lane half h takes k = 8q+4h+t).
+// ------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 32, LDP = 36;
+
+struct GemmArgs {
+  const float* A; int lda;
+  const float* W; int ldw;
+  const float* bias;        // [N] or null
+  const float* group_bias;  // [M / rows_per_group][N] or null
+  int rows_per_group;
+  float* C; int ldc;        // EPI_STORE
+  float* gmax;              // EPI_MAX: [M / rows_per_group][N], pre-filled with -inf
+  int M, N, K;
+  int act; float slope;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDP];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;  // staging: row lr (+32*i), k offset lc
+
+  float4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = lr + 32 * i;
+      const int m = m0 + r, n = n0 + r;
+      ra[i] = (m < g.M) ? *reinterpret_cast<const float4*>(g.A + (int64_t)m * g.lda + k0 + lc) : make_float4(0, 0, 0, 0);
+      rb[i] = (n < g.N) ? *reinterpret_cast<const float4*>(g.W + (int64_t)n * g.ldw + k0 + lc) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = lr + 32 * i;
+      *reinterpret_cast<float4*>(&As[buf][r * LDP + lc]) = ra[i];
+      *reinterpret_cast<float4*>(&Bs[buf][r * LDP + lc]) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), kh = 4 * (lane >> 5);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const float4*>(&As[buf][(arow + 32 * i) * LDP + kg * 8 + kh]);
+        b[i] = *reinterpret_cast<const float4*>(&Bs[buf][(brow + 32 * i) * LDP + kg * 8 + kh]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    const bool cok = col < g.N;
+    const float bv = (cok && g.bias) ? g.bias[col] : 0.f;
+    float cmax = -INFINITY;
+    int cgroup = -1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (!cok || row >= g.M) continue;
+        const int grp = row / g.rows_per_group;
+        float v = acc[i][j][r] + bv;
+        if (g.group_bias) v += g.group_bias[(int64_t)grp * g.N + col];
+        v = apply_act(v, g.act, g.slope);
+        if (EPI & EPI_STORE) g.C[(int64_t)row * g.ldc + col] = v;
+        if (EPI & EPI_MAX) {
+          if (grp != cgroup) {
+            if (cgroup >= 0) atomic_max_f32(&g.gmax[(int64_t)cgroup * g.N + col], cmax);
+            cgroup = grp;
+            cmax = v;
+          } else {
+            cmax = fmaxf(cmax, v);
+          }
+        }
+      }
+    }
+    if (EPI & EPI_MAX) {
+      // combine the two lane halves when they ended in the same group (the common case: tile inside one object)
+      const float omax = __shfl_xor(cmax, 32, 64);
+      const int ogroup = __shfl_xor(cgroup, 32, 64);
+      if (cgroup >= 0) {
+        if (ogroup == cgroup) {
+          if (h == 0) atomic_max_f32(&g.gmax[(int64_t)cgroup * g.N + col], fmaxf(cmax, omax));
+        } else {
+          atomic_max_f32(&g.gmax[(int64_t)cgroup * g.N + col], cmax);
+        }
+      }
+    }
+  }
+}
+
+__global__ void k_fill_f32(float* p, int64_t n, float v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+extern "C" int sv_fill_f32(float* dst, int64_t n, float value, void* stream) {
+  if (n <= 0) return SV_OK;
+  SV_CHECK_ARG(dst, "fill_f32: null pointer");
+  hipLaunchKernelGGL(k_fill_f32, dim3(sv_grid_1d(n, 256)), dim3(256), 0, sv_stream(stream), dst, n, value);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_gemm_bias_act(const float* A, int lda, const float* W, int ldw, const float* bias,
+                                const float* group_bias, int rows_per_group, float* C, int ldc, float* group_max,
+                                int M, int N, int K, int act, float slope, void* stream) {
+  SV_CHECK_ARG(A && W && (C || group_max), "gemm_bias_act: null pointer");
+  SV_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0, "gemm_bias_act: K=%d must be a positive multiple of %d", K, BK);
+  SV_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= K, "gemm_bias_act: lda/ldw must be >= K and multiples of 4");
+  SV_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "gemm_bias_act: A/W must be 16-byte aligned");
+  SV_CHECK_ARG(rows_per_group >= 1, "gemm_bias_act: rows_per_group must be >= 1");
+  SV_CHECK_ARG(act >= 0 && act <= 2, "gemm_bias_act: unknown activation %d", act);
+  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, C, ldc, group_max, M, N, K, act, slope};
+  dim3 grid(sv_div_up(N, BN), sv_div_up(M, BM));
+  hipStream_t st = sv_stream(stream);
+  if (C && group_max)
+    hipLaunchKernelGGL(k_gemm_f32<EPI_STORE | EPI_MAX>, grid, dim3(256), 0, st, g);
+  else if (C)
+    hipLaunchKernelGGL(k_gemm_f32<EPI_STORE>, grid, dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL(k_gemm_f32<EPI_MAX>, grid, dim3(256), 0, st, g);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[m][c] = act(w[c][0]*x + w[c][1]*y + w[c][2]*z + b[c]) : the K=3 first layers (VALU, HBM-write-bound)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pointwise3(const float* __restrict__ xyz, const float* __restrict__ w,
+                                                    const float* __restrict__ b, float* __restrict__ out, int64_t M,
+                                                    int C, int act, float slope) {
+  const int cq = C / 4;
+  const int64_t total = M * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / cq;
+    const int c = (int)(i - m * cq) * 4;
+    const float x = xyz[m * 3], y = xyz[m * 3 + 1], z = xyz[m * 3 + 2];
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* wr = w + (c + j) * 3;
+      // same association as a K=3 dot product accumulated left to right, then bias
+      float v = fmaf(wr[2], z, fmaf(wr[1], y, wr[0] * x));
+      v += b ? b[c + j] : 0.f;
+      o[j] = apply_act(v, act, slope);
+    }
+    *reinterpret_cast<float4*>(out + m * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int sv_pointwise_conv3(const float* xyz, const float* weight, const float* bias, float* out, int64_t M,
+                                  int C, int act, float slope, void* stream) {
+  SV_CHECK_ARG(xyz && weight && out && M > 0 && C > 0 && C % 4 == 0, "pointwise_conv3: bad arguments (C must be a multiple of 4)");
+  hipLaunchKernelGGL(k_pointwise3, dim3(sv_grid_1d(M * (C / 4), 256)), dim3(256), 0, sv_stream(stream), xyz, weight, bias,
+                     out, M, C, act, slope);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-object geometry (one workgroup per object; n points).  state[b] = 32 floats:
+//   [0] frustum angle  [1..3] mean of the frustum-view cloud  [4..6] centre  [7..15] rot (row-major 3x3)
+// ------------------------------------------------------------------------------------------------
+constexpr int ST = 32;
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// VCN_VC.py:185-190: angle = atan2(mean y, mean x); rotate by -angle; subtract the mean of the rotated cloud
+__global__ __launch_bounds__(256) void k_vcn_vc_prep(const float* __restrict__ in, int n, float* __restrict__ fview,
+                                                     float* __restrict__ centred, float* __restrict__ state) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float* p = in + (int64_t)b * n * 3;
+  float sx = 0.f, sy = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { sx += p[i * 3]; sy += p[i * 3 + 1]; }
+  const float mx = block_sum_256(sx, red) / (float)n;
+  const float my = block_sum_256(sy, red) / (float)n;
+  const float ang = atan2f(my, mx);
+  // rotate_points_along_z(points, -angle) (utils/transform.py:33-57): R = [[c,s,0],[-s,c,0],[0,0,1]], p @ R
+  const float c = cosf(-ang), s = sinf(-ang);
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  float* f = fview + (int64_t)b * n * 3;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
+    const float rx = x * c - y * s, ry = x * s + y * c;
+    f[i * 3] = rx; f[i * 3 + 1] = ry; f[i * 3 + 2] = z;
+    ax += rx; ay += ry; az += z;
+  }
+  const float m0 = block_sum_256(ax, red) / (float)n;
+  const float m1 = block_sum_256(ay, red) / (float)n;
+  const float m2 = block_sum_256(az, red) / (float)n;
+  float* o = centred + (int64_t)b * n * 3;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    o[i * 3] = f[i * 3] - m0; o[i * 3 + 1] = f[i * 3 + 1] - m1; o[i * 3 + 2] = f[i * 3 + 2] - m2;
+  }
+  if (threadIdx.x == 0) {
+    float* st = state + (int64_t)b * ST;
+    st[0] = ang; st[1] = m0; st[2] = m1; st[3] = m2;
+  }
+}
+
+// VCN_VC.py:195-200: centre = mean + trans; rot = ortho6d -> R (12-49); pc_cn = (fview - centre) @ R^T
+__global__ __launch_bounds__(256) void k_vcn_vc_pose(const float* __restrict__ fview, int n, const float* __restrict__ rel_pose,
+                                                     float* __restrict__ state, float* __restrict__ pc_cn) {
+  const int b = blockIdx.x;
+  float* st = state + (int64_t)b * ST;
+  const float* rp = rel_pose + (int64_t)b * 9;
+  const float cx = st[1] + rp[0], cy = st[2] + rp[1], cz = st[3] + rp[2];
+  // normalize_vector: v / max(|v|, 1e-8)
+  float x0 = rp[3], x1 = rp[4], x2 = rp[5];
+  const float y0 = rp[6], y1 = rp[7], y2 = rp[8];
+  float mag = fmaxf(sqrtf(x0 * x0 + x1 * x1 + x2 * x2), 1e-8f);
+  x0 /= mag; x1 /= mag; x2 /= mag;
+  float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
+  mag = fmaxf(sqrtf(z0 * z0 + z1 * z1 + z2 * z2), 1e-8f);
+  z0 /= mag; z1 /= mag; z2 /= mag;
+  const float w0 = z1 * x2 - z2 * x1, w1 = z2 * x0 - z0 * x2, w2 = z0 * x1 - z1 * x0;  // y = z cross x
+  // matrix = cat(x, y, z) as COLUMNS: R[r][0]=x[r], R[r][1]=y[r], R[r][2]=z[r]
+  const float R[9] = {x0, w0, z0, x1, w1, z1, x2, w2, z2};
+  const float* f = fview + (int64_t)b * n * 3;
+  float* o = pc_cn + (int64_t)b * n * 3;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float px = f[i * 3] - cx, py = f[i * 3 + 1] - cy, pz = f[i * 3 + 2] - cz;
+    // p @ R^T : out[j] = sum_k p[k] * R[j][k]
+    o[i * 3] = px * R[0] + py * R[1] + pz * R[2];
+    o[i * 3 + 1] = px * R[3] + py * R[4] + pz * R[5];
+    o[i * 3 + 2] = px * R[6] + py * R[7] + pz * R[8];
+  }
+  if (threadIdx.x == 0) {
+    st[4] = cx; st[5] = cy; st[6] = cz;
+    for (int k = 0; k < 9; ++k) st[7 + k] = R[k];
+  }
+}
+
+// VCN_VC.py:205-212: coarse_vc = coarse @ R + centre; rotate back by +angle; reg_rot = R @ Rz(angle); reg_centre
+__global__ __launch_bounds__(256) void k_vcn_vc_finish(const float* __restrict__ coarse_cn, int nc, const float* __restrict__ state,
+                                                       float* __restrict__ coarse, float* __restrict__ reg_rot,
+                                                       float* __restrict__ reg_centre) {
+  const int b = blockIdx.x;
+  const float* st = state + (int64_t)b * ST;
+  const float ang = st[0];
+  const float c = cosf(ang), s = sinf(ang);
+  const float cx = st[4], cy = st[5], cz = st[6];
+  float R[9];
+  for (int k = 0; k < 9; ++k) R[k] = st[7 + k];
+  const float* p = coarse_cn + (int64_t)b * nc * 3;
+  float* o = coarse + (int64_t)b * nc * 3;
+  for (int i = threadIdx.x; i < nc; i += 256) {
+    const float x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
+    // p @ R : out[j] = sum_k p[k] * R[k][j]
+    const float vx = x * R[0] + y * R[3] + z * R[6] + cx;
+    const float vy = x * R[1] + y * R[4] + z * R[7] + cy;
+    const float vz = x * R[2] + y * R[5] + z * R[8] + cz;
+    o[i * 3] = vx * c - vy * s; o[i * 3 + 1] = vx * s + vy * c; o[i * 3 + 2] = vz;
+  }
+  if (threadIdx.x == 0) {
+    // rot_from_heading(angle) = [[c,s,0],[-s,c,0],[0,0,1]] (utils/transform.py:6-31); reg_rot = R @ that
+    float* rr = reg_rot + (int64_t)b * 9;
+    for (int r = 0; r < 3; ++r) {
+      rr[r * 3] = R[r * 3] * c - R[r * 3 + 1] * s;
+      rr[r * 3 + 1] = R[r * 3] * s + R[r * 3 + 1] * c;
+      rr[r * 3 + 2] = R[r * 3 + 2];
+    }
+    float* rc = reg_centre + (int64_t)b * 3;
+    rc[0] = cx * c - cy * s; rc[1] = cx * s + cy * c; rc[2] = cz;
+  }
+}
+
+extern "C" int sv_vcn_vc_prep(const float* input, int batch, int n, float* fview, float* centred, float* state, void* stream) {
+  SV_CHECK_ARG(input && fview && centred && state && batch > 0 && n > 0, "vcn_vc_prep: bad arguments");
+  hipLaunchKernelGGL(k_vcn_vc_prep, dim3(batch), dim3(256), 0, sv_stream(stream), input, n, fview, centred, state);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_vcn_vc_pose(const float* fview, int batch, int n, const float* rel_pose, float* state, float* pc_cn, void* stream) {
+  SV_CHECK_ARG(fview && rel_pose && state && pc_cn && batch > 0 && n > 0, "vcn_vc_pose: bad arguments");
+  hipLaunchKernelGGL(k_vcn_vc_pose, dim3(batch), dim3(256), 0, sv_stream(stream), fview, n, rel_pose, state, pc_cn);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_vcn_vc_finish(const float* coarse_cn, int batch, int num_coarse, const float* state, float* coarse,
+                                float* reg_rot, float* reg_centre, void* stream) {
+  SV_CHECK_ARG(coarse_cn && state && coarse && reg_rot && reg_centre && batch > 0 && num_coarse > 0, "vcn_vc_finish: bad arguments");
+  hipLaunchKernelGGL(k_vcn_vc_finish, dim3(batch), dim3(256), 0, sv_stream(stream), coarse_cn, num_coarse, state, coarse,
+                     reg_rot, reg_centre);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// VCN_CN geometry (VCN_CN.py:142-156 with utils/transform.py:91-160):
+//   to_cn:   out = rotate_z(p - box.xyz, -box.yaw) / box.dx        (vc_to_cn + normalize_scale)
+//   to_vc:   out = rotate_z(p * box.dx, +box.yaw) + box.xyz        (restore_scale + cn_to_vc)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vcn_cn_xform(const float* __restrict__ in, int n, const float* __restrict__ boxes,
+                                                      int inverse, float* __restrict__ out) {
+  const int b = blockIdx.x;
+  const float* bx = boxes + (int64_t)b * 7;
+  const float cx = bx[0], cy = bx[1], cz = bx[2], len = bx[3], yaw = bx[6];
+  const float a = inverse ? yaw : -yaw;
+  const float c = cosf(a), s = sinf(a);
+  const float* p = in + (int64_t)b * n * 3;
+  float* o = out + (int64_t)b * n * 3;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
+    if (!inverse) {
+      x -= cx; y -= cy; z -= cz;
+      o[i * 3] = (x * c - y * s) / len; o[i * 3 + 1] = (x * s + y * c) / len; o[i * 3 + 2] = z / len;
+    } else {
+      x *= len; y *= len; z *= len;
+      o[i * 3] = (x * c - y * s) + cx; o[i * 3 + 1] = (x * s + y * c) + cy; o[i * 3 + 2] = z + cz;
+    }
+  }
+}
+
+extern "C" int sv_vcn_cn_transform(const float* in, int batch, int n, const float* gt_boxes, int inverse, float* out, void* stream) {
+  SV_CHECK_ARG(in && gt_boxes && out && batch > 0 && n > 0, "vcn_cn_transform: bad arguments");
+  hipLaunchKernelGGL(k_vcn_cn_xform, dim3(batch), dim3(256), 0, sv_stream(stream), in, n, gt_boxes, inverse, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -28,7 +28,7 @@ def voxelize_dynamic(points, pc_range, voxel_size, grid_size, batch_size, num_fe
     points = points.contiguous()
     P, stride = points.shape
     C = stride - 1 if num_features is None else int(num_features)
-    cap = int(P if capacity is None else capacity)
+    cap = max(int(P if capacity is None else capacity), 1)
     dev = points.device
     ncells = int(batch_size) * int(grid_size[0]) * int(grid_size[1]) * int(grid_size[2])
     ws = _lib.workspace.persistent("vox_index", lib.sv_index_persistent_bytes(ncells), dev)

@@ -1,0 +1,131 @@
+"""Parameter containers with the reference's state_dict keys + the HIP execution of the VCN layer chain."""
+import torch
+import torch.nn as nn
+
+from ... import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+LRELU_SLOPE = 0.01  # nn.LeakyReLU() default, VCN_VC.py:118-120,126
+
+
+def fc_layers(layer_dims, last_as_linear=True):
+    """Linear/ReLU stack with the reference's module indices (VCN_VC.py:66-79) so state_dict keys match."""
+    layers, in_ch = [], layer_dims[0]
+    for out_ch in layer_dims[1:]:
+        if out_ch == layer_dims[-1] and last_as_linear:
+            layers.append(nn.Linear(in_ch, out_ch))
+            break
+        layers += [nn.Linear(in_ch, out_ch), nn.ReLU(inplace=True)]
+        in_ch = out_ch
+    return nn.Sequential(*layers)
+
+
+class FeatureEncoder(nn.Module):
+    """Holds the parameters of the reference FeatureEncoder (VCN_VC.py:81-106); executed by `encode()`."""
+
+    def __init__(self, dims):
+        super().__init__()
+        self.mlp_conv1 = nn.Sequential(
+            nn.Conv1d(dims[0], dims[1], 1), nn.BatchNorm1d(dims[1]), nn.ReLU(inplace=True), nn.Conv1d(dims[1], dims[2], 1))
+        self.mlp_conv2 = nn.Sequential(
+            nn.Conv1d(dims[3], dims[4], 1), nn.BatchNorm1d(dims[4]), nn.ReLU(inplace=True), nn.Conv1d(dims[4], dims[5], 1))
+
+
+def fold_conv_bn(conv, bn):
+    """Eval-mode BatchNorm folded into the preceding 1x1 conv: w' = w*g/sqrt(var+eps), b' = (b-mean)*g/sqrt(var+eps)+beta."""
+    w = conv.weight.detach().reshape(conv.out_channels, -1).float()
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels, device=w.device)
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    return (w * scale[:, None]).contiguous(), ((b - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()).contiguous()
+
+
+def conv_wb(conv):
+    w = conv.weight.detach().reshape(conv.out_channels, -1).float().contiguous()
+    b = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+    return w, b
+
+
+def lin_wb(lin):
+    return lin.weight.detach().float().contiguous(), (lin.bias.detach().float().contiguous() if lin.bias is not None else None)
+
+
+class PreparedCache:
+    """Folded / contiguous weights cached until any parameter or buffer changes (tensor version counters)."""
+
+    def __init__(self, module, builder):
+        self.module, self.builder, self.key, self.value = module, builder, None, None
+
+    def get(self):
+        tensors = list(self.module.parameters()) + list(self.module.buffers())
+        key = tuple((t.data_ptr(), t._version, t.device) for t in tensors)
+        if key != self.key:
+            self.value = self.builder()
+            self.key = key
+        return self.value
+
+
+def gemm(a, w, bias=None, act=ACT_NONE, group_bias=None, rows_per_group=1, store=True, group_max=None, slope=LRELU_SLOPE):
+    """act(a @ w.T + bias + group_bias[row // rows_per_group]) via sv_gemm_bias_act (fp32 MFMA).
+
+    Returns the (M,N) output (or None when store=False); `group_max` (M/rows_per_group, N) must be pre-filled with -inf."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.is_contiguous() and w.is_contiguous()
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device) if store else None
+    rc = lib.sv_gemm_bias_act(_lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(bias), _lib.ptr(group_bias), int(rows_per_group),
+                              _lib.ptr(out), N, _lib.ptr(group_max), M, N, K, int(act), float(slope), _lib.stream())
+    _lib.check(rc, "sv_gemm_bias_act")
+    return out
+
+
+def pointwise3(xyz, w, b, act, slope=LRELU_SLOPE):
+    lib = _lib.load()
+    M = xyz.shape[0]
+    C = w.shape[0]
+    out = torch.empty((M, C), dtype=torch.float32, device=xyz.device)
+    rc = lib.sv_pointwise_conv3(_lib.ptr(xyz), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, C, int(act), float(slope), _lib.stream())
+    _lib.check(rc, "sv_pointwise_conv3")
+    return out
+
+
+def neg_inf(shape, device):
+    lib = _lib.load()
+    t = torch.empty(shape, dtype=torch.float32, device=device)
+    _lib.check(lib.sv_fill_f32(_lib.ptr(t), t.numel(), float("-inf"), _lib.stream()), "sv_fill_f32")
+    return t
+
+
+def prepare_encoder(enc):
+    """Weights of FeatureEncoder in execution form. mlp_conv2[0] is split into its global (first 256 inputs)
+    and local halves: the global half multiplies a per-object constant, so it becomes a per-object bias."""
+    w1a, b1a = fold_conv_bn(enc.mlp_conv1[0], enc.mlp_conv1[1])
+    w1b, b1b = conv_wb(enc.mlp_conv1[3])
+    w2a, b2a = fold_conv_bn(enc.mlp_conv2[0], enc.mlp_conv2[1])
+    w2b, b2b = conv_wb(enc.mlp_conv2[3])
+    cg = w1b.shape[0]  # channels of the global feature (256)
+    return dict(w1a=w1a, b1a=b1a, w1b=w1b, b1b=b1b, w2a_g=w2a[:, :cg].contiguous(), w2a_l=w2a[:, cg:].contiguous(),
+                b2a=b2a, w2b=w2b, b2b=b2b)
+
+
+def encode(p, pts, batch, n):
+    """FeatureEncoder.forward (VCN_VC.py:97-106) on channel-last activations. pts: (B*n, 3) -> (B, 1024)."""
+    dev = pts.device
+    f1 = pointwise3(pts, p["w1a"], p["b1a"], ACT_RELU)                               # conv 3->128 + BN + ReLU
+    g1 = neg_inf((batch, p["w1b"].shape[0]), dev)
+    local = gemm(f1, p["w1b"], p["b1b"], ACT_NONE, rows_per_group=n, group_max=g1)  # conv 128->256, max over n
+    gb = gemm(g1, p["w2a_g"], None, ACT_NONE)                                        # global half of conv 512->512
+    f2 = gemm(local, p["w2a_l"], p["b2a"], ACT_RELU, group_bias=gb, rows_per_group=n)  # + BN + ReLU
+    g2 = neg_inf((batch, p["w2b"].shape[0]), dev)
+    gemm(f2, p["w2b"], p["b2b"], ACT_NONE, rows_per_group=n, store=False, group_max=g2)  # conv 512->1024, max over n
+    return g2
+
+
+def prepare_fc(seq):
+    return [lin_wb(m) for m in seq if isinstance(m, nn.Linear)]
+
+
+def run_fc(layers, x, hidden_act):
+    for i, (w, b) in enumerate(layers):
+        x = gemm(x, w, b, hidden_act if i + 1 < len(layers) else ACT_NONE)
+    return x

@@ -1,0 +1,137 @@
+"""VCN_VC / VCN_CN: oracle vs the reference's goldens (CPU); HIP path vs goldens and oracle (GPU).
+Tolerance: 1e-3 relative on feature/point tensors (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vcn as ovcn
+from seeding import seeded_state_dict
+
+RTOL = 1e-3
+
+
+def _rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def _models():
+    import seevcn_amd.vcn as V
+    return V
+
+
+def test_registry_and_state_dict_keys():
+    V = _models()
+    assert set(V.MODELS.module_dict) >= {"VCN_VC", "VCN_CN"}
+    m = V.MODELS.build({"NAME": "VCN_VC"})
+    assert sum(p.numel() for p in m.parameters()) == 7534476
+    keys = list(m.state_dict())
+    assert "pose_encoder.4.weight" in keys and "encoder.mlp_conv2.1.running_var" in keys and "final_conv.6.bias" in keys
+    with pytest.raises(KeyError):
+        V.MODELS.build({"NAME": "nope"})
+    with pytest.raises(KeyError):
+        V.MODELS.build({})
+
+
+def test_oracle_vcn_vc_matches_reference_golden(golden_dir):
+    V = _models()
+    g = np.load(os.path.join(golden_dir, "vcn_vc.npz"))
+    sd = seeded_state_dict(V.MODELS.build({"NAME": "VCN_VC"}), seed=0)
+    out = ovcn.vcn_vc_forward(sd, torch.from_numpy(g["input"]))
+    for k in ("coarse", "reg_rot", "reg_centre"):
+        assert _rel_err(out[k].numpy(), g[k]) < 1e-4, k
+
+
+def test_oracle_vcn_cn_matches_reference_golden(golden_dir):
+    V = _models()
+    g = np.load(os.path.join(golden_dir, "vcn_cn.npz"))
+    sd = seeded_state_dict(V.MODELS.build({"NAME": "VCN_CN"}), seed=0)
+    out = ovcn.vcn_cn_forward(sd, torch.from_numpy(g["input"]), torch.from_numpy(g["gt_boxes"]))
+    assert _rel_err(out["coarse"].numpy(), g["coarse"]) < 1e-4
+
+
+def test_forward_refuses_cpu_and_train_mode():
+    V = _models()
+    import seevcn_amd._lib as L
+    m = V.MODELS.build({"NAME": "VCN_VC"})
+    with pytest.raises(RuntimeError):
+        m({"input": torch.zeros(1, 1024, 3)})   # training mode
+    with pytest.raises(L.SeevcnHipError):
+        m.eval()({"input": torch.zeros(1, 1024, 3)})  # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_gemm_epilogues(cuda, hip_lib):
+    """sv_gemm_bias_act against a torch fp32 reference: masks on M/N, bias, group bias, activations, group max."""
+    from seevcn_amd.vcn.models import layers as L
+    g = torch.Generator().manual_seed(0)
+    for (M, N, K, rpg) in [(256, 128, 64, 128), (300, 9, 32, 100), (1024, 200, 96, 1024), (64, 3072, 1024, 1), (2048, 256, 128, 512)]:
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        ng = (M + rpg - 1) // rpg
+        gb = torch.randn(ng, N, generator=g)
+        ref = a.double() @ w.double().t() + b.double() + gb.double().repeat_interleave(rpg, 0)[:M]
+        for act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU):
+            r = ref.clone()
+            if act == L.ACT_RELU:
+                r = r.clamp_min(0)
+            elif act == L.ACT_LRELU:
+                r = torch.where(r >= 0, r, r * 0.01)
+            gm = L.neg_inf((ng, N), cuda)
+            out = L.gemm(a.to(cuda), w.to(cuda), b.to(cuda), act, group_bias=gb.to(cuda), rows_per_group=rpg, group_max=gm)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(out.cpu().numpy(), r.numpy(), rtol=1e-4, atol=1e-4)
+            rmax = torch.stack([r[i * rpg:(i + 1) * rpg].max(0)[0] for i in range(ng)])
+            np.testing.assert_allclose(gm.cpu().numpy(), rmax.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_vcn_vc_matches_reference_golden(golden_dir, cuda, hip_lib):
+    V = _models()
+    g = np.load(os.path.join(golden_dir, "vcn_vc.npz"))
+    m = V.MODELS.build({"NAME": "VCN_VC"})
+    m.load_state_dict(seeded_state_dict(m, seed=0))
+    m = m.to(cuda).eval()
+    out = m({"input": torch.from_numpy(g["input"]).to(cuda)})
+    torch.cuda.synchronize()
+    for k in ("coarse", "reg_rot", "reg_centre"):
+        assert out[k].shape == g[k].shape
+        assert _rel_err(out[k].cpu().numpy(), g[k]) < RTOL, (k, _rel_err(out[k].cpu().numpy(), g[k]))
+
+
+@pytest.mark.gpu
+def test_hip_vcn_cn_matches_reference_golden(golden_dir, cuda, hip_lib):
+    V = _models()
+    g = np.load(os.path.join(golden_dir, "vcn_cn.npz"))
+    m = V.MODELS.build({"NAME": "VCN_CN"})
+    m.load_state_dict(seeded_state_dict(m, seed=0))
+    m = m.to(cuda).eval()
+    out = m({"input": torch.from_numpy(g["input"]).to(cuda), "gt_boxes": torch.from_numpy(g["gt_boxes"]).to(cuda)})
+    torch.cuda.synchronize()
+    assert _rel_err(out["coarse"].cpu().numpy(), g["coarse"]) < RTOL
+
+
+@pytest.mark.gpu
+def test_hip_vcn_vc_batch64_vs_oracle_and_batch_invariance(cuda, hip_lib):
+    """BASELINE config 2 size (64 objects x 1024 pts): vs oracle, and each object's result must not depend on its batch."""
+    import seevcn_amd.synth as synth
+    V = _models()
+    clouds, _ = synth.make_object_batch(64, seed=1000)
+    m = V.MODELS.build({"NAME": "VCN_VC"})
+    sd = seeded_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    m = m.to(cuda).eval()
+    x = torch.from_numpy(clouds).to(cuda)
+    out = m({"input": x})
+    ref = ovcn.vcn_vc_forward(sd, torch.from_numpy(clouds[:8]))
+    for k in ("coarse", "reg_rot", "reg_centre"):
+        assert _rel_err(out[k][:8].cpu().numpy(), ref[k].numpy()) < RTOL, k
+    sub = m({"input": x[5:8].contiguous()})
+    assert _rel_err(sub["coarse"].cpu().numpy(), out["coarse"][5:8].cpu().numpy()) < 1e-5
+    # padded zero objects (VCN.inference pads chunks with zeros, models/VCN.py:55-59) must not produce NaN
+    z = m({"input": torch.zeros(2, 1024, 3, device=cuda)})
+    assert torch.isfinite(z["coarse"]).all()
