@@ -100,6 +100,54 @@ int sv_vcn_vc_finish(const float* coarse_cn, int batch, int num_coarse, const fl
 /* VCN_CN.py:146-154 with utils/transform.py:91-160: inverse=0: vc_to_cn + normalize_scale; 1: restore_scale + cn_to_vc */
 int sv_vcn_cn_transform(const float* in, int batch, int n, const float* gt_boxes, int inverse, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Sparse 3-D convolution (replaces the un-vendored third-party `spconv`; call sites
+ * detector3d/pcdet/models/backbones_3d/spconv_backbone.py:8-27,77-117,141-157, height_compression.py:21).
+ * Coordinates are (N,4) int32 [b,z,y,x]; shapes/kernel/stride/padding/dilation are host int32[3] in z,y,x order.
+ * Kernel offset index k = (kz*Ky + ky)*Kx + kx.  Rulebooks are output-major tables nbr[k][row] (or -1).
+ * ---------------------------------------------------------------------------------------------- */
+/* out_shape = floor((in + 2*pad - dil*(k-1) - 1)/stride) + 1 */
+int sv_conv_out_shape(const int32_t* in_shape_host, const int32_t* ksize_host, const int32_t* stride_host,
+                      const int32_t* padding_host, const int32_t* dilation_host, int32_t* out_shape_host);
+/* scratch for either rulebook entry; `ncells` = batch * prod(shape of the level being indexed) */
+size_t sv_rulebook_scratch_bytes(int64_t n_in, int64_t ncells);
+/* SubMConv3d rulebook: nbr (K, n): row j with coord[j] = coord[i] + (k - K/2)*dilation (output set = input set,
+ * caller's row order).  index_ws: sv_index_persistent_bytes(batch*Z*Y*X). dilation_host may be NULL (=1). */
+int sv_rulebook_subm(const int32_t* coords, int64_t n, int batch, const int32_t* shape_host,
+                     const int32_t* ksize_host, const int32_t* dilation_host, void* index_ws, void* scratch,
+                     int32_t* nbr, void* stream);
+/* SparseConv3d rulebook, phase 1: output coordinates in canonical (ascending ((b*Z+z)*Y+y)*X+x) order and the
+ * input-major table nbr_in (K, n_in) = output row fed by (k, input) or -1; *num_out on the device.
+ * index_ws: sv_index_persistent_bytes(batch * prod(out_shape)). */
+int sv_rulebook_sparse(const int32_t* coords, int64_t n_in, int batch, const int32_t* in_shape_host,
+                       const int32_t* ksize_host, const int32_t* stride_host, const int32_t* padding_host,
+                       const int32_t* dilation_host, void* index_ws, void* scratch, int32_t* out_coords,
+                       int32_t* nbr_in, int64_t capacity, int32_t* num_out, void* stream);
+/* phase 2 (after the caller knows n_out): nbr_out (K, n_out) output-major table from nbr_in */
+int sv_rulebook_invert(const int32_t* nbr_in, int64_t n_in, int K, int32_t* nbr_out, int64_t n_out, void* stream);
+/* counts[k] = number of (in,out) pairs of offset k (spconv's indice_pair_num) */
+int sv_rulebook_pair_counts(const int32_t* nbr, int64_t n_out, int K, int32_t* counts, void* stream);
+
+/* Y[o][n] = epi( sum_k sum_c X[nbr[k][o]][c] * Wt[k][n][c] ),  epi: +bias, *scale+shift (folded BN), +residual, relu.
+ *   forward:       X = features (N_in,C_in),  nbr = output-major table, Wt = weight as (K, C_out, C_in)
+ *   backward-data: X = grad_out (N_out,C_out), nbr = input-major table, Wt = weight as (K, C_in, C_out)
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32) when Kd and Nc are multiples of 16, VALU otherwise. */
+int sv_sparse_conv_gather_gemm(const float* X, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows,
+                               int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
+                               const float* residual, int relu, void* stream);
+/* dW (K, C_in, C_out) = sum_o X[nbr[k][o]]^T dY[o]; deterministic two-stage reduction */
+size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout);
+int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
+                         int Cin, int Cout, void* scratch, void* stream);
+
+/* SparseConvTensor.dense(): (N,C) + coords -> (B, C, D, H, W), every element written once */
+size_t sv_sparse_to_dense_scratch_bytes(int batch, int D, int H, int W);
+int sv_sparse_to_dense(const float* features, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W,
+                       void* scratch, float* out, void* stream);
+/* its backward: gather (B,C,D,H,W) at coords -> (N,C) */
+int sv_dense_to_sparse(const float* dense, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W,
+                       float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,18 @@ SIGNATURES = {
     "sv_vcn_vc_pose": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_vcn_vc_finish": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_vcn_cn_transform": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p]),
+    "sv_conv_out_shape": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sv_rulebook_scratch_bytes": (c_sz, [c_i64, c_i64]),
+    "sv_rulebook_subm": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sv_rulebook_sparse": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
+    "sv_rulebook_invert": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p]),
+    "sv_rulebook_pair_counts": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
+    "sv_sparse_conv_gather_gemm": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "sv_sparse_conv_wgrad_scratch_bytes": (c_sz, [c_i64, c_i, c_i, c_i]),
+    "sv_sparse_conv_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
+    "sv_sparse_to_dense_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "sv_sparse_to_dense": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "sv_dense_to_sparse": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
 }
 
 _lib = None

@@ -1,0 +1,91 @@
+// Sparse -> dense BEV scatter (HBM-write bound: 4*B*C*D*H*W bytes written once + 4*V*C read).
+//
+// SparseConvTensor.dense() as used by HeightCompression (detector3d/pcdet/models/backbones_2d/map_to_bev/
+// height_compression.py:21-23) and PointPillarScatter (pointpillar_scatter.py:14-37).  Instead of a memset
+// followed by a scatter (every output byte written twice on the occupied part and the zero fill as a separate
+// launch), a small cell->row map is scattered first and ONE pass writes every output element exactly once,
+// coalesced along x.
+#include "common.h"
+
+constexpr int DN_THREADS = 256;
+
+__global__ __launch_bounds__(DN_THREADS) void k_cellmap_scatter(const int4* __restrict__ coords, int64_t n, int B, int D, int H, int W,
+                                                                int32_t* __restrict__ cellmap) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = coords[i];
+    if (c.x >= 0 && c.x < B && c.y >= 0 && c.y < D && c.z >= 0 && c.z < H && c.w >= 0 && c.w < W)
+      cellmap[(((int64_t)c.x * D + c.y) * H + c.z) * W + c.w] = (int32_t)i;
+  }
+}
+
+// out (B, C, D, H, W); one thread per spatial cell, looping over channels (writes coalesced over x per channel)
+__global__ __launch_bounds__(DN_THREADS) void k_dense_write(const float* __restrict__ feat, const int32_t* __restrict__ cellmap, int B, int C,
+                                                            int64_t spatial /*D*H*W*/, float* __restrict__ out) {
+  const int64_t total = (int64_t)B * spatial;
+  for (int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cell < total; cell += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t row = cellmap[cell];
+    const int64_t b = cell / spatial, s = cell - b * spatial;
+    float* o = out + (b * C) * spatial + s;
+    if (row < 0) {
+      for (int c = 0; c < C; ++c) o[(int64_t)c * spatial] = 0.f;
+    } else {
+      const float* f = feat + (int64_t)row * C;
+      for (int c = 0; c < C; c += 4) {
+        if (c + 4 <= C) {
+          const float4 v = *reinterpret_cast<const float4*>(f + c);
+          o[(int64_t)c * spatial] = v.x; o[(int64_t)(c + 1) * spatial] = v.y;
+          o[(int64_t)(c + 2) * spatial] = v.z; o[(int64_t)(c + 3) * spatial] = v.w;
+        } else {
+          for (int u = c; u < C; ++u) o[(int64_t)u * spatial] = f[u];
+        }
+      }
+    }
+  }
+}
+
+extern "C" size_t sv_sparse_to_dense_scratch_bytes(int batch, int D, int H, int W) { return (size_t)batch * D * H * W * sizeof(int32_t); }
+
+extern "C" int sv_sparse_to_dense(const float* features, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W,
+                                  void* scratch, float* out, void* stream) {
+  SV_CHECK_ARG(n >= 0 && batch > 0 && C > 0 && D > 0 && H > 0 && W > 0 && out && scratch, "sparse_to_dense: bad arguments");
+  SV_CHECK_ARG(n == 0 || (features && coords), "sparse_to_dense: null pointer");
+  SV_CHECK_ARG(C % 4 != 0 || ((uintptr_t)features % 16 == 0), "sparse_to_dense: features must be 16-byte aligned");
+  hipStream_t st = sv_stream(stream);
+  const int64_t spatial = (int64_t)D * H * W;
+  int32_t* cellmap = reinterpret_cast<int32_t*>(scratch);
+  SV_HIP(hipMemsetAsync(cellmap, 0xFF, (size_t)batch * spatial * 4, st));
+  if (n > 0)
+    hipLaunchKernelGGL(k_cellmap_scatter, dim3(sv_grid_1d(n, DN_THREADS)), dim3(DN_THREADS), 0, st, reinterpret_cast<const int4*>(coords), n,
+                       batch, D, H, W, cellmap);
+  hipLaunchKernelGGL(k_dense_write, dim3(sv_grid_1d(batch * spatial, DN_THREADS, 256 * 16)), dim3(DN_THREADS), 0, st, features, cellmap, batch,
+                     C, spatial, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// backward of dense(): grad_features[i][c] = grad_dense[b][c][z][y][x]
+__global__ __launch_bounds__(DN_THREADS) void k_dense_gather(const float* __restrict__ dense, const int4* __restrict__ coords, int64_t n, int B,
+                                                             int C, int D, int H, int W, float* __restrict__ out) {
+  const int64_t spatial = (int64_t)D * H * W;
+  const int64_t total = n * C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx / n);           // channel-major so that lanes walk neighbouring cells of one channel plane
+    const int64_t i = idx - (int64_t)c * n;
+    const int4 p = coords[i];
+    float v = 0.f;
+    if (p.x >= 0 && p.x < B && p.y >= 0 && p.y < D && p.z >= 0 && p.z < H && p.w >= 0 && p.w < W)
+      v = dense[((int64_t)p.x * C + c) * spatial + ((int64_t)p.y * H + p.z) * W + p.w];
+    out[i * C + c] = v;
+  }
+}
+
+extern "C" int sv_dense_to_sparse(const float* dense, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W, float* out,
+                                  void* stream) {
+  SV_CHECK_ARG(n >= 0 && batch > 0 && C > 0 && D > 0 && H > 0 && W > 0, "dense_to_sparse: bad arguments");
+  if (n == 0) return SV_OK;
+  SV_CHECK_ARG(dense && coords && out, "dense_to_sparse: null pointer");
+  hipLaunchKernelGGL(k_dense_gather, dim3(sv_grid_1d(n * C, DN_THREADS, 256 * 16)), dim3(DN_THREADS), 0, sv_stream(stream), dense,
+                     reinterpret_cast<const int4*>(coords), n, batch, C, D, H, W, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -1,0 +1,327 @@
+// Sparse-convolution rulebook build on the coordinate index (HBM + integer bound).
+//
+// The rulebook is kept "output-major": nbr[k][o] = input row feeding output row o through kernel offset k
+// (or -1).  That is the same information as spconv's indice_pairs[k] = {(in, out)} lists, but regular, so
+// the convolution kernels gather without atomics and produce every output row exactly once.
+//
+//  * submanifold conv (SubMConv3d): output set = input set in the caller's row order;
+//    nbr[k][i] = row j with coord[j] = coord[i] + (k - K/2)*dilation.
+//  * regular / strided conv (SparseConv3d): out = (in + pad - k*dilation) / stride where divisible and inside
+//    [0, out_shape); the output set is the unique set of those coordinates in CANONICAL order = ascending
+//    linear key ((b*Z + z)*Y + y)*X + x (spconv's own order is implementation-defined).
+//
+// spconv is an un-vendored third-party dependency of the reference (docker/Dockerfile:58); call sites replaced:
+// detector3d/pcdet/models/backbones_3d/spconv_backbone.py:77-117 (layer definitions), :141-157 (forward).
+#include "common.h"
+
+struct ConvGeom {
+  int batch;
+  int in_shape[3];   // Z, Y, X
+  int out_shape[3];
+  int ksize[3];
+  int stride[3];
+  int pad[3];
+  int dil[3];
+  int K;
+};
+
+constexpr int RB_THREADS = 256;
+
+__device__ __forceinline__ int64_t lin_key(int b, int z, int y, int x, const int* shape) {
+  return (((int64_t)b * shape[0] + z) * shape[1] + y) * shape[2] + x;
+}
+
+__device__ __forceinline__ bool coord_ok(const int4 c, int batch, const int* shape) {
+  return c.x >= 0 && c.x < batch && c.y >= 0 && c.y < shape[0] && c.z >= 0 && c.z < shape[1] && c.w >= 0 && c.w < shape[2];
+}
+
+// --------------------------------------------------------------------------- index finalisation
+// For every occupied chunk: words[w].y = chunk_base + popcount of the chunk's earlier words.
+// One wave inspects 64 chunk counters at a time and walks the occupied ones with 32 lanes per chunk.
+__global__ __launch_bounds__(RB_THREADS) void k_index_prefix(SvIndexView ix, int64_t nchunks) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t c0 = wave * 64; c0 < nchunks; c0 += nwaves * 64) {
+    const int64_t c = c0 + lane;
+    const int cnt = c < nchunks ? ix.chunk_cnt[c] : 0;
+    unsigned long long occ = __ballot(cnt > 0);
+    while (occ) {
+      // two occupied chunks per step: lanes 0-31 take the first, lanes 32-63 the second
+      const int first = __ffsll((long long)occ) - 1;
+      occ &= occ - 1;
+      int second = -1;
+      if (occ) { second = __ffsll((long long)occ) - 1; occ &= occ - 1; }
+      const int mine = lane < 32 ? first : second;
+      if (mine >= 0) {
+        const int64_t cc = c0 + mine;
+        const int64_t w = cc * SV_CHUNK_WORDS + (lane & 31);
+        const uint32_t bits = ix.words[w].x;
+        int p = __popc(bits);
+        int incl = p;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+          const int t = __shfl_up(incl, d, 32);
+          if ((lane & 31) >= d) incl += t;
+        }
+        if (bits) ix.words[w].y = (uint32_t)(ix.chunk_base[cc] + incl - p);
+      }
+    }
+  }
+}
+
+static int launch_index_prefix(const SvIndexView& ix, hipStream_t st) {
+  const int64_t nchunks = sv_index_nchunks(ix.ncells);
+  const int grid = sv_grid_1d((nchunks + 63) / 64 * 64, RB_THREADS);
+  hipLaunchKernelGGL(k_index_prefix, dim3(grid), dim3(RB_THREADS), 0, st, ix, nchunks);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// --------------------------------------------------------------------------- submanifold
+__global__ __launch_bounds__(RB_THREADS) void k_subm_mark(const int4* __restrict__ coords, int64_t n, ConvGeom g, SvIndexView ix) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = coords[i];
+    if (coord_ok(c, g.batch, g.in_shape)) sv_index_mark(ix, lin_key(c.x, c.y, c.z, c.w, g.in_shape));
+  }
+}
+
+__global__ __launch_bounds__(RB_THREADS) void k_subm_perm(const int4* __restrict__ coords, int64_t n, ConvGeom g, SvIndexView ix,
+                                                          int32_t* __restrict__ perm) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = coords[i];
+    if (coord_ok(c, g.batch, g.in_shape)) {
+      const int32_t r = sv_index_lookup(ix, lin_key(c.x, c.y, c.z, c.w, g.in_shape));
+      perm[r] = (int32_t)i;
+    }
+  }
+}
+
+// one thread per (row, kernel offset); offsets vary fastest across a row's lanes is NOT wanted (stores to
+// nbr[k][i] must be coalesced over i), so the grid is laid out k-major: idx = k*n + i.
+__global__ __launch_bounds__(RB_THREADS) void k_subm_query(const int4* __restrict__ coords, int64_t n, ConvGeom g, SvIndexView ix,
+                                                           const int32_t* __restrict__ perm, int32_t* __restrict__ nbr) {
+  const int64_t total = n * g.K;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx / n);
+    const int64_t i = idx - (int64_t)k * n;
+    const int kx = k % g.ksize[2], ky = (k / g.ksize[2]) % g.ksize[1], kz = k / (g.ksize[2] * g.ksize[1]);
+    const int4 c = coords[i];
+    int32_t r = -1;
+    if (coord_ok(c, g.batch, g.in_shape)) {
+      const int z = c.y + (kz - g.ksize[0] / 2) * g.dil[0];
+      const int y = c.z + (ky - g.ksize[1] / 2) * g.dil[1];
+      const int x = c.w + (kx - g.ksize[2] / 2) * g.dil[2];
+      if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2]) {
+        const int32_t rank = sv_index_lookup(ix, lin_key(c.x, z, y, x, g.in_shape));
+        if (rank >= 0) r = perm[rank];
+      }
+    }
+    nbr[idx] = r;
+  }
+}
+
+__global__ __launch_bounds__(RB_THREADS) void k_subm_clear(const int4* __restrict__ coords, int64_t n, ConvGeom g, SvIndexView ix) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = coords[i];
+    if (coord_ok(c, g.batch, g.in_shape)) {
+      const int64_t key = lin_key(c.x, c.y, c.z, c.w, g.in_shape);
+      ix.words[key >> 5] = make_uint2(0u, 0u);
+      ix.chunk_cnt[key >> SV_CHUNK_SHIFT] = 0;
+    }
+  }
+}
+
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+extern "C" size_t sv_rulebook_scratch_bytes(int64_t n_in, int64_t ncells) {
+  return align256((size_t)(n_in > 0 ? n_in : 1) * 4) + align256(sv_index_scan_tmp_bytes(ncells)) + 256;
+}
+
+static int fill_geom(ConvGeom& g, int batch, const int32_t* in_shape, const int32_t* ksize, const int32_t* stride,
+                     const int32_t* pad, const int32_t* dil, bool subm) {
+  g.batch = batch;
+  g.K = 1;
+  for (int d = 0; d < 3; ++d) {
+    g.in_shape[d] = in_shape[d];
+    g.ksize[d] = ksize[d];
+    g.stride[d] = subm ? 1 : stride[d];
+    g.pad[d] = subm ? (ksize[d] / 2) * (dil ? dil[d] : 1) : pad[d];
+    g.dil[d] = dil ? dil[d] : 1;
+    SV_CHECK_ARG(g.in_shape[d] > 0 && g.ksize[d] > 0 && g.stride[d] > 0 && g.pad[d] >= 0 && g.dil[d] > 0, "rulebook: bad conv geometry");
+    // floor((D + 2p - dil*(K-1) - 1)/s) + 1
+    g.out_shape[d] = subm ? g.in_shape[d] : (g.in_shape[d] + 2 * g.pad[d] - g.dil[d] * (g.ksize[d] - 1) - 1) / g.stride[d] + 1;
+    SV_CHECK_ARG(g.out_shape[d] > 0, "rulebook: empty output shape");
+    g.K *= g.ksize[d];
+  }
+  return SV_OK;
+}
+
+extern "C" int sv_rulebook_subm(const int32_t* coords, int64_t n, int batch, const int32_t* shape_host,
+                                const int32_t* ksize_host, const int32_t* dilation_host, void* index_ws, void* scratch,
+                                int32_t* nbr, void* stream) {
+  SV_CHECK_ARG(n >= 0 && batch > 0 && shape_host && ksize_host, "rulebook_subm: bad arguments");
+  if (n == 0) return SV_OK;
+  SV_CHECK_ARG(coords && index_ws && scratch && nbr, "rulebook_subm: null pointer");
+  ConvGeom g;
+  int rc = fill_geom(g, batch, shape_host, ksize_host, nullptr, nullptr, dilation_host, true);
+  if (rc) return rc;
+  SV_CHECK_ARG((g.ksize[0] & 1) && (g.ksize[1] & 1) && (g.ksize[2] & 1), "rulebook_subm: kernel sizes must be odd");
+  hipStream_t st = sv_stream(stream);
+  const int64_t ncells = (int64_t)batch * g.in_shape[0] * g.in_shape[1] * g.in_shape[2];
+  SvIndexView ix = sv_index_view(index_ws, ncells);
+  char* s = reinterpret_cast<char*>(scratch);
+  int32_t* perm = reinterpret_cast<int32_t*>(s);
+  s += align256((size_t)n * 4);
+  void* scan_tmp = s;
+  s += align256(sv_index_scan_tmp_bytes(ncells));
+  int32_t* total = reinterpret_cast<int32_t*>(s);
+  const int4* c4 = reinterpret_cast<const int4*>(coords);
+  const int grid = sv_grid_1d(n, RB_THREADS);
+  hipLaunchKernelGGL(k_subm_mark, dim3(grid), dim3(RB_THREADS), 0, st, c4, n, g, ix);
+  rc = sv_index_scan_launch(ix, total, scan_tmp, st);
+  if (rc) return rc;
+  rc = launch_index_prefix(ix, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_subm_perm, dim3(grid), dim3(RB_THREADS), 0, st, c4, n, g, ix, perm);
+  hipLaunchKernelGGL(k_subm_query, dim3(sv_grid_1d(n * g.K, RB_THREADS, 256 * 16)), dim3(RB_THREADS), 0, st, c4, n, g, ix, perm, nbr);
+  hipLaunchKernelGGL(k_subm_clear, dim3(grid), dim3(RB_THREADS), 0, st, c4, n, g, ix);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// --------------------------------------------------------------------------- regular / strided
+// candidate output coordinate of input c through offset (kz,ky,kx); false when not on the output lattice
+__device__ __forceinline__ bool out_coord(const int4 c, int kz, int ky, int kx, const ConvGeom& g, int& oz, int& oy, int& ox) {
+  const int tz = c.y + g.pad[0] - kz * g.dil[0];
+  const int ty = c.z + g.pad[1] - ky * g.dil[1];
+  const int tx = c.w + g.pad[2] - kx * g.dil[2];
+  if (tz < 0 || ty < 0 || tx < 0) return false;
+  if (tz % g.stride[0] || ty % g.stride[1] || tx % g.stride[2]) return false;
+  oz = tz / g.stride[0]; oy = ty / g.stride[1]; ox = tx / g.stride[2];
+  return oz < g.out_shape[0] && oy < g.out_shape[1] && ox < g.out_shape[2];
+}
+
+template <int PHASE>  // 0: mark output cells; 1: write nbr_in + out_coords; 2: clear
+__global__ __launch_bounds__(RB_THREADS) void k_sparse_phase(const int4* __restrict__ coords, int64_t n, ConvGeom g, SvIndexView ix,
+                                                             int32_t* __restrict__ nbr_in, int4* __restrict__ out_coords,
+                                                             int64_t capacity) {
+  const int64_t total = n * g.K;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx / n);
+    const int64_t i = idx - (int64_t)k * n;
+    const int kx = k % g.ksize[2], ky = (k / g.ksize[2]) % g.ksize[1], kz = k / (g.ksize[2] * g.ksize[1]);
+    const int4 c = coords[i];
+    int oz, oy, ox;
+    int32_t r = -1;
+    if (coord_ok(c, g.batch, g.in_shape) && out_coord(c, kz, ky, kx, g, oz, oy, ox)) {
+      const int64_t key = lin_key(c.x, oz, oy, ox, g.out_shape);
+      if (PHASE == 0) {
+        sv_index_mark(ix, key);
+      } else if (PHASE == 1) {
+        r = sv_index_lookup(ix, key);
+        if (r >= capacity) r = -1;
+        if (r >= 0) out_coords[r] = make_int4(c.x, oz, oy, ox);  // identical value from every contributor
+      } else {
+        ix.words[key >> 5] = make_uint2(0u, 0u);
+        ix.chunk_cnt[key >> SV_CHUNK_SHIFT] = 0;
+      }
+    }
+    if (PHASE == 1) nbr_in[idx] = r;
+  }
+}
+
+extern "C" int sv_conv_out_shape(const int32_t* in_shape_host, const int32_t* ksize_host, const int32_t* stride_host,
+                                 const int32_t* padding_host, const int32_t* dilation_host, int32_t* out_shape_host) {
+  ConvGeom g;
+  int rc = fill_geom(g, 1, in_shape_host, ksize_host, stride_host, padding_host, dilation_host, false);
+  if (rc) return rc;
+  for (int d = 0; d < 3; ++d) out_shape_host[d] = g.out_shape[d];
+  return SV_OK;
+}
+
+extern "C" int sv_rulebook_sparse(const int32_t* coords, int64_t n_in, int batch, const int32_t* in_shape_host,
+                                  const int32_t* ksize_host, const int32_t* stride_host, const int32_t* padding_host,
+                                  const int32_t* dilation_host, void* index_ws, void* scratch, int32_t* out_coords,
+                                  int32_t* nbr_in, int64_t capacity, int32_t* num_out, void* stream) {
+  SV_CHECK_ARG(n_in >= 0 && batch > 0 && capacity >= 0 && num_out, "rulebook_sparse: bad arguments");
+  hipStream_t st = sv_stream(stream);
+  if (n_in == 0) {
+    SV_HIP(hipMemsetAsync(num_out, 0, 4, st));
+    return SV_OK;
+  }
+  SV_CHECK_ARG(coords && index_ws && scratch && out_coords && nbr_in, "rulebook_sparse: null pointer");
+  ConvGeom g;
+  int rc = fill_geom(g, batch, in_shape_host, ksize_host, stride_host, padding_host, dilation_host, false);
+  if (rc) return rc;
+  const int64_t ncells = (int64_t)batch * g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+  SvIndexView ix = sv_index_view(index_ws, ncells);
+  char* s = reinterpret_cast<char*>(scratch) + align256((size_t)n_in * 4);
+  void* scan_tmp = s;
+  const int4* c4 = reinterpret_cast<const int4*>(coords);
+  int4* oc4 = reinterpret_cast<int4*>(out_coords);
+  const int grid = sv_grid_1d(n_in * g.K, RB_THREADS, 256 * 16);
+  hipLaunchKernelGGL(k_sparse_phase<0>, dim3(grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, nbr_in, oc4, capacity);
+  rc = sv_index_scan_launch(ix, num_out, scan_tmp, st);
+  if (rc) return rc;
+  rc = launch_index_prefix(ix, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sparse_phase<1>, dim3(grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, nbr_in, oc4, capacity);
+  hipLaunchKernelGGL(k_sparse_phase<2>, dim3(grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, nbr_in, oc4, capacity);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// nbr_in (K, n_in) [input-major: output row per (k, input)]  ->  nbr_out (K, n_out) [output-major]
+__global__ __launch_bounds__(RB_THREADS) void k_invert(const int32_t* __restrict__ nbr_in, int64_t n_in, int K, int32_t* __restrict__ nbr_out,
+                                                       int64_t n_out) {
+  const int64_t total = n_in * K;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t o = nbr_in[idx];
+    if (o >= 0 && o < n_out) {
+      const int k = (int)(idx / n_in);
+      nbr_out[(int64_t)k * n_out + o] = (int32_t)(idx - (int64_t)k * n_in);  // unique writer: (k, o) fixes the input coord
+    }
+  }
+}
+
+extern "C" int sv_rulebook_invert(const int32_t* nbr_in, int64_t n_in, int K, int32_t* nbr_out, int64_t n_out, void* stream) {
+  SV_CHECK_ARG(n_in >= 0 && n_out >= 0 && K > 0, "rulebook_invert: bad arguments");
+  if (n_out == 0) return SV_OK;
+  SV_CHECK_ARG(nbr_out, "rulebook_invert: null pointer");
+  hipStream_t st = sv_stream(stream);
+  SV_HIP(hipMemsetAsync(nbr_out, 0xFF, (size_t)K * n_out * 4, st));
+  if (n_in == 0) return SV_OK;
+  SV_CHECK_ARG(nbr_in, "rulebook_invert: null pointer");
+  hipLaunchKernelGGL(k_invert, dim3(sv_grid_1d(n_in * K, RB_THREADS, 256 * 16)), dim3(RB_THREADS), 0, st, nbr_in, n_in, K, nbr_out, n_out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// --------------------------------------------------------------------------- pair compaction (spconv-style lists)
+// From the output-major table build, per kernel offset, the compact ascending list of (in,out) pairs and
+// the pair counts — wavefront ballot + prefix popcount, order-preserving (ascending output row).
+// Used for the Pairs statistic of the roofline model and by the weight-gradient kernel's work estimate.
+__global__ __launch_bounds__(RB_THREADS) void k_pair_count(const int32_t* __restrict__ nbr, int64_t n_out, int K, int32_t* __restrict__ counts) {
+  // grid: (blocks over rows, K)
+  const int k = blockIdx.y;
+  const int32_t* row = nbr + (int64_t)k * n_out;
+  int local = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long m = __ballot(row[i] >= 0);
+    if ((threadIdx.x & 63) == 0) local += __popcll(m);
+  }
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[k], local);
+}
+
+extern "C" int sv_rulebook_pair_counts(const int32_t* nbr, int64_t n_out, int K, int32_t* counts, void* stream) {
+  SV_CHECK_ARG(K > 0 && n_out >= 0 && counts, "rulebook_pair_counts: bad arguments");
+  hipStream_t st = sv_stream(stream);
+  SV_HIP(hipMemsetAsync(counts, 0, (size_t)K * 4, st));
+  if (n_out == 0) return SV_OK;
+  SV_CHECK_ARG(nbr, "rulebook_pair_counts: null pointer");
+  dim3 grid(sv_grid_1d(n_out, RB_THREADS, 64), K);
+  hipLaunchKernelGGL(k_pair_count, grid, dim3(RB_THREADS), 0, st, nbr, n_out, K, counts);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -1,0 +1,304 @@
+// Sparse 3-D convolution: output-stationary gather-GEMM over the output-major rulebook.
+//
+//   Y[o][n] = epilogue( sum_k sum_c X[nbr[k][o]][c] * Wt[k][n][c] )       (rows with nbr < 0 contribute 0)
+//
+// One kernel serves three uses (the caller picks the table and the weight view):
+//   forward        X = features,  nbr = output-major table,            Wt[k][n][c] = W[k][c_in=c][c_out=n]
+//   backward-data  X = grad_out,  nbr = input-major table (nbr_in),    Wt[k][n][c] = W[k][c_in=n][c_out=c]
+// and a second kernel reduces the weight gradient dW[k][c][n] = sum_o X[nbr[k][o]][c] * dY[o][n].
+//
+// Every output row is produced exactly once, in registers, with a fixed summation order (k ascending):
+// no atomics, bitwise reproducible.  The dense per-voxel products run on the fp32 MFMA
+// (v_mfma_f32_16x16x4_f32, exact fp32) — 16-row tiles so that a (tile, offset) pair with no neighbour is skipped.
+// Algorithmic traffic per layer: 4*(N_in*C_in + N_out*C_out) + 4*K*C_in*C_out + 4*K*N_out (table) bytes.
+//
+// Replaces the third-party spconv kernels behind SubMConv3d / SparseConv3d
+// (call sites: detector3d/pcdet/models/backbones_3d/spconv_backbone.py:8-27,77-117).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SC_THREADS = 256;
+constexpr int SC_ROWS_PER_WAVE = 32;  // two 16-row MFMA tiles
+constexpr int SC_ROWS_PER_BLOCK = SC_ROWS_PER_WAVE * (SC_THREADS / 64);
+
+struct ConvArgs {
+  const float* X;         // (n_src, Kd)
+  const int32_t* nbr;     // (K, n_rows)
+  const float* Wt;        // (K, Nc, Kd)
+  float* Y;               // (n_rows, Nc)
+  const float* bias;      // (Nc) or null        : y += bias
+  const float* scale;     // (Nc) or null        : y = y*scale + shift   (folded eval-mode BatchNorm)
+  const float* shift;     // (Nc) or null
+  const float* residual;  // (n_rows, Nc) or null: y += residual (after scale/shift, before relu)
+  int relu;
+  int64_t n_rows;
+  int K, Kd, Nc;
+};
+
+__device__ __forceinline__ float conv_epilogue(float v, int col, int64_t row, const ConvArgs& a) {
+  if (a.bias) v += a.bias[col];
+  if (a.scale) v = v * a.scale[col] + a.shift[col];
+  if (a.residual) v += a.residual[row * a.Nc + col];
+  if (a.relu) v = fmaxf(v, 0.f);
+  return v;
+}
+
+// NT = Nc/16 column tiles held in registers. LDS holds Wt[k] as [Nc][Kd+4].
+template <int NT>
+__global__ __launch_bounds__(SC_THREADS) void k_spconv_mfma(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float Ws[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, kk = lane >> 4;
+  const int pitch = a.Kd + 4;
+  const int64_t row0 = (int64_t)blockIdx.x * SC_ROWS_PER_BLOCK + wid * SC_ROWS_PER_WAVE;
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int wq = a.Kd / 4;                 // float4 per weight row
+  const int wtotal = a.Nc * wq;            // float4 per offset
+  for (int k = 0; k < a.K; ++k) {
+    // gather indices of this wave's 2x16 rows for offset k (coalesced 64 B reads)
+    int32_t j[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int64_t r = row0 + g * 16 + li;
+      j[g] = r < a.n_rows ? a.nbr[(int64_t)k * a.n_rows + r] : -1;
+    }
+    const bool any0 = __ballot(j[0] >= 0) != 0ull, any1 = __ballot(j[1] >= 0) != 0ull;
+    const unsigned long long blk_any = __syncthreads_or(any0 || any1);
+    if (!blk_any) continue;                // nobody in the workgroup needs W[k] (uniform across the block)
+    // stage Wt[k] -> LDS
+    const float4* src = reinterpret_cast<const float4*>(a.Wt + (int64_t)k * a.Nc * a.Kd);
+    for (int e = tid; e < wtotal; e += SC_THREADS) {
+      const int n = e / wq, c4 = e - n * wq;
+      *reinterpret_cast<float4*>(&Ws[n * pitch + c4 * 4]) = src[e];
+    }
+    __syncthreads();
+    if (any0 || any1) {
+      for (int q = 0; q < a.Kd / 16; ++q) {
+        float4 av[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          av[g] = j[g] >= 0 ? *reinterpret_cast<const float4*>(a.X + (int64_t)j[g] * a.Kd + q * 16 + kk * 4) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 b = *reinterpret_cast<const float4*>(&Ws[(t * 16 + li) * pitch + q * 16 + kk * 4]);
+          if (any0) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].x, b.x, acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].y, b.y, acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].z, b.z, acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].w, b.w, acc[0][t], 0, 0, 0);
+          }
+          if (any1) {
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].x, b.x, acc[1][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].y, b.y, acc[1][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].z, b.z, acc[1][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].w, b.w, acc[1][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();                       // Ws is overwritten by the next offset
+  }
+  // D layout (16x16): col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + g * 16 + kk * 4 + r;
+        const int col = t * 16 + li;
+        if (row < a.n_rows) a.Y[row * a.Nc + col] = conv_epilogue(acc[g][t][r], col, row, a);
+      }
+}
+
+// Generic VALU path for channel counts the MFMA tiling does not cover (e.g. the C_in = 3 input layer):
+// one thread per (row, 4 output columns), weights read through L1/L2.
+__global__ __launch_bounds__(256) void k_spconv_valu(ConvArgs a) {
+  const int nq = (a.Nc + 3) / 4;
+  const int64_t total = a.n_rows * nq;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / nq;
+    const int n0 = (int)(idx - row * nq) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < a.K; ++k) {
+      const int32_t j = a.nbr[(int64_t)k * a.n_rows + row];
+      if (j < 0) continue;
+      const float* x = a.X + (int64_t)j * a.Kd;
+      for (int u = 0; u < 4; ++u) {
+        if (n0 + u >= a.Nc) break;
+        const float* w = a.Wt + ((int64_t)k * a.Nc + n0 + u) * a.Kd;
+        float s = acc[u];
+        for (int c = 0; c < a.Kd; ++c) s = fmaf(x[c], w[c], s);
+        acc[u] = s;
+      }
+    }
+    for (int u = 0; u < 4 && n0 + u < a.Nc; ++u) a.Y[row * a.Nc + n0 + u] = conv_epilogue(acc[u], n0 + u, row, a);
+  }
+}
+
+extern "C" int sv_sparse_conv_gather_gemm(const float* X, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows,
+                                          int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
+                                          const float* residual, int relu, void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && K > 0 && Kd > 0 && Nc > 0, "sparse_conv: bad sizes");
+  if (n_rows == 0) return SV_OK;
+  SV_CHECK_ARG(X && nbr && Wt && Y, "sparse_conv: null pointer");
+  SV_CHECK_ARG((scale == nullptr) == (shift == nullptr), "sparse_conv: scale and shift go together");
+  ConvArgs a{X, nbr, Wt, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc};
+  hipStream_t st = sv_stream(stream);
+  const int nt = Nc / 16;
+  const bool mfma_ok = (Kd % 16 == 0) && (Nc % 16 == 0) && (nt == 1 || nt == 2 || nt == 4 || nt == 8) &&
+                       ((uintptr_t)X % 16 == 0) && ((uintptr_t)Wt % 16 == 0);
+  if (mfma_ok) {
+    const int grid = sv_div_up(n_rows, SC_ROWS_PER_BLOCK);
+    const size_t lds = (size_t)Nc * (Kd + 4) * sizeof(float);
+    switch (nt) {
+      case 1: hipLaunchKernelGGL(k_spconv_mfma<1>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
+      case 2: hipLaunchKernelGGL(k_spconv_mfma<2>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
+      case 4: hipLaunchKernelGGL(k_spconv_mfma<4>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
+      default:
+        if (lds > 64 * 1024) {  // opt in to > 64 KiB dynamic LDS (C_in = C_out = 128)
+          static bool raised = false;
+          if (!raised) {
+            SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spconv_mfma<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+          }
+        }
+        hipLaunchKernelGGL(k_spconv_mfma<8>, dim3(grid), dim3(SC_THREADS), lds, st, a);
+        break;
+    }
+  } else {
+    hipLaunchKernelGGL(k_spconv_valu, dim3(sv_grid_1d(n_rows * ((Nc + 3) / 4), 256, 256 * 16)), dim3(256), 0, st, a);
+  }
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient: dW[k][c][n] = sum_o X[nbr[k][o]][c] * dY[o][n]   (reduction over rows)
+// Stage 1: each workgroup reduces a chunk of rows for one offset k into a partial (Cin x Cout) slab
+//          (MFMA 16x16x4 with the row index as the contraction dimension); stage 2 sums the slabs in a
+//          fixed order -> bitwise reproducible, no atomics.
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_CHUNK = 2048;  // rows per stage-1 workgroup
+
+struct WgradArgs {
+  const float* X;        // (n_src, Cin)
+  const int32_t* nbr;    // (K, n_rows)
+  const float* dY;       // (n_rows, Cout)
+  float* partial;        // (nchunks, K, Cin, Cout)
+  int64_t n_rows;
+  int K, Cin, Cout, nchunks;
+};
+
+// grid = (nchunks, K, tile groups); 4 waves split the chunk's rows, each wave writes its own partial slab
+// (slab index = chunk*4 + wave) so no cross-wave reduction is needed inside the kernel.
+template <int CT, int NTL>  // register tile grid: CT x NTL tiles of 16x16 (rows = c_in, cols = c_out)
+__global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {
+  const int k = blockIdx.y, chunk = blockIdx.x;
+  const int ngroups_n = (a.Cout / 16) / NTL;
+  const int c_base = (blockIdx.z / ngroups_n) * CT * 16, n_base = (blockIdx.z % ngroups_n) * NTL * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, kk = lane >> 4;
+  f32x4 acc[CT][NTL];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int64_t r_begin = (int64_t)chunk * WG_CHUNK, r_end = min(r_begin + (int64_t)WG_CHUNK, a.n_rows);
+  const int32_t* nb = a.nbr + (int64_t)k * a.n_rows;
+  // wave-uniform loop: 4 consecutive rows per MFMA (lane quarter kk takes row rb + kk), waves interleave by 4 rows
+  for (int64_t rb = r_begin + wid * 4; rb < r_end; rb += 16) {
+    const int64_t r = rb + kk;
+    const int32_t j = r < r_end ? nb[r] : -1;
+    if (__ballot(j >= 0) == 0ull) continue;
+    float xa[CT], yb[NTL];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) xa[c] = j >= 0 ? a.X[(int64_t)j * a.Cin + c_base + c * 16 + li] : 0.f;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) yb[t] = j >= 0 ? a.dY[r * a.Cout + n_base + t * 16 + li] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[c], yb[t], acc[c][t], 0, 0, 0);
+  }
+  // D layout: col = lane&15 (c_out), row = 4*(lane>>4) + reg (c_in)
+  float* out = a.partial + ((((int64_t)chunk * 4 + wid) * a.K + k) * a.Cin) * a.Cout;
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(int64_t)(c_base + c * 16 + kk * 4 + r) * a.Cout + n_base + t * 16 + li] = acc[c][t][r];
+}
+
+// generic (any Cin/Cout) stage 1: one thread per (c, n) element, rows of the chunk streamed
+__global__ __launch_bounds__(256) void k_spconv_wgrad_valu(WgradArgs a) {
+  const int k = blockIdx.y, chunk = blockIdx.x;
+  const int64_t r_begin = (int64_t)chunk * WG_CHUNK, r_end = min(r_begin + (int64_t)WG_CHUNK, a.n_rows);
+  const int32_t* nb = a.nbr + (int64_t)k * a.n_rows;
+  float* out = a.partial + (((int64_t)chunk * a.K + k) * a.Cin) * a.Cout;  // one slab per chunk on this path
+  for (int e = threadIdx.x; e < a.Cin * a.Cout; e += blockDim.x) {
+    const int c = e / a.Cout, n = e - c * a.Cout;
+    float s = 0.f;
+    for (int64_t r = r_begin; r < r_end; ++r) {
+      const int32_t j = nb[r];
+      if (j >= 0) s = fmaf(a.X[(int64_t)j * a.Cin + c], a.dY[r * a.Cout + n], s);
+    }
+    out[e] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nchunks, int64_t slab, float* __restrict__ dW) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < slab; e += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * slab + e];
+    dW[e] = s;
+  }
+}
+
+extern "C" size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout) {
+  const int64_t nchunks = (n_rows + WG_CHUNK - 1) / WG_CHUNK;
+  return (size_t)(nchunks > 0 ? nchunks : 1) * 4 * K * Cin * Cout * sizeof(float);
+}
+
+template <int CT, int NTL>
+static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
+  const int groups = ((a.Cin / 16) / CT) * ((a.Cout / 16) / NTL);
+  hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL>), dim3(a.nchunks, a.K, groups), dim3(256), 0, st, a);
+}
+
+extern "C" int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
+                                    int Cin, int Cout, void* scratch, void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && K > 0 && Cin > 0 && Cout > 0 && dW, "sparse_conv_wgrad: bad arguments");
+  hipStream_t st = sv_stream(stream);
+  const int64_t slab = (int64_t)K * Cin * Cout;
+  if (n_rows == 0) {
+    SV_HIP(hipMemsetAsync(dW, 0, (size_t)slab * 4, st));
+    return SV_OK;
+  }
+  SV_CHECK_ARG(X && nbr && dY && scratch, "sparse_conv_wgrad: null pointer");
+  WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, (int)((n_rows + WG_CHUNK - 1) / WG_CHUNK)};
+  const int ct = Cin / 16, nt = Cout / 16;
+  int nslabs = a.nchunks * 4;
+  if (Cin % 16 == 0 && Cout % 16 == 0) {
+    if (ct % 4 == 0 && nt % 4 == 0) launch_wgrad<4, 4>(a, st);
+    else if (ct % 2 == 0 && nt % 4 == 0) launch_wgrad<2, 4>(a, st);
+    else if (ct % 2 == 0 && nt % 2 == 0) launch_wgrad<2, 2>(a, st);
+    else if (nt % 2 == 0) launch_wgrad<1, 2>(a, st);
+    else launch_wgrad<1, 1>(a, st);
+  } else {
+    hipLaunchKernelGGL(k_spconv_wgrad_valu, dim3(a.nchunks, K), dim3(256), 0, st, a);
+    nslabs = a.nchunks;
+  }
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(sv_grid_1d(slab, 256)), dim3(256), 0, st, a.partial, nslabs, slab, dW);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -1,0 +1,5 @@
+from .height_compression import HeightCompression
+
+__all__ = {
+    'HeightCompression': HeightCompression,
+}

@@ -1,0 +1,85 @@
+import math
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fsp
+from .core import SparseConvTensor
+from .modules import SparseModule
+
+
+def _triple(v):
+    return [int(x) for x in v] if isinstance(v, (list, tuple)) else [int(v)] * 3
+
+
+class SparseConvolution(SparseModule):
+    """Base of SubMConv3d / SparseConv3d (the class pcdet/utils/spconv_utils.py:19 tests with isinstance).
+
+    weight: (C_out, kz, ky, kx, C_in) — the spconv 2.x layout, so the reference's checkpoint loader
+    (detector3d_template.py:330-359) adapts 1.x checkpoints to it and loads 2.x ones as they are."""
+
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None, **kwargs):
+        super().__init__()
+        assert ndim == 3 and groups == 1 and not transposed and not inverse, "only 3-D forward (sub)manifold convs are built"
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _triple(kernel_size), _triple(stride)
+        self.padding, self.dilation = _triple(padding), _triple(dilation)
+        self.subm, self.indice_key = subm, indice_key
+        self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, subm={self.subm}, indice_key={self.indice_key}")
+
+    def weight_kio(self):
+        """(K, C_in, C_out) view of the parameter (autograd-tracked)."""
+        co = self.out_channels
+        return self.weight.reshape(co, -1, self.in_channels).permute(1, 2, 0)
+
+    def get_rulebook(self, x):
+        rb = x.find_indice_pair(self.indice_key)
+        if rb is not None and self.subm:
+            assert rb.subm and rb.ksize == self.kernel_size, f"indice_key {self.indice_key} reused with a different kernel"
+            return rb
+        if self.subm:
+            rb = Fsp.build_subm_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation)
+        else:
+            rb = Fsp.build_sparse_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding,
+                                           self.dilation)
+        if self.indice_key is not None:
+            x.indice_dict[self.indice_key] = rb
+        return rb
+
+    def forward(self, x):
+        assert isinstance(x, SparseConvTensor)
+        rb = self.get_rulebook(x)
+        feats = Fsp.SparseConvFunction.apply(x.features, self.weight_kio(), rb)
+        if self.bias is not None:
+            feats = feats + self.bias
+        out = SparseConvTensor(feats, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.indice_dict)
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, **kwargs):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
+                         indice_key=indice_key, **kwargs)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, **kwargs):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, False,
+                         indice_key=indice_key, **kwargs)

@@ -1,0 +1,58 @@
+from collections import OrderedDict
+
+import torch.nn as nn
+
+
+class SparseModule(nn.Module):
+    """Marker base: modules that take and return a SparseConvTensor (spconv.SparseModule)."""
+
+
+def _is_sparse(m):
+    return isinstance(m, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """Sequential that feeds SparseModules the sparse tensor and plain nn.Modules (BatchNorm1d, ReLU) the
+    `.features` matrix — the behaviour post_act_block relies on (spconv_backbone.py:21-25)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError(f"index {idx} is out of range")
+        if idx < 0:
+            idx += len(self)
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, input):
+        from .core import SparseConvTensor
+        for module in self._modules.values():
+            if _is_sparse(module):
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input = input.replace_feature(module(input.features))
+            else:
+                input = module(input)
+        return input

@@ -1,0 +1,261 @@
+"""Sparse conv: oracle cross-checked against torch's dense conv3d (CPU); HIP rulebooks bit-exact vs the oracle,
+HIP conv forward/backward/dense within 1e-3 rel (GPU).  spconv itself is unpinned third-party (oracle/spconv.py header)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import spconv as osp
+
+RTOL = 1e-3
+
+
+def _rand_coords(rng, n, batch, shape, clustered=True):
+    """Unique voxel coordinates, clustered so that neighbours exist."""
+    z = rng.integers(0, shape[0], size=4 * n)
+    y = rng.integers(0, shape[1], size=4 * n)
+    x = rng.integers(0, shape[2], size=4 * n)
+    if clustered:
+        y = (y // 3) % max(shape[1] // 2, 1) + shape[1] // 4
+        x = (x // 3) % max(shape[2] // 2, 1) + shape[2] // 4
+    b = rng.integers(0, batch, size=4 * n)
+    c = np.unique(np.stack([b, z, y, x], 1), axis=0)
+    c = c[rng.permutation(len(c))[:n]]
+    return c.astype(np.int32)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+GEOMS = [  # (ksize, stride, padding)
+    (3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0), (3, 1, 1), (2, 2, 0),
+]
+
+
+# ---------------------------------------------------------------------------------- CPU: oracle vs dense conv3d
+@pytest.mark.parametrize("ksize,stride,padding", GEOMS)
+def test_oracle_sparse_conv_equals_dense_conv3d(ksize, stride, padding):
+    rng = np.random.default_rng(0)
+    batch, shape, cin, cout = 2, (9, 14, 12), 5, 7
+    coords = _rand_coords(rng, 150, batch, shape)
+    feats = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    k3 = osp._triple(ksize)
+    w2x = rng.normal(size=(cout, *k3, cin)).astype(np.float32)
+    oc, nbr_out, nbr_in, oshape = osp.rulebook_sparse(coords, shape, ksize, stride, padding)
+    out = osp.conv_forward(feats, nbr_out, osp.weight_to_kio(w2x))
+    dense_in = torch.from_numpy(osp.dense(feats, coords, batch, shape)).double()
+    wt = torch.from_numpy(w2x).permute(0, 4, 1, 2, 3).double()          # (Cout, Cin, kz, ky, kx)
+    dense_out = F.conv3d(dense_in, wt, stride=osp._triple(stride), padding=osp._triple(padding)).numpy()
+    assert dense_out.shape[2:] == tuple(oshape)
+    # values at the active output sites
+    got = dense_out[oc[:, 0], :, oc[:, 1], oc[:, 2], oc[:, 3]]
+    np.testing.assert_allclose(out, got, rtol=1e-9, atol=1e-9)
+    # the output set is exactly the set of sites that see at least one active input
+    occ = torch.from_numpy(osp.dense(np.ones((len(coords), 1), np.float32), coords, batch, shape)).double()
+    reach = F.conv3d(occ, torch.ones(1, 1, *k3).double(), stride=osp._triple(stride), padding=osp._triple(padding)).numpy()[:, 0] > 0
+    mask = np.zeros_like(reach)
+    mask[oc[:, 0], oc[:, 1], oc[:, 2], oc[:, 3]] = True
+    assert np.array_equal(mask, reach)
+    # canonical order = ascending linear key; tables are mutually consistent
+    key = ((oc[:, 0].astype(np.int64) * oshape[0] + oc[:, 1]) * oshape[1] + oc[:, 2]) * oshape[2] + oc[:, 3]
+    assert (np.diff(key) > 0).all()
+    for k in range(nbr_out.shape[0]):
+        v = nbr_in[k] >= 0
+        assert np.array_equal(nbr_out[k, nbr_in[k, v]], np.nonzero(v)[0])
+
+
+def test_oracle_subm_equals_dense_conv3d_at_input_sites():
+    rng = np.random.default_rng(1)
+    batch, shape, cin, cout = 2, (7, 10, 11), 4, 6
+    coords = _rand_coords(rng, 120, batch, shape)
+    feats = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    w2x = rng.normal(size=(cout, 3, 3, 3, cin)).astype(np.float32)
+    nbr = osp.rulebook_subm(coords, shape, 3)
+    out = osp.conv_forward(feats, nbr, osp.weight_to_kio(w2x))
+    dense_in = torch.from_numpy(osp.dense(feats, coords, batch, shape)).double()
+    dense_out = F.conv3d(dense_in, torch.from_numpy(w2x).permute(0, 4, 1, 2, 3).double(), padding=1).numpy()
+    np.testing.assert_allclose(out, dense_out[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]], rtol=1e-9, atol=1e-9)
+    assert np.array_equal(nbr[13], np.arange(len(coords)))  # centre offset maps every row to itself
+
+
+def test_oracle_backward_matches_autograd_of_dense_conv():
+    rng = np.random.default_rng(2)
+    batch, shape, cin, cout = 1, (6, 8, 8), 3, 4
+    coords = _rand_coords(rng, 60, batch, shape)
+    feats = rng.normal(size=(len(coords), cin))
+    w2x = rng.normal(size=(cout, 3, 3, 3, cin))
+    oc, nbr_out, _, oshape = osp.rulebook_sparse(coords, shape, 3, 2, 1)
+    go = rng.normal(size=(len(oc), cout))
+    gf, gw = osp.conv_backward(feats, nbr_out, osp.weight_to_kio(w2x), go)
+    f = torch.tensor(feats, requires_grad=True)
+    w = torch.tensor(w2x, requires_grad=True)
+    ci = [torch.tensor(coords[:, i]).long() for i in range(4)]
+    dense_in = torch.zeros(batch, *shape, cin, dtype=torch.float64)
+    dense_in[ci[0], ci[1], ci[2], ci[3]] = f
+    dense_in = dense_in.permute(0, 4, 1, 2, 3)
+    o = F.conv3d(dense_in, w.permute(0, 4, 1, 2, 3), stride=2, padding=1)
+    sel = o[torch.tensor(oc[:, 0]).long(), :, torch.tensor(oc[:, 1]).long(), torch.tensor(oc[:, 2]).long(), torch.tensor(oc[:, 3]).long()]
+    (sel * torch.tensor(go)).sum().backward()
+    np.testing.assert_allclose(gf, f.grad.numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(gw, osp.weight_to_kio(w.grad.numpy()), rtol=1e-9, atol=1e-9)
+
+
+def test_shim_api_surface():
+    import seevcn_amd.spconv as spconv
+    from seevcn_amd.pcdet.models import backbones_3d
+    from seevcn_amd.pcdet.utils.spconv_utils import find_all_spconv_keys
+    m = backbones_3d.__all__["VoxelBackBone8x"]({}, 3, [1408, 1600, 40])
+    assert m.sparse_shape == [41, 1600, 1408] and m.num_point_features == 128
+    assert sum(p.numel() for p in m.parameters()) == 711440
+    keys = find_all_spconv_keys(m)
+    assert "conv_input.0.weight" in keys and "conv_out.0.weight" in keys and len(keys) == 12
+    assert m.conv4[0][0].weight.shape == (64, 3, 3, 3, 64) and m.conv_out[0].weight.shape == (128, 3, 1, 1, 64)
+    t = spconv.SparseConvTensor(torch.zeros(2, 3), torch.zeros(2, 4, dtype=torch.int32), [4, 4, 4], 1)
+    t2 = t.replace_feature(torch.ones(2, 3))
+    assert t2.indices is t.indices and t2.indice_dict is t.indice_dict and float(t2.features.sum()) == 6
+    r = backbones_3d.__all__["VoxelResBackBone8x"]({}, 5, [1440, 1440, 40])
+    assert r.backbone_channels["x_conv4"] == 128
+
+
+# ---------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("ksize,stride,padding", GEOMS)
+def test_hip_sparse_rulebook_bit_exact(cuda, hip_lib, ksize, stride, padding):
+    from seevcn_amd.spconv import functional as Fsp
+    rng = np.random.default_rng(3)
+    batch, shape = 3, (11, 40, 36)
+    coords = _rand_coords(rng, 3000, batch, shape)
+    oc, nbr_out, nbr_in, oshape = osp.rulebook_sparse(coords, shape, ksize, stride, padding)
+    rb = Fsp.build_sparse_rulebook(torch.from_numpy(coords).to(cuda), batch, shape, osp._triple(ksize), osp._triple(stride),
+                                   osp._triple(padding))
+    torch.cuda.synchronize()
+    assert list(rb.out_shape) == list(oshape)
+    assert np.array_equal(rb.out_indices.cpu().numpy(), oc)
+    assert np.array_equal(rb.nbr_in.cpu().numpy(), nbr_in)
+    assert np.array_equal(rb.nbr_out.cpu().numpy(), nbr_out)
+    assert np.array_equal(rb.pair_counts().cpu().numpy(), osp.pair_counts(nbr_out))
+    # rebuilding on the cleaned persistent index gives the same tables
+    rb2 = Fsp.build_sparse_rulebook(torch.from_numpy(coords).to(cuda), batch, shape, osp._triple(ksize), osp._triple(stride),
+                                    osp._triple(padding))
+    assert np.array_equal(rb2.nbr_out.cpu().numpy(), nbr_out)
+
+
+@pytest.mark.gpu
+def test_hip_subm_rulebook_bit_exact(cuda, hip_lib):
+    from seevcn_amd.spconv import functional as Fsp
+    rng = np.random.default_rng(4)
+    for batch, shape, n, ks in [(2, (41, 160, 140), 6000, (3, 3, 3)), (1, (5, 30, 30), 900, (3, 3, 3)), (2, (9, 20, 20), 500, (1, 3, 3))]:
+        coords = _rand_coords(rng, n, batch, shape)          # random row order (like the voxeliser's (b,x,y,z) order)
+        nbr = osp.rulebook_subm(coords, shape, ks)
+        rb = Fsp.build_subm_rulebook(torch.from_numpy(coords).to(cuda), batch, shape, list(ks))
+        torch.cuda.synchronize()
+        assert np.array_equal(rb.nbr_out.cpu().numpy(), nbr)
+        assert np.array_equal(rb.table_for_backward_data().cpu().numpy(), nbr[::-1])
+    # empty input
+    rb = Fsp.build_subm_rulebook(torch.zeros((0, 4), dtype=torch.int32, device=cuda), 1, (4, 4, 4), [3, 3, 3])
+    assert rb.nbr_out.shape == (27, 0)
+    rb = Fsp.build_sparse_rulebook(torch.zeros((0, 4), dtype=torch.int32, device=cuda), 1, (4, 4, 4), [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    assert rb.n_out == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(3, 16), (16, 16), (16, 32), (32, 64), (64, 64), (64, 128), (128, 128), (5, 7)])
+def test_hip_conv_forward_backward_vs_oracle(cuda, hip_lib, cin, cout):
+    import seevcn_amd.spconv as spconv
+    rng = np.random.default_rng(5)
+    batch, shape = 2, (9, 48, 40)
+    coords = _rand_coords(rng, 2500, batch, shape)
+    feats = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    for subm in (True, False):
+        torch.manual_seed(0)
+        conv = (spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="k") if subm
+                else spconv.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False)).to(cuda)
+        x = spconv.SparseConvTensor(torch.from_numpy(feats).to(cuda).requires_grad_(True), torch.from_numpy(coords).to(cuda), shape, batch)
+        y = conv(x)
+        w = osp.weight_to_kio(conv.weight.detach().cpu().numpy())
+        if subm:
+            nbr = osp.rulebook_subm(coords, shape, 3)
+            oc = coords
+        else:
+            oc, nbr, _, _ = osp.rulebook_sparse(coords, shape, 3, 2, 1)
+        ref = osp.conv_forward(feats, nbr, w)
+        assert np.array_equal(y.indices.cpu().numpy(), oc)
+        assert _rel(y.features.detach().cpu().numpy(), ref) < RTOL
+        go = rng.normal(size=ref.shape).astype(np.float32)
+        y.features.backward(torch.from_numpy(go).to(cuda))
+        gf, gw = osp.conv_backward(feats, nbr, w, go)
+        assert _rel(x.features.grad.cpu().numpy(), gf) < RTOL
+        gw_hip = osp.weight_to_kio(conv.weight.grad.cpu().numpy())
+        assert _rel(gw_hip, gw) < RTOL
+
+
+@pytest.mark.gpu
+def test_hip_conv_is_bitwise_reproducible(cuda, hip_lib):
+    import seevcn_amd.spconv as spconv
+    rng = np.random.default_rng(6)
+    coords = _rand_coords(rng, 4000, 2, (9, 64, 64))
+    feats = torch.from_numpy(rng.normal(size=(len(coords), 32)).astype(np.float32)).to(cuda)
+    conv = spconv.SubMConv3d(32, 32, 3, padding=1, bias=False).to(cuda)
+    outs = []
+    for _ in range(2):
+        x = spconv.SparseConvTensor(feats.clone().requires_grad_(True), torch.from_numpy(coords).to(cuda), (9, 64, 64), 2)
+        y = conv(x)
+        conv.weight.grad = None
+        y.features.sum().backward()
+        outs.append((y.features.detach().clone(), x.features.grad.clone(), conv.weight.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_hip_dense_and_height_compression(cuda, hip_lib):
+    import seevcn_amd.spconv as spconv
+    from seevcn_amd.pcdet.models.backbones_2d import map_to_bev
+    rng = np.random.default_rng(7)
+    batch, shape, c = 3, (2, 50, 44), 128
+    coords = _rand_coords(rng, 1500, batch, shape, clustered=False)
+    feats = rng.normal(size=(len(coords), c)).astype(np.float32)
+    f = torch.from_numpy(feats).to(cuda).requires_grad_(True)
+    t = spconv.SparseConvTensor(f, torch.from_numpy(coords).to(cuda), shape, batch)
+    hc = map_to_bev.__all__["HeightCompression"]({"NUM_BEV_FEATURES": 256})
+    bd = hc({"encoded_spconv_tensor": t, "encoded_spconv_tensor_stride": 8})
+    ref = osp.dense(feats, coords, batch, shape).reshape(batch, c * shape[0], shape[1], shape[2])
+    assert bd["spatial_features"].shape == ref.shape and bd["spatial_features_stride"] == 8
+    assert np.array_equal(bd["spatial_features"].detach().cpu().numpy(), ref)
+    g = rng.normal(size=ref.shape).astype(np.float32)
+    bd["spatial_features"].backward(torch.from_numpy(g).to(cuda))
+    gd = g.reshape(batch, c, *shape)
+    assert np.array_equal(f.grad.cpu().numpy(), gd[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]])
+
+
+@pytest.mark.gpu
+def test_hip_backbone8x_vs_oracle(cuda, hip_lib):
+    """DynMeanVFE -> VoxelBackBone8x (eval) on a small KITTI-geometry batch against the oracle chain."""
+    import seevcn_amd.synth as synth
+    from seeding import seeded_state_dict
+    from seevcn_amd.pcdet.models import backbones_3d
+    from seevcn_amd.pcdet.models.backbones_3d import vfe
+    pts, _ = synth.make_scene_batch(2, seed=2000, n_az=100)
+    pc_range, vs, grid = [0, -40, -3, 70.4, 40, 1], [0.05, 0.05, 0.1], [1408, 1600, 40]
+    bd = {"batch_size": 2, "points": torch.from_numpy(pts).to(cuda)}
+    bd = vfe.__all__["DynMeanVFE"](model_cfg={}, num_point_features=3, voxel_size=vs, grid_size=grid, point_cloud_range=pc_range)(bd)
+    m = backbones_3d.__all__["VoxelBackBone8x"]({}, 3, grid)
+    sd = seeded_state_dict(m, seed=1)
+    m.load_state_dict(sd)
+    m = m.to(cuda).eval()
+    with torch.no_grad():
+        bd = m(bd)
+    ref = osp.voxel_backbone8x_forward({k: v.numpy() for k, v in sd.items()}, bd["voxel_features"].cpu().numpy(),
+                                       bd["voxel_coords"].cpu().numpy(), 2, m.sparse_shape)
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        t = bd["multi_scale_3d_features"][name]
+        f, c, shape = ref[name]
+        assert list(t.spatial_shape) == list(shape), name
+        assert np.array_equal(t.indices.cpu().numpy(), c), name
+        assert _rel(t.features.cpu().numpy(), f) < RTOL, name
+    t = bd["encoded_spconv_tensor"]
+    f, c, shape = ref["out"]
+    assert list(t.spatial_shape) == [2, 200, 176] == list(shape)
+    assert np.array_equal(t.indices.cpu().numpy(), c) and _rel(t.features.cpu().numpy(), f) < RTOL
