@@ -21,6 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SC_THREADS = 256;
 constexpr int SC_ROWS_PER_WAVE = 32;  // two 16-row MFMA tiles
 constexpr int SC_ROWS_PER_BLOCK = SC_ROWS_PER_WAVE * (SC_THREADS / 64);
+constexpr int SC_KSLICE = 64;         // contraction channels staged in LDS at a time
 
 struct ConvArgs {
   const float* X;         // (n_src, Kd)
@@ -44,13 +45,13 @@ __device__ __forceinline__ float conv_epilogue(float v, int col, int64_t row, co
   return v;
 }
 
-// NT = Nc/16 column tiles held in registers. LDS holds Wt[k] as [Nc][Kd+4].
+// NT = Nc/16 column tiles held in registers. LDS holds a slice of Wt[k] as [Nc][min(Kd,64)+4].
 template <int NT>
 __global__ __launch_bounds__(SC_THREADS) void k_spconv_mfma(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Ws[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, kk = lane >> 4;
-  const int pitch = a.Kd + 4;
+  const int pitch = min(a.Kd, SC_KSLICE) + 4;
   const int64_t row0 = (int64_t)blockIdx.x * SC_ROWS_PER_BLOCK + wid * SC_ROWS_PER_WAVE;
 
   f32x4 acc[2][NT];
@@ -59,8 +60,6 @@ __global__ __launch_bounds__(SC_THREADS) void k_spconv_mfma(ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int wq = a.Kd / 4;                 // float4 per weight row
-  const int wtotal = a.Nc * wq;            // float4 per offset
   for (int k = 0; k < a.K; ++k) {
     // gather indices of this wave's 2x16 rows for offset k (coalesced 64 B reads)
     int32_t j[2];
@@ -72,38 +71,42 @@ __global__ __launch_bounds__(SC_THREADS) void k_spconv_mfma(ConvArgs a) {
     const bool any0 = __ballot(j[0] >= 0) != 0ull, any1 = __ballot(j[1] >= 0) != 0ull;
     const unsigned long long blk_any = __syncthreads_or(any0 || any1);
     if (!blk_any) continue;                // nobody in the workgroup needs W[k] (uniform across the block)
-    // stage Wt[k] -> LDS
-    const float4* src = reinterpret_cast<const float4*>(a.Wt + (int64_t)k * a.Nc * a.Kd);
-    for (int e = tid; e < wtotal; e += SC_THREADS) {
-      const int n = e / wq, c4 = e - n * wq;
-      *reinterpret_cast<float4*>(&Ws[n * pitch + c4 * 4]) = src[e];
-    }
-    __syncthreads();
-    if (any0 || any1) {
-      for (int q = 0; q < a.Kd / 16; ++q) {
-        float4 av[2];
+    // stage Wt[k] -> LDS in contraction slices of <= SC_KSLICE channels (bounds LDS at Nc*(SC_KSLICE+4)*4 bytes)
+    for (int ks = 0; ks < a.Kd; ks += SC_KSLICE) {
+      const int kw = min(SC_KSLICE, a.Kd - ks);      // slice width (multiple of 16)
+      const int wq = kw / 4;                          // float4 per weight row in the slice
+      const float* src = a.Wt + (int64_t)k * a.Nc * a.Kd + ks;
+      for (int e = tid; e < a.Nc * wq; e += SC_THREADS) {
+        const int n = e / wq, c4 = e - n * wq;
+        *reinterpret_cast<float4*>(&Ws[n * pitch + c4 * 4]) = *reinterpret_cast<const float4*>(src + (int64_t)n * a.Kd + c4 * 4);
+      }
+      __syncthreads();
+      if (any0 || any1) {
+        for (int q = 0; q < kw / 16; ++q) {
+          float4 av[2];
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
-          av[g] = j[g] >= 0 ? *reinterpret_cast<const float4*>(a.X + (int64_t)j[g] * a.Kd + q * 16 + kk * 4) : make_float4(0, 0, 0, 0);
+          for (int g = 0; g < 2; ++g)
+            av[g] = j[g] >= 0 ? *reinterpret_cast<const float4*>(a.X + (int64_t)j[g] * a.Kd + ks + q * 16 + kk * 4) : make_float4(0, 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float4 b = *reinterpret_cast<const float4*>(&Ws[(t * 16 + li) * pitch + q * 16 + kk * 4]);
-          if (any0) {
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].x, b.x, acc[0][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].y, b.y, acc[0][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].z, b.z, acc[0][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].w, b.w, acc[0][t], 0, 0, 0);
-          }
-          if (any1) {
-            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].x, b.x, acc[1][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].y, b.y, acc[1][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].z, b.z, acc[1][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].w, b.w, acc[1][t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) {
+            const float4 b = *reinterpret_cast<const float4*>(&Ws[(t * 16 + li) * pitch + q * 16 + kk * 4]);
+            if (any0) {
+              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].x, b.x, acc[0][t], 0, 0, 0);
+              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].y, b.y, acc[0][t], 0, 0, 0);
+              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].z, b.z, acc[0][t], 0, 0, 0);
+              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].w, b.w, acc[0][t], 0, 0, 0);
+            }
+            if (any1) {
+              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].x, b.x, acc[1][t], 0, 0, 0);
+              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].y, b.y, acc[1][t], 0, 0, 0);
+              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].z, b.z, acc[1][t], 0, 0, 0);
+              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].w, b.w, acc[1][t], 0, 0, 0);
+            }
           }
         }
       }
+      __syncthreads();                     // Ws is overwritten by the next slice / offset
     }
-    __syncthreads();                       // Ws is overwritten by the next offset
   }
   // D layout (16x16): col = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll
@@ -157,21 +160,12 @@ extern "C" int sv_sparse_conv_gather_gemm(const float* X, const int32_t* nbr, co
                        ((uintptr_t)X % 16 == 0) && ((uintptr_t)Wt % 16 == 0);
   if (mfma_ok) {
     const int grid = sv_div_up(n_rows, SC_ROWS_PER_BLOCK);
-    const size_t lds = (size_t)Nc * (Kd + 4) * sizeof(float);
+    const size_t lds = (size_t)Nc * ((Kd < SC_KSLICE ? Kd : SC_KSLICE) + 4) * sizeof(float);
     switch (nt) {
       case 1: hipLaunchKernelGGL(k_spconv_mfma<1>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
       case 2: hipLaunchKernelGGL(k_spconv_mfma<2>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
       case 4: hipLaunchKernelGGL(k_spconv_mfma<4>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
-      default:
-        if (lds > 64 * 1024) {  // opt in to > 64 KiB dynamic LDS (C_in = C_out = 128)
-          static bool raised = false;
-          if (!raised) {
-            SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spconv_mfma<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-          }
-        }
-        hipLaunchKernelGGL(k_spconv_mfma<8>, dim3(grid), dim3(SC_THREADS), lds, st, a);
-        break;
+      default: hipLaunchKernelGGL(k_spconv_mfma<8>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
     }
   } else {
     hipLaunchKernelGGL(k_spconv_valu, dim3(sv_grid_1d(n_rows * ((Nc + 3) / 4), 256, 256 * 16)), dim3(256), 0, st, a);
