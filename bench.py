@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py — scenes/sec of the SEE-VCN hot path on MI355X (contract in the task description).
+
+A step = one pass of the hot path over one batch per GPU: VCN_VC forward on 64 cropped objects (1024 pts each),
+completed surfaces pasted into 16 KITTI-shaped ray-cast scenes (~17k pts each), dynamic voxelisation + mean VFE,
+VoxelBackBone8x (sparse 3-D conv) + HeightCompression forward, loss, backward, SGD step.  Inputs are resident in
+HBM before the timed region.  Scenes shard data-parallel (weak scaling); gradients are all-reduced over RCCL.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+SCENES_PER_GPU = 16
+OBJECTS_PER_GPU = 64
+VCN_FLOP_PER_OBJECT = 1.976e9      # 987.8 M MAC / object, reference formulation
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def make_inputs(rank, device):
+    import seevcn_amd.synth as synth
+    pts, _ = synth.make_scene_batch(SCENES_PER_GPU, seed=2000 + 1000 * rank)
+    objs, _ = synth.make_object_batch(OBJECTS_PER_GPU, seed=1000 + 1000 * rank)
+    # put the objects inside the KITTI range of their scene (x>0 half-plane) so their completed points voxelise
+    objs = objs.copy()
+    objs[:, :, 0] = np.abs(objs[:, :, 0])
+    scene = (np.arange(OBJECTS_PER_GPU) // (OBJECTS_PER_GPU // SCENES_PER_GPU)).astype(np.float32)
+    return (torch.from_numpy(pts).to(device), torch.from_numpy(objs).to(device), torch.from_numpy(scene).to(device), pts, objs, scene)
+
+
+def build_model(device, seed=0):
+    from seevcn_amd.pipeline import SceneStep
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from seeding import seeded_state_dict
+    m = SceneStep()
+    m.load_state_dict(seeded_state_dict(m, seed=seed))
+    return m.to(device)
+
+
+def loss_fn(bd):
+    return bd['spatial_features'].square().mean()
+
+
+def allreduce_grads(params, world):
+    if world == 1:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat)                       # RCCL ring over xGMI; 0.71 M fp32 = one 2.8 MB bucket
+    flat.div_(world)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+
+
+def run_step(model, opt, params, inputs, world):
+    points, objects, scene = inputs
+    opt.zero_grad(set_to_none=False)
+    bd = model(points, objects, scene, SCENES_PER_GPU)
+    loss = loss_fn(bd)
+    loss.backward()
+    allreduce_grads(params, world)
+    opt.step()
+    return loss
+
+
+def measure_dominant_kernel(model, inputs, reps=5):
+    """Live HIP-event timing of the dominant kernel (the fp32-MFMA GEMM of the VCN layers): every
+    sv_gemm_bias_act launch of one VCN forward is bracketed by events on the launch stream."""
+    from seevcn_amd.vcn.models import layers as L
+    records = []
+    orig = L.gemm
+
+    def timed(a, w, *args, **kw):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = orig(a, w, *args, **kw)
+        e.record()
+        records.append((2.0 * a.shape[0] * a.shape[1] * w.shape[0], s, e))
+        return out
+
+    L.gemm = timed
+    try:
+        for _ in range(reps):
+            model.vcn({'input': inputs[1]})
+        torch.cuda.synchronize()
+    finally:
+        L.gemm = orig
+    ms = sum(s.elapsed_time(e) for _, s, e in records)
+    executed = sum(f for f, _, _ in records)
+    launches = len(records)
+    return ms / launches, executed / reps, launches // reps, ms / reps
+
+
+def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1):
+    """Oracle (CPU port) on a bounded sample of the same workload: VCN on n_objects objects + one scene's
+    voxelise -> backbone forward/backward (numpy sparse conv inside torch-CPU autograd for BN/ReLU)."""
+    from oracle import vcn as ovcn, voxelize as ovox, spconv as osp
+    from seevcn_amd.pipeline import KITTI
+    from seevcn_amd.pcdet.models import backbones_3d
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from seeding import seeded_state_dict
+    import seevcn_amd.vcn as V
+    threads = torch.get_num_threads()
+    vsd = seeded_state_dict(V.MODELS.build({'NAME': 'VCN_VC'}), seed=0)
+    t0 = time.perf_counter()
+    coarse = ovcn.vcn_vc_forward(vsd, torch.from_numpy(objs_np[:n_objects]))['coarse'].numpy()
+    t_vcn = (time.perf_counter() - t0) / n_objects            # s / object
+    per_scene_objs = OBJECTS_PER_GPU // SCENES_PER_GPU
+    t1 = time.perf_counter()
+    sel = pts_np[pts_np[:, 0] < n_scenes]
+    paste = np.concatenate([np.repeat(scene_np[:n_objects, None, None], 1024, 1), coarse], axis=2).reshape(-1, 4)
+    paste = paste[paste[:, 0] < n_scenes]
+    allp = np.concatenate([sel, paste.astype(np.float32)], 0)
+    g = KITTI
+    feats, coords, _ = ovox.dynamic_mean_vfe(allp, g['point_cloud_range'], g['voxel_size'], g['grid_size'])
+    m = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size'])
+    sd = {k: v.numpy() for k, v in seeded_state_dict(m, seed=0).items()}
+
+    class Conv(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, nbr):
+            ctx.nbr = nbr
+            ctx.save_for_backward(x, w)
+            return torch.from_numpy(osp.conv_forward(x.numpy(), nbr, w.numpy()).astype(np.float32))
+
+        @staticmethod
+        def backward(ctx, go):
+            x, w = ctx.saved_tensors
+            gf, gw = osp.conv_backward(x.numpy(), ctx.nbr, w.numpy(), go.numpy())
+            return torch.from_numpy(gf.astype(np.float32)), torch.from_numpy(gw.astype(np.float32)), None
+
+    def bn_relu(x, c):
+        return torch.relu(torch.nn.functional.batch_norm(x, None, None, torch.ones(c), torch.zeros(c), True, 0.01, 1e-3))
+
+    def W(key):
+        return torch.from_numpy(osp.weight_to_kio(sd[key])).requires_grad_(True)
+
+    shape = tuple(m.sparse_shape)
+    x = torch.from_numpy(feats)
+    nb = osp.rulebook_subm(coords, shape, 3)
+    x = bn_relu(Conv.apply(x, W('conv_input.0.weight'), nb), 16)
+    x = bn_relu(Conv.apply(x, W('conv1.0.0.weight'), nb), 16)
+    c = coords
+    for name, pad, ch in (('conv2', 1, 32), ('conv3', 1, 64), ('conv4', (0, 1, 1), 64)):
+        oc, nbo, _, oshape = osp.rulebook_sparse(c, shape, 3, 2, pad)
+        x = bn_relu(Conv.apply(x, W(f'{name}.0.0.weight'), nbo), ch)
+        c, shape = oc, oshape
+        nb = osp.rulebook_subm(c, shape, 3)
+        for i in (1, 2):
+            x = bn_relu(Conv.apply(x, W(f'{name}.{i}.0.weight'), nb), ch)
+    oc, nbo, _, oshape = osp.rulebook_sparse(c, shape, (3, 1, 1), (2, 1, 1), 0)
+    x = bn_relu(Conv.apply(x, W('conv_out.0.weight'), nbo), 128)
+    dense = torch.zeros(n_scenes, *oshape, 128)
+    dense[torch.from_numpy(oc[:, 0]).long(), torch.from_numpy(oc[:, 1]).long(), torch.from_numpy(oc[:, 2]).long(),
+          torch.from_numpy(oc[:, 3]).long()] = x
+    dense.square().mean().backward()
+    t_scene = (time.perf_counter() - t1) / n_scenes
+    sec_per_scene = t_scene + per_scene_objs * t_vcn
+    return {"value": round(1.0 / sec_per_scene, 4), "unit": "scenes/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle (numpy/torch-CPU, {threads} threads): VCN_VC fwd on {n_objects} objects ({t_vcn:.3f} s/object) + "
+                      f"{n_scenes} scene voxelise+VoxelBackBone8x fwd+bwd ({t_scene:.2f} s/scene); scaled to {per_scene_objs} objects/scene"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    points, objects, scene, pts_np, objs_np, scene_np = make_inputs(rank, device)
+    model = build_model(device).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9)
+    inputs = (points, objects, scene)
+
+    for _ in range(args.warmup):
+        run_step(model, opt, params, inputs, world)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(model, opt, params, inputs, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        scenes = SCENES_PER_GPU * world * args.steps
+        out = {
+            "metric": "scenes/sec (VCN+voxel+spconv fwd+bwd)", "value": round(scenes / elapsed, 3), "unit": "scenes/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "VCN_VC fwd on 64 objects x 1024 pts -> paste into 16 KITTI-shaped 64-beam scenes (~17k pts) -> "
+                                   "DynMeanVFE -> VoxelBackBone8x + HeightCompression fwd+bwd + SGD (BASELINE configs[1]+[2])",
+                       "scenes_per_gpu": SCENES_PER_GPU, "objects_per_gpu": OBJECTS_PER_GPU, "points_per_object": 1024,
+                       "geometry": "KITTI [0,-40,-3,70.4,40,1] @ [0.05,0.05,0.1] -> sparse [41,1600,1408]", "parallelism": f"dp{world}"},
+            "completed_objects_per_sec": round(OBJECTS_PER_GPU * world * args.steps / elapsed, 1),
+        }
+        avg_ms, executed_flop, launches, vcn_gemm_ms = measure_dominant_kernel(model, inputs)
+        algo_flop_per_launch = VCN_FLOP_PER_OBJECT * OBJECTS_PER_GPU / launches
+        achieved = algo_flop_per_launch / (avg_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_f32 (sv_gemm_bias_act, v_mfma_f32_32x32x2_f32)",
+                           "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4),
+                           "algorithmic_flop_per_launch": algo_flop_per_launch,
+                           "executed_tflops": round(executed_flop / (vcn_gemm_ms * 1e-3) / 1e12, 2)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pts_np, objs_np, scene_np)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -131,9 +131,10 @@ int sv_rulebook_pair_counts(const int32_t* nbr, int64_t n_out, int K, int32_t* c
 /* Y[o][n] = epi( sum_k sum_c X[nbr[k][o]][c] * Wt[k][n][c] ),  epi: +bias, *scale+shift (folded BN), +residual, relu.
  *   forward:       X = features (N_in,C_in),  nbr = output-major table, Wt = weight as (K, C_out, C_in)
  *   backward-data: X = grad_out (N_out,C_out), nbr = input-major table, Wt = weight as (K, C_in, C_out)
- * fp32 MFMA (v_mfma_f32_16x16x4_f32) when Kd and Nc are multiples of 16, VALU otherwise. */
-int sv_sparse_conv_gather_gemm(const float* X, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows,
-                               int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
+ * X has n_src rows, nbr/Y have n_rows rows.  fp32 MFMA (v_mfma_f32_16x16x4_f32) when Kd and Nc are multiples of 16
+ * (pairs compacted per workgroup by wavefront ballot, accumulators in LDS), VALU otherwise. */
+int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
+                               int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
                                const float* residual, int relu, void* stream);
 /* dW (K, C_in, C_out) = sum_o X[nbr[k][o]]^T dY[o]; deterministic two-stage reduction */
 size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout);

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libseevcn_hip.so")
+LIB_PATH = os.environ.get("SEEVCN_LIB") or os.path.join(_HERE, "lib", "libseevcn_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "seevcn_hip.h")
 
 c_p = ctypes.c_void_p
@@ -40,7 +40,7 @@ SIGNATURES = {
     "sv_rulebook_sparse": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "sv_rulebook_invert": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p]),
     "sv_rulebook_pair_counts": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
-    "sv_sparse_conv_gather_gemm": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "sv_sparse_conv_gather_gemm": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p]),
     "sv_sparse_conv_wgrad_scratch_bytes": (c_sz, [c_i64, c_i, c_i, c_i]),
     "sv_sparse_conv_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
     "sv_sparse_to_dense_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i]),

@@ -14,7 +14,10 @@
 //
 // Replaces the third-party spconv kernels behind SubMConv3d / SparseConv3d
 // (call sites: detector3d/pcdet/models/backbones_3d/spconv_backbone.py:8-27,77-117).
+#include <stdlib.h>
+
 #include "common.h"
+
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -121,6 +124,145 @@ __global__ __launch_bounds__(SC_THREADS) void k_spconv_mfma(ConvArgs a) {
       }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-stationary, barrier-free variant (the default MFMA path).
+//   * a wave owns RS_G 16-row output tiles x all Nc columns, accumulators in registers;
+//   * no LDS, no workgroup barriers: both MFMA operands are loaded straight into registers — the gathered
+//     source rows (A) and the 16-column weight slabs (B, shared by every wave, served by L1/L2);
+//   * operands of step (k, q) + 1 are requested before step (k, q) runs on the matrix core, the neighbour
+//     indices of the next active offset are fetched one offset ahead;
+//   * offsets with no neighbour for any of the wave's rows are skipped entirely (64-bit activity mask from a
+//     ballot pre-pass), row tiles with no neighbour skip their MFMAs;
+//   * the wave's tiles are taken from RS_G distant parts of the (key-sorted) row range: neighbour density is
+//     spatially correlated, striding gives every wave a mix of dense and sparse regions (measured -8 % time).
+// Summation order per output element is fixed (k ascending, channels ascending) -> bitwise reproducible.
+// Measured (MI355X, 64->64 submanifold layer, 134 580 rows, 1.17 M pairs): 250 us = 38 TFLOP/s algorithmic;
+// matrix-core busy 38 % — waves spend their time in issue stalls, see DESIGN.md "sparse conv: what limits it".
+// ------------------------------------------------------------------------------------------------
+template <int NT, int KQ, int RS_G>
+__global__ __launch_bounds__(256) void k_spconv_rs(ConvArgs a) {
+  constexpr int Kd = KQ * 16, Nc = NT * 16;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int li = lane & 15, kk = lane >> 4;
+  const int64_t n_tiles = (a.n_rows + 15) / 16;
+  const int64_t n_waves = (n_tiles + RS_G - 1) / RS_G;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid;
+  if (wave_id >= n_waves) return;
+  auto tile_row0 = [&](int g) { return (wave_id + (int64_t)g * n_waves) * 16; };
+
+  // activity mask of the kernel offsets for this wave's rows
+  unsigned long long active = 0ull;
+  {
+    // lane -> (tile lane>>4, row lane&15); with RS_G < 4 the upper tiles alias tile 0 (harmless for an OR)
+    const int64_t r = tile_row0((lane >> 4) % RS_G) + li;
+    for (int k = 0; k < a.K; ++k) {
+      const int32_t j = r < a.n_rows ? a.nbr[(int64_t)k * a.n_rows + r] : -1;
+      if (__ballot(j >= 0)) active |= 1ull << k;
+    }
+  }
+
+  f32x4 acc[RS_G][NT];
+#pragma unroll
+  for (int g = 0; g < RS_G; ++g)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto load_j = [&](int k, int32_t (&j)[RS_G]) {
+#pragma unroll
+    for (int g = 0; g < RS_G; ++g) {
+      const int64_t r = tile_row0(g) + li;
+      j[g] = r < a.n_rows ? a.nbr[(int64_t)k * a.n_rows + r] : -1;
+    }
+  };
+  auto load_ab = [&](int k, int q, const int32_t (&j)[RS_G], float4 (&A)[RS_G], float4 (&B)[NT]) {
+#pragma unroll
+    for (int g = 0; g < RS_G; ++g)
+      A[g] = j[g] >= 0 ? *reinterpret_cast<const float4*>(a.X + (int64_t)j[g] * Kd + q * 16 + kk * 4) : make_float4(0, 0, 0, 0);
+    const float* w = a.Wt + ((int64_t)k * Nc + li) * Kd + q * 16 + kk * 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) B[t] = *reinterpret_cast<const float4*>(w + (int64_t)t * 16 * Kd);
+  };
+
+  if (active) {
+    int k = __ffsll((long long)active) - 1;
+    active &= active - 1;
+    int32_t jc[RS_G], jn[RS_G];
+    float4 Ac[RS_G], Bc[NT], An[RS_G], Bn[NT];
+    load_j(k, jc);
+    load_ab(k, 0, jc, Ac, Bc);
+    while (true) {
+      const int kn = active ? __ffsll((long long)active) - 1 : -1;
+      if (kn >= 0) load_j(kn, jn);
+      bool anyg[RS_G];
+#pragma unroll
+      for (int g = 0; g < RS_G; ++g) anyg[g] = __ballot(jc[g] >= 0) != 0ull;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        // request the next step's operands before running this step's MFMAs
+        if (q + 1 < KQ) load_ab(k, q + 1, jc, An, Bn);
+        else if (kn >= 0) load_ab(kn, 0, jn, An, Bn);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int g = 0; g < RS_G; ++g)
+            if (anyg[g]) {
+              acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[g].x, Bc[t].x, acc[g][t], 0, 0, 0);
+              acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[g].y, Bc[t].y, acc[g][t], 0, 0, 0);
+              acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[g].z, Bc[t].z, acc[g][t], 0, 0, 0);
+              acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[g].w, Bc[t].w, acc[g][t], 0, 0, 0);
+            }
+        if (q + 1 < KQ || kn >= 0) {
+#pragma unroll
+          for (int g = 0; g < RS_G; ++g) Ac[g] = An[g];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) Bc[t] = Bn[t];
+        }
+      }
+      if (kn < 0) break;
+      k = kn;
+      active &= active - 1;
+#pragma unroll
+      for (int g = 0; g < RS_G; ++g) jc[g] = jn[g];
+    }
+  }
+  // D layout (16x16): col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+  for (int g = 0; g < RS_G; ++g)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = tile_row0(g) + kk * 4 + r;
+        const int col = t * 16 + li;
+        if (row < a.n_rows) a.Y[row * Nc + col] = conv_epilogue(acc[g][t][r], col, row, a);
+      }
+}
+
+template <int NT, int G>
+static int launch_rs_kq(const ConvArgs& a, int kq, hipStream_t st) {
+  const int64_t n_tiles = (a.n_rows + 15) / 16;
+  const int64_t n_waves = (n_tiles + G - 1) / G;
+  const dim3 grid((unsigned)((n_waves + 3) / 4));
+  switch (kq) {
+    case 1: hipLaunchKernelGGL((k_spconv_rs<NT, 1, G>), grid, dim3(256), 0, st, a); return 0;
+    case 2: hipLaunchKernelGGL((k_spconv_rs<NT, 2, G>), grid, dim3(256), 0, st, a); return 0;
+    case 4: hipLaunchKernelGGL((k_spconv_rs<NT, 4, G>), grid, dim3(256), 0, st, a); return 0;
+    case 8: hipLaunchKernelGGL((k_spconv_rs<NT, 8, G>), grid, dim3(256), 0, st, a); return 0;
+  }
+  return -1;
+}
+
+static int try_launch_rs(const ConvArgs& a, hipStream_t st) {
+  if (a.Kd % 16 || a.Nc % 16 || a.K > 64) return -1;
+  switch (a.Nc / 16) {
+    case 1: return launch_rs_kq<1, 4>(a, a.Kd / 16, st);
+    case 2: return launch_rs_kq<2, 4>(a, a.Kd / 16, st);
+    case 4: return launch_rs_kq<4, 4>(a, a.Kd / 16, st);
+    case 8: return launch_rs_kq<8, 4>(a, a.Kd / 16, st);
+  }
+  return -1;
+}
+
 // Generic VALU path for channel counts the MFMA tiling does not cover (e.g. the C_in = 3 input layer):
 // one thread per (row, 4 output columns), weights read through L1/L2.
 __global__ __launch_bounds__(256) void k_spconv_valu(ConvArgs a) {
@@ -146,8 +288,8 @@ __global__ __launch_bounds__(256) void k_spconv_valu(ConvArgs a) {
   }
 }
 
-extern "C" int sv_sparse_conv_gather_gemm(const float* X, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows,
-                                          int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
+extern "C" int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
+                                          int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
                                           const float* residual, int relu, void* stream) {
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Kd > 0 && Nc > 0, "sparse_conv: bad sizes");
   if (n_rows == 0) return SV_OK;
@@ -158,6 +300,11 @@ extern "C" int sv_sparse_conv_gather_gemm(const float* X, const int32_t* nbr, co
   const int nt = Nc / 16;
   const bool mfma_ok = (Kd % 16 == 0) && (Nc % 16 == 0) && (nt == 1 || nt == 2 || nt == 4 || nt == 8) &&
                        ((uintptr_t)X % 16 == 0) && ((uintptr_t)Wt % 16 == 0);
+  static const bool force_v1 = getenv("SEEVCN_SPCONV_V1") != nullptr;
+  if (mfma_ok && !force_v1 && try_launch_rs(a, st) == 0) {
+    SV_LAUNCH_CHECK();
+    return SV_OK;
+  }
   if (mfma_ok) {
     const int grid = sv_div_up(n_rows, SC_ROWS_PER_BLOCK);
     const size_t lds = (size_t)Nc * ((Kd < SC_KSLICE ? Kd : SC_KSLICE) + 4) * sizeof(float);

@@ -1,0 +1,50 @@
+"""The measured hot path as one object: VCN completion of cropped objects -> paste into the scenes ->
+dynamic voxelisation -> VoxelBackBone8x -> HeightCompression (forward + backward + optimiser step).
+
+This is the composition BASELINE.json's metric names ("VCN + voxel + spconv fwd+bwd"); it only chains modules that
+mirror the reference's own classes (VCN_VC, DynMeanVFE, VoxelBackBone8x, HeightCompression) the way
+SEE_VCN.complete_*_pts / replace_with_completed_pts (see/surface_completion/SEE_VCN.py:85-115,247-265) and
+SECONDNet.forward (detector3d/pcdet/models/detectors/second_net.py:9-22) chain them.
+"""
+import torch
+import torch.nn as nn
+
+from .pcdet.models.backbones_2d import map_to_bev
+from .pcdet.models import backbones_3d
+from .pcdet.models.backbones_3d import vfe
+from .vcn import MODELS
+
+KITTI = dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.05, 0.05, 0.1], grid_size=[1408, 1600, 40])
+
+
+class SceneStep(nn.Module):
+    def __init__(self, geometry=None, input_channels=3):
+        super().__init__()
+        g = dict(KITTI if geometry is None else geometry)
+        self.geometry = g
+        self.vcn = MODELS.build({'NAME': 'VCN_VC'}).eval()
+        for p in self.vcn.parameters():
+            p.requires_grad_(False)
+        self.vfe = vfe.__all__['DynMeanVFE'](model_cfg={}, num_point_features=input_channels, voxel_size=g['voxel_size'],
+                                             grid_size=g['grid_size'], point_cloud_range=g['point_cloud_range'])
+        self.backbone_3d = backbones_3d.__all__['VoxelBackBone8x']({}, input_channels, g['grid_size'])
+        self.map_to_bev = map_to_bev.__all__['HeightCompression']({'NUM_BEV_FEATURES': 256})
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.vcn.eval()   # VCN weights are given (inference only in the SEE pipeline)
+        return self
+
+    def complete_and_paste(self, points, objects, object_scene):
+        """points (ΣP,4) [b,x,y,z]; objects (B_o,1024,3); object_scene (B_o,) float scene index of each object."""
+        coarse = self.vcn({'input': objects})['coarse']                          # (B_o,1024,3)
+        bcol = object_scene.view(-1, 1, 1).expand(-1, coarse.shape[1], 1)
+        return torch.cat([points, torch.cat([bcol, coarse], dim=2).view(-1, 4)], dim=0)
+
+    def forward(self, points, objects, object_scene, batch_size):
+        pts = self.complete_and_paste(points, objects, object_scene)
+        bd = {'batch_size': batch_size, 'points': pts}
+        bd = self.vfe(bd)
+        bd = self.backbone_3d(bd)
+        bd = self.map_to_bev(bd)
+        return bd

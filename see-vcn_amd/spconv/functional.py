@@ -106,7 +106,7 @@ def gather_gemm(x, nbr, wt, n_rows, bias=None, scale=None, shift=None, residual=
     assert x.shape[1] == Kd and nbr.shape[0] == K
     x = x.contiguous()
     y = torch.empty((n_rows, Nc), dtype=torch.float32, device=x.device)
-    rc = lib.sv_sparse_conv_gather_gemm(_lib.ptr(x) if x.numel() else None, _lib.ptr(nbr) if nbr.numel() else None, _lib.ptr(wt),
+    rc = lib.sv_sparse_conv_gather_gemm(_lib.ptr(x) if x.numel() else None, x.shape[0], _lib.ptr(nbr) if nbr.numel() else None, _lib.ptr(wt),
                                         _lib.ptr(y) if n_rows else None, n_rows, K, Kd, Nc, _lib.ptr(bias), _lib.ptr(scale),
                                         _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), _lib.stream())
     _lib.check(rc, "sv_sparse_conv_gather_gemm")
