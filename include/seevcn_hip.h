@@ -149,6 +149,33 @@ int sv_sparse_to_dense(const float* features, const int32_t* coords, int64_t n, 
 int sv_dense_to_sparse(const float* dense, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W,
                        float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * PointNet++ stacked-batch primitives (detector3d/pcdet/ops/pointnet2/pointnet2_stack/src/*.cu; pybind names in
+ * src/pointnet2_api.cpp:12-31).  Scenes are described by device int32 arrays of first row and row count.
+ * ---------------------------------------------------------------------------------------------- */
+/* farthest_point_sampling_wrapper(b, n, m, points, temp, idx) (src/sampling.cpp:24-36; kernel sampling_gpu.cu:24-140):
+ * xyz (b,n,3) -> idx (b,m) int32, first index 0, index-exact including the reference's tie rule.
+ * temp (b*n floats) is only used when n > 24576 (larger scenes stream from HBM); may be NULL otherwise. */
+int sv_farthest_point_sampling(const float* xyz, int b, int n, int m, float* temp, int32_t* idx, void* stream);
+/* the same over ragged scenes in one launch (replaces the per-scene Python loop of
+ * VoxelSetAbstraction.get_sampled_points, backbones_3d/pfe/voxel_set_abstraction.py:250-256): idx (batch,m) holds
+ * GLOBAL row indices (scene start + local index). max_n = largest scene. */
+int sv_stack_farthest_point_sampling(const float* xyz, const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int batch,
+                                     int max_n, int m, float* temp, int32_t* idx, void* stream);
+/* ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx) (src/ball_query.cpp:31-47,
+ * kernel ball_query_gpu.cu:16-66): idx (M,nsample) scene-local indices of the first nsample points with d^2 < r^2 in index
+ * order, padded with the first hit; idx[m][0] = -1 for an empty ball. */
+int sv_ball_query_stack(int batch, int M, int max_queries_per_scene, float radius, int nsample, const float* new_xyz,
+                        const int32_t* new_xyz_batch_start, const int32_t* new_xyz_batch_cnt, const float* xyz,
+                        const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int32_t* idx, void* stream);
+/* group_points_wrapper / group_points_grad_wrapper (src/group_points.cpp:31-69, kernels group_points_gpu.cu:15-102):
+ * out (M,C,nsample)[m][c][s] = features[row_start[m] + idx[m][s]][c]; row_start[m] = first feature row of query m's scene.
+ * The gradient zero-fills grad_features (N,C) and scatter-adds with fp32 atomics like the reference. */
+int sv_group_points_stack(int M, int C, int nsample, const float* features, const int32_t* idx, const int32_t* row_start,
+                          float* out, void* stream);
+int sv_group_points_grad_stack(int M, int C, int N, int nsample, const float* grad_out, const int32_t* idx,
+                               const int32_t* row_start, float* grad_features, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,82 @@
+"""Oracle: PointNet++ stacked-batch primitives (numpy).  Test infrastructure only.
+
+PARITY UNPINNED by reference tests (there are none) and the CUDA kernels cannot run here; the functions
+below restate the kernels line by line, including the thread/tree structure that fixes FPS tie-breaking.
+fp32 arithmetic is written without fused multiply-add (the reference's nvcc build may contract a*a+b*b into FMAs;
+that only matters for points within one ulp of a radius or of a tie)."""
+import numpy as np
+
+F = np.float32
+
+
+def farthest_point_sampling(xyz, m):
+    """farthest_point_sampling_kernel, ops/pointnet2/pointnet2_stack/src/sampling_gpu.cu:24-140 (one scene: xyz (n,3))."""
+    xyz = np.asarray(xyz, F)
+    n = len(xyz)
+    t = max(min(1 << int(np.log(n) / np.log(2.0)), 1024), 1)       # opt_n_threads, :9-13
+    temp = np.full(n, 1e10, F)                                     # pointnet2_utils.py:178
+    idxs = np.zeros(m, np.int32)
+    old = 0                                                         # :44-46
+    rows = -(-n // t)
+    pad = rows * t - n
+    for j in range(1, m):
+        d = xyz - xyz[old]
+        dist = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(F) + (d[:, 2] * d[:, 2]).astype(F)   # :62
+        d2 = np.minimum(dist, temp)                                 # :63 (min returns the non-NaN operand)
+        temp = d2
+        # per-thread strided scan with strict '>' (:55-67): first maximum of each residue class k mod t
+        grid = np.concatenate([d2, np.full(pad, -np.inf, F)]).reshape(rows, t)
+        arg = np.argmax(grid, axis=0)
+        vals = grid[arg, np.arange(t)].copy()
+        inds = (arg * t + np.arange(t)).astype(np.int64)
+        best_init = vals > -1                                        # best = -1, besti = 0 (:51-52)
+        vals = np.where(best_init, vals, F(-1))
+        inds = np.where(best_init, inds, 0)
+        half = t // 2
+        while half >= 1:                                             # tree with "keep idx1 unless strictly greater" (:16-21)
+            v1, v2 = vals[:half], vals[half:2 * half]
+            take = v2 > v1
+            vals[:half] = np.maximum(v1, v2)
+            inds[:half] = np.where(take, inds[half:2 * half], inds[:half])
+            half //= 2
+        old = int(inds[0])
+        idxs[j] = old
+    return idxs
+
+
+def ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+    """ball_query_kernel_stack, src/ball_query_gpu.cu:16-66 -> idx (M, nsample) int32 (raw kernel output: -1 marks an empty ball)."""
+    xyz, new_xyz = np.asarray(xyz, F), np.asarray(new_xyz, F)
+    r2 = F(radius) * F(radius)
+    idx = np.zeros((len(new_xyz), nsample), np.int32)
+    ps = np.concatenate([[0], np.cumsum(xyz_batch_cnt)])
+    qs = np.concatenate([[0], np.cumsum(new_xyz_batch_cnt)])
+    for b in range(len(xyz_batch_cnt)):
+        pts = xyz[ps[b]:ps[b + 1]]
+        for q in range(qs[b], qs[b + 1]):
+            d = new_xyz[q] - pts
+            d2 = ((d[:, 0] * d[:, 0]).astype(F) + (d[:, 1] * d[:, 1]).astype(F)).astype(F) + (d[:, 2] * d[:, 2]).astype(F)
+            hits = np.nonzero(d2 < r2)[0][:nsample]
+            if len(hits) == 0:
+                idx[q, 0] = -1                                       # :65
+            else:
+                idx[q, :] = hits[0]                                  # :55-59
+                idx[q, :len(hits)] = hits
+    return idx
+
+
+def group_points(features, features_batch_cnt, idx, idx_batch_cnt):
+    """group_points_kernel_stack, src/group_points_gpu.cu:71-102 -> (M, C, nsample)."""
+    fs = np.concatenate([[0], np.cumsum(features_batch_cnt)])[:-1]
+    row_start = np.repeat(fs, idx_batch_cnt)
+    return np.transpose(np.asarray(features)[row_start[:, None] + idx], (0, 2, 1)).copy()
+
+
+def group_points_grad(grad_out, idx, idx_batch_cnt, features_batch_cnt, n):
+    """group_points_grad_kernel_stack, :15-45 (scatter-add)."""
+    fs = np.concatenate([[0], np.cumsum(features_batch_cnt)])[:-1]
+    row_start = np.repeat(fs, idx_batch_cnt)
+    g = np.zeros((n, grad_out.shape[1]), np.float64)
+    rows = (row_start[:, None] + idx)                                # (M, ns)
+    np.add.at(g, rows.reshape(-1), np.transpose(grad_out, (0, 2, 1)).reshape(-1, grad_out.shape[1]))
+    return g

@@ -46,6 +46,11 @@ SIGNATURES = {
     "sv_sparse_to_dense_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "sv_sparse_to_dense": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_dense_to_sparse": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "sv_farthest_point_sampling": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "sv_stack_farthest_point_sampling": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "sv_ball_query_stack": (c_i, [c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sv_group_points_stack": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sv_group_points_grad_stack": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
 }
 
 _lib = None

@@ -1,0 +1,330 @@
+// PointNet++ stacked-batch primitives used by PV-RCNN's VoxelSetAbstraction / RoI-grid pooling:
+// farthest point sampling, ball query, grouping (+ its gradient).
+//
+// Reference kernels (one thread per query / per element, legacy stream, exit(-1) on error):
+//   detector3d/pcdet/ops/pointnet2/pointnet2_stack/src/sampling_gpu.cu:24-140      (FPS)
+//   detector3d/pcdet/ops/pointnet2/pointnet2_stack/src/ball_query_gpu.cu:16-66    (ball query)
+//   detector3d/pcdet/ops/pointnet2/pointnet2_stack/src/group_points_gpu.cu:15-102 (group / grad)
+// Re-designed for 64-wide wavefronts: FPS keeps a scene's points and running distances in registers (no HBM
+// traffic inside the M sequential rounds) and needs one barrier per round; ball query is wave-cooperative — a
+// wave scans the candidate points 64 at a time with coalesced loads from an LDS tile shared by the workgroup's
+// queries and appends hits in index order with ballot + prefix popcount.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// Farthest point sampling.  Selection rule reproduced exactly (index-exact, including ties):
+//   round j picks argmax_k temp[k] where temp[k] = min over picked p of |x_k - x_p|^2 (temp starts at 1e10),
+//   first index is 0.  Ties: the reference reduces per-thread strided maxima (strict '>' keeps the smallest k of a
+//   stride class) through a power-of-two tree that keeps the LOWER slot on ties (sampling_gpu.cu:16-21,55-134),
+//   i.e. among equal maxima the winner minimises (bitreverse(k mod T), k div T), T = 2^floor(log2 n) <= 1024.
+// ------------------------------------------------------------------------------------------------
+constexpr int FPS_THREADS = 1024;
+constexpr int FPS_MAXP = 24;   // points per thread held in registers -> n <= 24576 on the register path
+
+__device__ __forceinline__ unsigned long long fps_key(float d, int k, int log2t) {
+  // larger key wins: distance first (non-negative floats order as their bit patterns), then the tie rule
+  const unsigned int lo = (unsigned int)k & ((1u << log2t) - 1u);
+  const unsigned int rev = log2t ? (__brev(lo) >> (32 - log2t)) : 0u;
+  const unsigned int tie = (rev << (31 - log2t)) | ((unsigned int)k >> log2t);   // smaller tie = preferred
+  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(0x7FFFFFFFu - tie);
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = __shfl_xor(v, d, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// one workgroup per scene; xyz (n,3) of the scene, idx (m) output (scene-local indices, + start when add_offset)
+template <int P>
+__global__ __launch_bounds__(FPS_THREADS) void k_fps_reg(const float* __restrict__ xyz_all, const int32_t* __restrict__ starts,
+                                                         const int32_t* __restrict__ counts, int fixed_n, int m,
+                                                         int32_t* __restrict__ idx_all, int add_offset) {
+  constexpr int NW = FPS_THREADS / 64;
+  __shared__ unsigned long long skey[2][NW];
+  __shared__ float sxyz[2][NW][3];
+  const int b = blockIdx.x;
+  const int start = starts ? starts[b] : b * fixed_n;
+  const int n = counts ? counts[b] : fixed_n;
+  const float* xyz = xyz_all + (int64_t)start * 3;
+  int32_t* idx = idx_all + (int64_t)b * m;
+  if (n <= 0 || m <= 0) return;
+  int log2t = 0;
+  while ((2 << log2t) <= n && log2t < 10) ++log2t;             // T = 2^floor(log2 n), capped at 1024
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float px[P], py[P], pz[P], pt[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int k = tid + i * FPS_THREADS;
+    const bool ok = k < n;
+    px[i] = ok ? xyz[k * 3] : 0.f;
+    py[i] = ok ? xyz[k * 3 + 1] : 0.f;
+    pz[i] = ok ? xyz[k * 3 + 2] : 0.f;
+    pt[i] = 1e10f;
+  }
+  if (tid == 0) idx[0] = add_offset ? start : 0;
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];                  // first pick is index 0 (sampling_gpu.cu:44-46)
+  for (int j = 1; j < m; ++j) {
+    const int par = j & 1;
+    unsigned long long best = 0ull;
+    float bx = 0.f, by = 0.f, bz = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const int k = tid + i * FPS_THREADS;
+      // same expression order as the reference (sampling_gpu.cu:62); fp contraction is off for this library
+      const float d = (px[i] - x1) * (px[i] - x1) + (py[i] - y1) * (py[i] - y1) + (pz[i] - z1) * (pz[i] - z1);
+      const float d2 = fminf(d, pt[i]);
+      pt[i] = d2;
+      const unsigned long long key = k < n ? fps_key(d2, k, log2t) : 0ull;
+      const bool up = key > best;
+      best = up ? key : best;
+      bx = up ? px[i] : bx; by = up ? py[i] : by; bz = up ? pz[i] : bz;
+    }
+    const unsigned long long wbest = wave_max_u64(best);
+    // the lane that holds the wave's winner publishes key + coordinates (keys are unique per point)
+    if (best == wbest && best != 0ull) {
+      skey[par][wid] = wbest;
+      sxyz[par][wid][0] = bx; sxyz[par][wid][1] = by; sxyz[par][wid][2] = bz;
+    }
+    __syncthreads();                                            // the only barrier of the round (slots alternate by parity)
+    const int sl = lane & (NW - 1);
+    const unsigned long long mine = skey[par][sl];
+    const unsigned long long w = wave_max_u64(mine);            // every wave reduces the 16 partials redundantly
+    const int src = __ffsll((long long)__ballot(mine == w)) - 1;
+    x1 = __shfl(sxyz[par][sl][0], src, 64);
+    y1 = __shfl(sxyz[par][sl][1], src, 64);
+    z1 = __shfl(sxyz[par][sl][2], src, 64);
+    if (tid == 0) {
+      const unsigned int tie = 0x7FFFFFFFu - (unsigned int)(w & 0xFFFFFFFFull);
+      const unsigned int rev = log2t ? (tie >> (31 - log2t)) : 0u;
+      const unsigned int lo = log2t ? (__brev(rev) >> (32 - log2t)) : 0u;
+      const int old = (int)(((tie & ((1u << (31 - log2t)) - 1u)) << log2t) | lo);
+      idx[j] = add_offset ? start + old : old;
+    }
+  }
+}
+
+// streaming variant for scenes too large for the register file: temp lives in HBM (n floats, caller-provided)
+__global__ __launch_bounds__(FPS_THREADS) void k_fps_stream(const float* __restrict__ xyz_all, const int32_t* __restrict__ starts,
+                                                            const int32_t* __restrict__ counts, int fixed_n, int m,
+                                                            float* __restrict__ temp_all, int32_t* __restrict__ idx_all, int add_offset) {
+  __shared__ unsigned long long slot[2][FPS_THREADS / 64];
+  const int b = blockIdx.x;
+  const int start = starts ? starts[b] : b * fixed_n;
+  const int n = counts ? counts[b] : fixed_n;
+  const float* xyz = xyz_all + (int64_t)start * 3;
+  float* temp = temp_all + start;
+  int32_t* idx = idx_all + (int64_t)b * m;
+  if (n <= 0 || m <= 0) return;
+  int log2t = 0;
+  while ((2 << log2t) <= n && log2t < 10) ++log2t;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int k = tid; k < n; k += FPS_THREADS) temp[k] = 1e10f;
+  if (tid == 0) idx[0] = add_offset ? start : 0;
+  int old = 0;
+  __syncthreads();
+  for (int j = 1; j < m; ++j) {
+    const int par = j & 1;
+    const float x1 = xyz[old * 3], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
+    unsigned long long best = 0ull;
+    for (int k = tid; k < n; k += FPS_THREADS) {
+      const float x2 = xyz[k * 3], y2 = xyz[k * 3 + 1], z2 = xyz[k * 3 + 2];
+      const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+      const float d2 = fminf(d, temp[k]);
+      temp[k] = d2;
+      const unsigned long long key = fps_key(d2, k, log2t);
+      best = key > best ? key : best;
+    }
+    best = wave_max_u64(best);
+    if (lane == 0) slot[par][wid] = best;
+    __syncthreads();
+    unsigned long long w = slot[par][lane & (FPS_THREADS / 64 - 1)];
+    w = wave_max_u64(w);
+    const unsigned int tie = 0x7FFFFFFFu - (unsigned int)(w & 0xFFFFFFFFull);
+    const unsigned int rev = log2t ? (tie >> (31 - log2t)) : 0u;
+    const unsigned int lo = log2t ? (__brev(rev) >> (32 - log2t)) : 0u;
+    old = (int)(((tie & ((1u << (31 - log2t)) - 1u)) << log2t) | lo);
+    if (tid == 0) idx[j] = add_offset ? start + old : old;
+  }
+}
+
+static int fps_launch(const float* xyz, const int32_t* starts, const int32_t* counts, int batch, int fixed_n, int max_n, int m,
+                      float* temp, int32_t* idx, int add_offset, hipStream_t st) {
+  if (batch <= 0 || m <= 0) return SV_OK;
+  const int p = (max_n + FPS_THREADS - 1) / FPS_THREADS;
+  dim3 grid(batch), block(FPS_THREADS);
+  if (p <= 4) hipLaunchKernelGGL(k_fps_reg<4>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
+  else if (p <= 8) hipLaunchKernelGGL(k_fps_reg<8>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
+  else if (p <= 16) hipLaunchKernelGGL(k_fps_reg<16>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
+  else if (p <= FPS_MAXP) hipLaunchKernelGGL(k_fps_reg<FPS_MAXP>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
+  else {
+    SV_CHECK_ARG(temp, "farthest_point_sampling: scenes with more than %d points need the temp buffer", FPS_MAXP * FPS_THREADS);
+    hipLaunchKernelGGL(k_fps_stream, grid, block, 0, st, xyz, starts, counts, fixed_n, m, temp, idx, add_offset);
+  }
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_farthest_point_sampling(const float* xyz, int b, int n, int m, float* temp, int32_t* idx, void* stream) {
+  SV_CHECK_ARG(b >= 0 && n > 0 && m >= 0 && (b == 0 || (xyz && idx)), "farthest_point_sampling: bad arguments");
+  SV_CHECK_ARG((int64_t)n < (1ll << 30), "farthest_point_sampling: n too large");
+  return fps_launch(xyz, nullptr, nullptr, b, n, n, m, temp, idx, 0, sv_stream(stream));
+}
+
+extern "C" int sv_stack_farthest_point_sampling(const float* xyz, const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int batch,
+                                                int max_n, int m, float* temp, int32_t* idx, void* stream) {
+  SV_CHECK_ARG(batch >= 0 && m >= 0 && max_n >= 0, "stack_farthest_point_sampling: bad arguments");
+  if (batch == 0 || m == 0) return SV_OK;
+  SV_CHECK_ARG(xyz && xyz_batch_start && xyz_batch_cnt && idx, "stack_farthest_point_sampling: null pointer");
+  return fps_launch(xyz, xyz_batch_start, xyz_batch_cnt, batch, 0, max_n, m, temp, idx, 1, sv_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ball query (stacked batches).  idx (M, nsample): the first nsample points of the query's scene, in index order,
+// with |q - p|^2 < r^2; short lists are padded with the first hit; idx[0] = -1 for an empty ball
+// (ball_query_gpu.cu:47-65).  One wave per query at a time; a workgroup (4 waves) walks BQ_QPB queries over the
+// same scene so that the candidate tile staged in LDS is shared.
+// ------------------------------------------------------------------------------------------------
+constexpr int BQ_TILE = 1024;      // candidate points per LDS tile (12 KB)
+constexpr int BQ_QPW = 8;          // queries per wave
+constexpr int BQ_QPB = BQ_QPW * 4; // queries per workgroup
+
+__global__ __launch_bounds__(256) void k_ball_query(int M, float radius2, int nsample, const float* __restrict__ new_xyz,
+                                                    const int32_t* __restrict__ q_start, const int32_t* __restrict__ q_cnt,
+                                                    const float* __restrict__ xyz, const int32_t* __restrict__ p_start,
+                                                    const int32_t* __restrict__ p_cnt, int batch, int32_t* __restrict__ idx) {
+  __shared__ float tile[BQ_TILE * 3];
+  __shared__ int done_cnt;
+  // blockIdx.y = scene, blockIdx.x = query block inside the scene
+  const int b = blockIdx.y;
+  const int nq = q_cnt[b], qs = q_start[b];
+  const int q0 = blockIdx.x * BQ_QPB;
+  if (q0 >= nq) return;
+  const int np = p_cnt[b], ps = p_start[b];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float qx[BQ_QPW], qy[BQ_QPW], qz[BQ_QPW];
+  int cnt[BQ_QPW];
+  bool live[BQ_QPW];
+#pragma unroll
+  for (int u = 0; u < BQ_QPW; ++u) {
+    const int q = q0 + wid * BQ_QPW + u;
+    live[u] = q < nq;
+    const float* p = new_xyz + (int64_t)(qs + (live[u] ? q : 0)) * 3;
+    qx[u] = p[0]; qy[u] = p[1]; qz[u] = p[2];
+    cnt[u] = 0;
+  }
+  for (int t0 = 0; t0 < np; t0 += BQ_TILE) {
+    const int tn = min(BQ_TILE, np - t0);
+    if (tid == 0) done_cnt = 0;
+    __syncthreads();
+    for (int e = tid; e < tn * 3; e += 256) tile[e] = xyz[(int64_t)(ps + t0) * 3 + e];
+    __syncthreads();
+    int wave_done = 1;
+#pragma unroll
+    for (int u = 0; u < BQ_QPW; ++u) {
+      if (!live[u] || cnt[u] >= nsample) continue;
+      int32_t* out = idx + (int64_t)(qs + q0 + wid * BQ_QPW + u) * nsample;
+      for (int c0 = 0; c0 < tn && cnt[u] < nsample; c0 += 64) {
+        const int k = c0 + lane;
+        bool hit = false;
+        if (k < tn) {
+          const float x = tile[k * 3], y = tile[k * 3 + 1], z = tile[k * 3 + 2];
+          const float d2 = (qx[u] - x) * (qx[u] - x) + (qy[u] - y) * (qy[u] - y) + (qz[u] - z) * (qz[u] - z);
+          hit = d2 < radius2;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+          const int pos = cnt[u] + __popcll(m & ((1ull << lane) - 1ull));
+          if (cnt[u] == 0) {  // first hit of this query: pre-fill the whole row with it (the reference's padding rule)
+            const int first = t0 + c0 + (__ffsll((long long)m) - 1);
+            for (int l = lane; l < nsample; l += 64) out[l] = first;
+          }
+          if (hit && pos < nsample) out[pos] = t0 + k;
+          cnt[u] += __popcll(m);
+        }
+      }
+      if (cnt[u] < nsample) wave_done = 0;
+    }
+    if (lane == 0 && wave_done) atomicAdd(&done_cnt, 1);
+    __syncthreads();
+    if (done_cnt == 4) break;   // every query of the workgroup is full: stop streaming candidates
+  }
+#pragma unroll
+  for (int u = 0; u < BQ_QPW; ++u)
+    if (live[u] && cnt[u] == 0 && lane == 0) idx[(int64_t)(qs + q0 + wid * BQ_QPW + u) * nsample] = -1;
+}
+
+extern "C" int sv_ball_query_stack(int batch, int M, int max_queries_per_scene, float radius, int nsample, const float* new_xyz,
+                                   const int32_t* new_xyz_batch_start, const int32_t* new_xyz_batch_cnt, const float* xyz,
+                                   const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int32_t* idx, void* stream) {
+  SV_CHECK_ARG(batch >= 0 && M >= 0 && nsample > 0 && radius >= 0.f, "ball_query: bad arguments");
+  if (batch == 0 || M == 0 || max_queries_per_scene == 0) return SV_OK;
+  SV_CHECK_ARG(new_xyz && new_xyz_batch_start && new_xyz_batch_cnt && xyz && xyz_batch_start && xyz_batch_cnt && idx, "ball_query: null pointer");
+  dim3 grid(sv_div_up(max_queries_per_scene, BQ_QPB), batch);
+  hipLaunchKernelGGL(k_ball_query, grid, dim3(256), 0, sv_stream(stream), M, radius * radius, nsample, new_xyz, new_xyz_batch_start,
+                     new_xyz_batch_cnt, xyz, xyz_batch_start, xyz_batch_cnt, batch, idx);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouping: out (M, C, nsample)[m][c][s] = features[start(scene of m) + idx[m][s]][c]   (group_points_gpu.cu:71-102)
+// row_start[m] = first feature row of the scene that query m belongs to (precomputed once per batch on the host side).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_group_points(int64_t total, int C, int nsample, const float* __restrict__ features,
+                                                      const int32_t* __restrict__ idx, const int32_t* __restrict__ row_start,
+                                                      float* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(e % nsample);
+    const int64_t t = e / nsample;
+    const int c = (int)(t % C);
+    const int64_t m = t / C;
+    const int32_t j = idx[m * nsample + s];
+    out[e] = features[((int64_t)row_start[m] + j) * C + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_group_points_grad(int64_t total, int C, int nsample, const float* __restrict__ grad_out,
+                                                           const int32_t* __restrict__ idx, const int32_t* __restrict__ row_start,
+                                                           float* __restrict__ grad_features) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(e % nsample);
+    const int64_t t = e / nsample;
+    const int c = (int)(t % C);
+    const int64_t m = t / C;
+    const int32_t j = idx[m * nsample + s];
+    atomicAdd(&grad_features[((int64_t)row_start[m] + j) * C + c], grad_out[e]);   // group_points_gpu.cu:44
+  }
+}
+
+extern "C" int sv_group_points_stack(int M, int C, int nsample, const float* features, const int32_t* idx, const int32_t* row_start,
+                                     float* out, void* stream) {
+  SV_CHECK_ARG(M >= 0 && C > 0 && nsample > 0, "group_points: bad arguments");
+  if (M == 0) return SV_OK;
+  SV_CHECK_ARG(features && idx && row_start && out, "group_points: null pointer");
+  const int64_t total = (int64_t)M * C * nsample;
+  hipLaunchKernelGGL(k_group_points, dim3(sv_grid_1d(total, 256, 256 * 16)), dim3(256), 0, sv_stream(stream), total, C, nsample, features, idx,
+                     row_start, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_group_points_grad_stack(int M, int C, int N, int nsample, const float* grad_out, const int32_t* idx,
+                                          const int32_t* row_start, float* grad_features, void* stream) {
+  SV_CHECK_ARG(M >= 0 && C > 0 && nsample > 0 && N >= 0, "group_points_grad: bad arguments");
+  hipStream_t st = sv_stream(stream);
+  if (N > 0) {
+    SV_CHECK_ARG(grad_features, "group_points_grad: null pointer");
+    SV_HIP(hipMemsetAsync(grad_features, 0, (size_t)N * C * 4, st));
+  }
+  if (M == 0) return SV_OK;
+  SV_CHECK_ARG(grad_out && idx && row_start, "group_points_grad: null pointer");
+  const int64_t total = (int64_t)M * C * nsample;
+  hipLaunchKernelGGL(k_group_points_grad, dim3(sv_grid_1d(total, 256, 256 * 16)), dim3(256), 0, st, total, C, nsample, grad_out, idx, row_start,
+                     grad_features);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

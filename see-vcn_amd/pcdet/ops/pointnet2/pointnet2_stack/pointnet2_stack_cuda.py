@@ -1,0 +1,73 @@
+"""Same entry-point names and argument order as the reference's compiled extension `pointnet2_stack_cuda`
+(detector3d/pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp:12-31), bound to libseevcn_hip.so.
+Outputs are caller-allocated torch tensors, every function returns 1 like the reference wrappers."""
+import torch
+
+from ..... import _lib
+
+
+def _starts(cnt):
+    cnt = cnt.to(torch.int32)
+    return (torch.cumsum(cnt, 0, dtype=torch.int32) - cnt).contiguous(), cnt.contiguous()
+
+
+def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
+    lib = _lib.load()
+    _lib.require_cuda(new_xyz, xyz, idx)
+    qs, qc = _starts(new_xyz_batch_cnt)
+    ps, pc = _starts(xyz_batch_cnt)
+    max_q = int(M)  # upper bound of queries per scene without a host sync
+    rc = lib.sv_ball_query_stack(int(B), int(M), max_q, float(radius), int(nsample), _lib.ptr(new_xyz), _lib.ptr(qs), _lib.ptr(qc),
+                                 _lib.ptr(xyz), _lib.ptr(ps), _lib.ptr(pc), _lib.ptr(idx), _lib.stream())
+    _lib.check(rc, "sv_ball_query_stack")
+    return 1
+
+
+def _row_start(idx_batch_cnt, features_batch_cnt, M):
+    """first feature row of the scene each query belongs to (M,) int32"""
+    fs, _ = _starts(features_batch_cnt)
+    return torch.repeat_interleave(fs, idx_batch_cnt.long(), output_size=int(M)).contiguous()
+
+
+def group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, out):
+    lib = _lib.load()
+    _lib.require_cuda(features, idx, out)
+    rs = _row_start(idx_batch_cnt, features_batch_cnt, M)
+    rc = lib.sv_group_points_stack(int(M), int(C), int(nsample), _lib.ptr(features), _lib.ptr(idx), _lib.ptr(rs), _lib.ptr(out), _lib.stream())
+    _lib.check(rc, "sv_group_points_stack")
+    return 1
+
+
+def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features):
+    lib = _lib.load()
+    _lib.require_cuda(grad_out, idx, grad_features)
+    rs = _row_start(idx_batch_cnt, features_batch_cnt, M)
+    rc = lib.sv_group_points_grad_stack(int(M), int(C), int(N), int(nsample), _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(rs),
+                                        _lib.ptr(grad_features), _lib.stream())
+    _lib.check(rc, "sv_group_points_grad_stack")
+    return 1
+
+
+def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    lib = _lib.load()
+    _lib.require_cuda(points, idx)
+    rc = lib.sv_farthest_point_sampling(_lib.ptr(points), int(b), int(n), int(m), _lib.ptr(temp), _lib.ptr(idx), _lib.stream())
+    _lib.check(rc, "sv_farthest_point_sampling")
+    return 1
+
+
+def stack_farthest_point_sampling(points, xyz_batch_cnt, npoint, max_n=None):
+    """All ragged scenes in one launch -> (batch, npoint) int32 GLOBAL row indices (seevcn extension; replaces the
+    per-scene loop of voxel_set_abstraction.py:250-256)."""
+    lib = _lib.load()
+    _lib.require_cuda(points)
+    starts, cnt = _starts(xyz_batch_cnt)
+    batch = cnt.shape[0]
+    if max_n is None:
+        max_n = int(cnt.max().item())
+    idx = torch.empty((batch, npoint), dtype=torch.int32, device=points.device)
+    temp = torch.empty((points.shape[0],), dtype=torch.float32, device=points.device) if max_n > 24576 else None
+    rc = lib.sv_stack_farthest_point_sampling(_lib.ptr(points), _lib.ptr(starts), _lib.ptr(cnt), batch, int(max_n), int(npoint),
+                                              _lib.ptr(temp), _lib.ptr(idx), _lib.stream())
+    _lib.check(rc, "sv_stack_farthest_point_sampling")
+    return idx

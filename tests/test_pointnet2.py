@@ -1,0 +1,122 @@
+"""FPS / ball query / grouping: oracle self-checks (CPU) and HIP vs oracle, index-exact (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointnet2 as op2
+
+
+def _bitrev_rule_winner(d2, t):
+    """closed form of the reference's tie rule: argmax value, ties -> min (bitreverse(k mod T), k div T)."""
+    log2t = int(np.log2(t))
+    k = np.arange(len(d2))
+    lo = k & (t - 1)
+    rev = np.array([int(format(int(x), f"0{log2t}b")[::-1], 2) if log2t else 0 for x in lo])
+    order = np.lexsort((k >> log2t, rev, -d2.astype(np.float64)))
+    return int(order[0])
+
+
+def test_oracle_fps_basic_and_tie_rule():
+    rng = np.random.default_rng(0)
+    xyz = rng.normal(size=(300, 3)).astype(np.float32)
+    idx = op2.farthest_point_sampling(xyz, 64)
+    assert idx[0] == 0 and len(set(idx.tolist())) == 64
+    # greedy property: every pick maximises the distance to the already picked set
+    for j in range(1, 10):
+        d = ((xyz[:, None] - xyz[idx[:j]][None]) ** 2).sum(-1).min(1)
+        assert np.isclose(d[idx[j]], d.max())
+    # duplicates force exact ties: the literal thread/tree emulation must agree with the closed-form rule
+    dup = np.tile(rng.normal(size=(37, 3)).astype(np.float32), (9, 1))[:300]
+    got = op2.farthest_point_sampling(dup, 50)
+    temp = np.full(300, 1e10, np.float32)
+    old = 0
+    for j in range(1, 50):
+        d = dup - dup[old]
+        dist = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + (d[:, 2] * d[:, 2]).astype(np.float32)
+        temp = np.minimum(dist, temp)
+        old = _bitrev_rule_winner(temp, 256)
+        assert got[j] == old, j
+
+
+def test_oracle_ball_query_and_group():
+    rng = np.random.default_rng(1)
+    xyz = rng.uniform(-2, 2, size=(200, 3)).astype(np.float32)
+    new = xyz[:20] + 0.01
+    idx = op2.ball_query(0.8, 8, xyz, [120, 80], new, [12, 8])
+    assert idx.shape == (20, 8)
+    for q in range(20):
+        lo, hi = (0, 120) if q < 12 else (120, 200)
+        d = ((new[q] - xyz[lo:hi]) ** 2).sum(1)
+        hits = np.nonzero(d < 0.64)[0]
+        assert idx[q, 0] == (hits[0] if len(hits) else -1)
+    idx[idx[:, 0] == -1] = 0
+    g = op2.group_points(xyz, [120, 80], idx, [12, 8])
+    assert g.shape == (20, 3, 8)
+    assert np.array_equal(g[15, :, 2], xyz[120 + idx[15, 2]])
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m", [(300, 64), (1024, 128), (5000, 256), (20000, 2048), (1, 1), (7, 7), (30000, 64)])
+def test_hip_fps_index_exact(cuda, hip_lib, n, m):
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as pu
+    rng = np.random.default_rng(n)
+    xyz = rng.normal(size=(2, n, 3)).astype(np.float32) * 10
+    xyz[1, n // 2:] = xyz[1, : n - n // 2]            # exact duplicates -> ties
+    out = pu.farthest_point_sample(torch.from_numpy(xyz).to(cuda), m).cpu().numpy()
+    for b in range(2):
+        ref = op2.farthest_point_sampling(xyz[b], m)
+        assert np.array_equal(out[b], ref), (b, np.nonzero(out[b] != ref)[0][:5])
+
+
+@pytest.mark.gpu
+def test_hip_stack_fps_matches_per_scene(cuda, hip_lib):
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as pu
+    rng = np.random.default_rng(5)
+    counts = [4000, 17000, 900]
+    xyz = rng.normal(size=(sum(counts), 3)).astype(np.float32) * 20
+    idx = pu.stack_farthest_point_sample(torch.from_numpy(xyz).to(cuda), torch.tensor(counts, dtype=torch.int32, device=cuda), 512).cpu().numpy()
+    s = 0
+    for b, c in enumerate(counts):
+        assert np.array_equal(idx[b], op2.farthest_point_sampling(xyz[s:s + c], 512) + s)
+        s += c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("radius,nsample", [(0.4, 16), (0.8, 16), (2.4, 32), (0.05, 4)])
+def test_hip_ball_query_group_vs_oracle(cuda, hip_lib, radius, nsample):
+    import seevcn_amd.synth as synth
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as pu
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as raw
+    pts, _ = synth.make_scene_batch(3, seed=2000, n_az=40)
+    counts = np.bincount(pts[:, 0].astype(int), minlength=3)
+    xyz = np.ascontiguousarray(pts[:, 1:4])
+    rng = np.random.default_rng(2)
+    qcnt = [300, 257, 64]
+    new = np.concatenate([xyz[np.cumsum(counts)[b] - counts[b]:np.cumsum(counts)[b]][rng.integers(0, counts[b], q)] + rng.normal(0, 0.05, (q, 3))
+                          for b, q in enumerate(qcnt)]).astype(np.float32)
+    new[5] = [500, 500, 500]                           # an empty ball
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(cuda) if dt is None else torch.tensor(a, dtype=dt, device=cuda)
+    idx_raw = torch.zeros((len(new), nsample), dtype=torch.int32, device=cuda)
+    raw.ball_query_wrapper(3, len(new), radius, nsample, t(new), t(qcnt, torch.int32), t(xyz), t(counts.tolist(), torch.int32), idx_raw)
+    ref = op2.ball_query(radius, nsample, xyz, counts, new, qcnt)
+    assert np.array_equal(idx_raw.cpu().numpy(), ref)
+    # through the reference-shaped autograd API, with gradients
+    feats = rng.normal(size=(len(xyz), 16)).astype(np.float32)
+    f = t(feats).requires_grad_(True)
+    qg = pu.QueryAndGroup(radius, nsample, use_xyz=True)
+    new_feats, idx = qg(t(xyz), t(counts.tolist(), torch.int32), t(new), t(qcnt, torch.int32), f)
+    ref0 = ref.copy()
+    empty = ref0[:, 0] == -1
+    ref0[empty] = 0
+    assert np.array_equal(idx.cpu().numpy(), ref0) and empty[5]
+    gx = op2.group_points(xyz, counts, ref0, qcnt) - new[:, :, None]
+    gf = op2.group_points(feats, counts, ref0, qcnt)
+    gx[empty] = 0
+    gf[empty] = 0
+    np.testing.assert_array_equal(new_feats.detach().cpu().numpy(), np.concatenate([gx, gf], 1))
+    go = rng.normal(size=new_feats.shape).astype(np.float32)
+    new_feats.backward(t(go))
+    go_f = go[:, 3:].copy()
+    go_f[empty] = 0
+    np.testing.assert_allclose(f.grad.cpu().numpy(), op2.group_points_grad(go_f, ref0, qcnt, counts, len(xyz)), rtol=1e-4, atol=1e-4)
