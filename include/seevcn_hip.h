@@ -176,6 +176,20 @@ int sv_group_points_stack(int M, int C, int nsample, const float* features, cons
 int sv_group_points_grad_stack(int M, int C, int N, int nsample, const float* grad_out, const int32_t* idx,
                                const int32_t* row_start, float* grad_features, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Rotated-box geometry (detector3d/pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:12-17,
+ * detector3d/pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:172-177). Boxes are (N,7) fp32 [x,y,z,dx,dy,dz,heading].
+ * ---------------------------------------------------------------------------------------------- */
+/* boxes_overlap_bev_gpu (iou=0) / boxes_iou_bev_gpu (iou=1): out (num_a, num_b) */
+int sv_boxes_overlap_bev(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* out, int iou, void* stream);
+/* nms_gpu (normal=0, rotated BEV IoU) / nms_normal_gpu (normal=1, axis-aligned) over boxes ALREADY sorted by score:
+ * keep (n) int64 device indices of the kept boxes in order, *num_out device int32.  Unlike the reference
+ * (iou3d_nms.cpp:111-131: D2H copy of the mask + host sweep) the greedy sweep runs on the device. n <= 65536. */
+size_t sv_nms_scratch_bytes(int n);
+int sv_nms(const float* boxes, int n, float thresh, int normal, void* scratch, int64_t* keep, int32_t* num_out, void* stream);
+/* points_in_boxes_gpu: boxes (B,T,7), pts (B,M,3) -> out (B,M) int32 index of the first box containing the point or -1 */
+int sv_points_in_boxes(const float* boxes, const float* pts, int batch, int num_boxes, int num_points, int32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

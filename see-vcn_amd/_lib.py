@@ -51,6 +51,10 @@ SIGNATURES = {
     "sv_ball_query_stack": (c_i, [c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_group_points_stack": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_group_points_grad_stack": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sv_boxes_overlap_bev": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p]),
+    "sv_nms_scratch_bytes": (c_sz, [c_i]),
+    "sv_nms": (c_i, [c_p, c_i, c_f, c_i, c_p, c_p, c_p, c_p]),
+    "sv_points_in_boxes": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
 }
 
 _lib = None

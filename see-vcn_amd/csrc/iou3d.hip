@@ -1,0 +1,274 @@
+// Rotated-box geometry: BEV overlap / IoU for all pairs, rotated and axis-aligned NMS, points-in-boxes.
+//
+// Reference: detector3d/pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu (box_overlap :95-223, iou_bev :225-231,
+// nms_kernel :267-302, nms_normal_kernel :317-355) + host sweep iou3d_nms.cpp:90-135;
+// detector3d/pcdet/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:16-36,313-337 (points_in_boxes).
+//
+// What is different here (same results):
+//   * a conservative bounding-circle test skips the polygon construction for pairs that cannot touch (after the score
+//     sort of NMS that is almost every pair);
+//   * NMS masks are produced one 64-bit word per wave-wide ballot and only for the upper triangle; the greedy sweep
+//     runs ON THE GPU (one wave, 64 boxes per step: the diagonal word decides suppression inside the block, kept rows
+//     are OR-ed into the remaining words with coalesced loads) — the reference copies the N x N/64 mask to the host
+//     and sweeps there (iou3d_nms.cpp:111-131);
+//   * per-box sin/cos are computed once per tile/box, not once per pair.
+#include <math.h>
+
+#include "common.h"
+
+struct P2 { float x, y; };
+
+__device__ __forceinline__ float crs(P2 p1, P2 p2, P2 p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+
+struct RBox {       // a box with its trigonometry evaluated once
+  float x, y, dx, dy, ang, c, s;      // c = cos(ang), s = sin(ang)
+  float nc, ns;                       // cos(-ang), sin(-ang) (separate evaluations, as the reference does)
+};
+
+__device__ __forceinline__ RBox make_rbox(const float* b) {
+  RBox r;
+  r.x = b[0]; r.y = b[1]; r.dx = b[3]; r.dy = b[4]; r.ang = b[6];
+  r.c = cosf(r.ang); r.s = sinf(r.ang);
+  r.nc = cosf(-r.ang); r.ns = sinf(-r.ang);
+  return r;
+}
+
+__device__ __forceinline__ void corners(const RBox& b, P2 (&c)[5]) {
+  const float hx = b.dx / 2, hy = b.dy / 2;
+  const float px[4] = {b.x - hx, b.x + hx, b.x + hx, b.x - hx};
+  const float py[4] = {b.y - hy, b.y - hy, b.y + hy, b.y + hy};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    c[k].x = (px[k] - b.x) * b.c + (py[k] - b.y) * (-b.s) + b.x;
+    c[k].y = (px[k] - b.x) * b.s + (py[k] - b.y) * b.c + b.y;
+  }
+  c[4] = c[0];
+}
+
+__device__ __forceinline__ bool inside(const RBox& b, P2 p) {   // with the reference's 1e-2 margin
+  const float rx = (p.x - b.x) * b.nc + (p.y - b.y) * (-b.ns);
+  const float ry = (p.x - b.x) * b.ns + (p.y - b.y) * b.nc;
+  return fabsf(rx) < b.dx / 2 + 1e-2f && fabsf(ry) < b.dy / 2 + 1e-2f;
+}
+
+__device__ __forceinline__ bool seg_x(P2 p1, P2 p0, P2 q1, P2 q0, P2& ans) {
+  const bool boxes_meet = fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+                          fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y);
+  if (!boxes_meet) return false;
+  const float s1 = crs(q0, p1, p0), s2 = crs(p1, q1, p0), s3 = crs(p0, q1, q0), s4 = crs(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+  const float s5 = crs(q1, p1, p0);
+  if (fabsf(s5 - s1) > 1e-8f) {
+    ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    const float D = a0 * b1 - a1 * b0;
+    ans.x = (b0 * c1 - b1 * c0) / D;
+    ans.y = (a1 * c0 - a0 * c1) / D;
+  }
+  return true;
+}
+
+__device__ float overlap_area(const RBox& a, const RBox& b) {
+  // pairs whose bounding circles (+ the 1e-2 corner margin, + slack) are apart have no crossing and no corner inside:
+  // the construction below would return exactly 0
+  {
+    const float ra = 0.5f * sqrtf(a.dx * a.dx + a.dy * a.dy), rb = 0.5f * sqrtf(b.dx * b.dx + b.dy * b.dy);
+    const float ddx = a.x - b.x, ddy = a.y - b.y, reach = ra + rb + 0.05f;
+    if (ddx * ddx + ddy * ddy > reach * reach) return 0.f;
+  }
+  P2 A[5], B[5];
+  corners(a, A);
+  corners(b, B);
+  P2 pts[24];
+  float ang[24];
+  int cnt = 0;
+  float sx = 0.f, sy = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      P2 x;
+      if (seg_x(A[i + 1], A[i], B[j + 1], B[j], x)) { sx += x.x; sy += x.y; pts[cnt++] = x; }
+    }
+  for (int k = 0; k < 4; ++k) {
+    if (inside(a, B[k])) { sx += B[k].x; sy += B[k].y; pts[cnt++] = B[k]; }
+    if (inside(b, A[k])) { sx += A[k].x; sy += A[k].y; pts[cnt++] = A[k]; }
+  }
+  if (cnt < 3) return 0.f;                 // fewer than 3 points span no area (the reference's sums are empty or zero)
+  sx /= cnt; sy /= cnt;
+  for (int i = 0; i < cnt; ++i) ang[i] = atan2f(pts[i].y - sy, pts[i].x - sx);
+  for (int j = 0; j < cnt - 1; ++j)        // same bubble order as the reference (stable for equal angles)
+    for (int i = 0; i < cnt - j - 1; ++i)
+      if (ang[i] > ang[i + 1]) {
+        const P2 t = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = t;
+        const float u = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = u;
+      }
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; ++k)
+    area += (pts[k].x - pts[0].x) * (pts[k + 1].y - pts[0].y) - (pts[k].y - pts[0].y) * (pts[k + 1].x - pts[0].x);
+  return fabsf(area) / 2.0f;
+}
+
+__device__ __forceinline__ float iou_bev(const RBox& a, const RBox& b) {
+  const float sa = a.dx * a.dy, sb = b.dx * b.dy, so = overlap_area(a, b);
+  return so / fmaxf(sa + sb - so, 1e-8f);
+}
+
+__device__ __forceinline__ float iou_axis_aligned(const float* a, const float* b) {
+  const float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+  const float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+  const float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f), inter = w * h;
+  return inter / fmaxf(a[3] * a[4] + b[3] * b[4] - inter, 1e-8f);
+}
+
+// ------------------------------------------------------------------ all-pairs overlap / IoU: one thread per pair
+__global__ __launch_bounds__(256) void k_boxes_pairs(int na, const float* __restrict__ A, int nb, const float* __restrict__ B,
+                                                     float* __restrict__ out, int iou) {
+  __shared__ RBox sb[64];
+  // tile: 4 rows of A x 64 columns of B per workgroup
+  const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 4;
+  if (threadIdx.x < 64 && col0 + threadIdx.x < nb) sb[threadIdx.x] = make_rbox(B + (int64_t)(col0 + threadIdx.x) * 7);
+  __syncthreads();
+  const int r = row0 + (threadIdx.x >> 6), c = col0 + (threadIdx.x & 63);
+  if (r >= na || c >= nb) return;
+  const RBox a = make_rbox(A + (int64_t)r * 7);
+  const RBox& b = sb[threadIdx.x & 63];
+  out[(int64_t)r * nb + c] = iou ? iou_bev(a, b) : overlap_area(a, b);
+}
+
+extern "C" int sv_boxes_overlap_bev(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* out, int iou, void* stream) {
+  SV_CHECK_ARG(num_a >= 0 && num_b >= 0, "boxes_overlap_bev: bad arguments");
+  if (num_a == 0 || num_b == 0) return SV_OK;
+  SV_CHECK_ARG(boxes_a && boxes_b && out, "boxes_overlap_bev: null pointer");
+  dim3 grid(sv_div_up(num_b, 64), sv_div_up(num_a, 4));
+  hipLaunchKernelGGL(k_boxes_pairs, grid, dim3(256), 0, sv_stream(stream), num_a, boxes_a, num_b, boxes_b, out, iou);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ------------------------------------------------------------------ NMS: suppression masks (upper triangle)
+// one wave per 64x64 tile; lane = column box; each row contributes one ballot word
+__global__ __launch_bounds__(64) void k_nms_mask(int n, float thresh, const float* __restrict__ boxes, unsigned long long* __restrict__ mask,
+                                                 int col_blocks, int normal) {
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;                                       // the sweep never reads words left of the diagonal
+  const int lane = threadIdx.x;
+  const int col = cb * 64 + lane;
+  const bool col_ok = col < n;
+  float cbox[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) cbox[k] = col_ok ? boxes[(int64_t)col * 7 + k] : 0.f;
+  const RBox c = make_rbox(cbox);
+  const int rows = min(64, n - rb * 64);
+  for (int r = 0; r < rows; ++r) {
+    const int row = rb * 64 + r;
+    float rbox[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) rbox[k] = boxes[(int64_t)row * 7 + k];   // wave-uniform address: one broadcast load
+    bool sup = false;
+    if (col_ok && col > row) sup = (normal ? iou_axis_aligned(rbox, cbox) : iou_bev(make_rbox(rbox), c)) > thresh;
+    const unsigned long long w = __ballot(sup);
+    if (lane == 0) mask[(int64_t)row * col_blocks + cb] = w;
+  }
+}
+
+// greedy sweep on the device: single wave, removal bitmap in LDS (n <= 65536)
+constexpr int NMS_MAX_WORDS = 1024;
+__global__ __launch_bounds__(64) void k_nms_sweep(int n, const unsigned long long* __restrict__ mask, int col_blocks, int64_t* __restrict__ keep,
+                                                  int32_t* __restrict__ num_out) {
+  __shared__ unsigned long long remv[NMS_MAX_WORDS];
+  const int lane = threadIdx.x;
+  for (int j = lane; j < col_blocks; j += 64) remv[j] = 0ull;
+  __syncthreads();
+  int kept_total = 0;
+  for (int nb = 0; nb < col_blocks; ++nb) {
+    const int rows = min(64, n - nb * 64);
+    unsigned long long cur = remv[nb];
+    const unsigned long long diag = lane < rows ? mask[(int64_t)(nb * 64 + lane) * col_blocks + nb] : 0ull;
+    unsigned long long keptbits = 0ull;
+    for (int r = 0; r < rows; ++r) {
+      const unsigned long long d = __shfl(diag, r, 64);
+      if (!((cur >> r) & 1ull)) {
+        keptbits |= 1ull << r;
+        cur |= d;
+      }
+    }
+    if ((keptbits >> lane) & 1ull) keep[kept_total + __popcll(keptbits & ((1ull << lane) - 1ull))] = (int64_t)nb * 64 + lane;
+    kept_total += __popcll(keptbits);
+    // fold the kept rows into the words of the later blocks (lanes over words, coalesced per row)
+    for (int j = nb + 1 + lane; j < col_blocks; j += 64) {
+      unsigned long long acc = remv[j];
+      unsigned long long kb = keptbits;
+      while (kb) {
+        const int r = __ffsll((long long)kb) - 1;
+        kb &= kb - 1;
+        acc |= mask[(int64_t)(nb * 64 + r) * col_blocks + j];
+      }
+      remv[j] = acc;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) *num_out = kept_total;
+}
+
+extern "C" size_t sv_nms_scratch_bytes(int n) {
+  const size_t cb = (size_t)(n + 63) / 64;
+  return ((size_t)n * cb + 8) * sizeof(unsigned long long);
+}
+
+extern "C" int sv_nms(const float* boxes, int n, float thresh, int normal, void* scratch, int64_t* keep, int32_t* num_out, void* stream) {
+  SV_CHECK_ARG(n >= 0 && num_out, "nms: bad arguments");
+  hipStream_t st = sv_stream(stream);
+  if (n == 0) {
+    SV_HIP(hipMemsetAsync(num_out, 0, 4, st));
+    return SV_OK;
+  }
+  SV_CHECK_ARG(boxes && scratch && keep, "nms: null pointer");
+  const int cb = (n + 63) / 64;
+  SV_CHECK_ARG(cb <= NMS_MAX_WORDS, "nms: at most %d boxes", NMS_MAX_WORDS * 64);
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(scratch);
+  hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, st, n, thresh, boxes, mask, cb, normal);
+  hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, st, n, mask, cb, keep, num_out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ------------------------------------------------------------------ points in boxes
+// boxes (B,T,7), pts (B,M,3) -> idx (B,M): first box containing the point, else -1
+__global__ __launch_bounds__(256) void k_points_in_boxes(int T, int M, const float* __restrict__ boxes, const float* __restrict__ pts,
+                                                         int32_t* __restrict__ out) {
+  extern __shared__ float sbox[];                            // [T][9]: cx cy cz dx dy dz cos(-rz) sin(-rz)
+  const int b = blockIdx.y;
+  for (int k = threadIdx.x; k < T; k += blockDim.x) {
+    const float* bx = boxes + ((int64_t)b * T + k) * 7;
+    float* s = sbox + k * 8;
+    s[0] = bx[0]; s[1] = bx[1]; s[2] = bx[2]; s[3] = bx[3]; s[4] = bx[4]; s[5] = bx[5];
+    s[6] = cosf(-bx[6]); s[7] = sinf(-bx[6]);
+  }
+  __syncthreads();
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float* p = pts + ((int64_t)b * M + m) * 3;
+  const float x = p[0], y = p[1], z = p[2];
+  int32_t found = -1;
+  for (int k = 0; k < T; ++k) {
+    const float* s = sbox + k * 8;
+    if (fabsf(z - s[2]) > s[5] / 2.0) continue;              // double-precision compare like the reference (:28)
+    const float sx = x - s[0], sy = y - s[1];
+    const float lx = sx * s[6] + sy * (-s[7]), ly = sx * s[7] + sy * s[6];
+    if ((fabs(lx) < s[3] / 2.0 + (double)1e-5f) & (fabs(ly) < s[4] / 2.0 + (double)1e-5f)) { found = k; break; }
+  }
+  out[(int64_t)b * M + m] = found;
+}
+
+extern "C" int sv_points_in_boxes(const float* boxes, const float* pts, int batch, int num_boxes, int num_points, int32_t* out, void* stream) {
+  SV_CHECK_ARG(batch >= 0 && num_boxes >= 0 && num_points >= 0, "points_in_boxes: bad arguments");
+  if (batch == 0 || num_points == 0) return SV_OK;
+  SV_CHECK_ARG(pts && out && (num_boxes == 0 || boxes), "points_in_boxes: null pointer");
+  SV_CHECK_ARG((size_t)num_boxes * 32 <= 64 * 1024, "points_in_boxes: more than 2048 boxes per scene");
+  dim3 grid(sv_div_up(num_points, 256), batch);
+  hipLaunchKernelGGL(k_points_in_boxes, grid, dim3(256), (size_t)num_boxes * 32, sv_stream(stream), num_boxes, num_points, boxes, pts, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

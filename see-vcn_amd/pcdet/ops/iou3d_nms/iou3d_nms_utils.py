@@ -1,0 +1,71 @@
+"""Same functions as the reference's detector3d/pcdet/ops/iou3d_nms/iou3d_nms_utils.py on libseevcn_hip.so."""
+import torch
+
+from .... import _lib
+
+
+def _pairs(boxes_a, boxes_b, iou):
+    lib = _lib.load()
+    _lib.require_cuda(boxes_a, boxes_b)
+    a = boxes_a[:, :7].contiguous().float()
+    b = boxes_b[:, :7].contiguous().float()
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    rc = lib.sv_boxes_overlap_bev(_lib.ptr(a) if a.numel() else None, a.shape[0], _lib.ptr(b) if b.numel() else None, b.shape[0],
+                                  _lib.ptr(out) if out.numel() else None, int(iou), _lib.stream())
+    _lib.check(rc, "sv_boxes_overlap_bev")
+    return out
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    """(N,7),(M,7) -> (N,M) rotated BEV IoU (reference iou3d_nms_utils.py:33-45)."""
+    assert boxes_a.shape[1] == boxes_b.shape[1] == 7
+    return _pairs(boxes_a, boxes_b, True)
+
+
+def boxes_overlap_bev(boxes_a, boxes_b):
+    return _pairs(boxes_a, boxes_b, False)
+
+
+def boxes_iou3d_gpu(boxes_a, boxes_b):
+    """(N,7),(M,7) -> (N,M) 3-D IoU = BEV overlap x height overlap / union volume (reference :48-81)."""
+    assert boxes_a.shape[1] == boxes_b.shape[1] == 7
+    boxes_a_height_max = (boxes_a[:, 2] + boxes_a[:, 5] / 2).view(-1, 1)
+    boxes_a_height_min = (boxes_a[:, 2] - boxes_a[:, 5] / 2).view(-1, 1)
+    boxes_b_height_max = (boxes_b[:, 2] + boxes_b[:, 5] / 2).view(1, -1)
+    boxes_b_height_min = (boxes_b[:, 2] - boxes_b[:, 5] / 2).view(1, -1)
+    overlaps_bev = _pairs(boxes_a, boxes_b, False)
+    max_of_min = torch.max(boxes_a_height_min, boxes_b_height_min)
+    min_of_max = torch.min(boxes_a_height_max, boxes_b_height_max)
+    overlaps_h = torch.clamp(min_of_max - max_of_min, min=0)
+    overlaps_3d = overlaps_bev * overlaps_h
+    vol_a = (boxes_a[:, 3] * boxes_a[:, 4] * boxes_a[:, 5]).view(-1, 1)
+    vol_b = (boxes_b[:, 3] * boxes_b[:, 4] * boxes_b[:, 5]).view(1, -1)
+    return overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-6)
+
+
+def _nms(boxes, scores, thresh, pre_maxsize, normal):
+    lib = _lib.load()
+    _lib.require_cuda(boxes, scores)
+    assert boxes.shape[1] == 7
+    order = scores.sort(0, descending=True)[1]
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    sorted_boxes = boxes[order].contiguous().float()
+    n = sorted_boxes.shape[0]
+    dev = boxes.device
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
+    num_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+    scratch = _lib.workspace.scratch("nms", lib.sv_nms_scratch_bytes(n), dev)
+    rc = lib.sv_nms(_lib.ptr(sorted_boxes) if n else None, n, float(thresh), int(normal), _lib.ptr(scratch), _lib.ptr(keep), _lib.ptr(num_out),
+                    _lib.stream())
+    _lib.check(rc, "sv_nms")
+    return order[keep[:int(num_out.item())]].contiguous(), None
+
+
+def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
+    """Rotated NMS; returns (kept indices into `boxes` in score order, None) like the reference (:84-99)."""
+    return _nms(boxes, scores, thresh, pre_maxsize, False)
+
+
+def nms_normal_gpu(boxes, scores, thresh, **kwargs):
+    return _nms(boxes, scores, thresh, None, True)
