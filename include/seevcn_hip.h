@@ -190,6 +190,24 @@ int sv_nms(const float* boxes, int n, float thresh, int normal, void* scratch, i
 /* points_in_boxes_gpu: boxes (B,T,7), pts (B,M,3) -> out (B,M) int32 index of the first box containing the point or -1 */
 int sv_points_in_boxes(const float* boxes, const float* pts, int batch, int num_boxes, int num_points, int32_t* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Anchor head (detector3d/pcdet/models/dense_heads/anchor_head_template.py, target_assigner/axis_aligned_target_assigner.py)
+ * ---------------------------------------------------------------------------------------------- */
+/* generate_predicted_boxes (anchor_head_template.py:225-272) with ResidualCoder.decode_torch (box_coder_utils.py:48-77):
+ * anchors (A,7) shared by the batch, box_encodings (B,A,7), dir_cls_preds (B,A,num_dir_bins) or NULL -> out (B,A,7). */
+int sv_anchor_decode(const float* anchors, int64_t num_anchors, const float* box_encodings, const float* dir_cls_preds,
+                     int batch, int num_dir_bins, float dir_offset, float dir_limit_offset, float* out, void* stream);
+/* AxisAlignedTargetAssigner.assign_targets (axis_aligned_target_assigner.py:36-210), deterministic branch (POS_FRACTION < 0,
+ * MATCH_HEIGHT False, NORM_BY_NUM_EXAMPLES False): anchors (A,7) in head order [(z,y,x), set, size, rot]; set s owns the
+ * per-location slots [set_offset[s], set_offset[s+1]) and matches ground truth whose class id (column 7, 1-based) is
+ * set_class[s]; gt_boxes (B,G,8) zero-padded.  Outputs labels (B,A) int32 {-1 ignore, 0 background, class id},
+ * reg_targets (B,A,7) (ResidualCoder.encode_torch), reg_weights (B,A).  gt_max_scratch: B*G floats.  G <= 128.
+ * set_offset/set_class/thresholds are DEVICE arrays. */
+int sv_assign_targets_axis_aligned(const float* anchors, int64_t num_anchors, int anchors_per_location, int num_sets,
+                                   const int32_t* set_offset, const int32_t* set_class, const float* matched_thr,
+                                   const float* unmatched_thr, const float* gt_boxes, int batch, int max_gt, float* gt_max_scratch,
+                                   int32_t* labels, float* reg_targets, float* reg_weights, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,202 @@
+// Anchor head: fused box decode (+ direction-bin fix-up) and fused axis-aligned target assignment.
+//
+// Reference (a chain of ~25 small elementwise torch kernels per call, an (A,G) IoU matrix materialised per class,
+// python loops over batch x class):
+//   AnchorHeadTemplate.generate_predicted_boxes   detector3d/pcdet/models/dense_heads/anchor_head_template.py:225-272
+//   ResidualCoder.decode_torch / encode_torch     detector3d/pcdet/utils/box_coder_utils.py:13-77
+//   limit_period                                  detector3d/pcdet/utils/common_utils.py:22-25
+//   AxisAlignedTargetAssigner.assign_targets      dense_heads/target_assigner/axis_aligned_target_assigner.py:36-210
+//   boxes3d_nearest_bev_iou / boxes_iou_normal    detector3d/pcdet/utils/box_utils.py:286-335
+// HBM-bound: decode moves 4*(7 anchors + 7 deltas + NB dir + 7 out) bytes per anchor = 92*A for NB=2.
+#include <math.h>
+
+#include "common.h"
+
+constexpr float PI_F = 3.14159265358979323846f;
+
+// ------------------------------------------------------------------------------------------------ decode
+__global__ __launch_bounds__(256) void k_anchor_decode(int64_t total, int64_t A, const float* __restrict__ anchors, const float* __restrict__ enc,
+                                                       const float* __restrict__ dir_logits, int num_bins, float dir_offset,
+                                                       float dir_limit_offset, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* an = anchors + (i % A) * 7;
+    const float* t = enc + i * 7;
+    const float xa = an[0], ya = an[1], za = an[2], dxa = an[3], dya = an[4], dza = an[5], ra = an[6];
+    const float diag = sqrtf(dxa * dxa + dya * dya);
+    float* o = out + i * 7;
+    o[0] = t[0] * diag + xa;
+    o[1] = t[1] * diag + ya;
+    o[2] = t[2] * dza + za;
+    o[3] = expf(t[3]) * dxa;
+    o[4] = expf(t[4]) * dya;
+    o[5] = expf(t[5]) * dza;
+    float rg = t[6] + ra;
+    if (dir_logits) {
+      const float* d = dir_logits + i * num_bins;
+      int lab = 0;
+      float best = d[0];
+      for (int k = 1; k < num_bins; ++k)
+        if (d[k] > best) { best = d[k]; lab = k; }               // first maximum, like torch.max(dim=-1)[1] on ties
+      const float period = 2.0f * PI_F / (float)num_bins;
+      const float val = rg - dir_offset;
+      const float rot = val - floorf(val / period + dir_limit_offset) * period;   // limit_period
+      rg = rot + dir_offset + period * (float)lab;
+    }
+    o[6] = rg;
+  }
+}
+
+extern "C" int sv_anchor_decode(const float* anchors, int64_t num_anchors, const float* box_encodings, const float* dir_cls_preds,
+                                int batch, int num_dir_bins, float dir_offset, float dir_limit_offset, float* out, void* stream) {
+  SV_CHECK_ARG(num_anchors >= 0 && batch >= 0, "anchor_decode: bad arguments");
+  const int64_t total = num_anchors * batch;
+  if (total == 0) return SV_OK;
+  SV_CHECK_ARG(anchors && box_encodings && out && (!dir_cls_preds || num_dir_bins >= 1), "anchor_decode: null pointer");
+  hipLaunchKernelGGL(k_anchor_decode, dim3(sv_grid_1d(total, 256)), dim3(256), 0, sv_stream(stream), total, num_anchors, anchors, box_encodings,
+                     dir_cls_preds, num_dir_bins, dir_offset, dir_limit_offset, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ target assignment
+struct AlignedBox { float x1, y1, x2, y2; };
+
+__device__ __forceinline__ AlignedBox nearest_bev(const float* b) {          // box_utils.py:312-323
+  const float r = b[6];
+  const float rot = fabsf(r - floorf(r / PI_F + 0.5f) * PI_F);
+  const bool keep = rot < PI_F / 4;
+  const float d0 = keep ? b[3] : b[4], d1 = keep ? b[4] : b[3];
+  return {b[0] - d0 / 2, b[1] - d1 / 2, b[0] + d0 / 2, b[1] + d1 / 2};
+}
+
+__device__ __forceinline__ float iou_aligned(const AlignedBox& a, const AlignedBox& b) {   // box_utils.py:286-309
+  const float xl = fmaxf(fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1), 0.f);
+  const float yl = fmaxf(fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1), 0.f);
+  const float inter = xl * yl;
+  const float area_a = (a.x2 - a.x1) * (a.y2 - a.y1), area_b = (b.x2 - b.x1) * (b.y2 - b.y1);
+  return inter / fmaxf(area_a + area_b - inter, 1e-6f);
+}
+
+struct AssignArgs {
+  const float* anchors;        // (A,7) in output order [(z,y,x), set, size, rot]
+  const float* gt;             // (B,G,8) [box7, class]
+  int64_t A;
+  int B, G, per_loc, num_sets;
+  const int* set_offset;       // (num_sets+1) prefix of anchors per location per set
+  const int* set_class;        // (num_sets) 1-based class id matched by the set's anchors
+  const float* matched_thr;    // (num_sets)
+  const float* unmatched_thr;  // (num_sets)
+  float* gt_max;               // (B,G) scratch
+  int32_t* labels;             // (B,A)
+  float* targets;              // (B,A,7)
+  float* reg_weights;          // (B,A)
+};
+
+constexpr int AS_MAX_GT = 128;
+
+__device__ __forceinline__ int anchor_set(const AssignArgs& a, int64_t ai) {
+  const int o = (int)(ai % a.per_loc);
+  int s = 0;
+  while (s + 1 < a.num_sets && o >= a.set_offset[s + 1]) ++s;
+  return s;
+}
+
+// grid.y = scene; GT boxes of the scene staged in LDS
+template <int PASS>
+__global__ __launch_bounds__(256) void k_assign(AssignArgs a) {
+  __shared__ AlignedBox sg[AS_MAX_GT];
+  __shared__ int scls[AS_MAX_GT];
+  __shared__ float sgmax[AS_MAX_GT];
+  __shared__ float sraw[AS_MAX_GT][7];
+  const int b = blockIdx.y;
+  for (int g = threadIdx.x; g < a.G; g += blockDim.x) {
+    const float* p = a.gt + ((int64_t)b * a.G + g) * 8;
+    sg[g] = nearest_bev(p);
+    scls[g] = (int)p[7];
+    for (int k = 0; k < 7; ++k) sraw[g][k] = p[k];
+    if (PASS == 1) {
+      const float m = a.gt_max[(int64_t)b * a.G + g];
+      sgmax[g] = m == 0.f ? -1.f : m;                               // empty_gt_mask -> -1 (:152-153)
+    } else {
+      sgmax[g] = 0.f;
+    }
+  }
+  __syncthreads();
+  for (int64_t ai = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ai < a.A; ai += (int64_t)gridDim.x * blockDim.x) {
+    const float* an = a.anchors + ai * 7;
+    const int s = anchor_set(a, ai);
+    const int cls = a.set_class[s];
+    const AlignedBox ab = nearest_bev(an);
+    float best = -1.f;
+    int arg = -1;
+    bool force = false;
+    for (int g = 0; g < a.G; ++g) {
+      if (scls[g] != cls) continue;
+      const float v = iou_aligned(ab, sg[g]);
+      if (PASS == 0) {
+        if (v > 0.f) atomicMax(reinterpret_cast<int*>(&sgmax[g]), __float_as_int(v));   // IoU >= 0: int order = float order
+      } else {
+        if (v > best) { best = v; arg = g; }                         // first maximum (argmax on CPU)
+        force = force || (v == sgmax[g]);
+      }
+    }
+    if (PASS == 1) {
+      const int64_t o = (int64_t)b * a.A + ai;
+      int label;
+      if (arg < 0) {
+        label = 0;                                                   // no ground truth of this class: all background (:183-184)
+      } else {
+        const bool pos = best >= a.matched_thr[s];
+        label = (force || pos) ? cls : (best < a.unmatched_thr[s] ? 0 : -1);
+      }
+      a.labels[o] = label;
+      float* t = a.targets + o * 7;
+      if (label > 0) {
+        // ResidualCoder.encode_torch (box_coder_utils.py:13-46)
+        const float* gtb = sraw[arg];
+        const float dxa = fmaxf(an[3], 1e-5f), dya = fmaxf(an[4], 1e-5f), dza = fmaxf(an[5], 1e-5f);
+        const float dxg = fmaxf(gtb[3], 1e-5f), dyg = fmaxf(gtb[4], 1e-5f), dzg = fmaxf(gtb[5], 1e-5f);
+        const float diag = sqrtf(dxa * dxa + dya * dya);
+        t[0] = (gtb[0] - an[0]) / diag;
+        t[1] = (gtb[1] - an[1]) / diag;
+        t[2] = (gtb[2] - an[2]) / dza;
+        t[3] = logf(dxg / dxa);
+        t[4] = logf(dyg / dya);
+        t[5] = logf(dzg / dza);
+        t[6] = gtb[6] - an[6];
+        a.reg_weights[o] = 1.0f;
+      } else {
+        for (int k = 0; k < 7; ++k) t[k] = 0.f;
+        a.reg_weights[o] = 0.f;
+      }
+    }
+  }
+  if (PASS == 0) {
+    __syncthreads();
+    for (int g = threadIdx.x; g < a.G; g += blockDim.x)
+      if (sgmax[g] > 0.f) atomicMax(reinterpret_cast<int*>(&a.gt_max[(int64_t)b * a.G + g]), __float_as_int(sgmax[g]));
+  }
+}
+
+extern "C" int sv_assign_targets_axis_aligned(const float* anchors, int64_t num_anchors, int anchors_per_location, int num_sets,
+                                              const int32_t* set_offset, const int32_t* set_class, const float* matched_thr,
+                                              const float* unmatched_thr, const float* gt_boxes, int batch, int max_gt, float* gt_max_scratch,
+                                              int32_t* labels, float* reg_targets, float* reg_weights, void* stream) {
+  SV_CHECK_ARG(num_anchors >= 0 && batch >= 0 && max_gt >= 0 && num_sets >= 1 && anchors_per_location >= 1, "assign_targets: bad arguments");
+  SV_CHECK_ARG(max_gt <= AS_MAX_GT, "assign_targets: at most %d ground-truth boxes per scene", AS_MAX_GT);
+  if (num_anchors == 0 || batch == 0) return SV_OK;
+  SV_CHECK_ARG(anchors && set_offset && set_class && matched_thr && unmatched_thr && labels && reg_targets && reg_weights &&
+                   (max_gt == 0 || (gt_boxes && gt_max_scratch)),
+               "assign_targets: null pointer");
+  hipStream_t st = sv_stream(stream);
+  AssignArgs a{anchors, gt_boxes, num_anchors, batch, max_gt, anchors_per_location, num_sets, set_offset, set_class, matched_thr, unmatched_thr,
+               gt_max_scratch, labels, reg_targets, reg_weights};
+  dim3 grid(sv_grid_1d(num_anchors, 256, 512), batch);
+  if (max_gt > 0) {
+    SV_HIP(hipMemsetAsync(gt_max_scratch, 0, (size_t)batch * max_gt * 4, st));
+    hipLaunchKernelGGL(k_assign<0>, grid, dim3(256), 0, st, a);
+  }
+  hipLaunchKernelGGL(k_assign<1>, grid, dim3(256), 0, st, a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

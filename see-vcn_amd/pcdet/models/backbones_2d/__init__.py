@@ -1,0 +1,5 @@
+from .base_bev_backbone import BaseBEVBackbone
+
+__all__ = {
+    'BaseBEVBackbone': BaseBEVBackbone,
+}

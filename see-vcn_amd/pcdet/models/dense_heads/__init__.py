@@ -1,0 +1,8 @@
+from .anchor_head_single import AnchorHeadSingle
+from .anchor_head_template import AnchorHeadTemplate
+
+# same registry shape as the reference (dense_heads/__init__.py:9-17)
+__all__ = {
+    'AnchorHeadTemplate': AnchorHeadTemplate,
+    'AnchorHeadSingle': AnchorHeadSingle,
+}

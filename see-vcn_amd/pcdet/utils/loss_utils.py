@@ -1,0 +1,60 @@
+"""RPN losses with the reference's class names and call signatures (detector3d/pcdet/utils/loss_utils.py:9-206)."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class SigmoidFocalClassificationLoss(nn.Module):
+    """alpha-balanced sigmoid focal loss, un-reduced: (B, #anchors, #classes)  (loss_utils.py:9-72)"""
+
+    def __init__(self, gamma: float = 2.0, alpha: float = 0.25):
+        super().__init__()
+        self.alpha, self.gamma = alpha, gamma
+
+    @staticmethod
+    def sigmoid_cross_entropy_with_logits(input, target):
+        # max(x, 0) - x * z + log(1 + exp(-|x|))
+        return torch.clamp(input, min=0) - input * target + torch.log1p(torch.exp(-torch.abs(input)))
+
+    def forward(self, input, target, weights):
+        p = torch.sigmoid(input)
+        alpha_w = target * self.alpha + (1 - target) * (1 - self.alpha)
+        pt = target * (1.0 - p) + (1.0 - target) * p
+        loss = alpha_w * torch.pow(pt, self.gamma) * self.sigmoid_cross_entropy_with_logits(input, target)
+        if weights.dim() == 2 or (weights.dim() == 1 and target.dim() == 2):
+            weights = weights.unsqueeze(-1)
+        assert weights.dim() == loss.dim()
+        return loss * weights
+
+
+class WeightedSmoothL1Loss(nn.Module):
+    """code-wise weighted smooth-L1 (beta = 1/9), un-reduced (B, #anchors, #codes)  (loss_utils.py:75-136)"""
+
+    def __init__(self, beta: float = 1.0 / 9.0, code_weights: list = None):
+        super().__init__()
+        self.beta = beta
+        self.code_weights = None if code_weights is None else torch.from_numpy(np.array(code_weights, dtype=np.float32))
+
+    @staticmethod
+    def smooth_l1_loss(diff, beta):
+        n = torch.abs(diff)
+        return n if beta < 1e-5 else torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
+
+    def forward(self, input, target, weights=None):
+        target = torch.where(torch.isnan(target), input, target)  # ignore nan targets
+        diff = input - target
+        if self.code_weights is not None:
+            diff = diff * self.code_weights.to(diff.device).view(1, 1, -1)
+        loss = self.smooth_l1_loss(diff, self.beta)
+        if weights is not None:
+            assert weights.shape[0] == loss.shape[0] and weights.shape[1] == loss.shape[1]
+            loss = loss * weights.unsqueeze(-1)
+        return loss
+
+
+class WeightedCrossEntropyLoss(nn.Module):
+    """anchor-weighted softmax cross entropy on one-hot targets, un-reduced (B, #anchors)  (loss_utils.py:181-206)"""
+
+    def forward(self, input, target, weights):
+        return F.cross_entropy(input.permute(0, 2, 1), target.argmax(dim=-1), reduction='none') * weights

@@ -1,0 +1,94 @@
+"""SECOND dense path: BaseBEVBackbone + AnchorHeadSingle (anchors, fused target assignment, losses, fused decode) against the
+goldens produced by the reference's own modules (tests/golden/make_head_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import heads as oh
+from seeding import seeded_state_dict
+from seevcn_amd.pcdet import model_cfgs as C
+
+GRID = np.array([1408, 1600, 40])
+
+
+def _golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "second_head.npz"))
+    feat = (np.random.default_rng(int(g["feat_seed"])).normal(size=(2, 16, 200, 176)) * 0.5).astype(np.float32)
+    return g, feat
+
+
+def test_oracle_anchors_targets_decode_match_reference_golden(golden_dir):
+    g, _ = _golden(golden_dir)
+    cfgs = C.SECOND_DENSE_HEAD["ANCHOR_GENERATOR_CONFIG"]
+    anchors, per_set = oh.generate_anchors(cfgs, GRID, C.KITTI_RANGE)
+    assert anchors.shape == (211200, 7) and per_set == [2, 2, 2]
+    sel = g["sel"]
+    np.testing.assert_allclose(anchors[sel], g["anchors_head"], rtol=0, atol=2e-5)
+    labels, targets, weights = oh.assign_targets(anchors, per_set, [1, 2, 3], [c["matched_threshold"] for c in cfgs],
+                                                 [c["unmatched_threshold"] for c in cfgs], g["gt_boxes"])
+    assert np.array_equal(labels[:, sel], g["box_cls_labels"])
+    assert int((labels > 0).sum()) == int(g["num_pos"]) and int((labels < 0).sum()) == int(g["num_ignore"])
+    np.testing.assert_allclose(targets[:, sel], g["box_reg_targets"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(weights[:, sel], g["reg_weights"])
+
+
+def test_modules_state_dict_and_cpu_refusal():
+    from seevcn_amd.pcdet.models import backbones_2d, dense_heads
+    bb = backbones_2d.__all__["BaseBEVBackbone"](C.SECOND_BACKBONE_2D, 256)
+    assert bb.num_bev_features == 512 and "blocks.0.1.weight" in bb.state_dict() and "deblocks.1.0.weight" in bb.state_dict()
+    assert sum(p.numel() for p in bb.parameters()) == 4_576_768                       # BEV ~4.57 M
+    head = dense_heads.__all__["AnchorHeadSingle"](model_cfg=C.SECOND_DENSE_HEAD, input_channels=512, num_class=3, class_names=C.CLASS_NAMES,
+                                                   grid_size=GRID, point_cloud_range=np.array(C.KITTI_RANGE, np.float32))
+    assert head.num_anchors_per_location == 6 and head.conv_box.out_channels == 42 and head.conv_dir_cls.out_channels == 12
+    assert [tuple(a.shape) for a in head.anchors] == [(1, 200, 176, 1, 2, 7)] * 3
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_bev_backbone_matches_reference_golden(golden_dir, cuda, hip_lib):
+    from seevcn_amd.pcdet.models import backbones_2d
+    g = np.load(os.path.join(golden_dir, "bev_backbone.npz"))
+    cfg = dict(C.SECOND_BACKBONE_2D, LAYER_NUMS=[2, 2], NUM_FILTERS=[32, 64], NUM_UPSAMPLE_FILTERS=[64, 64])
+    bb = backbones_2d.__all__["BaseBEVBackbone"](cfg, 48)
+    bb.load_state_dict(seeded_state_dict(bb, seed=2))
+    bb = bb.to(cuda).eval()
+    with torch.no_grad():
+        out = bb({"spatial_features": torch.from_numpy(g["spatial_features"]).to(cuda)})["spatial_features_2d"].cpu().numpy()
+    assert np.abs(out - g["spatial_features_2d"]).max() / np.abs(g["spatial_features_2d"]).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_hip_anchor_head_matches_reference_golden(golden_dir, cuda, hip_lib):
+    from seevcn_amd.pcdet.models import dense_heads
+    g, feat = _golden(golden_dir)
+    head = dense_heads.__all__["AnchorHeadSingle"](model_cfg=C.SECOND_DENSE_HEAD, input_channels=16, num_class=3, class_names=C.CLASS_NAMES,
+                                                   grid_size=GRID, point_cloud_range=np.array(C.KITTI_RANGE, np.float32))
+    head.load_state_dict(seeded_state_dict(head, seed=3))
+    head = head.to(cuda).train()
+    dd = head({"spatial_features_2d": torch.from_numpy(feat).to(cuda), "gt_boxes": torch.from_numpy(g["gt_boxes"]).to(cuda), "batch_size": 2})
+    sel = g["sel"]
+    fr = head.forward_ret_dict
+    labels = fr["box_cls_labels"].cpu().numpy()
+    assert np.array_equal(labels[:, sel], g["box_cls_labels"])                              # integer labels: bit-exact
+    assert int((labels > 0).sum()) == int(g["num_pos"]) and int((labels < 0).sum()) == int(g["num_ignore"])
+    np.testing.assert_allclose(fr["box_reg_targets"].cpu().numpy()[:, sel], g["box_reg_targets"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(fr["reg_weights"].cpu().numpy()[:, sel], g["reg_weights"])
+    np.testing.assert_allclose(dd["batch_cls_preds"].detach().cpu().numpy()[:, sel], g["batch_cls_preds"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(dd["batch_box_preds"].cpu().numpy()[:, sel], g["batch_box_preds"], rtol=1e-3, atol=1e-4)
+    loss, tb = head.get_loss()
+    for k in ("rpn_loss", "rpn_loss_cls", "rpn_loss_loc", "rpn_loss_dir"):
+        assert abs(tb[k] - float(g[k])) <= 1e-3 * abs(float(g[k])) + 1e-5, (k, tb[k], float(g[k]))
+    loss.backward()
+    assert torch.isfinite(head.conv_box.weight.grad).all()
+    # against the oracle on ALL anchors (the golden stores a subsample)
+    anchors, per_set = oh.generate_anchors(C.SECOND_DENSE_HEAD["ANCHOR_GENERATOR_CONFIG"], GRID, C.KITTI_RANGE)
+    cfgs = C.SECOND_DENSE_HEAD["ANCHOR_GENERATOR_CONFIG"]
+    lo, to, wo = oh.assign_targets(anchors, per_set, [1, 2, 3], [c["matched_threshold"] for c in cfgs], [c["unmatched_threshold"] for c in cfgs],
+                                   g["gt_boxes"])
+    assert np.array_equal(labels, lo)
+    np.testing.assert_allclose(fr["box_reg_targets"].cpu().numpy(), to, rtol=1e-4, atol=1e-5)
+    # scenes without ground truth -> all background
+    head({"spatial_features_2d": torch.from_numpy(feat).to(cuda), "gt_boxes": torch.zeros((2, 3, 8), device=cuda), "batch_size": 2})
+    assert int(head.forward_ret_dict["box_cls_labels"].abs().sum()) == 0
