@@ -21,3 +21,28 @@ SECOND_DENSE_HEAD = dict(
 
 CLASS_NAMES = ['Car', 'Pedestrian', 'Cyclist']
 KITTI_RANGE = [0, -40, -3, 70.4, 40, 1]
+
+SECOND_POST_PROCESSING = dict(RECALL_THRESH_LIST=[0.3, 0.5, 0.7], SCORE_THRESH=0.1, OUTPUT_RAW_SCORE=False, EVAL_METRIC='kitti',
+                              NMS_CONFIG=dict(MULTI_CLASSES_NMS=False, NMS_TYPE='nms_gpu', NMS_THRESH=0.01, NMS_PRE_MAXSIZE=4096,
+                                              NMS_POST_MAXSIZE=500))
+
+
+def second_model_cfg(dynamic_vfe=True):
+    """MODEL section of kitti_models/second.yaml; dynamic_vfe swaps MeanVFE (hard voxels from the dataloader) for DynMeanVFE."""
+    return dict(NAME='SECONDNet', VFE=dict(NAME='DynMeanVFE' if dynamic_vfe else 'MeanVFE'), BACKBONE_3D=dict(NAME='VoxelBackBone8x'),
+                MAP_TO_BEV=dict(NAME='HeightCompression', NUM_BEV_FEATURES=256), BACKBONE_2D=SECOND_BACKBONE_2D,
+                DENSE_HEAD=SECOND_DENSE_HEAD, POST_PROCESSING=SECOND_POST_PROCESSING)
+
+
+class SyntheticDatasetInfo:
+    """The attributes Detector3DTemplate.build_networks reads from a dataset (detector3d_template.py:36-44)."""
+
+    def __init__(self, class_names=CLASS_NAMES, point_cloud_range=KITTI_RANGE, voxel_size=(0.05, 0.05, 0.1), num_point_features=3):
+        import numpy as np
+        from types import SimpleNamespace
+        self.class_names = list(class_names)
+        self.point_cloud_range = np.array(point_cloud_range, np.float32)
+        self.voxel_size = list(voxel_size)
+        self.grid_size = np.round((self.point_cloud_range[3:6] - self.point_cloud_range[0:3]) / np.array(voxel_size)).astype(np.int64)
+        self.point_feature_encoder = SimpleNamespace(num_point_features=num_point_features)
+        self.depth_downsample_factor = None

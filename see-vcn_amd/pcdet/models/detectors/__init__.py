@@ -1,0 +1,13 @@
+from .detector3d_template import Detector3DTemplate
+from .second_net import SECONDNet
+
+# same registry shape as the reference (detectors/__init__.py:13-26)
+__all__ = {
+    'Detector3DTemplate': Detector3DTemplate,
+    'SECONDNet': SECONDNet,
+}
+
+
+def build_detector(model_cfg, num_class, dataset):
+    name = model_cfg['NAME'] if isinstance(model_cfg, dict) else model_cfg.NAME
+    return __all__[name](model_cfg=model_cfg, num_class=num_class, dataset=dataset)

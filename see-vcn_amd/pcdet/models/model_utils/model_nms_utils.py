@@ -1,0 +1,25 @@
+import torch
+
+from ...ops.iou3d_nms import iou3d_nms_utils
+from ...utils.common_utils import cfg_get
+
+
+def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
+    """score threshold -> top-k (NMS_PRE_MAXSIZE) -> NMS_TYPE(NMS_THRESH) -> first NMS_POST_MAXSIZE; returns indices into the
+    original arrays and their scores (reference model_utils/model_nms_utils.py:6-25)."""
+    src_box_scores = box_scores
+    if score_thresh is not None:
+        scores_mask = (box_scores >= score_thresh)
+        box_scores = box_scores[scores_mask]
+        box_preds = box_preds[scores_mask]
+    selected = []
+    if box_scores.shape[0] > 0:
+        box_scores_nms, indices = torch.topk(box_scores, k=min(cfg_get(nms_config, 'NMS_PRE_MAXSIZE'), box_scores.shape[0]))
+        boxes_for_nms = box_preds[indices]
+        keep_idx, _ = getattr(iou3d_nms_utils, cfg_get(nms_config, 'NMS_TYPE'))(boxes_for_nms[:, 0:7], box_scores_nms,
+                                                                                 cfg_get(nms_config, 'NMS_THRESH'))
+        selected = indices[keep_idx[:cfg_get(nms_config, 'NMS_POST_MAXSIZE')]]
+    if score_thresh is not None:
+        original_idxs = scores_mask.nonzero().view(-1)
+        selected = original_idxs[selected]
+    return selected, src_box_scores[selected]
