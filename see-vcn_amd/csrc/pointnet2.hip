@@ -88,6 +88,8 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_reg(const float* __restrict
     if (best == wbest && best != 0ull) {
       skey[par][wid] = wbest;
       sxyz[par][wid][0] = bx; sxyz[par][wid][1] = by; sxyz[par][wid][2] = bz;
+    } else if (wbest == 0ull && lane == 0) {
+      skey[par][wid] = 0ull;                                    // a wave without points must still clear its slot
     }
     __syncthreads();                                            // the only barrier of the round (slots alternate by parity)
     const int sl = lane & (NW - 1);
