@@ -327,7 +327,17 @@ extern "C" int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const i
 //          (MFMA 16x16x4 with the row index as the contraction dimension); stage 2 sums the slabs in a
 //          fixed order -> bitwise reproducible, no atomics.
 // ------------------------------------------------------------------------------------------------
-constexpr int WG_CHUNK = 2048;  // rows per stage-1 workgroup
+constexpr int WG_CHUNK_MAX = 4096;  // rows per stage-1 workgroup (upper bound; sized per launch to fill the chip)
+
+struct WgradArgs;
+static int wgrad_chunk_rows(int64_t n_rows, int K, int groups) {
+  // aim at ~2048 workgroups: chunk = n_rows*K*groups/2048 rounded up to 256 rows, within [256, WG_CHUNK_MAX]
+  int64_t c = (n_rows * K * groups + 2047) / 2048;
+  c = (c + 255) / 256 * 256;
+  if (c < 256) c = 256;
+  if (c > WG_CHUNK_MAX) c = WG_CHUNK_MAX;
+  return (int)c;
+}
 
 struct WgradArgs {
   const float* X;        // (n_src, Cin)
@@ -335,13 +345,17 @@ struct WgradArgs {
   const float* dY;       // (n_rows, Cout)
   float* partial;        // (nchunks, K, Cin, Cout)
   int64_t n_rows;
-  int K, Cin, Cout, nchunks;
+  int K, Cin, Cout, nchunks, chunk_rows;
 };
 
-// grid = (nchunks, K, tile groups); 4 waves split the chunk's rows, each wave writes its own partial slab
-// (slab index = chunk*4 + wave) so no cross-wave reduction is needed inside the kernel.
+// grid = (nchunks, K, tile groups).  Each wave walks its share of the chunk 64 rows at a time: one coalesced read of the
+// neighbour table, ballot + prefix popcount compaction of the valid (row, source) pairs into a wave-private LDS list,
+// then MFMAs over the COMPACTED pairs only (4 pairs per 16x16x4 step) with the next step's operands requested first.
+// The four waves' accumulators are summed through LDS in a fixed order and one slab per (chunk, k) is stored.
 template <int CT, int NTL>  // register tile grid: CT x NTL tiles of 16x16 (rows = c_in, cols = c_out)
 __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {
+  __shared__ int32_t pj[4][64], pr[4][64];
+  __shared__ float red[CT * NTL * 256];
   const int k = blockIdx.y, chunk = blockIdx.x;
   const int ngroups_n = (a.Cout / 16) / NTL;
   const int c_base = (blockIdx.z / ngroups_n) * CT * 16, n_base = (blockIdx.z % ngroups_n) * NTL * 16;
@@ -352,38 +366,77 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {
   for (int c = 0; c < CT; ++c)
 #pragma unroll
     for (int t = 0; t < NTL; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int64_t r_begin = (int64_t)chunk * WG_CHUNK, r_end = min(r_begin + (int64_t)WG_CHUNK, a.n_rows);
+  const int64_t r_begin = (int64_t)chunk * a.chunk_rows, r_end = min(r_begin + (int64_t)a.chunk_rows, a.n_rows);
   const int32_t* nb = a.nbr + (int64_t)k * a.n_rows;
-  // wave-uniform loop: 4 consecutive rows per MFMA (lane quarter kk takes row rb + kk), waves interleave by 4 rows
-  for (int64_t rb = r_begin + wid * 4; rb < r_end; rb += 16) {
-    const int64_t r = rb + kk;
+
+  auto load_ops = [&](int p, int cnt, float (&xa)[CT], float (&yb)[NTL]) {
+    const bool ok = p < cnt;
+    const int32_t j = ok ? pj[wid][p] : 0;
+    const int32_t r = ok ? pr[wid][p] : 0;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) xa[c] = ok ? a.X[(int64_t)j * a.Cin + c_base + c * 16 + li] : 0.f;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) yb[t] = ok ? a.dY[((int64_t)r_begin + r) * a.Cout + n_base + t * 16 + li] : 0.f;
+  };
+
+  for (int64_t base = r_begin + wid * 64; base < r_end; base += 256) {
+    const int64_t r = base + lane;
     const int32_t j = r < r_end ? nb[r] : -1;
-    if (__ballot(j >= 0) == 0ull) continue;
-    float xa[CT], yb[NTL];
+    const unsigned long long m = __ballot(j >= 0);
+    const int cnt = __popcll(m);
+    if (cnt == 0) continue;
+    if (j >= 0) {
+      const int pos = __popcll(m & ((1ull << lane) - 1ull));
+      pj[wid][pos] = j;
+      pr[wid][pos] = (int32_t)(r - r_begin);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private list: LDS ops of one wave complete in order
+    float xa[CT], yb[NTL], xn[CT], yn[NTL];
+    load_ops(kk, cnt, xa, yb);
+    for (int g = 0; g < cnt; g += 4) {
+      if (g + 4 < cnt) load_ops(g + 4 + kk, cnt, xn, yn);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMA block
 #pragma unroll
-    for (int c = 0; c < CT; ++c) xa[c] = j >= 0 ? a.X[(int64_t)j * a.Cin + c_base + c * 16 + li] : 0.f;
+      for (int c = 0; c < CT; ++c)
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) yb[t] = j >= 0 ? a.dY[r * a.Cout + n_base + t * 16 + li] : 0.f;
+        for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[c], yb[t], acc[c][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 4 < cnt) {
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
+        for (int c = 0; c < CT; ++c) xa[c] = xn[c];
 #pragma unroll
-      for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[c], yb[t], acc[c][t], 0, 0, 0);
+        for (int t = 0; t < NTL; ++t) yb[t] = yn[t];
+      }
+    }
+  }
+  // fixed-order reduction over the 4 waves (wave 0 stores, waves 1..3 add in turn), then one slab per (chunk, k)
+  for (int w = 0; w < 4; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* d = &red[((c * NTL + t) * 4 + r) * 64 + lane];
+            *d = (w == 0 ? 0.f : *d) + acc[c][t][r];
+          }
+    }
+    __syncthreads();
   }
   // D layout: col = lane&15 (c_out), row = 4*(lane>>4) + reg (c_in)
-  float* out = a.partial + ((((int64_t)chunk * 4 + wid) * a.K + k) * a.Cin) * a.Cout;
-#pragma unroll
-  for (int c = 0; c < CT; ++c)
-#pragma unroll
-    for (int t = 0; t < NTL; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        out[(int64_t)(c_base + c * 16 + kk * 4 + r) * a.Cout + n_base + t * 16 + li] = acc[c][t][r];
+  float* out = a.partial + (((int64_t)chunk * a.K + k) * a.Cin) * a.Cout;
+  for (int e = tid; e < CT * NTL * 256; e += 256) {
+    const int ln = e & 63, r = (e >> 6) & 3, tile = e >> 8;
+    const int c = tile / NTL, t = tile - c * NTL;
+    out[(int64_t)(c_base + c * 16 + (ln >> 4) * 4 + r) * a.Cout + n_base + t * 16 + (ln & 15)] = red[e];
+  }
 }
 
 // generic (any Cin/Cout) stage 1: one thread per (c, n) element, rows of the chunk streamed
 __global__ __launch_bounds__(256) void k_spconv_wgrad_valu(WgradArgs a) {
   const int k = blockIdx.y, chunk = blockIdx.x;
-  const int64_t r_begin = (int64_t)chunk * WG_CHUNK, r_end = min(r_begin + (int64_t)WG_CHUNK, a.n_rows);
+  const int64_t r_begin = (int64_t)chunk * a.chunk_rows, r_end = min(r_begin + (int64_t)a.chunk_rows, a.n_rows);
   const int32_t* nb = a.nbr + (int64_t)k * a.n_rows;
   float* out = a.partial + (((int64_t)chunk * a.K + k) * a.Cin) * a.Cout;  // one slab per chunk on this path
   for (int e = threadIdx.x; e < a.Cin * a.Cout; e += blockDim.x) {
@@ -406,8 +459,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 }
 
 extern "C" size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout) {
-  const int64_t nchunks = (n_rows + WG_CHUNK - 1) / WG_CHUNK;
-  return (size_t)(nchunks > 0 ? nchunks : 1) * 4 * K * Cin * Cout * sizeof(float);
+  const int64_t nchunks = (n_rows + 255) / 256;   // worst case: smallest chunk
+  return (size_t)(nchunks > 0 ? nchunks : 1) * K * Cin * Cout * sizeof(float);
 }
 
 template <int CT, int NTL>
@@ -426,14 +479,24 @@ extern "C" int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const fl
     return SV_OK;
   }
   SV_CHECK_ARG(X && nbr && dY && scratch, "sparse_conv_wgrad: null pointer");
-  WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, (int)((n_rows + WG_CHUNK - 1) / WG_CHUNK)};
   const int ct = Cin / 16, nt = Cout / 16;
-  int nslabs = a.nchunks * 4;
-  if (Cin % 16 == 0 && Cout % 16 == 0) {
-    if (ct % 4 == 0 && nt % 4 == 0) launch_wgrad<4, 4>(a, st);
-    else if (ct % 2 == 0 && nt % 4 == 0) launch_wgrad<2, 4>(a, st);
-    else if (ct % 2 == 0 && nt % 2 == 0) launch_wgrad<2, 2>(a, st);
-    else if (nt % 2 == 0) launch_wgrad<1, 2>(a, st);
+  int tiles_c = 1, tiles_n = 1;
+  const bool mfma = Cin % 16 == 0 && Cout % 16 == 0;
+  if (mfma) {
+    if (ct % 4 == 0 && nt % 4 == 0) { tiles_c = 4; tiles_n = 4; }
+    else if (ct % 2 == 0 && nt % 4 == 0) { tiles_c = 2; tiles_n = 4; }
+    else if (ct % 2 == 0 && nt % 2 == 0) { tiles_c = 2; tiles_n = 2; }
+    else if (nt % 2 == 0) { tiles_c = 1; tiles_n = 2; }
+  }
+  const int groups = mfma ? (ct / tiles_c) * (nt / tiles_n) : 1;
+  const int chunk_rows = wgrad_chunk_rows(n_rows, K, groups);
+  WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, (int)((n_rows + chunk_rows - 1) / chunk_rows), chunk_rows};
+  int nslabs = a.nchunks;
+  if (mfma) {
+    if (tiles_c == 4) launch_wgrad<4, 4>(a, st);
+    else if (tiles_c == 2 && tiles_n == 4) launch_wgrad<2, 4>(a, st);
+    else if (tiles_c == 2) launch_wgrad<2, 2>(a, st);
+    else if (tiles_n == 2) launch_wgrad<1, 2>(a, st);
     else launch_wgrad<1, 1>(a, st);
   } else {
     hipLaunchKernelGGL(k_spconv_wgrad_valu, dim3(a.nchunks, K), dim3(256), 0, st, a);
