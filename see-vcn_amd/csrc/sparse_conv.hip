@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {
     const int32_t j = ok ? pj[wid][p] : 0;
     const int32_t r = ok ? pr[wid][p] : 0;
 #pragma unroll
-    for (int c = 0; c < CT; ++c) xa[c] = ok ? a.X[(int64_t)j * a.Cin + c_base + c * 16 + li] : 0.f;
+    for (int c = 0; c < CT; ++c) xa[c] = (ok && c_base + c * 16 + li < a.Cin) ? a.X[(int64_t)j * a.Cin + c_base + c * 16 + li] : 0.f;
 #pragma unroll
     for (int t = 0; t < NTL; ++t) yb[t] = ok ? a.dY[((int64_t)r_begin + r) * a.Cout + n_base + t * 16 + li] : 0.f;
   };
@@ -429,7 +429,8 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {
   for (int e = tid; e < CT * NTL * 256; e += 256) {
     const int ln = e & 63, r = (e >> 6) & 3, tile = e >> 8;
     const int c = tile / NTL, t = tile - c * NTL;
-    out[(int64_t)(c_base + c * 16 + (ln >> 4) * 4 + r) * a.Cout + n_base + t * 16 + (ln & 15)] = red[e];
+    const int crow = c_base + c * 16 + (ln >> 4) * 4 + r;
+    if (crow < a.Cin) out[(int64_t)crow * a.Cout + n_base + t * 16 + (ln & 15)] = red[e];
   }
 }
 
@@ -465,7 +466,7 @@ extern "C" size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int 
 
 template <int CT, int NTL>
 static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
-  const int groups = ((a.Cin / 16) / CT) * ((a.Cout / 16) / NTL);
+  const int groups = (((a.Cin + 15) / 16) / CT) * ((a.Cout / 16) / NTL);
   hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL>), dim3(a.nchunks, a.K, groups), dim3(256), 0, st, a);
 }
 
@@ -479,9 +480,10 @@ extern "C" int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const fl
     return SV_OK;
   }
   SV_CHECK_ARG(X && nbr && dY && scratch, "sparse_conv_wgrad: null pointer");
-  const int ct = Cin / 16, nt = Cout / 16;
+  const int ct = (Cin + 15) / 16, nt = Cout / 16;
   int tiles_c = 1, tiles_n = 1;
-  const bool mfma = Cin % 16 == 0 && Cout % 16 == 0;
+  // C_in that is not a multiple of 16 (the 3-channel input layer) runs on the MFMA path with zero-padded rows
+  const bool mfma = Cout % 16 == 0 && (Cin % 16 == 0 || Cin < 16);
   if (mfma) {
     if (ct % 4 == 0 && nt % 4 == 0) { tiles_c = 4; tiles_n = 4; }
     else if (ct % 2 == 0 && nt % 4 == 0) { tiles_c = 2; tiles_n = 4; }
