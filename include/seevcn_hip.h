@@ -208,6 +208,26 @@ int sv_assign_targets_axis_aligned(const float* anchors, int64_t num_anchors, in
                                    const float* unmatched_thr, const float* gt_boxes, int batch, int max_gt, float* gt_max_scratch,
                                    int32_t* labels, float* reg_targets, float* reg_weights, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Hard voxelisation + pillar features (PointPillars path)
+ * ---------------------------------------------------------------------------------------------- */
+/* spconv VoxelGenerator(V2) / Point2VoxelCPU3d semantics as called by DataProcessor.transform_points_to_voxels
+ * (detector3d/pcdet/datasets/processor/data_processor.py:15-60,115-143): first-come points per voxel (<= max_points),
+ * voxels numbered in order of first appearance (<= max_voxels).  One workgroup per scene.
+ * points rows of point_stride floats, x at column xyz_offset, num_features columns copied from there;
+ * scenes given by device arrays scene_start/scene_cnt.  Outputs per scene: voxels (B,max_voxels,max_points,C) zero-padded,
+ * coords (B,max_voxels,3) [z,y,x], num_points_per_voxel (B,max_voxels), num_voxels (B). */
+size_t sv_voxelize_hard_scratch_bytes(int batch, int64_t total_points, int max_scene_points);
+int sv_voxelize_hard(const float* points, int point_stride, int xyz_offset, int num_features, const int32_t* scene_start,
+                     const int32_t* scene_cnt, int batch, int64_t total_points, int max_scene_points,
+                     const float* pc_range_host, const float* voxel_size_host, const int32_t* grid_size_host, int max_points,
+                     int max_voxels, void* scratch, float* voxels, int32_t* coords, int32_t* num_points_per_voxel,
+                     int32_t* num_voxels, void* stream);
+/* PillarVFE.forward feature decoration (backbones_3d/vfe/pillar_vfe.py:94-118): (V,mp,C) -> (V,mp,C+6[+1]) */
+int sv_pillar_decorate(const float* voxels, const int32_t* num_points, const int32_t* coords, int64_t num_voxels, int max_points,
+                       int num_features, const float* voxel_size_host, const float* pc_range_host, int use_absolute_xyz,
+                       int with_distance, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

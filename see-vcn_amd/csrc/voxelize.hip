@@ -195,3 +195,251 @@ extern "C" int sv_mean_vfe(const float* voxels, const int32_t* num_points, int64
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Hard voxelisation (first-come semantics of spconv's VoxelGenerator / Point2VoxelCPU3d as called by
+// DataProcessor.transform_points_to_voxels, detector3d/pcdet/datasets/processor/data_processor.py:15-60,115-143):
+//   walk the points in order; a point whose cell is new opens the next voxel unless max_voxels are open (then it is
+//   dropped); a point is stored in its voxel's next slot unless the voxel already holds max_points points.
+// The reference runs this on the CPU inside dataloader workers.  Here: one workgroup per scene, everything in one launch —
+//   (1) cells go into an open-addressing hash table (64-bit key, CAS) with atomicMin of the first point index,
+//   (2) a point is "first" iff it owns its cell's minimum; an in-order block scan of the first-flags numbers the voxels
+//       in order of first appearance (no sort),
+//   (3) slots inside a voxel are handed out in rounds: round t gives slot t to the smallest unassigned point index of
+//       every cell (atomicMin), which reproduces the sequential order exactly.
+// Algorithmic bytes: 4*(1+C)*P read + (4*mp*C + 12 + 4)*V written.
+// ------------------------------------------------------------------------------------------------
+constexpr int HV_THREADS = 1024;
+constexpr unsigned long long HV_EMPTY = 0xFFFFFFFFFFFFFFFFull;
+
+struct HardVoxArgs {
+  const float* points;            // (sum P, stride) rows [x,y,z,...] (no batch column) or with batch column skipped by `xyz_offset`
+  const int32_t* scene_start;     // (B) first row of each scene
+  const int32_t* scene_cnt;       // (B)
+  int stride, xyz_offset, C;      // floats per row; column of x; features copied = columns xyz_offset .. xyz_offset+C-1
+  VoxGeom g;
+  int max_points, max_voxels;
+  unsigned long long* tab_key;    // (B, tab_size)
+  int32_t* tab_first;             // (B, tab_size)
+  int32_t* tab_vid;               // (B, tab_size)
+  int32_t* tab_cur;               // (B, tab_size)
+  int32_t* pt_slot;               // (sum P) table slot of each point or -1
+  int tab_size;                   // power of two >= 2 * max scene size
+  float* voxels;                  // (B, max_voxels, max_points, C)
+  int32_t* coords;                // (B, max_voxels, 3) [z,y,x]
+  int32_t* num_points;            // (B, max_voxels)
+  int32_t* num_voxels;            // (B)
+};
+
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* total, int* wsum /* [16] */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < HV_THREADS / 64; ++i) {
+    const int s = wsum[i];
+    if (i < wid) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+// table words are updated by atomics that execute in L2: read them past the vector L1 (a plain load may hit a stale line)
+__device__ __forceinline__ int32_t ld_l2(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(HV_THREADS) void k_voxelize_hard(HardVoxArgs a) {
+  __shared__ int wsum[HV_THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int p0 = a.scene_start[b], n = a.scene_cnt[b];
+  unsigned long long* tkey = a.tab_key + (int64_t)b * a.tab_size;
+  int32_t* tfirst = a.tab_first + (int64_t)b * a.tab_size;
+  int32_t* tvid = a.tab_vid + (int64_t)b * a.tab_size;
+  int32_t* tcur = a.tab_cur + (int64_t)b * a.tab_size;
+  float* vox = a.voxels + (int64_t)b * a.max_voxels * a.max_points * a.C;
+  int32_t* crd = a.coords + (int64_t)b * a.max_voxels * 3;
+  int32_t* npt = a.num_points + (int64_t)b * a.max_voxels;
+  const unsigned int tmask = (unsigned int)a.tab_size - 1u;
+
+  for (int s = tid; s < a.tab_size; s += HV_THREADS) { tkey[s] = HV_EMPTY; tfirst[s] = 0x7FFFFFFF; tvid[s] = -1; tcur[s] = 0x7FFFFFFF; }
+  for (int64_t e = tid; e < (int64_t)a.max_voxels * a.max_points * a.C; e += HV_THREADS) vox[e] = 0.f;
+  for (int e = tid; e < a.max_voxels; e += HV_THREADS) { npt[e] = 0; crd[e * 3] = 0; crd[e * 3 + 1] = 0; crd[e * 3 + 2] = 0; }
+  __syncthreads();
+
+  // (1) insert cells, remember each cell's first point
+  for (int i = tid; i < n; i += HV_THREADS) {
+    const float* p = a.points + (int64_t)(p0 + i) * a.stride + a.xyz_offset;
+    const float fx = floorf(__fdiv_rn(__fsub_rn(p[0], a.g.lo[0]), a.g.vs[0]));
+    const float fy = floorf(__fdiv_rn(__fsub_rn(p[1], a.g.lo[1]), a.g.vs[1]));
+    const float fz = floorf(__fdiv_rn(__fsub_rn(p[2], a.g.lo[2]), a.g.vs[2]));
+    int slot = -1;
+    if (fx >= 0.f && fx < (float)a.g.grid[0] && fy >= 0.f && fy < (float)a.g.grid[1] && fz >= 0.f && fz < (float)a.g.grid[2]) {
+      const unsigned long long key = ((unsigned long long)(int)fz * a.g.grid[1] + (int)fy) * a.g.grid[0] + (int)fx;
+      unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 40) & tmask;
+      while (true) {
+        const unsigned long long prev = atomicCAS(&tkey[h], HV_EMPTY, key);
+        if (prev == HV_EMPTY || prev == key) break;
+        h = (h + 1) & tmask;
+      }
+      slot = (int)h;
+      atomicMin(&tfirst[slot], i);
+    }
+    a.pt_slot[p0 + i] = slot;
+  }
+  __syncthreads();
+  // (2) number the voxels in order of first appearance: in-order scan of the "first point of its cell" flags
+  const int per = (n + HV_THREADS - 1) / HV_THREADS;
+  const int lo = min(tid * per, n), hi = min(lo + per, n);
+  int mine = 0;
+  for (int i = lo; i < hi; ++i) {
+    const int s = a.pt_slot[p0 + i];
+    mine += (s >= 0 && ld_l2(&tfirst[s]) == i) ? 1 : 0;
+  }
+  int total;
+  int vid = block_excl_scan_1024(mine, &total, wsum);
+  for (int i = lo; i < hi; ++i) {
+    const int s = a.pt_slot[p0 + i];
+    if (s >= 0 && ld_l2(&tfirst[s]) == i) {
+      if (vid < a.max_voxels) {
+        tvid[s] = vid;
+        const unsigned long long key = tkey[s];
+        crd[vid * 3 + 2] = (int)(key % a.g.grid[0]);
+        crd[vid * 3 + 1] = (int)((key / a.g.grid[0]) % a.g.grid[1]);
+        crd[vid * 3 + 0] = (int)(key / ((unsigned long long)a.g.grid[0] * a.g.grid[1]));
+      }
+      ++vid;
+    }
+  }
+  if (tid == 0) a.num_voxels[b] = min(total, a.max_voxels);
+  __syncthreads();
+  // (3) slots: round t hands slot t to the smallest unassigned point of every open voxel
+  for (int i = tid; i < n; i += HV_THREADS) {          // drop points without an open voxel
+    const int s = a.pt_slot[p0 + i];
+    if (s >= 0 && ld_l2(&tvid[s]) < 0) a.pt_slot[p0 + i] = -1;
+  }
+  __syncthreads();
+  for (int t = 0; t < a.max_points; ++t) {
+    int pending = 0;
+    for (int i = tid; i < n; i += HV_THREADS) {
+      const int s = a.pt_slot[p0 + i];
+      if (s >= 0) { atomicMin(&tcur[s], i); pending = 1; }
+    }
+    if (!__syncthreads_or(pending)) break;
+    for (int i = tid; i < n; i += HV_THREADS) {
+      const int s = a.pt_slot[p0 + i];
+      if (s >= 0 && ld_l2(&tcur[s]) == i) {
+        const int v = ld_l2(&tvid[s]);
+        const float* p = a.points + (int64_t)(p0 + i) * a.stride + a.xyz_offset;
+        float* dst = vox + ((int64_t)v * a.max_points + t) * a.C;
+        for (int c = 0; c < a.C; ++c) dst[c] = p[c];
+        npt[v] = t + 1;
+        a.pt_slot[p0 + i] = -1;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += HV_THREADS) {        // re-arm the per-cell minimum for the next round
+      const int s = a.pt_slot[p0 + i];
+      if (s >= 0) tcur[s] = 0x7FFFFFFF;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" size_t sv_voxelize_hard_scratch_bytes(int batch, int64_t total_points, int max_scene_points) {
+  int64_t tab = 64;
+  while (tab < 2ll * max_scene_points) tab <<= 1;
+  return (size_t)batch * tab * (8 + 4 + 4 + 4) + (size_t)(total_points > 0 ? total_points : 1) * 4 + 256;
+}
+
+extern "C" int sv_voxelize_hard(const float* points, int point_stride, int xyz_offset, int num_features, const int32_t* scene_start,
+                                const int32_t* scene_cnt, int batch, int64_t total_points, int max_scene_points,
+                                const float* pc_range_host, const float* voxel_size_host, const int32_t* grid_size_host, int max_points,
+                                int max_voxels, void* scratch, float* voxels, int32_t* coords, int32_t* num_points_per_voxel,
+                                int32_t* num_voxels, void* stream) {
+  SV_CHECK_ARG(batch >= 0 && max_points >= 1 && max_voxels >= 1 && num_features >= 3 && xyz_offset >= 0 &&
+                   xyz_offset + num_features <= point_stride, "voxelize_hard: bad arguments");
+  if (batch == 0) return SV_OK;
+  SV_CHECK_ARG(scene_start && scene_cnt && scratch && voxels && coords && num_points_per_voxel && num_voxels && (total_points == 0 || points),
+               "voxelize_hard: null pointer");
+  HardVoxArgs a;
+  a.points = points; a.scene_start = scene_start; a.scene_cnt = scene_cnt;
+  a.stride = point_stride; a.xyz_offset = xyz_offset; a.C = num_features;
+  for (int i = 0; i < 3; ++i) {
+    a.g.lo[i] = pc_range_host[i]; a.g.vs[i] = voxel_size_host[i]; a.g.grid[i] = grid_size_host[i];
+    SV_CHECK_ARG(a.g.grid[i] > 0 && a.g.vs[i] > 0.f, "voxelize_hard: bad grid/voxel size");
+  }
+  a.g.batch = batch;
+  a.max_points = max_points; a.max_voxels = max_voxels;
+  int64_t tab = 64;
+  while (tab < 2ll * max_scene_points) tab <<= 1;
+  a.tab_size = (int)tab;
+  char* s = reinterpret_cast<char*>(scratch);
+  a.tab_key = reinterpret_cast<unsigned long long*>(s); s += (size_t)batch * tab * 8;
+  a.tab_first = reinterpret_cast<int32_t*>(s); s += (size_t)batch * tab * 4;
+  a.tab_vid = reinterpret_cast<int32_t*>(s); s += (size_t)batch * tab * 4;
+  a.tab_cur = reinterpret_cast<int32_t*>(s); s += (size_t)batch * tab * 4;
+  a.pt_slot = reinterpret_cast<int32_t*>(s);
+  a.voxels = voxels; a.coords = coords; a.num_points = num_points_per_voxel; a.num_voxels = num_voxels;
+  hipLaunchKernelGGL(k_voxelize_hard, dim3(batch), dim3(HV_THREADS), 0, sv_stream(stream), a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PillarVFE feature decoration (backbones_3d/vfe/pillar_vfe.py:94-118): per point of a pillar
+//   [raw C, xyz - mean(xyz of the pillar's points), xyz - pillar centre] (+ optional range), padded slots zeroed.
+// voxels (V, mp, C), num_points (V), coords (V,4) [b,z,y,x] -> out (V, mp, C+6(+1))
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pillar_decorate(const float* __restrict__ voxels, const int32_t* __restrict__ nump,
+                                                         const int32_t* __restrict__ coords, int64_t V, int mp, int C, float vx, float vy, float vz,
+                                                         float ox, float oy, float oz, int use_abs_xyz, int with_distance, float* __restrict__ out) {
+  const int Cin = use_abs_xyz ? C : C - 3;
+  const int Co = Cin + 6 + (with_distance ? 1 : 0);
+  const int64_t total = V * mp;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = e / mp;
+    const int s = (int)(e - v * mp);
+    const float* base = voxels + v * mp * C;
+    const int np = nump[v];
+    float mx = 0.f, my = 0.f, mz = 0.f;
+    for (int k = 0; k < mp; ++k) { mx += base[k * C]; my += base[k * C + 1]; mz += base[k * C + 2]; }   // sum over ALL slots (:97)
+    const float fn = (float)np;
+    mx = __fdiv_rn(mx, fn); my = __fdiv_rn(my, fn); mz = __fdiv_rn(mz, fn);
+    const float* p = base + s * C;
+    const float m = s < np ? 1.f : 0.f;
+    float* o = out + e * Co;
+    int w = 0;
+    for (int c = use_abs_xyz ? 0 : 3; c < C; ++c) o[w++] = p[c] * m;
+    o[w++] = (p[0] - mx) * m; o[w++] = (p[1] - my) * m; o[w++] = (p[2] - mz) * m;
+    const int4 cd = reinterpret_cast<const int4*>(coords)[v];
+    o[w++] = (p[0] - ((float)cd.w * vx + ox)) * m;
+    o[w++] = (p[1] - ((float)cd.z * vy + oy)) * m;
+    o[w++] = (p[2] - ((float)cd.y * vz + oz)) * m;
+    if (with_distance) o[w++] = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) * m;
+  }
+}
+
+extern "C" int sv_pillar_decorate(const float* voxels, const int32_t* num_points, const int32_t* coords, int64_t num_voxels, int max_points,
+                                  int num_features, const float* voxel_size_host, const float* pc_range_host, int use_absolute_xyz,
+                                  int with_distance, float* out, void* stream) {
+  SV_CHECK_ARG(num_voxels >= 0 && max_points >= 1 && num_features >= 3, "pillar_decorate: bad arguments");
+  if (num_voxels == 0) return SV_OK;
+  SV_CHECK_ARG(voxels && num_points && coords && out, "pillar_decorate: null pointer");
+  const float vx = voxel_size_host[0], vy = voxel_size_host[1], vz = voxel_size_host[2];
+  // offsets are computed in double by the reference's python (voxel/2 + range) and used as python floats
+  const float ox = (float)((double)vx / 2 + pc_range_host[0]), oy = (float)((double)vy / 2 + pc_range_host[1]),
+              oz = (float)((double)vz / 2 + pc_range_host[2]);
+  hipLaunchKernelGGL(k_pillar_decorate, dim3(sv_grid_1d(num_voxels * max_points, 256)), dim3(256), 0, sv_stream(stream), voxels, num_points,
+                     coords, num_voxels, max_points, num_features, vx, vy, vz, ox, oy, oz, use_absolute_xyz, with_distance, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

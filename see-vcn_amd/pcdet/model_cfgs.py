@@ -46,3 +46,11 @@ class SyntheticDatasetInfo:
         self.grid_size = np.round((self.point_cloud_range[3:6] - self.point_cloud_range[0:3]) / np.array(voxel_size)).astype(np.int64)
         self.point_feature_encoder = SimpleNamespace(num_point_features=num_point_features)
         self.depth_downsample_factor = None
+
+# detector3d/tools/cfgs/kitti_models/pointpillar.yaml:5-60 (values as data)
+PP_RANGE = [0, -39.68, -3, 69.12, 39.68, 1]
+PP_VOXEL = dict(VOXEL_SIZE=[0.16, 0.16, 4], MAX_POINTS_PER_VOXEL=32, MAX_NUMBER_OF_VOXELS={'train': 16000, 'test': 40000})
+PP_VFE = dict(NAME='PillarVFE', WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, USE_NORM=True, NUM_FILTERS=[64])
+PP_MAP_TO_BEV = dict(NAME='PointPillarScatter', NUM_BEV_FEATURES=64)
+PP_BACKBONE_2D = dict(NAME='BaseBEVBackbone', LAYER_NUMS=[3, 5, 5], LAYER_STRIDES=[2, 2, 2], NUM_FILTERS=[64, 128, 256],
+                      UPSAMPLE_STRIDES=[1, 2, 4], NUM_UPSAMPLE_FILTERS=[128, 128, 128])

@@ -1,10 +1,12 @@
 from .dynamic_mean_vfe import DynamicMeanVFE
 from .mean_vfe import MeanVFE
+from .pillar_vfe import PillarVFE
 from .vfe_template import VFETemplate
 
 # same registry shape as the reference (backbones_3d/vfe/__init__.py:8-15): name -> class
 __all__ = {
     'VFETemplate': VFETemplate,
     'MeanVFE': MeanVFE,
+    'PillarVFE': PillarVFE,
     'DynMeanVFE': DynamicMeanVFE,
 }
