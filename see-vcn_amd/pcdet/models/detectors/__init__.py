@@ -1,10 +1,12 @@
 from .detector3d_template import Detector3DTemplate
+from .pointpillar import PointPillar
 from .second_net import SECONDNet
 
 # same registry shape as the reference (detectors/__init__.py:13-26)
 __all__ = {
     'Detector3DTemplate': Detector3DTemplate,
     'SECONDNet': SECONDNet,
+    'PointPillar': PointPillar,
 }
 
 

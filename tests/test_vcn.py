@@ -135,3 +135,35 @@ def test_hip_vcn_vc_batch64_vs_oracle_and_batch_invariance(cuda, hip_lib):
     # padded zero objects (VCN.inference pads chunks with zeros, models/VCN.py:55-59) must not produce NaN
     z = m({"input": torch.zeros(2, 1024, 3, device=cuda)})
     assert torch.isfinite(z["coarse"]).all()
+
+
+def test_resample_points_contract():
+    from seevcn_amd.vcn.datasets.data_transforms import ResamplePoints
+    pts = np.arange(90, dtype=np.float64).reshape(30, 3)
+    np.random.seed(0)
+    out = ResamplePoints({"n_points": 1024})(pts)
+    np.random.seed(0)
+    ref = np.tile(pts, (35, 1))[np.random.permutation(1050)[:1024]]          # data_transforms.py:254-262
+    assert out.shape == (1024, 3) and np.array_equal(out, ref)
+    big = np.random.default_rng(0).normal(size=(5000, 3))
+    assert ResamplePoints({"n_points": 1024})(big).shape == (1024, 3)
+
+
+@pytest.mark.gpu
+def test_hip_vcn_inference_wrapper_chunking(cuda, hip_lib):
+    """VCN.inference: resample -> pad to BATCH_SIZE_LIMIT -> chunks -> first num_objs rows (models/VCN.py:43-83)."""
+    import seevcn_amd.synth as synth
+    from seevcn_amd.vcn.VCN import VCN
+    V = _models()
+    sd = seeded_state_dict(V.MODELS.build({"NAME": "VCN_VC"}), seed=0)
+    vcn = VCN({"MODEL": "VCN_VC", "NORM_WITH_GT": False, "SEL_K_NEAREST": 20, "CLUSTER_EPS": 0.3, "BATCH_SIZE_LIMIT": 4}, 0,
+              state_dict={"module." + k: v for k, v in sd.items()})
+    objs = [synth.make_object(np.random.default_rng(1000 + i))[0] for i in range(6)]
+    np.random.seed(3)
+    out = vcn.inference(objs, batch_size_limit=4)
+    assert out["input"].shape == (6, 1024, 3) and out["coarse"].shape == (6, 1024, 3)
+    ref = ovcn.vcn_vc_forward(sd, torch.from_numpy(out["input"]))["coarse"].numpy()
+    assert _rel_err(out["coarse"], ref) < RTOL
+    np.random.seed(3)
+    single = vcn.inference(objs[0])
+    assert np.array_equal(single["input"][0], out["input"][0]) and _rel_err(single["coarse"][0], ref[0]) < RTOL
