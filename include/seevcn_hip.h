@@ -228,6 +228,13 @@ int sv_pillar_decorate(const float* voxels, const int32_t* num_points, const int
                        int num_features, const float* voxel_size_host, const float* pc_range_host, int use_absolute_xyz,
                        int with_distance, float* out, void* stream);
 
+/* interpolate_from_bev_features (detector3d/pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py:11-42,176-204):
+ * keypoints (M,4) [b,x,y,z], bev (B,C,H,W) -> out (M,C); the gradient scatter-adds into grad_bev (zero-filled here). */
+int sv_bev_interpolate(const float* keypoints, int64_t num_keypoints, const float* bev, int batch, int C, int H, int W, float x_min,
+                       float y_min, float voxel_x, float voxel_y, float bev_stride, float* out, void* stream);
+int sv_bev_interpolate_grad(const float* keypoints, int64_t num_keypoints, const float* grad_out, int batch, int C, int H, int W,
+                            float x_min, float y_min, float voxel_x, float voxel_y, float bev_stride, float* grad_bev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

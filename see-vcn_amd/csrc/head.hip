@@ -200,3 +200,87 @@ extern "C" int sv_assign_targets_axis_aligned(const float* anchors, int64_t num_
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear interpolation of BEV features at keypoints (interpolate_from_bev_features + bilinear_interpolate_torch,
+// detector3d/pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py:11-42,176-204).  The reference permutes every scene's
+// (C,H,W) map to (H,W,C) (a full copy) and gathers with advanced indexing in a python loop over the batch; here one launch
+// reads the NCHW map in place.  keypoints (M,4) [b,x,y,z] -> out (M,C).
+// ------------------------------------------------------------------------------------------------
+struct BevGeom { float x0, y0, vx, vy, stride; int B, C, H, W; };
+
+__device__ __forceinline__ void bev_taps(const float* kp, const BevGeom& g, int& b, int& x0, int& x1, int& y0, int& y1, float& wa, float& wb,
+                                         float& wc, float& wd) {
+  b = (int)kp[0];
+  const float x = ((kp[1] - g.x0) / g.vx) / g.stride, y = ((kp[2] - g.y0) / g.vy) / g.stride;
+  const int fx0 = (int)floorf(x), fy0 = (int)floorf(y);
+  x0 = min(max(fx0, 0), g.W - 1); x1 = min(max(fx0 + 1, 0), g.W - 1);
+  y0 = min(max(fy0, 0), g.H - 1); y1 = min(max(fy0 + 1, 0), g.H - 1);
+  wa = ((float)x1 - x) * ((float)y1 - y);      // weights use the CLAMPED corners, like the reference (:36-39)
+  wb = ((float)x1 - x) * (y - (float)y0);
+  wc = (x - (float)x0) * ((float)y1 - y);
+  wd = (x - (float)x0) * (y - (float)y0);
+}
+
+__global__ __launch_bounds__(256) void k_bev_interp(const float* __restrict__ kps, int64_t M, const float* __restrict__ bev, BevGeom g,
+                                                    float* __restrict__ out) {
+  const int64_t total = M * g.C;
+  const int64_t hw = (int64_t)g.H * g.W;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = e / g.C;
+    const int c = (int)(e - m * g.C);
+    int b, x0, x1, y0, y1; float wa, wb, wc, wd;
+    bev_taps(kps + m * 4, g, b, x0, x1, y0, y1, wa, wb, wc, wd);
+    float v = 0.f;
+    if (b >= 0 && b < g.B) {
+      const float* p = bev + ((int64_t)b * g.C + c) * hw;
+      v = p[(int64_t)y0 * g.W + x0] * wa + p[(int64_t)y1 * g.W + x0] * wb + p[(int64_t)y0 * g.W + x1] * wc + p[(int64_t)y1 * g.W + x1] * wd;
+    }
+    out[e] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bev_interp_grad(const float* __restrict__ kps, int64_t M, const float* __restrict__ gout, BevGeom g,
+                                                         float* __restrict__ gbev) {
+  const int64_t total = M * g.C;
+  const int64_t hw = (int64_t)g.H * g.W;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = e / g.C;
+    const int c = (int)(e - m * g.C);
+    int b, x0, x1, y0, y1; float wa, wb, wc, wd;
+    bev_taps(kps + m * 4, g, b, x0, x1, y0, y1, wa, wb, wc, wd);
+    if (b < 0 || b >= g.B) continue;
+    float* p = gbev + ((int64_t)b * g.C + c) * hw;
+    const float go = gout[e];
+    atomicAdd(&p[(int64_t)y0 * g.W + x0], go * wa);
+    atomicAdd(&p[(int64_t)y1 * g.W + x0], go * wb);
+    atomicAdd(&p[(int64_t)y0 * g.W + x1], go * wc);
+    atomicAdd(&p[(int64_t)y1 * g.W + x1], go * wd);
+  }
+}
+
+extern "C" int sv_bev_interpolate(const float* keypoints, int64_t num_keypoints, const float* bev, int batch, int C, int H, int W, float x_min,
+                                  float y_min, float voxel_x, float voxel_y, float bev_stride, float* out, void* stream) {
+  SV_CHECK_ARG(num_keypoints >= 0 && batch > 0 && C > 0 && H > 0 && W > 0, "bev_interpolate: bad arguments");
+  if (num_keypoints == 0) return SV_OK;
+  SV_CHECK_ARG(keypoints && bev && out, "bev_interpolate: null pointer");
+  BevGeom g{x_min, y_min, voxel_x, voxel_y, bev_stride, batch, C, H, W};
+  hipLaunchKernelGGL(k_bev_interp, dim3(sv_grid_1d(num_keypoints * C, 256, 256 * 16)), dim3(256), 0, sv_stream(stream), keypoints, num_keypoints,
+                     bev, g, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_bev_interpolate_grad(const float* keypoints, int64_t num_keypoints, const float* grad_out, int batch, int C, int H, int W,
+                                       float x_min, float y_min, float voxel_x, float voxel_y, float bev_stride, float* grad_bev, void* stream) {
+  SV_CHECK_ARG(num_keypoints >= 0 && batch > 0 && C > 0 && H > 0 && W > 0 && grad_bev, "bev_interpolate_grad: bad arguments");
+  hipStream_t st = sv_stream(stream);
+  SV_HIP(hipMemsetAsync(grad_bev, 0, (size_t)batch * C * H * W * 4, st));
+  if (num_keypoints == 0) return SV_OK;
+  SV_CHECK_ARG(keypoints && grad_out, "bev_interpolate_grad: null pointer");
+  BevGeom g{x_min, y_min, voxel_x, voxel_y, bev_stride, batch, C, H, W};
+  hipLaunchKernelGGL(k_bev_interp_grad, dim3(sv_grid_1d(num_keypoints * C, 256, 256 * 16)), dim3(256), 0, st, keypoints, num_keypoints, grad_out, g,
+                     grad_bev);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -54,3 +54,42 @@ PP_VFE = dict(NAME='PillarVFE', WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, USE_N
 PP_MAP_TO_BEV = dict(NAME='PointPillarScatter', NUM_BEV_FEATURES=64)
 PP_BACKBONE_2D = dict(NAME='BaseBEVBackbone', LAYER_NUMS=[3, 5, 5], LAYER_STRIDES=[2, 2, 2], NUM_FILTERS=[64, 128, 256],
                       UPSAMPLE_STRIDES=[1, 2, 4], NUM_UPSAMPLE_FILTERS=[128, 128, 128])
+
+
+def _sa(mlps, radii, nsample, factor=None):
+    d = dict(MLPS=[list(m) for m in mlps], POOL_RADIUS=list(radii), NSAMPLE=list(nsample))
+    if factor is not None:
+        d['DOWNSAMPLE_FACTOR'] = factor
+    return d
+
+
+def pvrcnn_cfg(num_keypoints=2048, features_source=('bev', 'x_conv1', 'x_conv2', 'x_conv3', 'x_conv4', 'raw_points'), roi_per_image=128,
+               nms_post_train=512, nms_pre_train=9000, dp_ratio=0.3):
+    """PFE / POINT_HEAD / ROI_HEAD sections of detector3d/tools/cfgs/kitti_models/pv_rcnn.yaml:113-219 (values as data)."""
+    pfe = dict(NAME='VoxelSetAbstraction', POINT_SOURCE='raw_points', NUM_KEYPOINTS=num_keypoints, NUM_OUTPUT_FEATURES=128, SAMPLE_METHOD='FPS',
+               FEATURES_SOURCE=list(features_source),
+               SA_LAYER=dict(raw_points=_sa([[16, 16], [16, 16]], [0.4, 0.8], [16, 16]),
+                             x_conv1=_sa([[16, 16], [16, 16]], [0.4, 0.8], [16, 16], 1),
+                             x_conv2=_sa([[32, 32], [32, 32]], [0.8, 1.2], [16, 32], 2),
+                             x_conv3=_sa([[64, 64], [64, 64]], [1.2, 2.4], [16, 32], 4),
+                             x_conv4=_sa([[64, 64], [64, 64]], [2.4, 4.8], [16, 32], 8)))
+    point_head = dict(NAME='PointHeadSimple', CLS_FC=[256, 256], CLASS_AGNOSTIC=True, USE_POINT_FEATURES_BEFORE_FUSION=True,
+                      TARGET_CONFIG=dict(GT_EXTRA_WIDTH=[0.2, 0.2, 0.2]), LOSS_CONFIG=dict(LOSS_REG='smooth-l1', LOSS_WEIGHTS=dict(point_cls_weight=1.0)))
+    roi_head = dict(
+        NAME='PVRCNNHead', CLASS_AGNOSTIC=True, SHARED_FC=[256, 256], CLS_FC=[256, 256], REG_FC=[256, 256], DP_RATIO=dp_ratio,
+        NMS_CONFIG=dict(TRAIN=dict(NMS_TYPE='nms_gpu', MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=nms_pre_train, NMS_POST_MAXSIZE=nms_post_train, NMS_THRESH=0.8),
+                        TEST=dict(NMS_TYPE='nms_gpu', MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=1024, NMS_POST_MAXSIZE=100, NMS_THRESH=0.7)),
+        ROI_GRID_POOL=dict(GRID_SIZE=6, MLPS=[[64, 64], [64, 64]], POOL_RADIUS=[0.8, 1.6], NSAMPLE=[16, 16], POOL_METHOD='max_pool'),
+        TARGET_CONFIG=dict(BOX_CODER='ResidualCoder', ROI_PER_IMAGE=roi_per_image, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True, CLS_SCORE_TYPE='roi_iou',
+                           CLS_FG_THRESH=0.75, CLS_BG_THRESH=0.25, CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8, REG_FG_THRESH=0.55),
+        LOSS_CONFIG=dict(CLS_LOSS='BinaryCrossEntropy', REG_LOSS='smooth-l1', CORNER_LOSS_REGULARIZATION=True,
+                         LOSS_WEIGHTS=dict(rcnn_cls_weight=1.0, rcnn_reg_weight=1.0, rcnn_corner_weight=1.0, code_weights=[1.0] * 7)))
+    return pfe, point_head, roi_head
+
+
+def pvrcnn_model_cfg(**kw):
+    pfe, point_head, roi_head = pvrcnn_cfg(**kw)
+    pp = dict(SECOND_POST_PROCESSING, NMS_CONFIG=dict(SECOND_POST_PROCESSING['NMS_CONFIG'], NMS_THRESH=0.1))
+    return dict(NAME='PVRCNN', VFE=dict(NAME='DynMeanVFE'), BACKBONE_3D=dict(NAME='VoxelBackBone8x'),
+                MAP_TO_BEV=dict(NAME='HeightCompression', NUM_BEV_FEATURES=256), BACKBONE_2D=SECOND_BACKBONE_2D, DENSE_HEAD=SECOND_DENSE_HEAD,
+                PFE=pfe, POINT_HEAD=point_head, ROI_HEAD=roi_head, POST_PROCESSING=pp)

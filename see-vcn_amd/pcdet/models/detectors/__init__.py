@@ -1,5 +1,6 @@
 from .detector3d_template import Detector3DTemplate
 from .pointpillar import PointPillar
+from .pv_rcnn import PVRCNN
 from .second_net import SECONDNet
 
 # same registry shape as the reference (detectors/__init__.py:13-26)
@@ -7,6 +8,7 @@ __all__ = {
     'Detector3DTemplate': Detector3DTemplate,
     'SECONDNet': SECONDNet,
     'PointPillar': PointPillar,
+    'PVRCNN': PVRCNN,
 }
 
 

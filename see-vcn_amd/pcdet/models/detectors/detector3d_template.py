@@ -1,9 +1,9 @@
 import torch
 import torch.nn as nn
 
-from .. import backbones_2d, backbones_3d, dense_heads
+from .. import backbones_2d, backbones_3d, dense_heads, roi_heads
 from ..backbones_2d import map_to_bev
-from ..backbones_3d import vfe
+from ..backbones_3d import pfe, vfe
 from ..model_utils import model_nms_utils
 from ...ops.iou3d_nms import iou3d_nms_utils
 from ...utils.common_utils import cfg_get
@@ -99,19 +99,42 @@ class Detector3DTemplate(nn.Module):
         model_info_dict['module_list'].append(m)
         return m, model_info_dict
 
-    def _absent(self, section, model_info_dict):
-        if cfg_get(self.model_cfg, section, None) is not None:
-            raise NotImplementedError(f"{section} modules are not built yet (SURVEY.md §8a rows D14-D22)")
-        return None, model_info_dict
-
     def build_pfe(self, model_info_dict):
-        return self._absent('PFE', model_info_dict)
+        cfg = cfg_get(self.model_cfg, 'PFE', None)
+        if cfg is None:
+            return None, model_info_dict
+        m = pfe.__all__[cfg_get(cfg, 'NAME')](
+            model_cfg=cfg, voxel_size=model_info_dict['voxel_size'], point_cloud_range=model_info_dict['point_cloud_range'],
+            num_bev_features=model_info_dict['num_bev_features'], num_rawpoint_features=model_info_dict['num_rawpoint_features'])
+        model_info_dict['module_list'].append(m)
+        model_info_dict['num_point_features'] = m.num_point_features
+        model_info_dict['num_point_features_before_fusion'] = m.num_point_features_before_fusion
+        return m, model_info_dict
 
     def build_point_head(self, model_info_dict):
-        return self._absent('POINT_HEAD', model_info_dict)
+        cfg = cfg_get(self.model_cfg, 'POINT_HEAD', None)
+        if cfg is None:
+            return None, model_info_dict
+        if cfg_get(cfg, 'USE_POINT_FEATURES_BEFORE_FUSION', False):
+            c = model_info_dict['num_point_features_before_fusion']
+        else:
+            c = model_info_dict['num_point_features']
+        m = dense_heads.__all__[cfg_get(cfg, 'NAME')](
+            model_cfg=cfg, input_channels=c, num_class=self.num_class if not cfg_get(cfg, 'CLASS_AGNOSTIC', False) else 1,
+            predict_boxes_when_training=cfg_get(self.model_cfg, 'ROI_HEAD', None) is not None)
+        model_info_dict['module_list'].append(m)
+        return m, model_info_dict
 
     def build_roi_head(self, model_info_dict):
-        return self._absent('ROI_HEAD', model_info_dict)
+        cfg = cfg_get(self.model_cfg, 'ROI_HEAD', None)
+        if cfg is None:
+            return None, model_info_dict
+        m = roi_heads.__all__[cfg_get(cfg, 'NAME')](
+            model_cfg=cfg, input_channels=model_info_dict['num_point_features'], backbone_channels=model_info_dict.get('backbone_channels'),
+            point_cloud_range=model_info_dict['point_cloud_range'], voxel_size=model_info_dict['voxel_size'],
+            num_class=self.num_class if not cfg_get(cfg, 'CLASS_AGNOSTIC', False) else 1)
+        model_info_dict['module_list'].append(m)
+        return m, model_info_dict
 
     def forward(self, **kwargs):
         raise NotImplementedError
@@ -144,7 +167,7 @@ class Detector3DTemplate(nn.Module):
             if cfg_get(pp, 'OUTPUT_RAW_SCORE', False):
                 selected_scores = torch.max(src_cls_preds, dim=-1)[0][selected]
             final_boxes = box_preds[selected]
-            recall_dict = self.generate_recall_record(box_preds=final_boxes, recall_dict=recall_dict, batch_index=index, data_dict=batch_dict,
+            recall_dict = self.generate_recall_record(box_preds=final_boxes if 'rois' not in batch_dict else box_preds, recall_dict=recall_dict, batch_index=index, data_dict=batch_dict,
                                                       thresh_list=cfg_get(pp, 'RECALL_THRESH_LIST'))
             pred_dicts.append({'pred_boxes': final_boxes, 'pred_scores': selected_scores, 'pred_labels': label_preds[selected]})
         return pred_dicts, recall_dict

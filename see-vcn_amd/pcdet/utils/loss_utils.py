@@ -58,3 +58,16 @@ class WeightedCrossEntropyLoss(nn.Module):
 
     def forward(self, input, target, weights):
         return F.cross_entropy(input.permute(0, 2, 1), target.argmax(dim=-1), reduction='none') * weights
+
+
+def get_corner_loss_lidar(pred_bbox3d, gt_bbox3d):
+    """(N,7),(N,7) -> (N,) smooth-L1 (beta 1) corner distance, min over the gt box and its flipped heading (loss_utils.py:209-232)."""
+    from . import box_utils
+    assert pred_bbox3d.shape[0] == gt_bbox3d.shape[0]
+    pred = box_utils.boxes_to_corners_3d(pred_bbox3d)
+    gt = box_utils.boxes_to_corners_3d(gt_bbox3d)
+    gt_flip = gt_bbox3d.clone()
+    gt_flip[:, 6] += np.pi
+    gtf = box_utils.boxes_to_corners_3d(gt_flip)
+    dist = torch.min(torch.norm(pred - gt, dim=2), torch.norm(pred - gtf, dim=2))   # (N, 8)
+    return WeightedSmoothL1Loss.smooth_l1_loss(dist, beta=1.0).mean(dim=1)

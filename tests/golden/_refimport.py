@@ -136,16 +136,80 @@ def import_vcn():
     return importlib.import_module("models.vcn.models")
 
 
+def _install_oracle_ops():
+    """The reference's compiled CUDA extensions cannot run here; the Python layers above them can.  These modules give those
+    layers CPU implementations backed by the ORACLE (oracle/pointnet2.py, oracle/boxes.py) with the extension's own call
+    signatures, so that goldens of the Python-level logic (VoxelSetAbstraction, PointHeadSimple, PVRCNNHead,
+    ProposalTargetLayer, post-processing) can be produced by the reference's own classes.  The kernels themselves are pinned
+    separately (tests/test_pointnet2.py, tests/test_boxes.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import boxes as ob
+    from oracle import pointnet2 as op2
+
+    def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
+        idx.copy_(torch.from_numpy(op2.ball_query(radius, nsample, xyz.numpy(), xyz_batch_cnt.numpy(), new_xyz.numpy(), new_xyz_batch_cnt.numpy())))
+        return 1
+
+    def group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, out):
+        out.copy_(torch.from_numpy(op2.group_points(features.detach().numpy(), features_batch_cnt.numpy(), idx.numpy(), idx_batch_cnt.numpy())))
+        return 1
+
+    def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features):
+        g = op2.group_points_grad(grad_out.numpy(), idx.numpy(), idx_batch_cnt.numpy(), features_batch_cnt.numpy(), N)
+        grad_features.copy_(torch.from_numpy(g.astype(np.float32)))
+        return 1
+
+    def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+        for i in range(b):
+            idx[i] = torch.from_numpy(op2.farthest_point_sampling(points[i].numpy(), m))
+        return 1
+
+    _mod("pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda", ball_query_wrapper=ball_query_wrapper,
+         group_points_wrapper=group_points_wrapper, group_points_grad_wrapper=group_points_grad_wrapper,
+         farthest_point_sampling_wrapper=farthest_point_sampling_wrapper)
+
+    def boxes_overlap_bev_gpu(a, b, out):
+        out.copy_(torch.from_numpy(ob.boxes_overlap_bev(a.numpy(), b.numpy())))
+        return 1
+
+    def boxes_iou_bev_gpu(a, b, out):
+        out.copy_(torch.from_numpy(ob.boxes_iou_bev(a.numpy(), b.numpy())))
+        return 1
+
+    def nms_gpu(boxes, keep, thresh):
+        k = ob.nms(boxes.numpy(), thresh)
+        keep[:len(k)] = torch.from_numpy(k)
+        return len(k)
+
+    def nms_normal_gpu(boxes, keep, thresh):
+        k = ob.nms(boxes.numpy(), thresh, normal=True)
+        keep[:len(k)] = torch.from_numpy(k)
+        return len(k)
+
+    _mod("pcdet.ops.iou3d_nms.iou3d_nms_cuda", boxes_overlap_bev_gpu=boxes_overlap_bev_gpu, boxes_iou_bev_gpu=boxes_iou_bev_gpu, nms_gpu=nms_gpu,
+         nms_normal_gpu=nms_normal_gpu)
+
+    def points_in_boxes_gpu(boxes, pts, out):
+        out.copy_(torch.from_numpy(ob.points_in_boxes(pts.numpy(), boxes.numpy())))
+        return 1
+
+    _mod("pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda", points_in_boxes_gpu=points_in_boxes_gpu)
+    # the reference allocates with the legacy torch.cuda.*Tensor constructors
+    torch.cuda.IntTensor = lambda *a: torch.IntTensor(*a)
+    torch.cuda.FloatTensor = lambda *a: torch.FloatTensor(*a)
+    torch.cuda.LongTensor = lambda *a: torch.LongTensor(*a)
+
+
 def import_pcdet():
     install_stubs()
     root = os.path.join(REF, "detector3d")
     if root not in sys.path:
         sys.path.insert(0, root)
-    for ext in ("pcdet.ops.iou3d_nms.iou3d_nms_cuda", "pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda",
-                "pcdet.ops.roipoint_pool3d.roipoint_pool3d_cuda",
-                "pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda",
-                "pcdet.ops.pointnet2.pointnet2_batch.pointnet2_batch_cuda"):
+    for ext in ("pcdet.ops.roipoint_pool3d.roipoint_pool3d_cuda", "pcdet.ops.pointnet2.pointnet2_batch.pointnet2_batch_cuda"):
         _mod(ext)
+    _install_oracle_ops()
     import importlib
     return importlib.import_module("pcdet")
 
