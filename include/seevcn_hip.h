@@ -235,6 +235,18 @@ int sv_bev_interpolate(const float* keypoints, int64_t num_keypoints, const floa
 int sv_bev_interpolate_grad(const float* keypoints, int64_t num_keypoints, const float* grad_out, int batch, int C, int H, int W,
                             float x_min, float y_min, float voxel_x, float voxel_y, float bev_stride, float* grad_bev, void* stream);
 
+/* CenterHead.assign_targets (detector3d/pcdet/models/dense_heads/center_head.py:103-213; gaussian_radius /
+ * draw_gaussian_to_heatmap, models/model_utils/centernet_utils.py:9-69): all heads and scenes in one launch.
+ * gt_boxes (B,G,box_dim) with the global 1-based class id in the last column (0 = padding); cls_to_local
+ * (num_heads, num_class+1) device table = 1-based class index inside the head or 0.  Outputs: heatmaps (B,total_cls,H,W)
+ * (head h owns channels [head_cls_offset[h], +head_num_class[h])), target_boxes (num_heads,B,num_max_objs,box_dim)
+ * [dx, dy, z, log dims, cos, sin, extras], inds / masks (num_heads,B,num_max_objs) int64. */
+int sv_center_assign_targets(const float* gt_boxes, int batch, int max_gt, int box_dim, int num_heads, int num_class,
+                             const int32_t* cls_to_local, const int32_t* head_num_class, const int32_t* head_cls_offset, int total_cls,
+                             int fm_w, int fm_h, float x_min, float y_min, float voxel_x, float voxel_y, float fm_stride,
+                             int num_max_objs, float gaussian_overlap, int min_radius, float* heatmaps, float* target_boxes,
+                             int64_t* inds, int64_t* masks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,3 +123,82 @@ def assign_targets(anchors, per_set, set_classes, matched, unmatched, gt_boxes):
             targets[b, idx] = t
             weights[b, idx] = (lab > 0).astype(F)                                # :195-201
     return labels, targets, weights
+
+
+# ------------------------------------------------------------------------------------------ CenterHead targets
+def gaussian_radius(h, w, min_overlap=0.5):
+    """CenterNet radius from box size on the feature map (reference model_utils/centernet_utils.py:10-33)."""
+    a1, b1, c1 = 1.0, h + w, w * h * (1 - min_overlap) / (1 + min_overlap)
+    r1 = (b1 + np.sqrt(b1 ** 2 - 4 * a1 * c1)) / 2
+    a2, b2, c2 = 4.0, 2 * (h + w), (1 - min_overlap) * w * h
+    r2 = (b2 + np.sqrt(b2 ** 2 - 4 * a2 * c2)) / 2
+    a3, b3, c3 = 4 * min_overlap, -2 * min_overlap * (h + w), (min_overlap - 1) * w * h
+    r3 = (b3 + np.sqrt(b3 ** 2 - 4 * a3 * c3)) / 2
+    return min(r1, r2, r3)
+
+
+def center_assign_single_head(num_classes, gt_boxes, fm_size, stride, pc_range, voxel_size, num_max_objs=500, gaussian_overlap=0.1, min_radius=2):
+    """One head, one scene (reference dense_heads/center_head.py:112-173 + centernet_utils.py:36-78).
+    gt_boxes (N, 8+) with the head-local 1-based class in the last column; fm_size = (W, H)."""
+    W, H = fm_size
+    D = gt_boxes.shape[1]
+    heat = np.zeros((num_classes, H, W), np.float32)
+    ret = np.zeros((num_max_objs, D - 1 + 1), np.float32)
+    inds = np.zeros(num_max_objs, np.int64)
+    mask = np.zeros(num_max_objs, np.int64)
+    for k in range(min(num_max_objs, len(gt_boxes))):
+        x, y, z, dx, dy = [np.float32(v) for v in gt_boxes[k, :5]]
+        cx = np.float32(np.float32(np.float32(x - np.float32(pc_range[0])) / np.float32(voxel_size[0])) / np.float32(stride))
+        cy = np.float32(np.float32(np.float32(y - np.float32(pc_range[1])) / np.float32(voxel_size[1])) / np.float32(stride))
+        cx = min(max(cx, np.float32(0)), np.float32(W - 0.5))
+        cy = min(max(cy, np.float32(0)), np.float32(H - 0.5))
+        ix, iy = int(cx), int(cy)
+        fdx = np.float32(np.float32(dx / np.float32(voxel_size[0])) / np.float32(stride))
+        fdy = np.float32(np.float32(dy / np.float32(voxel_size[1])) / np.float32(stride))
+        if fdx <= 0 or fdy <= 0:
+            continue
+        if not (0 <= ix <= W and 0 <= iy <= H):
+            continue
+        radius = max(int(np.float32(gaussian_radius(np.float32(fdx), np.float32(fdy), np.float32(gaussian_overlap)))), min_radius)
+        cls = int(gt_boxes[k, -1]) - 1
+        sigma = (2 * radius + 1) / 6
+        left, right, top, bottom = min(ix, radius), min(W - ix, radius + 1), min(iy, radius), min(H - iy, radius + 1)
+        yy, xx = np.ogrid[-radius:radius + 1, -radius:radius + 1]
+        g = np.exp(-(xx * xx + yy * yy) / (2 * sigma * sigma))
+        g[g < np.finfo(g.dtype).eps * g.max()] = 0
+        sub = heat[cls, iy - top:iy + bottom, ix - left:ix + right]
+        gs = g[radius - top:radius + bottom, radius - left:radius + right].astype(np.float32)
+        if min(gs.shape) > 0 and min(sub.shape) > 0:
+            np.maximum(sub, gs, out=sub)
+        inds[k] = iy * W + ix
+        mask[k] = 1
+        ret[k, 0:2] = [cx - np.float32(ix), cy - np.float32(iy)]
+        ret[k, 2] = z
+        ret[k, 3:6] = np.log(gt_boxes[k, 3:6].astype(np.float32))
+        ret[k, 6], ret[k, 7] = np.cos(np.float32(gt_boxes[k, 6])), np.sin(np.float32(gt_boxes[k, 6]))
+        if D > 8:
+            ret[k, 8:] = gt_boxes[k, 7:-1]
+    return heat, ret, inds, mask
+
+
+def center_assign_targets(gt_boxes, class_names, class_names_each_head, fm_size, stride, pc_range, voxel_size, **kw):
+    """All heads / scenes (reference center_head.py:175-231): boxes routed to the head holding their class, original order kept."""
+    names = ['bg'] + list(class_names)
+    out = {'heatmaps': [], 'target_boxes': [], 'inds': [], 'masks': []}
+    for head_names in class_names_each_head:
+        per = [[], [], [], []]
+        for b in range(gt_boxes.shape[0]):
+            rows = []
+            for box in gt_boxes[b]:
+                n = names[int(box[-1])]
+                if n in head_names:
+                    r = box.copy()
+                    r[-1] = head_names.index(n) + 1
+                    rows.append(r)
+            cur = np.stack(rows) if rows else np.zeros((0, gt_boxes.shape[-1]), np.float32)
+            res = center_assign_single_head(len(head_names), cur, fm_size, stride, pc_range, voxel_size, **kw)
+            for lst, r in zip(per, res):
+                lst.append(r)
+        for key, lst in zip(out, per):
+            out[key].append(np.stack(lst))
+    return out

@@ -60,6 +60,8 @@ SIGNATURES = {
     "sv_pillar_decorate": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "sv_bev_interpolate": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
     "sv_bev_interpolate_grad": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
+    "sv_center_assign_targets": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_p, c_p, c_p,
+                                       c_p, c_p]),
     "sv_anchor_decode": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p]),
     "sv_assign_targets_axis_aligned": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
 }

@@ -284,3 +284,122 @@ extern "C" int sv_bev_interpolate_grad(const float* keypoints, int64_t num_keypo
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// CenterHead target assignment (CenterHead.assign_targets / assign_target_of_single_head,
+// detector3d/pcdet/models/dense_heads/center_head.py:103-213 with gaussian_radius / draw_gaussian_to_heatmap,
+// models/model_utils/centernet_utils.py:9-69).  The reference loops over heads x scenes x boxes in python on CPU tensors
+// (`.cpu()` at :204) and copies every map back; here one launch covers all heads and scenes: a workgroup per (head, scene)
+// ranks the head's boxes in order (slot k = k-th box of the head), splats the Gaussians with an order-independent atomic max
+// and writes inds / masks / regression targets.
+// ------------------------------------------------------------------------------------------------
+struct CenterArgs {
+  const float* gt;            // (B, G, box_dim) last column = global class id (1-based), 0 = padding
+  int B, G, box_dim, num_heads, num_class;
+  const int32_t* cls_to_local;  // (num_heads, num_class + 1): local class id (1-based) of a global class in that head or 0
+  const int32_t* head_ncls;     // (num_heads) classes per head
+  const int32_t* head_cls_off;  // (num_heads) first heatmap channel of the head in the concatenated output
+  int total_cls;
+  int W, H;                   // feature map size (x, y)
+  float x0, y0, vx, vy, stride;
+  int num_max_objs, min_radius;
+  float min_overlap;
+  float* heatmap;             // (B, total_cls, H, W)  zero-filled by the launcher
+  float* target_boxes;        // (num_heads, B, num_max_objs, box_dim)    [dx,dy offset, z, log dims(3), cos, sin, extras...]
+  int64_t* inds;              // (num_heads, B, num_max_objs)
+  int64_t* masks;             // (num_heads, B, num_max_objs)
+};
+
+__device__ __forceinline__ float gaussian_radius_f(float height, float width, float min_overlap) {   // centernet_utils.py:9-37
+  const float b1 = height + width;
+  const float c1 = width * height * (1 - min_overlap) / (1 + min_overlap);
+  const float r1 = (b1 + sqrtf(b1 * b1 - 4 * 1 * c1)) / 2;
+  const float b2 = 2 * (height + width);
+  const float c2 = (1 - min_overlap) * width * height;
+  const float r2 = (b2 + sqrtf(b2 * b2 - 4 * 4 * c2)) / 2;
+  const float a3 = 4 * min_overlap, b3 = -2 * min_overlap * (height + width), c3 = (min_overlap - 1) * width * height;
+  const float r3 = (b3 + sqrtf(b3 * b3 - 4 * a3 * c3)) / 2;
+  return fminf(fminf(r1, r2), r3);
+}
+
+__global__ __launch_bounds__(256) void k_center_targets(CenterArgs a) {
+  __shared__ int s_count;
+  __shared__ int wcnt[4];
+  const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int tb_dim = a.box_dim;                       // box_dim - 1 (class) + 1 (heading split into cos, sin)
+  float* tbox = a.target_boxes + ((int64_t)head * a.B + b) * a.num_max_objs * tb_dim;
+  int64_t* inds = a.inds + ((int64_t)head * a.B + b) * a.num_max_objs;
+  int64_t* masks = a.masks + ((int64_t)head * a.B + b) * a.num_max_objs;
+  for (int e = tid; e < a.num_max_objs * tb_dim; e += 256) tbox[e] = 0.f;
+  for (int e = tid; e < a.num_max_objs; e += 256) { inds[e] = 0; masks[e] = 0; }
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+  // rank the head's boxes in their original order: slot k = number of earlier boxes of this head (center_head.py:136)
+  for (int g0 = 0; g0 < a.G; g0 += 256) {
+    const int g = g0 + tid;
+    int local = 0;
+    if (g < a.G) {
+      const int cls = (int)a.gt[((int64_t)b * a.G + g) * a.box_dim + a.box_dim - 1];
+      if (cls >= 1 && cls <= a.num_class) local = a.cls_to_local[head * (a.num_class + 1) + cls];
+    }
+    const unsigned long long m = __ballot(local > 0);
+    if (lane == 0) wcnt[wid] = __popcll(m);
+    __syncthreads();
+    int base = s_count;
+    for (int w = 0; w < wid; ++w) base += wcnt[w];
+    // process this chunk's boxes
+    if (g < a.G && local > 0) {
+      const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (k < a.num_max_objs) {
+        const float* bx = a.gt + ((int64_t)b * a.G + g) * a.box_dim;
+        float cx = (bx[0] - a.x0) / a.vx / a.stride, cy = (bx[1] - a.y0) / a.vy / a.stride;
+        cx = fminf(fmaxf(cx, 0.f), (float)a.W - 0.5f);
+        cy = fminf(fmaxf(cy, 0.f), (float)a.H - 0.5f);
+        const int ix = (int)cx, iy = (int)cy;
+        const float dx = bx[3] / a.vx / a.stride, dy = bx[4] / a.vy / a.stride;
+        if (dx > 0.f && dy > 0.f && ix >= 0 && ix <= a.W && iy >= 0 && iy <= a.H) {
+          int radius = (int)gaussian_radius_f(dx, dy, a.min_overlap);
+          radius = max(radius, a.min_radius);
+          // draw_gaussian_to_heatmap (centernet_utils.py:48-69): sigma = diameter/6, window clipped to the map
+          const double sigma = (double)(2 * radius + 1) / 6.0;
+          const int left = min(ix, radius), right = min(a.W - ix, radius + 1), top = min(iy, radius), bottom = min(a.H - iy, radius + 1);
+          float* hm = a.heatmap + (((int64_t)b * a.total_cls + a.head_cls_off[head] + (local - 1)) * a.H) * a.W;
+          for (int yy = -top; yy < bottom; ++yy)
+            for (int xx = -left; xx < right; ++xx) {
+              const double h = exp(-(double)(xx * xx + yy * yy) / (2.0 * sigma * sigma));
+              const float v = h < 2.220446049250313e-16 ? 0.f : (float)h;
+              atomicMax(reinterpret_cast<int*>(&hm[(int64_t)(iy + yy) * a.W + ix + xx]), __float_as_int(v));
+            }
+          inds[k] = (int64_t)iy * a.W + ix;
+          masks[k] = 1;
+          float* t = tbox + (int64_t)k * tb_dim;
+          t[0] = cx - (float)ix; t[1] = cy - (float)iy; t[2] = bx[2];
+          t[3] = logf(bx[3]); t[4] = logf(bx[4]); t[5] = logf(bx[5]);
+          t[6] = cosf(bx[6]); t[7] = sinf(bx[6]);
+          for (int e = 7; e < a.box_dim - 1; ++e) t[e + 1] = bx[e];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_count += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+}
+
+extern "C" int sv_center_assign_targets(const float* gt_boxes, int batch, int max_gt, int box_dim, int num_heads, int num_class,
+                                        const int32_t* cls_to_local, const int32_t* head_num_class, const int32_t* head_cls_offset, int total_cls,
+                                        int fm_w, int fm_h, float x_min, float y_min, float voxel_x, float voxel_y, float fm_stride,
+                                        int num_max_objs, float gaussian_overlap, int min_radius, float* heatmaps, float* target_boxes,
+                                        int64_t* inds, int64_t* masks, void* stream) {
+  SV_CHECK_ARG(batch > 0 && max_gt >= 0 && box_dim >= 8 && num_heads > 0 && fm_w > 0 && fm_h > 0 && num_max_objs > 0, "center_assign_targets: bad arguments");
+  SV_CHECK_ARG(cls_to_local && head_num_class && head_cls_offset && heatmaps && target_boxes && inds && masks && (max_gt == 0 || gt_boxes),
+               "center_assign_targets: null pointer");
+  hipStream_t st = sv_stream(stream);
+  SV_HIP(hipMemsetAsync(heatmaps, 0, (size_t)batch * total_cls * fm_h * fm_w * 4, st));
+  CenterArgs a{gt_boxes, batch, max_gt, box_dim, num_heads, num_class, cls_to_local, head_num_class, head_cls_offset, total_cls, fm_w, fm_h,
+               x_min, y_min, voxel_x, voxel_y, fm_stride, num_max_objs, min_radius, gaussian_overlap, heatmaps, target_boxes, inds, masks};
+  hipLaunchKernelGGL(k_center_targets, dim3(num_heads, batch), dim3(256), 0, st, a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

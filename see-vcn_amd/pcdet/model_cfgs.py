@@ -93,3 +93,18 @@ def pvrcnn_model_cfg(**kw):
     return dict(NAME='PVRCNN', VFE=dict(NAME='DynMeanVFE'), BACKBONE_3D=dict(NAME='VoxelBackBone8x'),
                 MAP_TO_BEV=dict(NAME='HeightCompression', NUM_BEV_FEATURES=256), BACKBONE_2D=SECOND_BACKBONE_2D, DENSE_HEAD=SECOND_DENSE_HEAD,
                 PFE=pfe, POINT_HEAD=point_head, ROI_HEAD=roi_head, POST_PROCESSING=pp)
+
+# detector3d/tools/cfgs/nuscenes_models/cbgs_voxel0075_res3d_centerpoint.yaml:1-140 (values as data)
+NUSC_CLASS_NAMES = ['car', 'truck', 'construction_vehicle', 'bus', 'trailer', 'barrier', 'motorcycle', 'bicycle', 'pedestrian', 'traffic_cone']
+CENTER_HEAD = dict(
+    NAME='CenterHead', CLASS_AGNOSTIC=False,
+    CLASS_NAMES_EACH_HEAD=[['car'], ['truck', 'construction_vehicle'], ['bus', 'trailer'], ['barrier'], ['motorcycle', 'bicycle'],
+                           ['pedestrian', 'traffic_cone']],
+    SHARED_CONV_CHANNEL=64, USE_BIAS_BEFORE_NORM=True, NUM_HM_CONV=2,
+    SEPARATE_HEAD_CFG=dict(HEAD_ORDER=['center', 'center_z', 'dim', 'rot', 'vel'],
+                           HEAD_DICT=dict(center=dict(out_channels=2, num_conv=2), center_z=dict(out_channels=1, num_conv=2),
+                                          dim=dict(out_channels=3, num_conv=2), rot=dict(out_channels=2, num_conv=2), vel=dict(out_channels=2, num_conv=2))),
+    TARGET_ASSIGNER_CONFIG=dict(FEATURE_MAP_STRIDE=8, NUM_MAX_OBJS=500, GAUSSIAN_OVERLAP=0.1, MIN_RADIUS=2),
+    LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=0.25, code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 1.0, 1.0])),
+    POST_PROCESSING=dict(SCORE_THRESH=0.1, POST_CENTER_LIMIT_RANGE=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], MAX_OBJ_PER_SAMPLE=500,
+                         NMS_CONFIG=dict(NMS_TYPE='nms_gpu', NMS_THRESH=0.2, NMS_PRE_MAXSIZE=1000, NMS_POST_MAXSIZE=83)))

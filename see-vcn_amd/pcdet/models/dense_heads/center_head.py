@@ -1,0 +1,184 @@
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.init import kaiming_normal_
+
+from .... import _lib
+from ...utils import loss_utils
+from ...utils.common_utils import cfg_get
+from ..model_utils import centernet_utils, model_nms_utils
+
+
+class SeparateHead(nn.Module):
+    """One 3x3-conv branch per regression target + heat map; branch names become attributes so the state_dict keys are the
+    reference's (`heads_list.0.center.0.0.weight`, ...; center_head.py:11-45)."""
+
+    def __init__(self, input_channels, sep_head_dict, init_bias=-2.19, use_bias=False):
+        super().__init__()
+        self.sep_head_dict = sep_head_dict
+        for name in self.sep_head_dict:
+            out_ch, num_conv = self.sep_head_dict[name]['out_channels'], self.sep_head_dict[name]['num_conv']
+            layers = [nn.Sequential(nn.Conv2d(input_channels, input_channels, kernel_size=3, stride=1, padding=1, bias=use_bias),
+                                    nn.BatchNorm2d(input_channels), nn.ReLU()) for _ in range(num_conv - 1)]
+            layers.append(nn.Conv2d(input_channels, out_ch, kernel_size=3, stride=1, padding=1, bias=True))
+            fc = nn.Sequential(*layers)
+            if 'hm' in name:
+                fc[-1].bias.data.fill_(init_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        kaiming_normal_(m.weight.data)
+                        if getattr(m, 'bias', None) is not None:
+                            nn.init.constant_(m.bias, 0)
+            self.__setattr__(name, fc)
+
+    def forward(self, x):
+        return {name: self.__getattr__(name)(x) for name in self.sep_head_dict}
+
+
+class CenterHead(nn.Module):
+    """Drop-in for the reference CenterHead (dense_heads/center_head.py:48-355).  Heat-map / regression targets for all heads
+    and scenes are produced by one HIP launch (sv_center_assign_targets) instead of a python loop on CPU tensors."""
+
+    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, voxel_size,
+                 predict_boxes_when_training=True):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.grid_size = grid_size
+        self.point_cloud_range = [float(v) for v in point_cloud_range]
+        self.voxel_size = [float(v) for v in voxel_size]
+        tcfg = cfg_get(model_cfg, 'TARGET_ASSIGNER_CONFIG')
+        self.feature_map_stride = cfg_get(tcfg, 'FEATURE_MAP_STRIDE', None)
+        self.class_names = list(class_names)
+        self.class_names_each_head = [[x for x in names if x in class_names] for names in cfg_get(model_cfg, 'CLASS_NAMES_EACH_HEAD')]
+        self.class_id_mapping_each_head = [torch.tensor([self.class_names.index(x) for x in names], dtype=torch.long)
+                                           for names in self.class_names_each_head]
+        assert sum(len(x) for x in self.class_names_each_head) == len(self.class_names), f'class_names_each_head={self.class_names_each_head}'
+        use_bias = cfg_get(model_cfg, 'USE_BIAS_BEFORE_NORM', False)
+        ch = cfg_get(model_cfg, 'SHARED_CONV_CHANNEL')
+        self.shared_conv = nn.Sequential(nn.Conv2d(input_channels, ch, 3, stride=1, padding=1, bias=use_bias), nn.BatchNorm2d(ch), nn.ReLU())
+        self.heads_list = nn.ModuleList()
+        self.separate_head_cfg = cfg_get(model_cfg, 'SEPARATE_HEAD_CFG')
+        for names in self.class_names_each_head:
+            head_dict = copy.deepcopy(dict(cfg_get(self.separate_head_cfg, 'HEAD_DICT')))
+            head_dict['hm'] = dict(out_channels=len(names), num_conv=cfg_get(model_cfg, 'NUM_HM_CONV'))
+            self.heads_list.append(SeparateHead(input_channels=ch, sep_head_dict=head_dict, init_bias=-2.19, use_bias=use_bias))
+        self.predict_boxes_when_training = predict_boxes_when_training
+        self.forward_ret_dict = {}
+        self.add_module('hm_loss_func', loss_utils.FocalLossCenterNet())
+        self.add_module('reg_loss_func', loss_utils.RegLossCenterNet())
+        self._tables = {}
+
+    def _device_tables(self, dev):
+        if dev not in self._tables:
+            nh, nc = len(self.class_names_each_head), len(self.class_names)
+            tab = np.zeros((nh, nc + 1), np.int32)
+            for h, names in enumerate(self.class_names_each_head):
+                for li, n in enumerate(names):
+                    tab[h, self.class_names.index(n) + 1] = li + 1
+            ncls = np.array([len(n) for n in self.class_names_each_head], np.int32)
+            off = (np.cumsum(ncls) - ncls).astype(np.int32)
+            self._tables[dev] = tuple(torch.from_numpy(x).to(dev) for x in (tab, ncls, off)) + (int(ncls.sum()),)
+        return self._tables[dev]
+
+    def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
+        """gt_boxes (B,M,8+) -> dict of per-head lists: heatmaps (B,ncls,H,W), target_boxes (B,500,dim), inds, masks."""
+        lib = _lib.load()
+        _lib.require_cuda(gt_boxes)
+        H, W = int(feature_map_size[0]), int(feature_map_size[1])
+        tcfg = cfg_get(self.model_cfg, 'TARGET_ASSIGNER_CONFIG')
+        gt = gt_boxes.contiguous().float()
+        B, G, D = gt.shape
+        dev = gt.device
+        tab, ncls, off, total = self._device_tables(dev)
+        nh, nmax = len(self.class_names_each_head), cfg_get(tcfg, 'NUM_MAX_OBJS')
+        heat = torch.empty((B, total, H, W), dtype=torch.float32, device=dev)
+        tbox = torch.empty((nh, B, nmax, D), dtype=torch.float32, device=dev)
+        inds = torch.empty((nh, B, nmax), dtype=torch.int64, device=dev)
+        masks = torch.empty((nh, B, nmax), dtype=torch.int64, device=dev)
+        rc = lib.sv_center_assign_targets(_lib.ptr(gt) if G else None, B, G, D, nh, len(self.class_names), _lib.ptr(tab), _lib.ptr(ncls), _lib.ptr(off),
+                                          total, W, H, self.point_cloud_range[0], self.point_cloud_range[1], self.voxel_size[0], self.voxel_size[1],
+                                          float(cfg_get(tcfg, 'FEATURE_MAP_STRIDE')), nmax, float(cfg_get(tcfg, 'GAUSSIAN_OVERLAP')),
+                                          int(cfg_get(tcfg, 'MIN_RADIUS')), _lib.ptr(heat), _lib.ptr(tbox), _lib.ptr(inds), _lib.ptr(masks), _lib.stream())
+        _lib.check(rc, "sv_center_assign_targets")
+        offs = off.tolist() + [total]
+        return {'heatmaps': [heat[:, offs[h]:offs[h + 1]] for h in range(nh)], 'target_boxes': [tbox[h] for h in range(nh)],
+                'inds': [inds[h] for h in range(nh)], 'masks': [masks[h] for h in range(nh)], 'heatmap_masks': []}
+
+    @staticmethod
+    def sigmoid(x):
+        return torch.clamp(x.sigmoid(), min=1e-4, max=1 - 1e-4)
+
+    def get_loss(self):
+        pred_dicts, target_dicts = self.forward_ret_dict['pred_dicts'], self.forward_ret_dict['target_dicts']
+        lw = cfg_get(self.model_cfg, 'LOSS_CONFIG')['LOSS_WEIGHTS']
+        tb_dict, loss = {}, 0
+        for idx, pred in enumerate(pred_dicts):
+            pred['hm'] = self.sigmoid(pred['hm'])
+            hm_loss = self.hm_loss_func(pred['hm'], target_dicts['heatmaps'][idx]) * lw['cls_weight']
+            pred_boxes = torch.cat([pred[name] for name in cfg_get(self.separate_head_cfg, 'HEAD_ORDER')], dim=1)
+            reg_loss = self.reg_loss_func(pred_boxes, target_dicts['masks'][idx], target_dicts['inds'][idx], target_dicts['target_boxes'][idx])
+            loc_loss = (reg_loss * reg_loss.new_tensor(lw['code_weights'])).sum() * lw['loc_weight']
+            loss = loss + hm_loss + loc_loss
+            tb_dict['hm_loss_head_%d' % idx] = hm_loss.item()
+            tb_dict['loc_loss_head_%d' % idx] = loc_loss.item()
+        tb_dict['rpn_loss'] = loss.item()
+        return loss, tb_dict
+
+    @torch.no_grad()
+    def generate_predicted_boxes(self, batch_size, pred_dicts):
+        pp = cfg_get(self.model_cfg, 'POST_PROCESSING')
+        nms_cfg = cfg_get(pp, 'NMS_CONFIG')
+        dev = pred_dicts[0]['hm'].device
+        limit = torch.tensor(cfg_get(pp, 'POST_CENTER_LIMIT_RANGE'), device=dev).float()
+        ret = [{'pred_boxes': [], 'pred_scores': [], 'pred_labels': []} for _ in range(batch_size)]
+        order = cfg_get(self.separate_head_cfg, 'HEAD_ORDER')
+        for idx, pred in enumerate(pred_dicts):
+            finals = centernet_utils.decode_bbox_from_heatmap(
+                heatmap=pred['hm'].sigmoid(), rot_cos=pred['rot'][:, 0].unsqueeze(1), rot_sin=pred['rot'][:, 1].unsqueeze(1), center=pred['center'],
+                center_z=pred['center_z'], dim=pred['dim'].exp(), vel=pred['vel'] if 'vel' in order else None,
+                point_cloud_range=self.point_cloud_range, voxel_size=self.voxel_size, feature_map_stride=self.feature_map_stride,
+                K=cfg_get(pp, 'MAX_OBJ_PER_SAMPLE'), circle_nms=(cfg_get(nms_cfg, 'NMS_TYPE') == 'circle_nms'), score_thresh=cfg_get(pp, 'SCORE_THRESH'),
+                post_center_limit_range=limit)
+            mapping = self.class_id_mapping_each_head[idx].to(dev)
+            for k, fd in enumerate(finals):
+                fd['pred_labels'] = mapping[fd['pred_labels'].long()]
+                if cfg_get(nms_cfg, 'NMS_TYPE') != 'circle_nms':
+                    selected, selected_scores = model_nms_utils.class_agnostic_nms(box_scores=fd['pred_scores'], box_preds=fd['pred_boxes'],
+                                                                                   nms_config=nms_cfg, score_thresh=None)
+                    fd['pred_boxes'], fd['pred_scores'], fd['pred_labels'] = fd['pred_boxes'][selected], selected_scores, fd['pred_labels'][selected]
+                for key in ('pred_boxes', 'pred_scores', 'pred_labels'):
+                    ret[k][key].append(fd[key])
+        for k in range(batch_size):
+            ret[k]['pred_boxes'] = torch.cat(ret[k]['pred_boxes'], dim=0)
+            ret[k]['pred_scores'] = torch.cat(ret[k]['pred_scores'], dim=0)
+            ret[k]['pred_labels'] = torch.cat(ret[k]['pred_labels'], dim=0) + 1
+        return ret
+
+    @staticmethod
+    def reorder_rois_for_refining(batch_size, pred_dicts):
+        n = max(1, max(len(d['pred_boxes']) for d in pred_dicts))
+        pb = pred_dicts[0]['pred_boxes']
+        rois, scores, labels = pb.new_zeros((batch_size, n, pb.shape[-1])), pb.new_zeros((batch_size, n)), pb.new_zeros((batch_size, n)).long()
+        for b in range(batch_size):
+            m = len(pred_dicts[b]['pred_boxes'])
+            rois[b, :m], scores[b, :m], labels[b, :m] = pred_dicts[b]['pred_boxes'], pred_dicts[b]['pred_scores'], pred_dicts[b]['pred_labels']
+        return rois, scores, labels
+
+    def forward(self, data_dict):
+        x = self.shared_conv(data_dict['spatial_features_2d'])
+        pred_dicts = [head(x) for head in self.heads_list]
+        if self.training:
+            self.forward_ret_dict['target_dicts'] = self.assign_targets(data_dict['gt_boxes'], feature_map_size=data_dict['spatial_features_2d'].size()[2:])
+        self.forward_ret_dict['pred_dicts'] = pred_dicts
+        if not self.training or self.predict_boxes_when_training:
+            preds = self.generate_predicted_boxes(data_dict['batch_size'], pred_dicts)
+            if self.predict_boxes_when_training:
+                data_dict['rois'], data_dict['roi_scores'], data_dict['roi_labels'] = self.reorder_rois_for_refining(data_dict['batch_size'], preds)
+                data_dict['has_class_labels'] = True
+            else:
+                data_dict['final_box_dicts'] = preds
+        return data_dict

@@ -1,3 +1,4 @@
+from .centerpoint import CenterPoint
 from .detector3d_template import Detector3DTemplate
 from .pointpillar import PointPillar
 from .pv_rcnn import PVRCNN
@@ -9,6 +10,7 @@ __all__ = {
     'SECONDNet': SECONDNet,
     'PointPillar': PointPillar,
     'PVRCNN': PVRCNN,
+    'CenterPoint': CenterPoint,
 }
 
 

@@ -95,7 +95,7 @@ class Detector3DTemplate(nn.Module):
             model_cfg=cfg, input_channels=model_info_dict['num_bev_features'],
             num_class=self.num_class if not cfg_get(cfg, 'CLASS_AGNOSTIC', False) else 1, class_names=self.class_names,
             grid_size=model_info_dict['grid_size'], point_cloud_range=model_info_dict['point_cloud_range'],
-            predict_boxes_when_training=cfg_get(self.model_cfg, 'ROI_HEAD', None) is not None)
+            predict_boxes_when_training=cfg_get(self.model_cfg, 'ROI_HEAD', None) is not None, voxel_size=model_info_dict.get('voxel_size', False))
         model_info_dict['module_list'].append(m)
         return m, model_info_dict
 

@@ -71,3 +71,44 @@ def get_corner_loss_lidar(pred_bbox3d, gt_bbox3d):
     gtf = box_utils.boxes_to_corners_3d(gt_flip)
     dist = torch.min(torch.norm(pred - gt, dim=2), torch.norm(pred - gtf, dim=2))   # (N, 8)
     return WeightedSmoothL1Loss.smooth_l1_loss(dist, beta=1.0).mean(dim=1)
+
+
+def neg_loss_cornernet(pred, gt, mask=None):
+    """CornerNet focal loss on a Gaussian heat map (loss_utils.py:264-300)."""
+    pos_inds = gt.eq(1).float()
+    neg_inds = gt.lt(1).float()
+    neg_weights = torch.pow(1 - gt, 4)
+    pos_loss = torch.log(pred) * torch.pow(1 - pred, 2) * pos_inds
+    neg_loss = torch.log(1 - pred) * torch.pow(pred, 2) * neg_weights * neg_inds
+    if mask is not None:
+        mask = mask[:, None, :, :].float()
+        pos_loss, neg_loss = pos_loss * mask, neg_loss * mask
+        num_pos = (pos_inds.float() * mask).sum()
+    else:
+        num_pos = pos_inds.float().sum()
+    pos_loss, neg_loss = pos_loss.sum(), neg_loss.sum()
+    return -neg_loss if num_pos == 0 else -(pos_loss + neg_loss) / num_pos
+
+
+class FocalLossCenterNet(nn.Module):
+    def forward(self, out, target, mask=None):
+        return neg_loss_cornernet(out, target, mask=mask)
+
+
+def _transpose_and_gather_feat(feat, ind):
+    """(B,C,H,W), ind (B,K) -> (B,K,C) rows at flat positions ind (loss_utils.py:342-357)."""
+    feat = feat.permute(0, 2, 3, 1).contiguous()
+    feat = feat.view(feat.size(0), -1, feat.size(3))
+    return feat.gather(1, ind.unsqueeze(2).expand(ind.size(0), ind.size(1), feat.size(2)))
+
+
+class RegLossCenterNet(nn.Module):
+    """masked L1 per code, normalised by the object count (loss_utils.py:303-385) -> (dim,)"""
+
+    def forward(self, output, mask, ind=None, target=None):
+        pred = output if ind is None else _transpose_and_gather_feat(output, ind)
+        num = mask.float().sum()
+        m = mask.unsqueeze(2).expand_as(target).float() * (~torch.isnan(target)).float()
+        loss = torch.abs(pred * m - target * m).transpose(2, 0)
+        loss = torch.sum(torch.sum(loss, dim=2), dim=1)
+        return loss / torch.clamp_min(num, min=1.0)
