@@ -104,6 +104,47 @@ def measure_dominant_kernel(model, inputs, reps=5):
     return ms / launches, executed / reps, launches // reps, ms / reps
 
 
+def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
+    """Live HIP-event timing of every sv_sparse_conv_gather_gemm launch (forward and data-gradient) of `reps` full steps, grouped
+    by kernel instance k_spconv_rs<Cout/16, Cin/16, 4>.  Returns the instance with the largest total time: (name, avg launch ms,
+    algorithmic flop per launch = 2*pairs*Cin*Cout averaged over its launches, algorithmic bytes per launch, launches per step,
+    ms per step).  Pairs are counted from the rulebook actually used (outside the timed events)."""
+    from seevcn_amd.spconv import functional as F
+    records = []
+    orig = F.gather_gemm
+
+    def timed(x, nbr, wt, n_rows, *args, **kw):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = orig(x, nbr, wt, n_rows, *args, **kw)
+        e.record()
+        records.append((int(wt.shape[2]), int(wt.shape[1]), int(wt.shape[0]), int(x.shape[0]), int(n_rows), nbr, s, e))
+        return out
+
+    F.gather_gemm = timed
+    try:
+        for _ in range(reps):
+            run_step(model, opt, params, inputs, world)
+        torch.cuda.synchronize()
+    finally:
+        F.gather_gemm = orig
+    groups, pair_cache = {}, {}
+    for kd, nc, K, n_src, n_rows, nbr, s, e in records:
+        if kd % 16 or nc % 16:
+            continue                                   # the 3->16 input conv runs on the VALU kernel
+        key = nbr.data_ptr()
+        if key not in pair_cache:
+            pair_cache[key] = int((nbr >= 0).sum().item())
+        pairs = pair_cache[key]
+        g = groups.setdefault((nc // 16, kd // 16), [0.0, 0.0, 0.0, 0])
+        g[0] += s.elapsed_time(e)
+        g[1] += 2.0 * pairs * kd * nc
+        g[2] += 4.0 * (n_src * kd + n_rows * nc) + 4.0 * K * kd * nc + 8.0 * pairs    # SURVEY 8(d): features in+out, weights, rulebook pairs
+        g[3] += 1
+    (nt, kq), (ms, flop, byt, n) = max(groups.items(), key=lambda kv: kv[1][0])
+    return f"k_spconv_rs<{nt}, {kq}, 4>", ms / n, flop / n, byt / n, n // reps, ms / reps
+
+
 def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1):
     """Oracle (CPU port) on a bounded sample of the same workload: VCN on n_objects objects + one scene's
     voxelise -> backbone forward/backward (numpy sparse conv inside torch-CPU autograd for BN/ReLU)."""
@@ -233,12 +274,22 @@ def main():
         avg_ms, executed_flop, launches, vcn_gemm_ms = measure_dominant_kernel(model, inputs)
         algo_flop_per_launch = VCN_FLOP_PER_OBJECT * OBJECTS_PER_GPU / launches
         achieved = algo_flop_per_launch / (avg_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_f32 (sv_gemm_bias_act, v_mfma_f32_32x32x2_f32)",
-                           "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                           "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4),
-                           "algorithmic_flop_per_launch": algo_flop_per_launch,
-                           "executed_tflops": round(executed_flop / (vcn_gemm_ms * 1e-3) / 1e12, 2)}
+        vcn_roof = {"bound": "mfma", "kernel": "k_gemm_f32 (sv_gemm_bias_act, v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4), "ms_per_step": round(vcn_gemm_ms, 3),
+                    "algorithmic_flop_per_launch": algo_flop_per_launch,
+                    "executed_tflops": round(executed_flop / (vcn_gemm_ms * 1e-3) / 1e12, 2)}
+        # dominant kernel by time in the step: the register-stationary sparse-conv gather-GEMM (forward + data gradient)
+        name, c_ms, c_flop, c_bytes, c_launches, c_step_ms = measure_spconv_kernel(model, opt, params, inputs, world)
+        c_ach = c_flop / (c_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": f"{name} (sv_sparse_conv_gather_gemm, v_mfma_f32_16x16x4_f32)",
+                           "achieved": round(c_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(c_ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": c_launches, "avg_launch_ms": round(c_ms, 4), "ms_per_step": round(c_step_ms, 3),
+                           "algorithmic_flop_per_launch": round(c_flop), "algorithmic_bytes_per_launch": round(c_bytes),
+                           "algorithmic_GBps": round(c_bytes / (c_ms * 1e-3) / 1e9, 1)}
+        out["roofline_vcn_gemm"] = vcn_roof
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pts_np, objs_np, scene_np)
         print(json.dumps(out), flush=True)

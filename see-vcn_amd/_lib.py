@@ -16,6 +16,7 @@ c_p = ctypes.c_void_p
 c_i = ctypes.c_int
 c_i64 = ctypes.c_int64
 c_f = ctypes.c_float
+c_d = ctypes.c_double
 c_sz = ctypes.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/seevcn_hip.h declares
@@ -62,6 +63,9 @@ SIGNATURES = {
     "sv_bev_interpolate_grad": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
     "sv_center_assign_targets": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_p, c_p, c_p,
                                        c_p, c_p]),
+    "sv_vcn_surface_select": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "sv_vcn_largest_cluster": (c_i, [c_p, c_i, c_i, c_d, c_i, c_i, c_p, c_p, c_p]),
+    "sv_points_near_set": (c_i, [c_p, c_i64, c_p, c_i64, c_d, c_p, c_p]),
     "sv_anchor_decode": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p]),
     "sv_assign_targets_axis_aligned": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
 }

@@ -6,6 +6,7 @@ import torch
 
 from .datasets.data_transforms import ResamplePoints
 from .models import build_model_from_cfg
+from .utils.sampling import get_largest_cluster_batch_device, get_partial_mesh_batch_device
 
 
 def _get(cfg, key, default=None):
@@ -16,8 +17,9 @@ class VCN:
     """cfg keys: MODEL, NORM_WITH_GT, SEL_K_NEAREST, CLUSTER_EPS, BATCH_SIZE_LIMIT, CKPT_PATH (VCN.py:27-32).
     `inference` resamples every object to `resample_num` points, pads the object count to a multiple of
     `batch_size_limit` with zero clouds, runs the HIP forward per chunk and returns numpy arrays.
-    Built: 'input' and 'coarse'. The CPU post-processing of the reference ('surface' = kd-tree k-NN selection,
-    'clustered' = open3d DBSCAN, VCN.py:89-93) is a next-tier row and is not produced yet."""
+    'surface' (k-NN selection of coarse points around the input, sampling.py:8-41) and 'clustered' (largest DBSCAN cluster,
+    sampling.py:83-100) are computed on the GPU by sv_vcn_surface_select / sv_vcn_largest_cluster; the reference does both on
+    the CPU (VCN.py:89-93).  `inference_device` returns the same dict as CUDA tensors without any host copy."""
 
     def __init__(self, cfg, gpu_id=0, state_dict=None):
         self.cfg = cfg
@@ -40,6 +42,13 @@ class VCN:
         self.model.eval()
 
     def inference(self, pts, gtboxes=None, batch_size_limit=None, resample_num=1024, k=30, eps=0.4):
+        """numpy dict like the reference: input/surface/coarse float32, clustered float64 (open3d points are doubles)."""
+        out = self.inference_device(pts, gtboxes, batch_size_limit, resample_num, k, eps)
+        ret = {key: v.cpu().numpy() for key, v in out.items()}
+        ret['clustered'] = ret['clustered'].astype(np.float64)
+        return ret
+
+    def inference_device(self, pts, gtboxes=None, batch_size_limit=None, resample_num=1024, k=30, eps=0.4):
         resample = ResamplePoints({'n_points': resample_num})
         if type(pts) == list:
             resampled = np.concatenate([resample(pc)[np.newaxis, ...] for pc in pts], axis=0)
@@ -66,4 +75,6 @@ class VCN:
             if self.norm_with_gt:
                 in_dict['gt_boxes'] = torch.from_numpy(gt).float().to(self.device)
             output = self.model(in_dict)['coarse']
-        return {'input': in_pc.cpu().numpy(), 'coarse': output.detach().cpu().numpy()}
+        surface, _ = get_partial_mesh_batch_device(in_pc, output, k=k)
+        clustered, _ = get_largest_cluster_batch_device(surface, eps=eps, min_points=2, total_pts=output.shape[1])
+        return {'input': in_pc, 'surface': surface, 'clustered': clustered, 'coarse': output.detach()}

@@ -1,0 +1,42 @@
+"""Scene-level merge of completed objects, the tail of SEE_VCN.complete_gt_pts / complete_det_pts
+(see/surface_completion/SEE_VCN.py:115,244-265) on the GPU."""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def merge_instances_device(clustered):
+    """np.unique(np.vstack(clustered), axis=0): (B,N,3) or list of (N,3) -> row-sorted unique (M,3) tensor."""
+    x = torch.cat(list(clustered), dim=0) if isinstance(clustered, (list, tuple)) else clustered.reshape(-1, 3)
+    return torch.unique(x, dim=0)
+
+
+def points_near_set(query, ref, thresh):
+    """bool (Nq,) : query point closer than `thresh` to any ref point (float64 distances)."""
+    lib = _lib.load()
+    _lib.require_cuda(query, ref)
+    q, r = query.detach().float().contiguous(), ref.detach().float().contiguous()
+    near = torch.empty((q.shape[0],), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.sv_points_near_set(_lib.ptr(q) if q.numel() else None, q.shape[0], _lib.ptr(r) if r.numel() else None, r.shape[0], float(thresh),
+                                      _lib.ptr(near) if q.numel() else None, _lib.stream()), "sv_points_near_set")
+    return near.bool()
+
+
+def replace_with_completed_pts_device(points, sc_instances, point_dist_thresh=0.1):
+    """points (N,3+) scene cloud, sc_instances (M,3): completed points first, then the scene points farther than the threshold
+    from every completed point (only xyz is kept, as the reference's open3d cloud does)."""
+    if sc_instances is None:
+        return points[:, :3]
+    xyz = points[:, :3].contiguous()
+    near = points_near_set(xyz, sc_instances, point_dist_thresh)
+    return torch.cat([sc_instances.to(xyz.dtype), xyz[~near]], dim=0)
+
+
+def replace_with_completed_pts(points, sc_instances, point_dist_thresh=0.1, device='cuda'):
+    """numpy in / numpy float64 out, like the reference."""
+    if sc_instances is None:
+        return np.asarray(points)
+    p = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(device)
+    r = torch.from_numpy(np.ascontiguousarray(sc_instances, dtype=np.float32)).to(device)
+    return replace_with_completed_pts_device(p, r, point_dist_thresh).cpu().numpy().astype(np.float64)

@@ -1,0 +1,111 @@
+"""VCN post-processing: surface selection (np.unique -> k-NN -> CPython set order -> tile), largest
+DBSCAN cluster, scene merge.  The surface selection is pinned to the reference's own get_partial_mesh_batch
+(tests/golden/vcn_post.npz); clustering is parity-unpinned w.r.t. open3d (absent) and cross-checked against sklearn."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import postprocess as opp
+from post_inputs import make_pairs
+
+
+def test_cpython_set_order_emulation_matches_interpreter():
+    rng = np.random.default_rng(0)
+    for trial in range(300):
+        hi = int(rng.choice([16, 100, 600, 1024]))
+        vals = rng.integers(0, hi, int(rng.integers(1, 20000)))
+        if trial % 3 == 0:
+            vals = np.concatenate([rng.permutation(hi)[:int(rng.integers(1, hi + 1))], vals])
+        assert [int(v) for v in set(list(vals))] == opp.cpython_set_order(vals)
+
+
+def test_oracle_surface_select_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vcn_post.npz"))
+    partial, coarse = make_pairs()
+    for k in (30, 5):
+        got = opp.get_partial_mesh_batch(partial, coarse, k=k)
+        assert got.dtype == np.float32 and np.array_equal(got, g[f"surface_k{k}"])
+
+
+def test_oracle_dbscan_largest_cluster_vs_sklearn(golden_dir):
+    from sklearn.cluster import DBSCAN
+    g = np.load(os.path.join(golden_dir, "vcn_post.npz"))
+    _, coarse = make_pairs()
+    for pc, eps in [(g["surface_k30"][2], 0.4), (g["surface_k5"][0], 0.2), (coarse[2], 0.15), (coarse[5], 0.1)]:
+        ret, size = opp.largest_cluster(pc, eps=eps, min_points=2, total_pts=1024)
+        labels = DBSCAN(eps=eps, min_samples=2).fit(pc.astype(np.float64)).labels_       # d <= eps vs open3d's d < eps: no ties in this data
+        sizes = np.bincount(labels[labels >= 0])
+        assert size == sizes.max()
+        if (sizes == sizes.max()).sum() == 1:
+            assert np.array_equal(ret[:size], pc[labels == np.argmax(sizes)].astype(np.float64))
+    with pytest.raises(ValueError):
+        opp.largest_cluster(np.arange(30, dtype=np.float32).reshape(10, 3) * 10, eps=0.4, min_points=2)
+
+
+def test_oracle_replace_with_completed_pts_vs_ckdtree():
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(1)
+    scene = rng.uniform(-5, 5, (4000, 3)).astype(np.float32)
+    inst = np.unique(rng.uniform(-2, 2, (900, 3)).astype(np.float32), axis=0)
+    merged, near = opp.replace_with_completed_pts(scene, inst, 0.3)
+    d = cKDTree(inst.astype(np.float64)).query(scene.astype(np.float64))[0]
+    assert np.array_equal(near, d < 0.3) and 0 < near.sum() < len(scene) and len(merged) == len(inst) + (~near).sum()
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_surface_select_bitexact_vs_reference_golden(golden_dir, cuda, hip_lib):
+    from seevcn_amd.vcn.utils import sampling as S
+    g = np.load(os.path.join(golden_dir, "vcn_post.npz"))
+    partial, coarse = make_pairs()
+    p, c = torch.from_numpy(partial).to(cuda), torch.from_numpy(coarse).to(cuda)
+    for k in (30, 5):
+        out, nsel = S.get_partial_mesh_batch_device(p, c, k=k)
+        assert np.array_equal(out.cpu().numpy(), g[f"surface_k{k}"])
+        want = [opp.partial_with_kdtree(partial[b], coarse[b], k)[1] for b in range(len(partial))]
+        assert nsel.cpu().tolist() == want
+    assert np.array_equal(S.get_partial_mesh_batch(p, c, k=30), g["surface_k30"])               # reference-named numpy API
+    assert np.array_equal(S.partial_with_KDTree(p[1], c[1], k=5), g["surface_k5"][1])
+    # other k / ragged sizes against the oracle (k = 1, k = 64, n = 700 partial points, m = 900 coarse points, 333 surface points)
+    for k, n, m, sp in [(1, 1024, 1024, 1024), (64, 1024, 1024, 1024), (20, 700, 900, 333), (3, 1, 17, 50)]:
+        out, _ = S.get_partial_mesh_batch_device(p[:, :n].contiguous(), c[:, :m].contiguous(), k=k, surface_pts=sp)
+        want = opp.get_partial_mesh_batch(partial[:, :n], coarse[:, :m], k=k, surface_pts=sp)
+        assert np.array_equal(out.cpu().numpy(), want), (k, n, m, sp)
+
+
+@pytest.mark.gpu
+def test_hip_largest_cluster_bitexact_vs_oracle(golden_dir, cuda, hip_lib):
+    from seevcn_amd.vcn.utils import sampling as S
+    g = np.load(os.path.join(golden_dir, "vcn_post.npz"))
+    _, coarse = make_pairs()
+    for pcs, eps, mp in [(g["surface_k30"], 0.4, 2), (g["surface_k5"], 0.2, 2), (coarse, 0.15, 2), (coarse, 0.1, 1), (coarse[:, :333], 0.12, 2)]:
+        out, cnt = S.get_largest_cluster_batch_device(torch.from_numpy(np.ascontiguousarray(pcs)).to(cuda), eps=eps, min_points=mp, total_pts=1024)
+        for b in range(len(pcs)):
+            want, size = opp.largest_cluster(pcs[b], eps=eps, min_points=mp, total_pts=1024)
+            assert int(cnt[b]) == size and np.array_equal(out[b].cpu().numpy().astype(np.float64), want), (eps, mp, b)
+    res = S.get_largest_cluster_batch(g["surface_k30"], eps=0.4, min_points=2, total_pts=1024)
+    assert res.dtype == np.float64 and res.shape == (8, 1024, 3)
+    with pytest.raises(ValueError):                                                                # all noise -> reference raises
+        S.get_largest_cluster_batch(np.arange(30, dtype=np.float32).reshape(1, 10, 3) * 10, eps=0.4, min_points=2)
+    with pytest.raises(Exception, match="min_points"):
+        S.get_largest_cluster_batch(coarse, eps=0.4, min_points=5)
+
+
+@pytest.mark.gpu
+def test_hip_scene_merge_vs_oracle(golden_dir, cuda, hip_lib):
+    import seevcn_amd.synth as synth
+    from seevcn_amd.vcn import scene_merge as M
+    g = np.load(os.path.join(golden_dir, "vcn_post.npz"))
+    clustered = opp.get_largest_cluster_batch(g["surface_k30"], eps=0.4, min_points=2)
+    # place the (object-frame) clusters into a scene at the first boxes' centres
+    scene_pts, boxes = synth.make_scene(2000)
+    world = [(clustered[b].astype(np.float32) + boxes[b % len(boxes), :3]).astype(np.float64) for b in range(len(clustered))]
+    want_inst = opp.merge_instances(world)
+    inst = M.merge_instances_device([torch.from_numpy(w.astype(np.float32)).to(cuda) for w in world])
+    assert np.array_equal(inst.cpu().numpy(), want_inst.astype(np.float32))
+    want, near = opp.replace_with_completed_pts(scene_pts[:, :3], want_inst, 0.1)
+    got = M.replace_with_completed_pts(scene_pts[:, :3], want_inst, 0.1)
+    assert 0 < near.sum() < len(scene_pts) and got.dtype == np.float64 and np.array_equal(got, want)
+    assert np.array_equal(M.points_near_set(torch.from_numpy(scene_pts[:, :3].copy()).to(cuda), inst, 0.1).cpu().numpy(), near)

@@ -164,6 +164,11 @@ def test_hip_vcn_inference_wrapper_chunking(cuda, hip_lib):
     assert out["input"].shape == (6, 1024, 3) and out["coarse"].shape == (6, 1024, 3)
     ref = ovcn.vcn_vc_forward(sd, torch.from_numpy(out["input"]))["coarse"].numpy()
     assert _rel_err(out["coarse"], ref) < RTOL
+    # post-processing on the GPU's own coarse output (models/VCN.py:89-93) against the CPU restatement
+    from oracle import postprocess as opp
+    surf = opp.get_partial_mesh_batch(out["input"], out["coarse"], k=30)
+    assert out["surface"].dtype == np.float32 and np.array_equal(out["surface"], surf)
+    assert out["clustered"].dtype == np.float64 and np.array_equal(out["clustered"], opp.get_largest_cluster_batch(surf, eps=0.4, min_points=2))
     np.random.seed(3)
     single = vcn.inference(objs[0])
     assert np.array_equal(single["input"][0], out["input"][0]) and _rel_err(single["coarse"][0], ref[0]) < RTOL
