@@ -148,7 +148,7 @@ def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
 def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1):
     """Oracle (CPU port) on a bounded sample of the same workload: VCN on n_objects objects + one scene's
     voxelise -> backbone forward/backward (numpy sparse conv inside torch-CPU autograd for BN/ReLU)."""
-    from oracle import vcn as ovcn, voxelize as ovox, spconv as osp
+    from oracle import vcn as ovcn, voxelize as ovox, spconv as osp, postprocess as opp
     from seevcn_amd.pipeline import KITTI
     from seevcn_amd.pcdet.models import backbones_3d
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -158,13 +158,23 @@ def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1):
     vsd = seeded_state_dict(V.MODELS.build({'NAME': 'VCN_VC'}), seed=0)
     t0 = time.perf_counter()
     coarse = ovcn.vcn_vc_forward(vsd, torch.from_numpy(objs_np[:n_objects]))['coarse'].numpy()
+    surface = opp.get_partial_mesh_batch(objs_np[:n_objects], coarse, k=30)
+    coarse = opp.get_largest_cluster_batch(surface, eps=0.4, min_points=2).astype(np.float32)      # 'clustered'
     t_vcn = (time.perf_counter() - t0) / n_objects            # s / object
     per_scene_objs = OBJECTS_PER_GPU // SCENES_PER_GPU
     t1 = time.perf_counter()
     sel = pts_np[pts_np[:, 0] < n_scenes]
     paste = np.concatenate([np.repeat(scene_np[:n_objects, None, None], 1024, 1), coarse], axis=2).reshape(-1, 4)
     paste = paste[paste[:, 0] < n_scenes]
-    allp = np.concatenate([sel, paste.astype(np.float32)], 0)
+    if len(paste):
+        inst = np.unique(paste.astype(np.float32), axis=0)
+        near = np.zeros(len(sel), bool)
+        for b in np.unique(inst[:, 0]):
+            qm = sel[:, 0] == b
+            near[qm] = opp.replace_with_completed_pts(sel[qm, 1:4], inst[inst[:, 0] == b, 1:4], 0.1)[1]
+        allp = np.concatenate([inst, sel[~near]], 0)
+    else:
+        allp = sel
     g = KITTI
     feats, coords, _ = ovox.dynamic_mean_vfe(allp, g['point_cloud_range'], g['voxel_size'], g['grid_size'])
     m = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size'])
@@ -211,7 +221,7 @@ def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1):
     t_scene = (time.perf_counter() - t1) / n_scenes
     sec_per_scene = t_scene + per_scene_objs * t_vcn
     return {"value": round(1.0 / sec_per_scene, 4), "unit": "scenes/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (numpy/torch-CPU, {threads} threads): VCN_VC fwd on {n_objects} objects ({t_vcn:.3f} s/object) + "
+            "sample": f"oracle (numpy/torch-CPU, {threads} threads): VCN_VC fwd + surface select + DBSCAN on {n_objects} objects ({t_vcn:.3f} s/object) + "
                       f"{n_scenes} scene voxelise+VoxelBackBone8x fwd+bwd ({t_scene:.2f} s/scene); scaled to {per_scene_objs} objects/scene"}
 
 
@@ -265,7 +275,8 @@ def main():
             "metric": "scenes/sec (VCN+voxel+spconv fwd+bwd)", "value": round(scenes / elapsed, 3), "unit": "scenes/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "VCN_VC fwd on 64 objects x 1024 pts -> paste into 16 KITTI-shaped 64-beam scenes (~17k pts) -> "
+            "config": {"workload": "VCN_VC fwd on 64 objects x 1024 pts -> kNN surface select (k=30) -> largest DBSCAN cluster (eps 0.4) -> unique + "
+                                   "replace (<0.1 m) into 16 KITTI-shaped 64-beam scenes (~17k pts) -> "
                                    "DynMeanVFE -> VoxelBackBone8x + HeightCompression fwd+bwd + SGD (BASELINE configs[1]+[2])",
                        "scenes_per_gpu": SCENES_PER_GPU, "objects_per_gpu": OBJECTS_PER_GPU, "points_per_object": 1024,
                        "geometry": "KITTI [0,-40,-3,70.4,40,1] @ [0.05,0.05,0.1] -> sparse [41,1600,1408]", "parallelism": f"dp{world}"},

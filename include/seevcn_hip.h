@@ -252,17 +252,19 @@ int sv_center_assign_targets(const float* gt_boxes, int batch, int max_gt, int b
  * np.unique(partial) -> k nearest coarse points each (float64 distances) -> list(set(indices)) in CPython's set iteration
  * order -> np.tile(...)[:surface_pts].  partial (B,n,3), complete (B,m,3), n,m <= 1024 -> surface (B,surface_pts,3),
  * n_selected (B) = size of the index set. */
+size_t sv_vcn_surface_select_scratch_bytes(int batch);
 int sv_vcn_surface_select(const float* partial, const float* complete, int batch, int n_partial, int n_complete, int k,
-                          int surface_pts, float* surface, int32_t* n_selected, void* stream);
+                          int surface_pts, void* scratch, float* surface, int32_t* n_selected, void* stream);
 /* get_largest_cluster(_batch) (sampling.py:83-110): open3d cluster_dbscan(eps, min_points) + np.argmax(np.bincount(labels>=0))
  * + tile to total_pts.  min_points <= 2 (VCN.inference passes 2, models/VCN.py:90-93).  n_cluster[b] = 0 when every point is
  * noise (the reference raises there); out rows of that object are left untouched. */
 int sv_vcn_largest_cluster(const float* points, int batch, int n, double eps, int min_points, int total_pts, float* out,
                            int32_t* n_cluster, void* stream);
 /* replace_with_completed_pts (see/surface_completion/SEE_VCN.py:247-265): near[i] = 1 iff some ref point lies closer than
- * thresh to query i (float64 distance, strict <).  ref is expected row-sorted (np.unique) for the tile culling to pay. */
-int sv_points_near_set(const float* query, int64_t n_query, const float* ref, int64_t n_ref, double thresh, uint8_t* near,
-                       void* stream);
+ * thresh to query i (float64 distance, strict <).  ref is expected row-sorted (np.unique) for the tile culling to pay.
+ * row_dim 3: rows [x,y,z]; row_dim 4: rows [b,x,y,z] (a batch of scenes, only rows with equal b are compared). */
+int sv_points_near_set(const float* query, int64_t n_query, const float* ref, int64_t n_ref, int row_dim, double thresh,
+                       uint8_t* near, void* stream);
 
 #ifdef __cplusplus
 }

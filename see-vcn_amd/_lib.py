@@ -63,9 +63,10 @@ SIGNATURES = {
     "sv_bev_interpolate_grad": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
     "sv_center_assign_targets": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_p, c_p, c_p,
                                        c_p, c_p]),
-    "sv_vcn_surface_select": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "sv_vcn_surface_select_scratch_bytes": (c_sz, [c_i]),
+    "sv_vcn_surface_select": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_vcn_largest_cluster": (c_i, [c_p, c_i, c_i, c_d, c_i, c_i, c_p, c_p, c_p]),
-    "sv_points_near_set": (c_i, [c_p, c_i64, c_p, c_i64, c_d, c_p, c_p]),
+    "sv_points_near_set": (c_i, [c_p, c_i64, c_p, c_i64, c_i, c_d, c_p, c_p]),
     "sv_anchor_decode": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p]),
     "sv_assign_targets_axis_aligned": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
 }

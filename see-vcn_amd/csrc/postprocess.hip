@@ -46,148 +46,276 @@ __device__ void set_insert_clean(short* table, int mask, int h) {
   }
 }
 
-__device__ int cpython_set_order(const unsigned short* seq, int n, short* tab_a, short* tab_b, unsigned short* order) {
-  short* table = tab_a;
-  short* other = tab_b;
-  int mask = 7, fill = 0;
-  for (int i = 0; i < 8; ++i) table[i] = -1;
-  for (int s = 0; s < n; ++s) {           // seq holds distinct values: every step is an insertion
-    const int h = seq[s];
-    unsigned perturb = h;
-    int i = h & mask;
-    bool done = false;
-    while (!done) {
-      const int probes = (i + 9 <= mask) ? 9 : 0;
-      for (int j = 0; j <= probes; ++j) {
-        if (table[i + j] < 0) {
-          table[i + j] = (short)h;
-          ++fill;
-          done = true;
-          break;
-        }
-      }
-      if (!done) {
-        perturb >>= 5;
-        i = (i * 5 + 1 + perturb) & mask;
-      }
-    }
-    if (fill * 5 >= mask * 3) {
-      int newsize = 8;
-      while (newsize <= fill * 4) newsize <<= 1;
-      for (int q = 0; q < newsize; ++q) other[q] = -1;
-      for (int q = 0; q <= mask; ++q)
-        if (table[q] >= 0) set_insert_clean(other, newsize - 1, table[q]);
-      short* t = table; table = other; other = t;
-      mask = newsize - 1;
-    }
-  }
-  int m = 0;
-  for (int q = 0; q <= mask; ++q)
-    if (table[q] >= 0) order[m++] = (unsigned short)table[q];
-  return m;
-}
-
 struct SurfaceArgs {
   const float* partial;   // (B, n, 3)
   const float* complete;  // (B, m, 3)
   float* surface;         // (B, surface_pts, 3)
   int* n_selected;        // (B)
   int n, m, k, surface_pts;
+  // scratch
+  unsigned short* query;  // (B, PP_MAXN) partial index of the u-th unique row, lexicographic order
+  int* nq;                // (B)
+  int* first;             // (B, PP_MAXN) first position of each coarse index in the reference's extend() list
 };
 
-__global__ __launch_bounds__(PP_THREADS) void k_surface_select(SurfaceArgs a) {
-  __shared__ float s_p[PP_MAXN * 3];            // partial cloud
-  __shared__ float s_c[PP_MAXN * 3];            // coarse (complete) cloud
-  __shared__ unsigned short s_rep[PP_MAXN];     // 1 = first copy of its coordinates
-  __shared__ unsigned short s_query[PP_MAXN];   // representative index by lexicographic rank
-  __shared__ int s_first[PP_MAXN];              // first position of each coarse index in the reference's extend() list
-  __shared__ unsigned short s_seq[PP_MAXN];     // distinct coarse indices in first-occurrence order
-  __shared__ unsigned short s_order[PP_MAXN];   // ... in CPython set iteration order
-  __shared__ short s_tab[2][2048];
-  __shared__ int s_nq, s_nsel;
+#define PP_INF 0x7fffffff
 
+// Bitonic sort of one element per thread over a 1024-thread workgroup: partners closer than a wave exchange by shuffle, the
+// 10 long-stride stages go through LDS.  The comparison must be a strict weak order; ties may land in any order.
+template <class FS, class FL>
+__device__ __forceinline__ void pp_bitonic_stages(int tid, FS exchange_shfl, FL exchange_lds) {
+  for (int size = 2; size <= PP_THREADS; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const bool take_min = ((tid & size) == 0) == ((tid & stride) == 0);
+      if (stride < SV_WAVE) exchange_shfl(stride, take_min);
+      else exchange_lds(stride, take_min);
+    }
+  }
+}
+
+// ---- A: np.unique(partial_pc, axis=0): sort the rows lexicographically (field-wise float compare, -0.0 == 0.0), flag the
+// first row of every run of equal rows, prefix-sum the flags -> query[u] = index of a copy of the u-th unique row.
+__global__ __launch_bounds__(PP_THREADS) void k_surface_prep(SurfaceArgs a) {
+  __shared__ float s_x[PP_THREADS], s_y[PP_THREADS], s_z[PP_THREADS];
+  __shared__ int s_v[PP_THREADS];
+  __shared__ int s_wcnt[PP_WAVES];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* P = a.partial + (size_t)b * a.n * 3;
+  float x = __builtin_inff(), y = 0.f, z = 0.f;          // padding rows sort to the end
+  int v = -1;
+  if (tid < a.n) x = P[tid * 3], y = P[tid * 3 + 1], z = P[tid * 3 + 2], v = tid;
+  a.first[(size_t)b * PP_MAXN + tid] = PP_INF;
+#define PREP_KEEP(ox, oy, oz, ov)                                                                     \
+  {                                                                                                   \
+    const bool sw = take_min ? lex_less(ox, oy, oz, x, y, z) : lex_less(x, y, z, ox, oy, oz);         \
+    x = sw ? ox : x, y = sw ? oy : y, z = sw ? oz : z, v = sw ? ov : v;                               \
+  }
+  pp_bitonic_stages(
+      tid,
+      [&](int stride, bool take_min) {
+        const float ox = __shfl_xor(x, stride), oy = __shfl_xor(y, stride), oz = __shfl_xor(z, stride);
+        const int ov = __shfl_xor(v, stride);
+        PREP_KEEP(ox, oy, oz, ov)
+      },
+      [&](int stride, bool take_min) {
+        __syncthreads();
+        s_x[tid] = x, s_y[tid] = y, s_z[tid] = z, s_v[tid] = v;
+        __syncthreads();
+        const int o = tid ^ stride;
+        const float ox = s_x[o], oy = s_y[o], oz = s_z[o];
+        const int ov = s_v[o];
+        PREP_KEEP(ox, oy, oz, ov)
+      });
+#undef PREP_KEEP
+  __syncthreads();
+  s_x[tid] = x, s_y[tid] = y, s_z[tid] = z;
+  __syncthreads();
+  const bool head = v >= 0 && (tid == 0 || !(s_x[tid - 1] == x && s_y[tid - 1] == y && s_z[tid - 1] == z));
+  const unsigned long long vote = __ballot(head);
+  if (lane == 0) s_wcnt[wave] = __popcll(vote);
+  __syncthreads();
+  int rank = __popcll(vote & ((1ull << lane) - 1)), total = 0;
+  for (int w = 0; w < PP_WAVES; ++w) {
+    rank += w < wave ? s_wcnt[w] : 0;
+    total += s_wcnt[w];
+  }
+  if (head) a.query[(size_t)b * PP_MAXN + rank] = (unsigned short)v;
+  if (tid == 0) a.nq[b] = total;
+}
+
+// wave-wide unsigned min on the DPP network (quad_perm xor1, xor2, row_ror 4/8, row_bcast 15/31), result from lane 63
+__device__ __forceinline__ unsigned wave_umin_dpp(unsigned v) {
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xb1, 0xf, 0xf, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4e, 0xf, 0xf, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// ---- B: k nearest coarse points per query in ascending distance (cKDTree.query(p, k)[1], float64 squared distances).
+// One wave per query; lane owns coarse points lane, lane+64, ... : it sorts its 16 keys once (bitonic network in registers,
+// sorted list parked in LDS), then k rounds of a wave-wide min over the lanes' heads pick the neighbours in order.
+#define KNN_THREADS 256
+#define KNN_WAVES (KNN_THREADS / SV_WAVE)
+__global__ __launch_bounds__(KNN_THREADS) void k_surface_knn(SurfaceArgs a, int nsplit) {
+  __shared__ float s_c[PP_MAXN * 3];
+  __shared__ unsigned long long s_sorted[KNN_WAVES][PP_CPL][SV_WAVE];
+  __shared__ int s_first[PP_MAXN];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* C = a.complete + (size_t)b * a.m * 3;
-  for (int i = tid; i < a.n * 3; i += PP_THREADS) s_p[i] = P[i];
-  for (int i = tid; i < a.m * 3; i += PP_THREADS) s_c[i] = C[i];
-  if (tid < PP_MAXN) s_first[tid] = 0x7fffffff;
-  if (tid == 0) s_nq = 0, s_nsel = 0;
+  const float* P = a.partial + (size_t)b * a.n * 3;
+  for (int i = tid; i < a.m * 3; i += KNN_THREADS) s_c[i] = C[i];
+  for (int i = tid; i < PP_MAXN; i += KNN_THREADS) s_first[i] = PP_INF;
   __syncthreads();
-
-  // ---- np.unique(partial_pc, axis=0): representatives (earliest copy) and their lexicographic rank
-  float px = 0, py = 0, pz = 0;
-  bool rep = false;
-  if (tid < a.n) {
-    px = s_p[tid * 3], py = s_p[tid * 3 + 1], pz = s_p[tid * 3 + 2];
-    rep = true;
-    for (int j = 0; j < tid; ++j)
-      if (s_p[j * 3] == px && s_p[j * 3 + 1] == py && s_p[j * 3 + 2] == pz) { rep = false; break; }
-    s_rep[tid] = rep;
-  }
-  __syncthreads();
-  if (rep) {
-    int rank = 0;
-    for (int j = 0; j < a.n; ++j)
-      if (s_rep[j] && lex_less(s_p[j * 3], s_p[j * 3 + 1], s_p[j * 3 + 2], px, py, pz)) ++rank;
-    s_query[rank] = (unsigned short)tid;
-    atomicAdd(&s_nq, 1);
-  }
-  __syncthreads();
-  const int nq = s_nq;
-
-  // ---- k nearest coarse points per query in ascending distance (cKDTree.query(p, k)[1], float64 squared distances);
-  //      one wave per query, lane owns coarse points lane, lane+64, ...; only the first position of each index is kept.
-  for (int u = wave; u < nq; u += PP_WAVES) {
-    const int qi = s_query[u];
-    const double qx = (double)s_p[qi * 3], qy = (double)s_p[qi * 3 + 1], qz = (double)s_p[qi * 3 + 2];
+  const int nq = a.nq[b];
+  unsigned long long(*mine)[SV_WAVE] = s_sorted[wave];
+  for (int u = blockIdx.x * KNN_WAVES + wave; u < nq; u += nsplit * KNN_WAVES) {
+    const int qi = a.query[(size_t)b * PP_MAXN + u];
+    const double qx = (double)P[qi * 3], qy = (double)P[qi * 3 + 1], qz = (double)P[qi * 3 + 2];
     unsigned long long d[PP_CPL];
+    unsigned tg[PP_CPL];
 #pragma unroll
     for (int t = 0; t < PP_CPL; ++t) {
       const int c = lane + SV_WAVE * t;
       const double dx = (double)s_c[c * 3] - qx, dy = (double)s_c[c * 3 + 1] - qy, dz = (double)s_c[c * 3 + 2] - qz;
       const double dd = dx * dx + dy * dy + dz * dz;
       d[t] = (c < a.m) ? (unsigned long long)__double_as_longlong(dd) : ~0ull;   // dd >= 0: bit order == value order
+      tg[t] = t;
     }
+    // bitonic sort of (key, slot) ascending; equal keys keep the lower slot first (= lower coarse index)
+#pragma unroll
+    for (int size = 2; size <= PP_CPL; size <<= 1) {
+#pragma unroll
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+        for (int i = 0; i < PP_CPL; ++i) {
+          const int j = i ^ stride;
+          if (j > i) {
+            const bool up = (i & size) == 0;
+            const bool lt = d[j] < d[i] || (d[j] == d[i] && tg[j] < tg[i]);
+            const bool sw = up ? lt : !lt;
+            const unsigned long long ki = d[i], kj = d[j];
+            const unsigned ti = tg[i], tj = tg[j];
+            d[i] = sw ? kj : ki, d[j] = sw ? ki : kj;
+            tg[i] = sw ? tj : ti, tg[j] = sw ? ti : tj;
+          }
+        }
+      }
+    }
+    unsigned long long tags = 0;
+#pragma unroll
+    for (int t = 0; t < PP_CPL; ++t) {
+      mine[t][lane] = d[t];
+      tags |= (unsigned long long)tg[t] << (4 * t);
+    }
+    unsigned long long cur = d[0];
+    int head = 0;
     for (int r = 0; r < a.k; ++r) {
-      unsigned long long best = d[0];
-      int bt = 0;
-#pragma unroll
-      for (int t = 1; t < PP_CPL; ++t)
-        if (d[t] < best) best = d[t], bt = t;
-      const unsigned long long wmin = wave_min_u64(best);
-      int cand = best == wmin ? bt * SV_WAVE + lane : 0x7fffffff;     // ties: lowest coarse index
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off));
-      if ((cand & (SV_WAVE - 1)) == lane) {
-        atomicMin(&s_first[cand], u * a.k + r);
-        const int wt = cand / SV_WAVE;
-#pragma unroll
-        for (int t = 0; t < PP_CPL; ++t)
-          if (t == wt) d[t] = ~0ull;
+      const unsigned hi = (unsigned)(cur >> 32), lo = (unsigned)cur;
+      const unsigned mhi = wave_umin_dpp(hi);
+      unsigned long long vote = __ballot(hi == mhi);
+      int wl;
+      if (__popcll(vote) == 1) {                       // almost always: the top 32 bits of the float64 already decide
+        wl = __ffsll((long long)vote) - 1;
+      } else {
+        const unsigned mlo = wave_umin_dpp(hi == mhi ? lo : 0xffffffffu);
+        const bool match = hi == mhi && lo == mlo;
+        vote = __ballot(match);
+        if (__popcll(vote) == 1) {
+          wl = __ffsll((long long)vote) - 1;
+        } else {                                       // exact distance tie between lanes: lowest coarse index
+          wl = (int)(wave_umin_dpp(match ? (unsigned)((tags & 15) * SV_WAVE + lane) : 0xffffffffu) & (SV_WAVE - 1));
+        }
+      }
+      if (lane == wl) {
+        atomicMin(&s_first[(int)(tags & 15) * SV_WAVE + lane], u * a.k + r);
+        ++head;
+        tags >>= 4;
+        cur = head < PP_CPL ? mine[head][lane] : ~0ull;
       }
     }
   }
   __syncthreads();
+  for (int i = tid; i < a.m; i += KNN_THREADS)
+    if (s_first[i] != PP_INF) atomicMin(&a.first[(size_t)b * PP_MAXN + i], s_first[i]);
+}
 
-  // ---- distinct indices in first-occurrence order, then CPython's set order
-  if (tid < a.m && s_first[tid] != 0x7fffffff) {
-    const int mine = s_first[tid];
-    int rank = 0;
-    for (int j = 0; j < a.m; ++j) rank += s_first[j] < mine;
-    s_seq[rank] = (unsigned short)tid;
-    atomicAdd(&s_nsel, 1);
+// ---- C: distinct indices in first-occurrence order -> CPython's set order -> np.tile(sel, [surface_pts, 1])[:surface_pts]
+// Table sizes follow the key count alone (8 -> 32 after 5 keys -> 128 after 19 -> 512 after 77 -> 2048 after 307): all four
+// small tables are cleared up front by the whole workgroup, one thread replays inserts and rehashes, and the final table is
+// compacted by everyone.  >= 307 keys: every key < 1024 sits in its own slot of the 2048 table -> ascending order, no replay.
+__device__ void set_replay(const unsigned short* seq, int n, short* t8, short* t32, short* t128, short* t512) {
+  short* tabs[4] = {t8, t32, t128, t512};
+  const int masks[4] = {7, 31, 127, 511};
+  int level = 0, fill = 0;
+  short* table = tabs[0];
+  int mask = masks[0];
+  for (int s = 0; s < n; ++s) {
+    set_insert_clean(table, mask, seq[s]);           // keys are distinct: add == insert into a free slot on the same probe path
+    ++fill;
+    if (fill * 5 >= mask * 3 && level < 3) {
+      short* nt = tabs[level + 1];
+      const int nmask = masks[level + 1];
+      for (int q = 0; q <= mask; ++q)
+        if (table[q] >= 0) set_insert_clean(nt, nmask, table[q]);
+      table = nt, mask = nmask, ++level;
+    }
   }
+}
+
+__global__ __launch_bounds__(PP_THREADS) void k_surface_finish(SurfaceArgs a) {
+  __shared__ float s_c[PP_MAXN * 3];
+  __shared__ int s_first[PP_MAXN];
+  __shared__ unsigned short s_seq[PP_MAXN];
+  __shared__ unsigned short s_order[PP_MAXN];
+  __shared__ short s_tab[8 + 32 + 128 + 512];
+  __shared__ int s_nsel, s_wcnt[PP_WAVES];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* C = a.complete + (size_t)b * a.m * 3;
+  for (int i = tid; i < a.m * 3; i += PP_THREADS) s_c[i] = C[i];
+  s_first[tid] = tid < a.m ? a.first[(size_t)b * PP_MAXN + tid] : PP_INF;
+  if (tid < 8 + 32 + 128 + 512) s_tab[tid] = -1;
+  if (tid == 0) s_nsel = 0;
   __syncthreads();
-  if (tid == 0) {
-    const int m = cpython_set_order(s_seq, s_nsel, s_tab[0], s_tab[1], s_order);
-    a.n_selected[b] = m;
+  const int mine = s_first[tid];
+  // selected indices in first-occurrence order: sort (first position, index); unselected (PP_INF) sink to the end
+  int key = mine, val = tid;
+#define FIN_KEEP(ok, ov)                                   \
+  {                                                        \
+    const bool sw = take_min ? ok < key : key < ok;        \
+    key = sw ? ok : key, val = sw ? ov : val;              \
   }
+  pp_bitonic_stages(
+      tid,
+      [&](int stride, bool take_min) {
+        const int ok = __shfl_xor(key, stride), ov = __shfl_xor(val, stride);
+        FIN_KEEP(ok, ov)
+      },
+      [&](int stride, bool take_min) {
+        __syncthreads();
+        s_first[tid] = key, s_seq[tid] = (unsigned short)val;
+        __syncthreads();
+        const int ok = s_first[tid ^ stride], ov = s_seq[tid ^ stride];
+        FIN_KEEP(ok, ov)
+      });
+#undef FIN_KEEP
+  __syncthreads();
+  s_seq[tid] = (unsigned short)val;
+  const unsigned long long sel_vote = __ballot(mine != PP_INF);
+  if (lane == 0) s_wcnt[wave] = __popcll(sel_vote);
+  __syncthreads();
+  int rank_value = __popcll(sel_vote & ((1ull << lane) - 1)), nsel_total = 0;
+  for (int w = 0; w < PP_WAVES; ++w) {
+    rank_value += w < wave ? s_wcnt[w] : 0;
+    nsel_total += s_wcnt[w];
+  }
+  if (tid == 0) s_nsel = nsel_total;
   __syncthreads();
   const int nsel = s_nsel;
+  if (nsel >= 307) {
+    if (mine != PP_INF) s_order[rank_value] = (unsigned short)tid;
+  } else {
+    if (tid == 0) set_replay(s_seq, nsel, s_tab, s_tab + 8, s_tab + 40, s_tab + 168);
+    __syncthreads();
+    const int off = nsel < 5 ? 0 : (nsel < 19 ? 8 : (nsel < 77 ? 40 : 168));       // final table by key count
+    const int size = nsel < 5 ? 8 : (nsel < 19 ? 32 : (nsel < 77 ? 128 : 512));
+    const short e = tid < size ? s_tab[off + tid] : (short)-1;
+    const unsigned long long vote = __ballot(e >= 0);
+    if (lane == 0) s_wcnt[wave] = __popcll(vote);
+    __syncthreads();
+    if (e >= 0) {
+      int pos = __popcll(vote & ((1ull << lane) - 1));
+      for (int w = 0; w < wave; ++w) pos += s_wcnt[w];
+      s_order[pos] = (unsigned short)e;
+    }
+  }
+  if (tid == 0) a.n_selected[b] = nsel;
+  __syncthreads();
   float* out = a.surface + (size_t)b * a.surface_pts * 3;
   if (nsel > 0) {
-    for (int i = tid; i < a.surface_pts * 3; i += PP_THREADS) {      // np.tile(sel, [surface_pts, 1])[:surface_pts]
+    for (int i = tid; i < a.surface_pts * 3; i += PP_THREADS) {
       const int row = i / 3, col = i - row * 3;
       out[i] = s_c[s_order[row % nsel] * 3 + col];
     }
@@ -237,19 +365,28 @@ __global__ __launch_bounds__(PP_THREADS) void k_largest_cluster(ClusterArgs a) {
     const double x = s_x[tid * 3], y = s_x[tid * 3 + 1], z = s_x[tid * 3 + 2];
     bool has_nbr = false;
     const int half = a.n / 2;
+    int my_parent = tid;
+#pragma unroll 4
     for (int s = 1; s <= half; ++s) {         // every unordered pair once (twice for s == n/2 when n is even: harmless)
       int j = tid + s;
       if (j >= a.n) j -= a.n;
-      const double dx = (double)s_x[j * 3] - x, dy = (double)s_x[j * 3 + 1] - y, dz = (double)s_x[j * 3 + 2] - z;
+      // parent[j] is fetched with the coordinates so the common "already merged" test needs no dependent LDS round trip;
+      // a stale value only sends us down the full union path, which re-reads
+      const float jx = s_x[j * 3], jy = s_x[j * 3 + 1], jz = s_x[j * 3 + 2];
+      const int pj = s_parent[j];
+      const double dx = (double)jx - x, dy = (double)jy - y, dz = (double)jz - z;
       if (dx * dx + dy * dy + dz * dz < a.eps2) {
         has_nbr = true;
         s_core[j] = 1;
-        int ra = tid, rb = j;
-        while (true) {
-          ra = uf_find(s_parent, ra), rb = uf_find(s_parent, rb);
-          if (ra == rb) break;
-          if (ra > rb) { const int t = ra; ra = rb; rb = t; }
-          if (atomicCAS(&s_parent[rb], rb, ra) == rb) break;
+        if (pj != my_parent) {
+          int ra = tid, rb = j;
+          while (true) {
+            ra = uf_find(s_parent, ra), rb = uf_find(s_parent, rb);
+            if (ra == rb) break;
+            if (ra > rb) { const int t = ra; ra = rb; rb = t; }
+            if (atomicCAS(&s_parent[rb], rb, ra) == rb) break;
+          }
+          my_parent = uf_find(s_parent, tid);
         }
       }
     }
@@ -298,49 +435,55 @@ __global__ __launch_bounds__(PP_THREADS) void k_largest_cluster(ClusterArgs a) {
 // row-sorted (np.unique), so a tile of 256 consecutive rows spans a thin x-slab: a wave skips tiles whose slab is farther
 // than thresh from all of its queries.
 #define NS_TILE 256
+// D = 3: rows [x,y,z]; D = 4: rows [b,x,y,z] and only points of the same scene b are compared (a batch of scenes in one launch;
+// the merged instances are row-sorted, so tiles are scene-pure except at the seams).
+template <int D>
 __global__ __launch_bounds__(256) void k_points_near_set(const float* __restrict__ q, long nq, const float* __restrict__ r, long nr,
                                                        double thresh, unsigned char* __restrict__ near) {
-  __shared__ float s_r[NS_TILE * 3];
-  __shared__ float s_wlo[4][3], s_whi[4][3];
+  __shared__ float s_r[NS_TILE * D];
+  __shared__ float s_wlo[4][D], s_whi[4][D];
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const bool live = i < nq;
-  const float fx = live ? q[i * 3] : 0.f, fy = live ? q[i * 3 + 1] : 0.f, fz = live ? q[i * 3 + 2] : 0.f;
-  const double x = fx, y = fy, z = fz;
+  float f[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) f[c] = live ? q[i * D + c] : 0.f;
+  const double x = f[D - 3], y = f[D - 2], z = f[D - 1];
   bool found = !live;
   for (long base = 0; base < nr; base += NS_TILE) {
     const int cnt = (int)((nr - base) < NS_TILE ? (nr - base) : NS_TILE);
     __syncthreads();
-    for (int t = threadIdx.x; t < cnt * 3; t += 256) s_r[t] = r[base * 3 + t];
+    for (int t = threadIdx.x; t < cnt * D; t += 256) s_r[t] = r[base * D + t];
     __syncthreads();
     {                                            // tile bounding box: wave shuffles, then 4 partials
       const int t = threadIdx.x < cnt ? threadIdx.x : 0;
-      float lo[3], hi[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        lo[c] = hi[c] = s_r[t * 3 + c];
+      for (int c = 0; c < D; ++c) {
+        float lo = s_r[t * D + c], hi = lo;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-          lo[c] = fminf(lo[c], __shfl_xor(lo[c], off));
-          hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], off));
+          lo = fminf(lo, __shfl_xor(lo, off));
+          hi = fmaxf(hi, __shfl_xor(hi, off));
         }
-        if ((threadIdx.x & 63) == 0) s_wlo[threadIdx.x >> 6][c] = lo[c], s_whi[threadIdx.x >> 6][c] = hi[c];
+        if ((threadIdx.x & 63) == 0) s_wlo[threadIdx.x >> 6][c] = lo, s_whi[threadIdx.x >> 6][c] = hi;
       }
     }
     __syncthreads();
-    double blo[3], bhi[3];
+    float blo[D], bhi[D];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      blo[c] = (double)fminf(fminf(s_wlo[0][c], s_wlo[1][c]), fminf(s_wlo[2][c], s_wlo[3][c]));
-      bhi[c] = (double)fmaxf(fmaxf(s_whi[0][c], s_whi[1][c]), fmaxf(s_whi[2][c], s_whi[3][c]));
+    for (int c = 0; c < D; ++c) {
+      blo[c] = fminf(fminf(s_wlo[0][c], s_wlo[1][c]), fminf(s_wlo[2][c], s_wlo[3][c]));
+      bhi[c] = fmaxf(fmaxf(s_whi[0][c], s_whi[1][c]), fmaxf(s_whi[2][c], s_whi[3][c]));
     }
-    const double ex = x < blo[0] ? blo[0] - x : (x > bhi[0] ? x - bhi[0] : 0.0);
-    const double ey = y < blo[1] ? blo[1] - y : (y > bhi[1] ? y - bhi[1] : 0.0);
-    const double ez = z < blo[2] ? blo[2] - z : (z > bhi[2] ? z - bhi[2] : 0.0);
-    const bool maybe = !found && sqrt(ex * ex + ey * ey + ez * ez) < thresh;   // box distance <= point distance
+    const double ex = x < (double)blo[D - 3] ? (double)blo[D - 3] - x : (x > (double)bhi[D - 3] ? x - (double)bhi[D - 3] : 0.0);
+    const double ey = y < (double)blo[D - 2] ? (double)blo[D - 2] - y : (y > (double)bhi[D - 2] ? y - (double)bhi[D - 2] : 0.0);
+    const double ez = z < (double)blo[D - 1] ? (double)blo[D - 1] - z : (z > (double)bhi[D - 1] ? z - (double)bhi[D - 1] : 0.0);
+    bool maybe = !found && sqrt(ex * ex + ey * ey + ez * ez) < thresh;   // box distance <= point distance
+    if (D == 4) maybe = maybe && f[0] >= blo[0] && f[0] <= bhi[0];
     if (__ballot(maybe) == 0ull) continue;
     if (maybe) {
       for (int t = 0; t < cnt; ++t) {
-        const double dx = x - (double)s_r[t * 3], dy = y - (double)s_r[t * 3 + 1], dz = z - (double)s_r[t * 3 + 2];
+        if (D == 4 && s_r[t * D] != f[0]) continue;
+        const double dx = x - (double)s_r[t * D + D - 3], dy = y - (double)s_r[t * D + D - 2], dz = z - (double)s_r[t * D + D - 1];
         if (sqrt(dx * dx + dy * dy + dz * dz) < thresh) { found = true; break; }
       }
     }
@@ -348,16 +491,28 @@ __global__ __launch_bounds__(256) void k_points_near_set(const float* __restrict
   if (live) near[i] = found ? 1 : 0;
 }
 
+extern "C" size_t sv_vcn_surface_select_scratch_bytes(int batch) {
+  return (size_t)(batch < 1 ? 1 : batch) * (PP_MAXN * (sizeof(int) + sizeof(unsigned short)) + 2 * sizeof(int));
+}
+
 extern "C" int sv_vcn_surface_select(const float* partial, const float* complete, int batch, int n_partial, int n_complete, int k,
-                                     int surface_pts, float* surface, int32_t* n_selected, void* stream) {
+                                     int surface_pts, void* scratch, float* surface, int32_t* n_selected, void* stream) {
   SV_CHECK_ARG(batch >= 0 && n_partial >= 1 && n_partial <= PP_MAXN && n_complete >= 1 && n_complete <= PP_MAXN,
                "sv_vcn_surface_select: 1 <= n_partial, n_complete <= %d (got %d, %d)", PP_MAXN, n_partial, n_complete);
   SV_CHECK_ARG(k >= 1 && k <= n_complete, "sv_vcn_surface_select: 1 <= k <= n_complete (k=%d)", k);
   SV_CHECK_ARG(surface_pts >= 1, "sv_vcn_surface_select: surface_pts >= 1");
   if (batch == 0) return SV_OK;
-  SV_CHECK_ARG(partial && complete && surface && n_selected, "sv_vcn_surface_select: null pointer");
-  SurfaceArgs a{partial, complete, surface, n_selected, n_partial, n_complete, k, surface_pts};
-  hipLaunchKernelGGL(k_surface_select, dim3(batch), dim3(PP_THREADS), 0, sv_stream(stream), a);
+  SV_CHECK_ARG(partial && complete && surface && n_selected && scratch, "sv_vcn_surface_select: null pointer");
+  SurfaceArgs a{partial, complete, surface, n_selected, n_partial, n_complete, k, surface_pts, nullptr, nullptr, nullptr};
+  a.first = reinterpret_cast<int*>(scratch);
+  a.nq = a.first + (size_t)batch * PP_MAXN;
+  a.query = reinterpret_cast<unsigned short*>(a.nq + batch + (batch & 1));
+  // enough query slices per object to give every CU a workgroup
+  int nsplit = 1024 / batch;
+  nsplit = nsplit < 1 ? 1 : (nsplit > 16 ? 16 : nsplit);
+  hipLaunchKernelGGL(k_surface_prep, dim3(batch), dim3(PP_THREADS), 0, sv_stream(stream), a);
+  hipLaunchKernelGGL(k_surface_knn, dim3(nsplit, batch), dim3(KNN_THREADS), 0, sv_stream(stream), a, nsplit);
+  hipLaunchKernelGGL(k_surface_finish, dim3(batch), dim3(PP_THREADS), 0, sv_stream(stream), a);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -376,13 +531,18 @@ extern "C" int sv_vcn_largest_cluster(const float* points, int batch, int n, dou
   return SV_OK;
 }
 
-extern "C" int sv_points_near_set(const float* query, int64_t n_query, const float* ref, int64_t n_ref, double thresh, uint8_t* near,
-                                  void* stream) {
+extern "C" int sv_points_near_set(const float* query, int64_t n_query, const float* ref, int64_t n_ref, int row_dim, double thresh,
+                                  uint8_t* near, void* stream) {
   SV_CHECK_ARG(n_query >= 0 && n_ref >= 0 && thresh >= 0, "sv_points_near_set: negative size");
+  SV_CHECK_ARG(row_dim == 3 || row_dim == 4, "sv_points_near_set: row_dim must be 3 ([x,y,z]) or 4 ([b,x,y,z]), got %d", row_dim);
   if (n_query == 0) return SV_OK;
   SV_CHECK_ARG(query && near && (ref || n_ref == 0), "sv_points_near_set: null pointer");
-  hipLaunchKernelGGL(k_points_near_set, dim3(sv_div_up(n_query, 256)), dim3(256), 0, sv_stream(stream), query, (long)n_query, ref,
-                     (long)n_ref, thresh, near);
+  if (row_dim == 3)
+    hipLaunchKernelGGL(k_points_near_set<3>, dim3(sv_div_up(n_query, 256)), dim3(256), 0, sv_stream(stream), query, (long)n_query, ref,
+                       (long)n_ref, thresh, near);
+  else
+    hipLaunchKernelGGL(k_points_near_set<4>, dim3(sv_div_up(n_query, 256)), dim3(256), 0, sv_stream(stream), query, (long)n_query, ref,
+                       (long)n_ref, thresh, near);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -1,4 +1,5 @@
-"""The measured hot path as one object: VCN completion of cropped objects -> paste into the scenes ->
+"""The measured hot path as one object: VCN completion of cropped objects (network + surface selection + largest
+cluster) -> merge into the scenes (unique + replace the original object points) ->
 dynamic voxelisation -> VoxelBackBone8x -> HeightCompression (forward + backward + optimiser step).
 
 This is the composition BASELINE.json's metric names ("VCN + voxel + spconv fwd+bwd"); it only chains modules that
@@ -13,13 +14,16 @@ from .pcdet.models.backbones_2d import map_to_bev
 from .pcdet.models import backbones_3d
 from .pcdet.models.backbones_3d import vfe
 from .vcn import MODELS
+from .vcn.scene_merge import complete_scene_batch_device
+from .vcn.utils.sampling import get_largest_cluster_batch_device, get_partial_mesh_batch_device
 
 KITTI = dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.05, 0.05, 0.1], grid_size=[1408, 1600, 40])
 
 
 class SceneStep(nn.Module):
-    def __init__(self, geometry=None, input_channels=3):
+    def __init__(self, geometry=None, input_channels=3, post_process=True, sel_k=30, cluster_eps=0.4):
         super().__init__()
+        self.post_process, self.sel_k, self.cluster_eps = post_process, sel_k, cluster_eps
         g = dict(KITTI if geometry is None else geometry)
         self.geometry = g
         self.vcn = MODELS.build({'NAME': 'VCN_VC'}).eval()
@@ -38,8 +42,13 @@ class SceneStep(nn.Module):
     def complete_and_paste(self, points, objects, object_scene):
         """points (ΣP,4) [b,x,y,z]; objects (B_o,1024,3); object_scene (B_o,) float scene index of each object."""
         coarse = self.vcn({'input': objects})['coarse']                          # (B_o,1024,3)
-        bcol = object_scene.view(-1, 1, 1).expand(-1, coarse.shape[1], 1)
-        return torch.cat([points, torch.cat([bcol, coarse], dim=2).view(-1, 4)], dim=0)
+        if not self.post_process:
+            bcol = object_scene.view(-1, 1, 1).expand(-1, coarse.shape[1], 1)
+            return torch.cat([points, torch.cat([bcol, coarse], dim=2).view(-1, 4)], dim=0)
+        # VCN.inference's post-processing (models/VCN.py:89-93) and the scene merge (SEE_VCN.py:115,247-265), all on the GPU
+        surface, _ = get_partial_mesh_batch_device(objects, coarse, k=self.sel_k)
+        clustered, _ = get_largest_cluster_batch_device(surface, eps=self.cluster_eps, min_points=2, total_pts=coarse.shape[1])
+        return complete_scene_batch_device(points, clustered, object_scene, 0.1)
 
     def forward(self, points, objects, object_scene, batch_size):
         pts = self.complete_and_paste(points, objects, object_scene)

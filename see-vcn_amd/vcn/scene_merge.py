@@ -13,12 +13,14 @@ def merge_instances_device(clustered):
 
 
 def points_near_set(query, ref, thresh):
-    """bool (Nq,) : query point closer than `thresh` to any ref point (float64 distances)."""
+    """bool (Nq,) : query point closer than `thresh` to any ref point (float64 distances).  Rows are [x,y,z] or, for a batch of
+    scenes in one launch, [b,x,y,z] (only rows of the same scene are compared)."""
     lib = _lib.load()
     _lib.require_cuda(query, ref)
     q, r = query.detach().float().contiguous(), ref.detach().float().contiguous()
+    assert q.dim() == 2 and q.shape[1] == r.shape[1] and q.shape[1] in (3, 4)
     near = torch.empty((q.shape[0],), dtype=torch.uint8, device=q.device)
-    _lib.check(lib.sv_points_near_set(_lib.ptr(q) if q.numel() else None, q.shape[0], _lib.ptr(r) if r.numel() else None, r.shape[0], float(thresh),
+    _lib.check(lib.sv_points_near_set(_lib.ptr(q) if q.numel() else None, q.shape[0], _lib.ptr(r) if r.numel() else None, r.shape[0], q.shape[1], float(thresh),
                                       _lib.ptr(near) if q.numel() else None, _lib.stream()), "sv_points_near_set")
     return near.bool()
 
@@ -40,3 +42,13 @@ def replace_with_completed_pts(points, sc_instances, point_dist_thresh=0.1, devi
     p = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(device)
     r = torch.from_numpy(np.ascontiguousarray(sc_instances, dtype=np.float32)).to(device)
     return replace_with_completed_pts_device(p, r, point_dist_thresh).cpu().numpy().astype(np.float64)
+
+
+def complete_scene_batch_device(points, clustered, object_scene, point_dist_thresh=0.1):
+    """Batched tail of SEE_VCN.complete_*_pts + replace_with_completed_pts for a whole batch of scenes in one pass:
+    points (SP,4) [b,x,y,z], clustered (B_o,N,3) completed objects, object_scene (B_o,) scene id of each object ->
+    (SP',4) rows [b,x,y,z]: per-scene unique completed points first, then the scene points not within the threshold of them."""
+    bcol = object_scene.to(clustered.dtype).view(-1, 1, 1).expand(-1, clustered.shape[1], 1)
+    inst = torch.unique(torch.cat([bcol, clustered], dim=2).view(-1, 4), dim=0)        # row-sorted: scene id first, like one np.unique per scene
+    near = points_near_set(points, inst, point_dist_thresh)
+    return torch.cat([inst, points[~near]], dim=0)

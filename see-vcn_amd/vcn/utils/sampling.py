@@ -24,7 +24,8 @@ def get_partial_mesh_batch_device(batch_partial, batch_complete, k=20, surface_p
     B = p.shape[0]
     out = torch.empty((B, surface_pts, 3), dtype=torch.float32, device=p.device)
     nsel = torch.empty((B,), dtype=torch.int32, device=p.device)
-    _lib.check(lib.sv_vcn_surface_select(_lib.ptr(p), _lib.ptr(c), B, p.shape[1], c.shape[1], int(k), int(surface_pts), _lib.ptr(out),
+    scratch = _lib.workspace.scratch("surface_select", lib.sv_vcn_surface_select_scratch_bytes(B), p.device)
+    _lib.check(lib.sv_vcn_surface_select(_lib.ptr(p), _lib.ptr(c), B, p.shape[1], c.shape[1], int(k), int(surface_pts), _lib.ptr(scratch), _lib.ptr(out),
                                          _lib.ptr(nsel), _lib.stream()), "sv_vcn_surface_select")
     return out, nsel
 

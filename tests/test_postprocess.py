@@ -109,3 +109,23 @@ def test_hip_scene_merge_vs_oracle(golden_dir, cuda, hip_lib):
     got = M.replace_with_completed_pts(scene_pts[:, :3], want_inst, 0.1)
     assert 0 < near.sum() < len(scene_pts) and got.dtype == np.float64 and np.array_equal(got, want)
     assert np.array_equal(M.points_near_set(torch.from_numpy(scene_pts[:, :3].copy()).to(cuda), inst, 0.1).cpu().numpy(), near)
+
+
+@pytest.mark.gpu
+def test_hip_batched_scene_completion_vs_per_scene_oracle(golden_dir, cuda, hip_lib):
+    """complete_scene_batch_device = one launch over rows [b,x,y,z]; must equal the per-scene reference sequence."""
+    import seevcn_amd.synth as synth
+    from seevcn_amd.vcn import scene_merge as M
+    g = np.load(os.path.join(golden_dir, "vcn_post.npz"))
+    clustered = opp.get_largest_cluster_batch(g["surface_k30"], eps=0.4, min_points=2).astype(np.float32)
+    pts, boxes = synth.make_scene_batch(3, seed=2000)
+    obj_scene = np.array([0, 0, 0, 2, 2, 2, 2, 0], np.float32)                       # scene 1 gets no completed object
+    world = np.stack([clustered[b] + boxes[int(obj_scene[b])][b, :3] for b in range(8)]).astype(np.float32)
+    out = M.complete_scene_batch_device(torch.from_numpy(pts).to(cuda), torch.from_numpy(world).to(cuda), torch.from_numpy(obj_scene).to(cuda), 0.1)
+    out = out.cpu().numpy()
+    for sc in range(3):
+        mine = out[out[:, 0] == sc][:, 1:]
+        objs = [world[b] for b in range(8) if obj_scene[b] == sc]
+        scene_xyz = pts[pts[:, 0] == sc][:, 1:4]
+        want = opp.replace_with_completed_pts(scene_xyz, opp.merge_instances(objs), 0.1)[0] if objs else scene_xyz
+        assert np.array_equal(mine.astype(np.float64), np.asarray(want, np.float64)), sc
