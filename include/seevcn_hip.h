@@ -247,6 +247,19 @@ int sv_center_assign_targets(const float* gt_boxes, int batch, int max_gt, int b
                              int num_max_objs, float gaussian_overlap, int min_radius, float* heatmaps, float* target_boxes,
                              int64_t* inds, int64_t* masks, void* stream);
 
+/* ---- BatchNorm1d (+ReLU) on (N,C) voxel features: the norm_fn -> ReLU tail of post_act_block
+ * (detector3d/pcdet/models/backbones_3d/spconv_backbone.py:9-27,73; torch.nn.BatchNorm1d semantics: biased batch variance for
+ * normalisation, unbiased for running_var, running = (1-momentum)*running + momentum*batch).  C multiple of 4, C/4 divides 256.
+ * scratch: sv_batchnorm_scratch_bytes(C) bytes (uninitialised).  gamma/beta may be null (affine=False); running_* may be null when training.
+ * Backward recomputes the ReLU mask from x, so only x, save_mean and save_invstd need to be kept. */
+size_t sv_batchnorm_scratch_bytes(int channels);
+int sv_batchnorm_relu_forward(const float* x, int64_t n, int channels, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float momentum, float eps, int training, int relu, void* scratch, float* y,
+                              float* save_mean, float* save_invstd, void* stream);
+int sv_batchnorm_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, int relu, void* scratch, float* dx, float* dgamma,
+                               float* dbeta, void* stream);
+
 /* ---- VCN post-processing (CPU code in the reference) ------------------------------------------
  * partial_with_KDTree / get_partial_mesh_batch (see/surface_completion/models/vcn/utils/sampling.py:8-41,69-81): per object,
  * np.unique(partial) -> k nearest coarse points each (float64 distances) -> list(set(indices)) in CPython's set iteration

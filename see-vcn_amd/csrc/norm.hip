@@ -1,0 +1,233 @@
+// BatchNorm1d (+ ReLU) over sparse-voxel feature matrices (N, C), channel-last — the `norm_fn -> ReLU` tail of every
+// post_act_block (detector3d/pcdet/models/backbones_3d/spconv_backbone.py:9-27,73: BatchNorm1d eps 1e-3, momentum 0.01).
+// HBM-bound: forward = read x twice + write y, backward = read x,dy twice + write dx.  Three launches each way: row-chunk
+// partial sums, a per-channel fp64 combine in a fixed order (deterministic), one elementwise pass.
+#include "common.h"
+
+#define BN_THREADS 256
+#define BN_MAX_C 512
+#define BN_MAX_WGS 1024
+
+struct BnArgs {
+  const float* x;       // (N, C) BN input
+  const float* dy;      // (N, C) gradient wrt the output (backward only)
+  float* out;           // y (forward) or dx (backward)
+  const float* gamma;   // may be null (1)
+  const float* beta;    // may be null (0)
+  float* running_mean;  // may be null
+  float* running_var;
+  float* save_mean;     // (C)
+  float* save_invstd;   // (C)
+  float* dgamma;        // (C)
+  float* dbeta;
+  float* partial;       // scratch: (wgs, 2, C)
+  float* coef;          // scratch: (4, C) per-channel constants of the elementwise pass
+  int64_t n;
+  int C, relu, wgs;
+  float momentum, eps;
+};
+
+// per-thread: channels c4*4..c4*4+3 of rows (row0 + tid / C4) + k * R
+template <bool BWD>
+__global__ __launch_bounds__(BN_THREADS) void k_bn_reduce(BnArgs a) {
+  __shared__ float s_red[2][BN_THREADS * 4];
+  const int tid = threadIdx.x, C4 = a.C >> 2;
+  const int R = BN_THREADS / C4;                       // rows per sweep (C4 divides 256 for C in {4..512} powers of two; else idle lanes)
+  const int c4 = tid % C4, rr = tid / C4;
+  const bool active = rr < R;
+  const int64_t rows_per_wg = (a.n + a.wgs - 1) / a.wgs;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(a.n, r0 + rows_per_wg);
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
+  float4 mean = make_float4(0, 0, 0, 0), istd = mean, g = make_float4(1, 1, 1, 1), bt = mean;
+  if (BWD && active) {
+    mean = reinterpret_cast<const float4*>(a.save_mean)[c4], istd = reinterpret_cast<const float4*>(a.save_invstd)[c4];
+    if (a.gamma) g = reinterpret_cast<const float4*>(a.gamma)[c4];
+    if (a.beta) bt = reinterpret_cast<const float4*>(a.beta)[c4];
+  }
+  if (active) {
+    for (int64_t r = r0 + rr; r < r1; r += R) {
+      const float4 v = reinterpret_cast<const float4*>(a.x + r * a.C)[c4];
+      if (!BWD) {
+        s0.x += v.x, s0.y += v.y, s0.z += v.z, s0.w += v.w;
+        s1.x += v.x * v.x, s1.y += v.y * v.y, s1.z += v.z * v.z, s1.w += v.w * v.w;
+      } else {
+        float4 d = reinterpret_cast<const float4*>(a.dy + r * a.C)[c4];
+        const float4 xh = make_float4((v.x - mean.x) * istd.x, (v.y - mean.y) * istd.y, (v.z - mean.z) * istd.z, (v.w - mean.w) * istd.w);
+        if (a.relu) {   // ReLU mask recomputed from x: y > 0  <=>  xhat * gamma + beta > 0
+          d.x = (xh.x * g.x + bt.x > 0.f) ? d.x : 0.f, d.y = (xh.y * g.y + bt.y > 0.f) ? d.y : 0.f;
+          d.z = (xh.z * g.z + bt.z > 0.f) ? d.z : 0.f, d.w = (xh.w * g.w + bt.w > 0.f) ? d.w : 0.f;
+        }
+        s0.x += d.x, s0.y += d.y, s0.z += d.z, s0.w += d.w;
+        s1.x += d.x * xh.x, s1.y += d.y * xh.y, s1.z += d.z * xh.z, s1.w += d.w * xh.w;
+      }
+    }
+  }
+  reinterpret_cast<float4*>(s_red[0])[tid] = s0;
+  reinterpret_cast<float4*>(s_red[1])[tid] = s1;
+  __syncthreads();
+  if (tid < C4) {       // fixed-order sum over the R row groups
+    float4 t0 = make_float4(0, 0, 0, 0), t1 = t0;
+    for (int q = 0; q < R; ++q) {
+      const float4 u0 = reinterpret_cast<float4*>(s_red[0])[q * C4 + tid], u1 = reinterpret_cast<float4*>(s_red[1])[q * C4 + tid];
+      t0.x += u0.x, t0.y += u0.y, t0.z += u0.z, t0.w += u0.w;
+      t1.x += u1.x, t1.y += u1.y, t1.z += u1.z, t1.w += u1.w;
+    }
+    float* p = a.partial + (size_t)blockIdx.x * 2 * a.C;
+    reinterpret_cast<float4*>(p)[tid] = t0;
+    reinterpret_cast<float4*>(p + a.C)[tid] = t1;
+  }
+}
+
+// per-channel statistics from the workgroup partials: one workgroup per channel, fp64 tree in a fixed order
+template <bool BWD>
+__global__ __launch_bounds__(BN_THREADS) void k_bn_finalize(BnArgs a) {
+  __shared__ double s0[BN_THREADS], s1[BN_THREADS];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double t0 = 0.0, t1 = 0.0;
+  for (int w = tid; w < a.wgs; w += BN_THREADS) {
+    t0 += (double)a.partial[(size_t)w * 2 * a.C + c];
+    t1 += (double)a.partial[(size_t)w * 2 * a.C + a.C + c];
+  }
+  s0[tid] = t0, s1[tid] = t1;
+  __syncthreads();
+  for (int off = BN_THREADS / 2; off > 0; off >>= 1) {
+    if (tid < off) s0[tid] += s0[tid + off], s1[tid] += s1[tid + off];
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  t0 = s0[0], t1 = s1[0];
+  const float gm = a.gamma ? a.gamma[c] : 1.f, bb = a.beta ? a.beta[c] : 0.f;
+  if (!BWD) {
+    const double m = t0 / (double)a.n;
+    double var = t1 / (double)a.n - m * m;             // biased variance of the batch
+    var = var < 0.0 ? 0.0 : var;
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    a.save_mean[c] = (float)m, a.save_invstd[c] = invstd;
+    if (a.running_mean) {
+      const double unbiased = a.n > 1 ? var * (double)a.n / (double)(a.n - 1) : var;
+      a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
+      a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+    }
+    a.coef[c] = invstd * gm;                            // y = x * scale + shift
+    a.coef[a.C + c] = bb - (float)m * invstd * gm;
+  } else {
+    const float invstd = a.save_invstd[c], m = a.save_mean[c];
+    a.dbeta[c] = (float)t0, a.dgamma[c] = (float)t1;
+    // dx = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat)),  xhat = (x - m) * invstd
+    a.coef[c] = gm * invstd;
+    a.coef[a.C + c] = (float)(t0 / (double)a.n);
+    a.coef[2 * a.C + c] = (float)(t1 / (double)a.n);
+    a.coef[3 * a.C + c] = m;
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void k_bn_apply_fwd(BnArgs a) {
+  const int C4 = a.C >> 2;
+  const int64_t total = a.n * C4;
+  for (int64_t i = (int64_t)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * BN_THREADS) {
+    const int c4 = (int)(i % C4);
+    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
+    const float4 sc = reinterpret_cast<const float4*>(a.coef)[c4], sh = reinterpret_cast<const float4*>(a.coef + a.C)[c4];
+    float4 y = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    if (a.relu) y.x = fmaxf(y.x, 0.f), y.y = fmaxf(y.y, 0.f), y.z = fmaxf(y.z, 0.f), y.w = fmaxf(y.w, 0.f);
+    reinterpret_cast<float4*>(a.out)[i] = y;
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void k_bn_apply_bwd(BnArgs a) {
+  const int C4 = a.C >> 2;
+  const int64_t total = a.n * C4;
+  for (int64_t i = (int64_t)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * BN_THREADS) {
+    const int c4 = (int)(i % C4);
+    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
+    float4 d = reinterpret_cast<const float4*>(a.dy)[i];
+    const float4 k = reinterpret_cast<const float4*>(a.coef)[c4], md = reinterpret_cast<const float4*>(a.coef + a.C)[c4];
+    const float4 mx = reinterpret_cast<const float4*>(a.coef + 2 * a.C)[c4], m = reinterpret_cast<const float4*>(a.coef + 3 * a.C)[c4];
+    const float4 istd = reinterpret_cast<const float4*>(a.save_invstd)[c4];
+    const float4 xh = make_float4((v.x - m.x) * istd.x, (v.y - m.y) * istd.y, (v.z - m.z) * istd.z, (v.w - m.w) * istd.w);
+    if (a.relu) {
+      const float4 g = a.gamma ? reinterpret_cast<const float4*>(a.gamma)[c4] : make_float4(1, 1, 1, 1);
+      const float4 bt = a.beta ? reinterpret_cast<const float4*>(a.beta)[c4] : make_float4(0, 0, 0, 0);
+      d.x = (xh.x * g.x + bt.x > 0.f) ? d.x : 0.f, d.y = (xh.y * g.y + bt.y > 0.f) ? d.y : 0.f;
+      d.z = (xh.z * g.z + bt.z > 0.f) ? d.z : 0.f, d.w = (xh.w * g.w + bt.w > 0.f) ? d.w : 0.f;
+    }
+    reinterpret_cast<float4*>(a.out)[i] = make_float4(k.x * (d.x - md.x - xh.x * mx.x), k.y * (d.y - md.y - xh.y * mx.y),
+                                                      k.z * (d.z - md.z - xh.z * mx.z), k.w * (d.w - md.w - xh.w * mx.w));
+  }
+}
+
+// eval mode: per-channel scale/shift from the running statistics (one tiny launch), then the same apply kernel
+__global__ void k_bn_eval_coef(BnArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  const float invstd = 1.f / sqrtf(a.running_var[c] + a.eps);
+  const float gm = a.gamma ? a.gamma[c] : 1.f, bb = a.beta ? a.beta[c] : 0.f;
+  a.coef[c] = invstd * gm;
+  a.coef[a.C + c] = bb - a.running_mean[c] * invstd * gm;
+}
+
+static int bn_wgs(int64_t n, int C) {
+  const int R = BN_THREADS / (C / 4);
+  int64_t w = (n + (int64_t)R * 8 - 1) / ((int64_t)R * 8);   // at least 8 sweeps per workgroup
+  if (w < 1) w = 1;
+  if (w > BN_MAX_WGS) w = BN_MAX_WGS;
+  return (int)w;
+}
+
+extern "C" size_t sv_batchnorm_scratch_bytes(int channels) {
+  return ((size_t)BN_MAX_WGS * 2 * channels + 4 * (size_t)channels) * sizeof(float);
+}
+
+static int bn_common_check(const char* who, int64_t n, int C) {
+  SV_CHECK_ARG(n >= 1, "%s: needs at least one row (got %ld)", who, (long)n);
+  SV_CHECK_ARG(C >= 4 && C <= BN_MAX_C && (C & 3) == 0 && BN_THREADS % (C / 4) == 0,
+               "%s: channels must be a multiple of 4 with C/4 dividing %d, <= %d (got %d)", who, BN_THREADS, BN_MAX_C, C);
+  return SV_OK;
+}
+
+static void bn_scratch(BnArgs& a, void* scratch) {
+  a.coef = reinterpret_cast<float*>(scratch);
+  a.partial = a.coef + 4 * (size_t)a.C;
+}
+
+extern "C" int sv_batchnorm_relu_forward(const float* x, int64_t n, int channels, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float momentum, float eps, int training, int relu,
+                                         void* scratch, float* y, float* save_mean, float* save_invstd, void* stream) {
+  if (int rc = bn_common_check("sv_batchnorm_relu_forward", n, channels)) return rc;
+  SV_CHECK_ARG(x && y && scratch, "sv_batchnorm_relu_forward: null pointer");
+  SV_CHECK_ARG(training ? (save_mean && save_invstd) : (running_mean && running_var),
+               "sv_batchnorm_relu_forward: training needs save_mean/save_invstd, eval needs running statistics");
+  BnArgs a{};
+  a.x = x, a.out = y, a.gamma = gamma, a.beta = beta, a.running_mean = running_mean, a.running_var = running_var;
+  a.save_mean = save_mean, a.save_invstd = save_invstd, a.n = n, a.C = channels, a.relu = relu, a.momentum = momentum, a.eps = eps;
+  a.wgs = bn_wgs(n, channels);
+  bn_scratch(a, scratch);
+  hipStream_t st = sv_stream(stream);
+  if (training) {
+    hipLaunchKernelGGL(k_bn_reduce<false>, dim3(a.wgs), dim3(BN_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_bn_finalize<false>, dim3(channels), dim3(BN_THREADS), 0, st, a);
+  } else
+    hipLaunchKernelGGL(k_bn_eval_coef, dim3(sv_div_up(channels, 128)), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(k_bn_apply_fwd, dim3(sv_grid_1d(n * (channels / 4), BN_THREADS)), dim3(BN_THREADS), 0, st, a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_batchnorm_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* gamma, const float* beta,
+                                          const float* save_mean, const float* save_invstd, int relu, void* scratch, float* dx,
+                                          float* dgamma, float* dbeta, void* stream) {
+  if (int rc = bn_common_check("sv_batchnorm_relu_backward", n, channels)) return rc;
+  SV_CHECK_ARG(x && dy && dx && dgamma && dbeta && save_mean && save_invstd && scratch, "sv_batchnorm_relu_backward: null pointer");
+  BnArgs a{};
+  a.x = x, a.dy = dy, a.out = dx, a.gamma = gamma, a.beta = beta, a.dgamma = dgamma, a.dbeta = dbeta;
+  a.save_mean = const_cast<float*>(save_mean), a.save_invstd = const_cast<float*>(save_invstd);
+  a.n = n, a.C = channels, a.relu = relu;
+  a.wgs = bn_wgs(n, channels);
+  bn_scratch(a, scratch);
+  hipStream_t st = sv_stream(stream);
+  hipLaunchKernelGGL(k_bn_reduce<true>, dim3(a.wgs), dim3(BN_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_bn_finalize<true>, dim3(channels), dim3(BN_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_bn_apply_bwd, dim3(sv_grid_1d(n * (channels / 4), BN_THREADS)), dim3(BN_THREADS), 0, st, a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -58,7 +58,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDP];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of the
+  // (row-block major) tile list: the N-tiles that share an A row-block then hit the same L2 instead of 8 different ones.
+  int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int total = gridDim.x * gridDim.y;
+  if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+  const int m0 = (lin / (int)gridDim.x) * BM, n0 = (lin % (int)gridDim.x) * BN;
   const int lr = tid >> 3, lc = (tid & 7) * 4;  // staging: row lr (+32*i), k offset lc
 
   float4 ra[4], rb[4];

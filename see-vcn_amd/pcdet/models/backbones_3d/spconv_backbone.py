@@ -2,6 +2,7 @@ from functools import partial
 
 import torch.nn as nn
 
+from ....spconv import norm
 from ...utils.spconv_utils import replace_feature, spconv
 
 
@@ -37,9 +38,15 @@ class SparseBasicBlock(spconv.SparseModule):
     def forward(self, x):
         identity = x
         out = self.conv1(x)
-        out = replace_feature(out, self.relu(self.bn1(out.features)))
+        if norm.fusable(self.bn1, out.features):
+            out = replace_feature(out, norm.batch_norm_relu(self.bn1, out.features, True))
+        else:
+            out = replace_feature(out, self.relu(self.bn1(out.features)))
         out = self.conv2(out)
-        out = replace_feature(out, self.bn2(out.features))
+        if norm.fusable(self.bn2, out.features):
+            out = replace_feature(out, norm.batch_norm_relu(self.bn2, out.features, False))
+        else:
+            out = replace_feature(out, self.bn2(out.features))
         if self.downsample is not None:
             identity = self.downsample(x)
         out = replace_feature(out, self.relu(out.features + identity.features))

@@ -47,12 +47,23 @@ class SparseSequential(SparseModule):
 
     def forward(self, input):
         from .core import SparseConvTensor
-        for module in self._modules.values():
+        from . import norm
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if _is_sparse(module):
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
-                    input = input.replace_feature(module(input.features))
+                    if norm.fusable(module, input.features):
+                        # BatchNorm1d [-> ReLU] in one pass over the features (sv_batchnorm_relu_forward)
+                        relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+                        input = input.replace_feature(norm.batch_norm_relu(module, input.features, relu))
+                        i += 1 if relu else 0
+                    else:
+                        input = input.replace_feature(module(input.features))
             else:
                 input = module(input)
+            i += 1
         return input

@@ -259,3 +259,40 @@ def test_hip_backbone8x_vs_oracle(cuda, hip_lib):
     f, c, shape = ref["out"]
     assert list(t.spatial_shape) == [2, 200, 176] == list(shape)
     assert np.array_equal(t.indices.cpu().numpy(), c) and _rel(t.features.cpu().numpy(), f) < RTOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c,relu", [(134580, 64, True), (50001, 16, True), (7, 128, False), (2, 32, True), (300000, 32, False)])
+def test_hip_fused_batchnorm_relu_matches_torch(cuda, hip_lib, n, c, relu):
+    """sv_batchnorm_relu_forward/backward vs torch.nn.BatchNorm1d(eps=1e-3, momentum=0.01) [+ ReLU] (spconv_backbone.py:73), the
+    reference's own norm layer: outputs, running statistics, input / weight / bias gradients; then eval mode."""
+    import torch.nn as nn
+    from seevcn_amd.spconv import norm
+    g = torch.Generator().manual_seed(n + c)
+    x0 = (torch.randn(n, c, generator=g) * 1.7 + 0.6).to(cuda)
+    dy = torch.randn(n, c, generator=g).to(cuda)
+    ref, mine = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(cuda), nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(cuda)
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(c, generator=g) + 0.5), ref.bias.copy_(torch.randn(c, generator=g) * 0.3)
+    mine.load_state_dict(ref.state_dict())
+    xr, xm = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    assert norm.fusable(mine, xm)
+    for _ in range(2):                                        # two steps: running statistics accumulate
+        yr = ref(xr)
+        yr = torch.relu(yr) if relu else yr
+        ym = norm.batch_norm_relu(mine, xm, relu)
+    tol = dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ym, yr, **tol)
+    torch.testing.assert_close(mine.running_mean, ref.running_mean, **tol)
+    torch.testing.assert_close(mine.running_var, ref.running_var, **tol)
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+    yr.backward(dy), ym.backward(dy)
+    scale = float(xr.grad.abs().max())
+    assert float((xm.grad - xr.grad).abs().max()) <= 1e-3 * scale + 1e-6
+    torch.testing.assert_close(mine.weight.grad, ref.weight.grad, rtol=1e-3, atol=1e-3 * float(ref.weight.grad.abs().max()))
+    torch.testing.assert_close(mine.bias.grad, ref.bias.grad, rtol=1e-3, atol=1e-3 * float(ref.bias.grad.abs().max()))
+    ref.eval(), mine.eval()
+    with torch.no_grad():
+        ye = ref(x0)
+        ye = torch.relu(ye) if relu else ye
+        torch.testing.assert_close(norm.batch_norm_relu(mine, x0, relu), ye, **tol)
