@@ -150,7 +150,7 @@ int sv_dense_to_sparse(const float* dense, const int32_t* coords, int64_t n, int
                        float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * PointNet++ stacked-batch primitives (detector3d/pcdet/ops/pointnet2/pointnet2_stack/src/*.cu; pybind names in
+ * PointNet++ stacked-batch primitives (detector3d/pcdet/ops/pointnet2/pointnet2_stack/src/ *.cu; pybind names in
  * src/pointnet2_api.cpp:12-31).  Scenes are described by device int32 arrays of first row and row count.
  * ---------------------------------------------------------------------------------------------- */
 /* farthest_point_sampling_wrapper(b, n, m, points, temp, idx) (src/sampling.cpp:24-36; kernel sampling_gpu.cu:24-140):
