@@ -138,6 +138,10 @@ __global__ __launch_bounds__(SC_THREADS) void k_spconv_mfma(ConvArgs a) {
 // Summation order per output element is fixed (k ascending, channels ascending) -> bitwise reproducible.
 // Measured (MI355X, 64->64 submanifold layer, 134 580 rows, 1.17 M pairs): 250 us = 38 TFLOP/s algorithmic;
 // matrix-core busy 38 % — waves spend their time in issue stalls, see DESIGN.md "sparse conv: what limits it".
+// Two LDS-DMA restructurings (global_load_lds row gathers into a ring, offset-major weight slabs) were built, verified
+// bit-compatible with the tests and measured slower (304 us with columns split over a workgroup's waves and a barrier per
+// position; 266 us wave-private with the next slab prefetched) — they are in the git history (commit "Experimental
+// wave-private LDS-DMA sparse conv kernel"), the findings in DESIGN.md.
 // ------------------------------------------------------------------------------------------------
 template <int NT, int KQ, int RS_G>
 __global__ __launch_bounds__(256) void k_spconv_rs(ConvArgs a) {
@@ -238,239 +242,6 @@ __global__ __launch_bounds__(256) void k_spconv_rs(ConvArgs a) {
       }
 }
 
-// ------------------------------------------------------------------------------------------------
-// LDS-DMA variant for 64 -> 64 channels (the layers that dominate the step).  Same ownership as k_spconv_rs — a wave owns
-// 4 strided 16-row tiles x all 64 columns, no workgroup barrier anywhere — but
-//   * offset-major: the 64x64 weight slab of an offset is loaded once per wave into 64 registers and serves all of the wave's
-//     tiles that have a neighbour at that offset (k_spconv_rs re-requested a quarter slab per 16-channel step);
-//   * the gathered rows arrive by LDS-DMA (global_load_lds_dwordx4: 4 whole 256-byte rows per instruction, the per-lane
-//     source address makes it a row gather) into a wave-private 2-slot ring, one position ahead of the matrix core, without
-//     occupying registers; the LDS image is XOR-swizzled on the SOURCE side (chunk ^ row) so that the MFMA operand reads
-//     (ds_read_b128, lane = (row, k-quarter)) are conflict free; the contraction index is permuted (k = 16s + 4q + j) so one
-//     b128 feeds 4 MFMAs of each of the 4 column tiles (64 MFMAs per position, 4 independent accumulation chains);
-//   * the wave's neighbour indices are parked in LDS once (27 x 64 ints), so the loop issues no register-destination loads
-//     except the weight slab at an offset change.
-// An earlier version split the columns over the 4 waves of a workgroup (shared rows, 16 MFMAs per wave and position, one
-// s_barrier per position): 304 us for the layer that k_spconv_rs does in 248 us — a 512-cycle position cannot carry a
-// barrier, ~23 branches and three LDS round trips.  Lessons kept here: LDS reads of the loop are inline asm (for a
-// compiler-visible ds_read of memory an LDS-DMA may be writing hipcc waits vmcnt(0)), accumulators are only ever touched in
-// statically indexed code (a switch over 8 accumulators became copies through phi registers at every step).
-// Summation order per output element is fixed -> bitwise reproducible.
-// ------------------------------------------------------------------------------------------------
-constexpr int DW_G = 4;            // 16-row tiles per wave
-constexpr int DW_KMAX = 27;
-constexpr int DW_RING = 3;         // 4 KB position buffers per wave: DW_RING - 1 gathers in flight ahead of the matrix core
-
-__device__ __attribute__((aligned(256))) float g_zero_row[64];
-
-typedef __attribute__((address_space(1))) const void* sv_gptr_t;
-typedef __attribute__((address_space(3))) void* sv_lptr_t;
-
-__device__ __forceinline__ uint32_t dm_lds_addr(const void* p) {
-  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
-__device__ __forceinline__ f32x4 dm_read_b128(uint32_t addr) {
-  f32x4 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-  return v;
-}
-__device__ __forceinline__ int dm_read_b32(uint32_t addr) {
-  int v;
-  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
-  return v;
-}
-#define DM_WAIT_LGKM4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-// register-destination load hidden from hipcc's waitcnt insertion (beside LDS-DMA it would wait vmcnt(0) at the first use):
-// the caller counts the queue by hand and waits with dm_wait_vmcnt_x4 before touching the result
-__device__ __forceinline__ f32x4 dm_global_load_b128(const float* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ void dm_wait_vmcnt_x4(int n) {   // wave-uniform: at most 4*n loads outstanding, n = 0..6
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void k_spconv_dmaw64(ConvArgs a, int64_t n_waves) {
-  // one __shared__ object (75 KB: two workgroups per CU); per wave: ring [DW_RING][16 rows x 64 ch] floats | idx int32 [DW_KMAX][64]
-  constexpr int RING_BYTES = DW_RING * 4096;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * (RING_BYTES + DW_KMAX * 64 * 4)];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int li = lane & 15, q = lane >> 4;
-  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid;
-  if (wave_id >= n_waves) return;                      // no barrier is ever used: waves are independent
-  unsigned char* my = smem + wid * RING_BYTES;
-  float(*s_ring)[1024] = reinterpret_cast<float(*)[1024]>(my);
-  int32_t(*s_idx)[64] = reinterpret_cast<int32_t(*)[64]>(smem + 4 * RING_BYTES + wid * (DW_KMAX * 64 * 4));
-  auto tile_row0 = [&](int g) { return (wave_id + (int64_t)g * n_waves) * 16; };
-
-  // ---- neighbour indices of the wave's 64 rows -> LDS; 4-bit tile mask per offset kept in lane k of `maskreg`
-  unsigned maskreg = 0;
-  {
-    const int64_t row = tile_row0(q) + li;             // lane <-> (tile q, row li)
-    const bool valid = row < a.n_rows;
-    int32_t j[DW_KMAX];
-#pragma unroll
-    for (int k = 0; k < DW_KMAX; ++k) j[k] = (valid && k < a.K) ? a.nbr[(int64_t)k * a.n_rows + row] : -1;
-#pragma unroll
-    for (int k = 0; k < DW_KMAX; ++k) {
-      s_idx[k][lane] = j[k];
-      const unsigned long long vote = __ballot(j[k] >= 0);
-      unsigned m = 0;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) m |= ((vote >> (16 * t)) & 0xffffull) ? (1u << t) : 0u;
-      if (lane == k) maskreg = m;
-    }
-  }
-  unsigned long long kbits = __ballot(maskreg != 0);   // offsets with at least one neighbour
-
-  f32x4 acc[DW_G][4];
-#pragma unroll
-  for (int g = 0; g < DW_G; ++g)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  if (kbits) {
-    const uint32_t idx_base = dm_lds_addr(&s_idx[0][0]);
-    const uint32_t ring_base = dm_lds_addr(&s_ring[0][li * 64]);
-    const uint32_t o0 = (uint32_t)(((0 + q) ^ li) << 4), o1 = (uint32_t)(((4 + q) ^ li) << 4), o2 = (uint32_t)(((8 + q) ^ li) << 4),
-                   o3 = (uint32_t)(((12 + q) ^ li) << 4);
-    // gather of position (k, g) into ring slot `slot`: 4 instructions x 4 rows; lane -> (row 4i + q, position li)
-    auto gather = [&](int k, int g, int slot) {
-      const uint32_t ib = idx_base + (uint32_t)((k * 64 + g * 16 + q) << 2);
-      int32_t j0 = dm_read_b32(ib), j1 = dm_read_b32(ib + 16), j2 = dm_read_b32(ib + 32), j3 = dm_read_b32(ib + 48);
-      DM_WAIT_LGKM4(j0, j1, j2, j3);
-      const int32_t jj[4] = {j0, j1, j2, j3};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = i * 4 + q;
-        const float* src = (jj[i] >= 0 ? a.X + (int64_t)jj[i] * 64 : g_zero_row) + ((li ^ r) << 2);
-        __builtin_amdgcn_global_load_lds((sv_gptr_t)src, (sv_lptr_t)&s_ring[slot][i * 256], 16, 0, 0);
-      }
-    };
-    auto load_b = [&](int k, f32x4 (&B)[4][4]) {    // 16 loads, invisible to hipcc's wait insertion
-      const float* w = a.Wt + ((int64_t)k * 64 + li) * 64 + q * 4;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) B[t][s] = dm_global_load_b128(w + (int64_t)t * 16 * 64 + s * 16);
-    };
-
-    // gather iterator: runs DW_RING - 1 positions ahead of the compute loop through the same (offset, tile) order
-    unsigned long long gk_bits = kbits;
-    int gk = -1, gslot = 0, in_flight = 0;
-    unsigned grest = 0;
-    auto gather_next = [&]() {                          // wave-uniform control
-      if (!grest) {
-        if (!gk_bits) return;
-        gk = __ffsll((long long)gk_bits) - 1;
-        gk_bits &= gk_bits - 1;
-        grest = (unsigned)__builtin_amdgcn_readlane((int)maskreg, gk);
-      }
-      const int g = __ffs(grest) - 1;
-      grest &= grest - 1;
-      gather(gk, g, gslot);
-      gslot = gslot + 1 == DW_RING ? 0 : gslot + 1;
-      ++in_flight;
-    };
-#pragma unroll
-    for (int i = 0; i < DW_RING - 1; ++i) gather_next();
-
-    int k = __ffsll((long long)kbits) - 1;
-    kbits &= kbits - 1;
-    unsigned m = (unsigned)__builtin_amdgcn_readlane((int)maskreg, k);
-    // weight slabs: B = current offset, Bn = next active offset, requested one offset ahead (16 loads in the same in-order
-    // queue as the gathers).  b_pending: Bn's loads may still be in flight; b_after: gathers issued after them.
-    f32x4 B[4][4], Bn[4][4];
-    load_b(k, B);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // once, before the loop (also lands the first gathers)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) asm volatile("" : "+v"(B[t][s2]));
-    int slot = 0, b_after = 0;
-    bool b_pending = false;
-    while (true) {
-      const int kn = kbits ? __ffsll((long long)kbits) - 1 : -1;
-      if (kn >= 0) load_b(kn, Bn), b_pending = true, b_after = 0;
-#pragma unroll
-      for (int g = 0; g < DW_G; ++g) {
-        if (!((m >> g) & 1u)) continue;                 // wave-uniform
-        {                                               // keep DW_RING - 1 positions in flight behind this one
-          const int before = in_flight;
-          gather_next();
-          b_after += in_flight - before;
-        }
-        // this position's 4 DMA instructions are the oldest gather in flight: everything issued after them may stay outstanding
-        {
-          const int newer = in_flight - 1;              // gathers issued after it
-          const bool b_newer = b_pending && newer >= b_after;   // the slab request came after it as well
-          dm_wait_vmcnt_x4(newer + (b_newer ? 4 : 0));
-        }
-        --in_flight;
-        const uint32_t ab = ring_base + ((uint32_t)slot << 12);
-        f32x4 A0 = dm_read_b128(ab + o0), A1 = dm_read_b128(ab + o1), A2 = dm_read_b128(ab + o2), A3 = dm_read_b128(ab + o3);
-        DM_WAIT_LGKM4(A0, A1, A2, A3);
-        const f32x4 A[4] = {A0, A1, A2, A3};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s].x, B[t][s].x, acc[g][t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s].y, B[t][s].y, acc[g][t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s].z, B[t][s].z, acc[g][t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s].w, B[t][s].w, acc[g][t], 0, 0, 0);
-        }
-        slot = slot + 1 == DW_RING ? 0 : slot + 1;
-      }
-      if (kn < 0) break;
-      // next offset: its slab must have landed = at most the gathers issued after the request are outstanding
-      dm_wait_vmcnt_x4(b_after < in_flight ? b_after : in_flight);
-      b_pending = false;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-          asm volatile("" : "+v"(Bn[t][s2]));
-          B[t][s2] = Bn[t][s2];
-        }
-      k = kn;
-      kbits &= kbits - 1;
-      m = (unsigned)__builtin_amdgcn_readlane((int)maskreg, k);
-    }
-  }
-
-  // D layout (16x16): col = lane&15, row = 4*(lane>>4) + reg
-#pragma unroll
-  for (int g = 0; g < DW_G; ++g)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = tile_row0(g) + q * 4 + r;
-        const int col = t * 16 + li;
-        if (row < a.n_rows) a.Y[row * 64 + col] = conv_epilogue(acc[g][t][r], col, row, a);
-      }
-}
-
-static int try_launch_dma64(const ConvArgs& a, hipStream_t st) {
-  if (a.Kd != 64 || a.Nc != 64 || a.K > DW_KMAX) return -1;
-  const int64_t n_tiles = (a.n_rows + 15) / 16;
-  const int64_t n_waves = (n_tiles + DW_G - 1) / DW_G;
-  hipLaunchKernelGGL(k_spconv_dmaw64, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, a, n_waves);
-  return 0;
-}
-
 template <int NT, int G>
 static int launch_rs_kq(const ConvArgs& a, int kq, hipStream_t st) {
   const int64_t n_tiles = (a.n_rows + 15) / 16;
@@ -534,11 +305,6 @@ extern "C" int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const i
   const bool mfma_ok = (Kd % 16 == 0) && (Nc % 16 == 0) && (nt == 1 || nt == 2 || nt == 4 || nt == 8) &&
                        ((uintptr_t)X % 16 == 0) && ((uintptr_t)Wt % 16 == 0);
   static const bool force_v1 = getenv("SEEVCN_SPCONV_V1") != nullptr;
-  static const bool no_dma = getenv("SEEVCN_SPCONV_NODMA") != nullptr;
-  if (mfma_ok && !force_v1 && !no_dma && try_launch_dma64(a, st) == 0) {
-    SV_LAUNCH_CHECK();
-    return SV_OK;
-  }
   if (mfma_ok && !force_v1 && try_launch_rs(a, st) == 0) {
     SV_LAUNCH_CHECK();
     return SV_OK;
