@@ -1,4 +1,5 @@
 from .dynamic_mean_vfe import DynamicMeanVFE
+from .dynamic_pillar_vfe import DynamicPillarVFE
 from .mean_vfe import MeanVFE
 from .pillar_vfe import PillarVFE
 from .vfe_template import VFETemplate
@@ -9,4 +10,5 @@ __all__ = {
     'MeanVFE': MeanVFE,
     'PillarVFE': PillarVFE,
     'DynMeanVFE': DynamicMeanVFE,
+    'DynPillarVFE': DynamicPillarVFE,
 }
