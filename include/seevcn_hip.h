@@ -260,6 +260,15 @@ int sv_batchnorm_relu_backward(const float* x, const float* dy, int64_t n, int c
                                const float* save_mean, const float* save_invstd, int relu, void* scratch, float* dx, float* dgamma,
                                float* dbeta, void* stream);
 
+/* ---- Chamfer distance of the VCN training loss: the reference's `chamfer` extension,
+ * see/surface_completion/models/vcn/extensions/chamfer_dist/chamfer_cuda.cpp:36-39 (forward -> [dist1, dist2, idx1, idx2],
+ * backward -> [grad_xyz1, grad_xyz2]) over chamfer.cu:15-201.  xyz1 (B,n,3), xyz2 (B,m,3); squared distances; idx = first
+ * nearest neighbour; backward zero-fills its outputs. */
+int sv_chamfer_forward(const float* xyz1, const float* xyz2, int batch, int n, int m, float* dist1, float* dist2, int32_t* idx1,
+                       int32_t* idx2, void* stream);
+int sv_chamfer_backward(const float* xyz1, const float* xyz2, const int32_t* idx1, const int32_t* idx2, const float* grad_dist1,
+                        const float* grad_dist2, int batch, int n, int m, float* grad_xyz1, float* grad_xyz2, void* stream);
+
 /* ---- VCN post-processing (CPU code in the reference) ------------------------------------------
  * partial_with_KDTree / get_partial_mesh_batch (see/surface_completion/models/vcn/utils/sampling.py:8-41,69-81): per object,
  * np.unique(partial) -> k nearest coarse points each (float64 distances) -> list(set(indices)) in CPython's set iteration

@@ -2,8 +2,31 @@ import torch
 import torch.nn as nn
 
 from ... import _lib
+from ..extensions.chamfer_dist import ChamferDistanceL2
+from ..utils import misc
+from ..utils.bbox_utils import get_bbox_from_keypoints
+from ..utils.losses import geodesic_distance
+from ..utils.sampling import get_partial_mesh_batch_device
+from ..utils.transform import rot_from_heading, rotate_points_along_z
 from . import layers as L
 from .build import MODELS
+
+
+def normalize_vector(v):
+    v_mag = torch.sqrt(v.pow(2).sum(1)).clamp_min(1e-8)          # VCN_VC.py:12-21 (max with 1e-8)
+    return v / v_mag.view(-1, 1)
+
+
+def cross_product(u, v):
+    return torch.stack((u[:, 1] * v[:, 2] - u[:, 2] * v[:, 1], u[:, 2] * v[:, 0] - u[:, 0] * v[:, 2], u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]), 1)
+
+
+def compute_rotation_matrix_from_ortho6d(ortho6d):
+    """Gram-Schmidt 6-D -> rotation matrix with columns x, y, z (VCN_VC.py:37-49)."""
+    x = normalize_vector(ortho6d[:, 0:3])
+    z = normalize_vector(cross_product(x, ortho6d[:, 3:6]))
+    y = cross_product(z, x)
+    return torch.cat((x.view(-1, 3, 1), y.view(-1, 3, 1), z.view(-1, 3, 1)), 2)
 
 
 @MODELS.register_module()
@@ -12,8 +35,9 @@ class VCN_VC(nn.Module):
 
     Same constructor (`VCN_VC(config)`), same state_dict keys (including the unused `final_conv`, :133-141),
     same forward contract: in_dict['input'] (B,n,3) -> {'coarse' (B,1024,3), 'reg_rot' (B,3,3), 'reg_centre' (B,3)}.
-    The forward runs entirely on libseevcn_hip.so (fp32 MFMA GEMMs with fused bias/BN/activation/max-pool
-    epilogues); inference only — the reference's training loss (get_loss, :150-176) is out of scope.
+    eval(): the forward runs entirely on libseevcn_hip.so (fp32 MFMA GEMMs with fused bias/BN/activation/max-pool epilogues,
+    BatchNorm folded).  train(): the same layer stack runs as plain torch ops with autograd (batch-statistics BatchNorm), and
+    get_loss (:150-176) uses the HIP Chamfer distance, farthest point sampling and surface selection.
     """
 
     def __init__(self, config):
@@ -30,19 +54,69 @@ class VCN_VC(nn.Module):
             nn.Conv1d(1024 + 3 + 2, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True), nn.Conv1d(512, 512, 1),
             nn.BatchNorm1d(512), nn.ReLU(inplace=True), nn.Conv1d(512, 3, 1))
         self._prepared = L.PreparedCache(self, self._prepare)
+        self.build_loss_func()
 
     def _prepare(self):
         pe = self.pose_encoder
         return dict(pose=[L.conv_wb(pe[0]), L.conv_wb(pe[2]), L.conv_wb(pe[4])], pose_fc=L.prepare_fc(self.pose_fc),
                     enc=L.prepare_encoder(self.encoder), shape_fc=L.prepare_fc(self.shape_fc))
 
-    def get_loss(self, ret_dict, in_dict):
-        raise NotImplementedError("VCN training loss (Chamfer + FPS, VCN_VC.py:150-176) is outside the built hot path")
+    def build_loss_func(self):
+        self.loss_coarse = ChamferDistanceL2()
+        self.loss_partial = ChamferDistanceL2()
+        self.loss_translation = nn.SmoothL1Loss(reduction='none')
+        self.loss_dims = nn.SmoothL1Loss(reduction='none')
 
-    @torch.no_grad()
+    def get_loss(self, ret_dict, in_dict):
+        """dims / translation / rotation / coarse (Chamfer vs the FPS-downsampled complete cloud) / partial (Chamfer between the
+        surfaces selected around the input from prediction and ground truth) — reference VCN_VC.py:150-176.  The reference
+        feeds the numpy output of get_partial_mesh_batch to the Chamfer module; here both surfaces stay on the GPU (values only,
+        no gradient: the index selection is not differentiable there either)."""
+        gt_boxes = in_dict['gt_boxes']
+        dev = ret_dict['coarse'].device
+        loss_dict = {}
+        pred_box = get_bbox_from_keypoints(ret_dict['coarse'], gt_boxes)
+        loss_dict['dims'] = self.loss_dims(gt_boxes[:, 3:6].to(dev), pred_box[:, 3:6]).mean()
+        loss_dict['translation'] = self.loss_translation(gt_boxes[:, :3].to(dev), ret_dict['reg_centre']).mean()
+        loss_dict['rotation'] = geodesic_distance(ret_dict['reg_rot'], rot_from_heading(gt_boxes[:, -1]).to(dev)).mean()
+        if in_dict['training']:
+            ds_complete = misc.fps(in_dict['complete'], ret_dict['coarse'].shape[1])
+            loss_dict['coarse'] = self.loss_coarse(ret_dict['coarse'], ds_complete)
+            pred_surface, _ = get_partial_mesh_batch_device(in_dict['input'], ret_dict['coarse'], k=self.sel_k)
+            gt_surface, _ = get_partial_mesh_batch_device(in_dict['input'], ds_complete, k=self.sel_k)
+            loss_dict['partial'] = self.loss_partial(pred_surface, gt_surface)
+        return loss_dict
+
+    def _forward_train(self, in_dict):
+        """The reference forward line by line (VCN_VC.py:178-214) on torch ops, differentiable."""
+        x = in_dict['input']
+        bs, n, _ = x.shape
+        frustum_angle = torch.atan2(x[:, :, 1].mean(dim=1), x[:, :, 0].mean(dim=1))
+        pc_fview = rotate_points_along_z(x, -frustum_angle)
+        pts_mean = pc_fview.mean(dim=1).unsqueeze(1)
+        pose_feat = self.pose_encoder((pc_fview - pts_mean).permute(0, 2, 1)).view(bs, -1)
+        rel_pose = self.pose_fc(pose_feat)
+        centre = pts_mean + rel_pose[:, :3].unsqueeze(1)
+        rot_mat = compute_rotation_matrix_from_ortho6d(rel_pose[:, 3:9])
+        pc_cn = torch.matmul(pc_fview - centre, rot_mat.permute(0, 2, 1))
+        enc = self.encoder
+        feature = enc.mlp_conv1(pc_cn.permute(0, 2, 1))
+        feature_global = torch.max(feature, dim=2, keepdim=True)[0]
+        feature = enc.mlp_conv2(torch.cat([feature_global.expand(-1, -1, n), feature], dim=1))
+        feature_global = torch.max(feature, dim=2)[0]
+        coarse = self.shape_fc(feature_global).reshape(-1, self.number_coarse, 3)
+        coarse_vc = torch.matmul(coarse, rot_mat) + centre
+        return {'coarse': rotate_points_along_z(coarse_vc.contiguous(), frustum_angle),
+                'reg_rot': torch.matmul(rot_mat, rot_from_heading(frustum_angle)),
+                'reg_centre': rotate_points_along_z(centre, frustum_angle).squeeze(1)}
+
     def forward(self, in_dict):
         if self.training:
-            raise RuntimeError("seevcn_amd VCN_VC implements the eval-mode forward (BatchNorm folded); call .eval()")
+            return self._forward_train(in_dict)
+        with torch.no_grad():
+            return self._forward_eval(in_dict)
+
+    def _forward_eval(self, in_dict):
         lib = _lib.load()
         x = in_dict['input']
         _lib.require_cuda(x)

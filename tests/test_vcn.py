@@ -52,14 +52,15 @@ def test_oracle_vcn_cn_matches_reference_golden(golden_dir):
     assert _rel_err(out["coarse"].numpy(), g["coarse"]) < 1e-4
 
 
-def test_forward_refuses_cpu_and_train_mode():
+def test_eval_forward_refuses_cpu_tensors():
     V = _models()
     import seevcn_amd._lib as L
     m = V.MODELS.build({"NAME": "VCN_VC"})
-    with pytest.raises(RuntimeError):
-        m({"input": torch.zeros(1, 1024, 3)})   # training mode
     with pytest.raises(L.SeevcnHipError):
-        m.eval()({"input": torch.zeros(1, 1024, 3)})  # CPU tensor: no fallback
+        m.eval()({"input": torch.zeros(1, 1024, 3)})  # the HIP inference path has no CPU fallback
+    with pytest.raises(L.SeevcnHipError):                # nor have the loss ops of the (torch-autograd) training path
+        m.get_loss({"coarse": torch.zeros(1, 1024, 3), "reg_rot": torch.eye(3)[None], "reg_centre": torch.zeros(1, 3)},
+                   {"gt_boxes": torch.ones(1, 7), "training": True, "complete": torch.zeros(1, 2048, 3), "input": torch.zeros(1, 1024, 3)})
 
 
 # ------------------------------------------------------------------------------------------ GPU
