@@ -108,3 +108,21 @@ CENTER_HEAD = dict(
     LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=0.25, code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 1.0, 1.0])),
     POST_PROCESSING=dict(SCORE_THRESH=0.1, POST_CENTER_LIMIT_RANGE=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], MAX_OBJ_PER_SAMPLE=500,
                          NMS_CONFIG=dict(NMS_TYPE='nms_gpu', NMS_THRESH=0.2, NMS_PRE_MAXSIZE=1000, NMS_POST_MAXSIZE=83)))
+
+
+# detector3d/tools/cfgs/kitti_models/second_iou.yaml:88-140 (values as data)
+def second_iou_roi_head(in_channel=512, shared_fc=(256, 256), iou_fc=(256, 256), roi_per_image=128, train_post=512, test_post=100):
+    return dict(
+        NAME='SECONDHead', CLASS_AGNOSTIC=True, SHARED_FC=list(shared_fc), IOU_FC=list(iou_fc), DP_RATIO=0.3,
+        NMS_CONFIG=dict(TRAIN=dict(NMS_TYPE='nms_gpu', MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=9000, NMS_POST_MAXSIZE=train_post, NMS_THRESH=0.8),
+                        TEST=dict(NMS_TYPE='nms_gpu', MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=1024, NMS_POST_MAXSIZE=test_post, NMS_THRESH=0.7)),
+        ROI_GRID_POOL=dict(GRID_SIZE=7, IN_CHANNEL=in_channel, DOWNSAMPLE_RATIO=8),
+        TARGET_CONFIG=dict(BOX_CODER='ResidualCoder', ROI_PER_IMAGE=roi_per_image, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True,
+                           CLS_SCORE_TYPE='roi_iou', CLS_FG_THRESH=0.75, CLS_BG_THRESH=0.25, CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8,
+                           REG_FG_THRESH=0.55),
+        LOSS_CONFIG=dict(IOU_LOSS='BinaryCrossEntropy', LOSS_WEIGHTS=dict(rcnn_iou_weight=1.0, code_weights=[1.0] * 7)))
+
+
+SECOND_IOU_POST = dict(RECALL_THRESH_LIST=[0.3, 0.5, 0.7], SCORE_THRESH=0.1, OUTPUT_RAW_SCORE=False, EVAL_METRIC='kitti',
+                       NMS_CONFIG=dict(MULTI_CLASSES_NMS=False, NMS_TYPE='nms_gpu', NMS_THRESH=0.01, NMS_PRE_MAXSIZE=4096, NMS_POST_MAXSIZE=500,
+                                       SCORE_TYPE='iou'))

@@ -3,11 +3,13 @@ from .detector3d_template import Detector3DTemplate
 from .pointpillar import PointPillar
 from .pv_rcnn import PVRCNN
 from .second_net import SECONDNet
+from .second_net_iou import SECONDNetIoU
 
 # same registry shape as the reference (detectors/__init__.py:13-26)
 __all__ = {
     'Detector3DTemplate': Detector3DTemplate,
     'SECONDNet': SECONDNet,
+    'SECONDNetIoU': SECONDNetIoU,
     'PointPillar': PointPillar,
     'PVRCNN': PVRCNN,
     'CenterPoint': CenterPoint,

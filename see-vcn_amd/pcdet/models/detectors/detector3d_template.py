@@ -177,6 +177,7 @@ class Detector3DTemplate(nn.Module):
         """recall of ground truth at 3-D IoU thresholds (reference :286-328)."""
         if 'gt_boxes' not in data_dict:
             return recall_dict
+        rois = data_dict['rois'][batch_index] if 'rois' in data_dict else None
         gt_boxes = data_dict['gt_boxes'][batch_index]
         if len(recall_dict) == 0:
             recall_dict = {'gt': 0}
@@ -190,9 +191,12 @@ class Detector3DTemplate(nn.Module):
         if cur_gt.shape[0] > 0:
             iou3d = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7], cur_gt[:, 0:7]) if box_preds.shape[0] > 0 \
                 else torch.zeros((0, cur_gt.shape[0]), device=cur_gt.device)
+            iou3d_roi = iou3d_nms_utils.boxes_iou3d_gpu(rois[:, 0:7], cur_gt[:, 0:7]) if rois is not None else None
             for t in thresh_list:
                 if iou3d.shape[0] > 0:
                     recall_dict['rcnn_%s' % str(t)] += int((iou3d.max(dim=0)[0] > t).sum().item())
+                if iou3d_roi is not None:
+                    recall_dict['roi_%s' % str(t)] += int((iou3d_roi.max(dim=0)[0] > t).sum().item())
             recall_dict['gt'] += cur_gt.shape[0]
         return recall_dict
 
