@@ -83,7 +83,7 @@ def allreduce_grads(params, world):
 
 def run_step(model, opt, params, inputs, world):
     points, objects, scene = inputs
-    opt.zero_grad(set_to_none=False)
+    opt.zero_grad(set_to_none=True)
     bd = model(points, objects, scene, SCENES_PER_GPU)
     loss = loss_fn(bd)
     loss.backward()
@@ -263,7 +263,7 @@ def main():
     points, objects, scene, pts_np, objs_np, scene_np = make_inputs(rank, device)
     model = build_model(device).train()
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9)
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, fused=True)     # one multi-tensor kernel instead of ~70 small launches
     inputs = (points, objects, scene)
 
     for _ in range(args.warmup):
@@ -301,12 +301,15 @@ def main():
         avg_ms, executed_flop, launches, vcn_gemm_ms = measure_dominant_kernel(model, inputs)
         algo_flop_per_launch = VCN_FLOP_PER_OBJECT * OBJECTS_PER_GPU / launches
         achieved = algo_flop_per_launch / (avg_ms * 1e-3) / 1e12
-        vcn_roof = {"bound": "mfma", "kernel": "k_gemm_f32 (sv_gemm_bias_act, v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        exec_tf = executed_flop / (vcn_gemm_ms * 1e-3) / 1e12
+        vcn_roof = {"bound": "mfma", "kernel": "k_gemm_f32 (sv_gemm_bias_act[_ragged], v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(exec_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(exec_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4), "ms_per_step": round(vcn_gemm_ms, 3),
-                    "algorithmic_flop_per_launch": algo_flop_per_launch,
-                    "executed_tflops": round(executed_flop / (vcn_gemm_ms * 1e-3) / 1e12, 2)}
+                    "note": "achieved = EXECUTED flops (matrix-core utilisation). Each object's 1024 rows are ResamplePoints copies of "
+                            "30-400 points: the per-point layers run on the distinct rows only (bit-identical output), so the time per "
+                            "object is far below what SURVEY 8(d)'s 1.976 GFLOP/object implies",
+                    "algorithmic_flop_per_launch": algo_flop_per_launch, "algorithmic_tflops": round(achieved, 2)}
         # dominant kernel by time in the step: the register-stationary sparse-conv gather-GEMM (forward + data gradient)
         name, c_ms, c_flop, c_bytes, c_launches, c_step_ms = measure_spconv_kernel(model, opt, params, inputs, world)
         c_ach = c_flop / (c_ms * 1e-3) / 1e12

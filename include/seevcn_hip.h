@@ -260,6 +260,16 @@ int sv_batchnorm_relu_backward(const float* x, const float* dy, int64_t n, int c
                                const float* save_mean, const float* save_invstd, int relu, void* scratch, float* dx, float* dgamma,
                                float* dbeta, void* stream);
 
+/* Ragged-group variant of sv_gemm_bias_act: row_group[M] (non-decreasing int32) names the group of every row; used after
+ * sv_unique_rows, when each object keeps only its distinct points (ResamplePoints, vcn/datasets/data_transforms.py:254-262,
+ * tiles Ni points to 1024 copies: every Conv1d(k=1) row and the max-pools over them only depend on the distinct rows). */
+int sv_gemm_bias_act_ragged(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias,
+                            const int32_t* row_group, float* C, int ldc, float* group_max, int M, int N, int K, int act, float slope,
+                            void* stream);
+/* x (B,n,3), n <= 1024 -> uniq_idx (B,n): the first counts[b] entries of row b index one copy of each distinct point of object b
+ * (exact float equality, -0.0 == 0.0), lexicographic order. */
+int sv_unique_rows(const float* x, int batch, int n, int32_t* uniq_idx, int32_t* counts, void* stream);
+
 /* ---- Chamfer distance of the VCN training loss: the reference's `chamfer` extension,
  * see/surface_completion/models/vcn/extensions/chamfer_dist/chamfer_cuda.cpp:36-39 (forward -> [dist1, dist2, idx1, idx2],
  * backward -> [grad_xyz1, grad_xyz2]) over chamfer.cu:15-201.  xyz1 (B,n,3), xyz2 (B,m,3); squared distances; idx = first

@@ -67,6 +67,8 @@ SIGNATURES = {
     "sv_vcn_surface_select": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_vcn_largest_cluster": (c_i, [c_p, c_i, c_i, c_d, c_i, c_i, c_p, c_p, c_p]),
     "sv_points_near_set": (c_i, [c_p, c_i64, c_p, c_i64, c_i, c_d, c_p, c_p]),
+    "sv_gemm_bias_act_ragged": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "sv_unique_rows": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "sv_chamfer_forward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_chamfer_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_batchnorm_scratch_bytes": (c_sz, [c_i]),

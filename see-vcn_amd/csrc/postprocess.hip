@@ -75,16 +75,17 @@ __device__ __forceinline__ void pp_bitonic_stages(int tid, FS exchange_shfl, FL 
 
 // ---- A: np.unique(partial_pc, axis=0): sort the rows lexicographically (field-wise float compare, -0.0 == 0.0), flag the
 // first row of every run of equal rows, prefix-sum the flags -> query[u] = index of a copy of the u-th unique row.
-__global__ __launch_bounds__(PP_THREADS) void k_surface_prep(SurfaceArgs a) {
+// this object's cloud P (n rows) -> query[u] = index of a copy of the u-th distinct row (lexicographic order), *nq = their number;
+// `first` (PP_MAXN ints, may be null) is reset to PP_INF for the k-NN pass
+__device__ __forceinline__ void surface_prep_body(const float* P, int n, unsigned short* query, int* nq, int* first) {
   __shared__ float s_x[PP_THREADS], s_y[PP_THREADS], s_z[PP_THREADS];
   __shared__ int s_v[PP_THREADS];
   __shared__ int s_wcnt[PP_WAVES];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* P = a.partial + (size_t)b * a.n * 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float x = __builtin_inff(), y = 0.f, z = 0.f;          // padding rows sort to the end
   int v = -1;
-  if (tid < a.n) x = P[tid * 3], y = P[tid * 3 + 1], z = P[tid * 3 + 2], v = tid;
-  a.first[(size_t)b * PP_MAXN + tid] = PP_INF;
+  if (tid < n) x = P[tid * 3], y = P[tid * 3 + 1], z = P[tid * 3 + 2], v = tid;
+  if (first) first[tid] = PP_INF;
 #define PREP_KEEP(ox, oy, oz, ov)                                                                     \
   {                                                                                                   \
     const bool sw = take_min ? lex_less(ox, oy, oz, x, y, z) : lex_less(x, y, z, ox, oy, oz);         \
@@ -119,8 +120,13 @@ __global__ __launch_bounds__(PP_THREADS) void k_surface_prep(SurfaceArgs a) {
     rank += w < wave ? s_wcnt[w] : 0;
     total += s_wcnt[w];
   }
-  if (head) a.query[(size_t)b * PP_MAXN + rank] = (unsigned short)v;
-  if (tid == 0) a.nq[b] = total;
+  if (head) query[rank] = (unsigned short)v;
+  if (tid == 0) *nq = total;
+}
+
+__global__ __launch_bounds__(PP_THREADS) void k_surface_prep(SurfaceArgs a) {
+  const int b = blockIdx.x;
+  surface_prep_body(a.partial + (size_t)b * a.n * 3, a.n, a.query + (size_t)b * PP_MAXN, a.nq + b, a.first + (size_t)b * PP_MAXN);
 }
 
 // wave-wide unsigned min on the DPP network (quad_perm xor1, xor2, row_ror 4/8, row_bcast 15/31), result from lane 63
@@ -489,6 +495,28 @@ __global__ __launch_bounds__(256) void k_points_near_set(const float* __restrict
     }
   }
   if (live) near[i] = found ? 1 : 0;
+}
+
+// Exact-duplicate detection per object (ResamplePoints tiles Ni points to 1024: every per-point layer of VCN only needs the
+// distinct rows).  Same sort as k_surface_prep; writes int32 indices and counts.
+__global__ __launch_bounds__(PP_THREADS) void k_unique_rows(const float* __restrict__ x, int n, int32_t* __restrict__ uniq_idx,
+                                                          int32_t* __restrict__ counts) {
+  __shared__ unsigned short s_q[PP_MAXN];
+  __shared__ int s_n;
+  surface_prep_body(x + (size_t)blockIdx.x * n * 3, n, s_q, &s_n, nullptr);
+  __syncthreads();
+  const int tid = threadIdx.x;
+  if (tid < s_n) uniq_idx[(size_t)blockIdx.x * n + tid] = s_q[tid];
+  if (tid == 0) counts[blockIdx.x] = s_n;
+}
+
+extern "C" int sv_unique_rows(const float* x, int batch, int n, int32_t* uniq_idx, int32_t* counts, void* stream) {
+  SV_CHECK_ARG(batch >= 0 && n >= 1 && n <= PP_MAXN, "sv_unique_rows: 1 <= n <= %d (got %d)", PP_MAXN, n);
+  if (batch == 0) return SV_OK;
+  SV_CHECK_ARG(x && uniq_idx && counts, "sv_unique_rows: null pointer");
+  hipLaunchKernelGGL(k_unique_rows, dim3(batch), dim3(PP_THREADS), 0, sv_stream(stream), x, n, uniq_idx, counts);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
 }
 
 extern "C" size_t sv_vcn_surface_select_scratch_bytes(int batch) {

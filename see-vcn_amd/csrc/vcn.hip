@@ -46,6 +46,7 @@ struct GemmArgs {
   const float* bias;        // [N] or null
   const float* group_bias;  // [M / rows_per_group][N] or null
   int rows_per_group;
+  const int32_t* row_group; // [M] group of each row (non-decreasing) or null: row / rows_per_group
   float* C; int ldc;        // EPI_STORE
   float* gmax;              // EPI_MAX: [M / rows_per_group][N], pre-filled with -inf
   int M, N, K;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (!cok || row >= g.M) continue;
-        const int grp = row / g.rows_per_group;
+        const int grp = g.row_group ? g.row_group[row] : row / g.rows_per_group;
         float v = acc[i][j][r] + bv;
         if (g.group_bias) v += g.group_bias[(int64_t)grp * g.N + col];
         v = apply_act(v, g.act, g.slope);
@@ -181,16 +182,16 @@ extern "C" int sv_fill_f32(float* dst, int64_t n, float value, void* stream) {
   return SV_OK;
 }
 
-extern "C" int sv_gemm_bias_act(const float* A, int lda, const float* W, int ldw, const float* bias,
-                                const float* group_bias, int rows_per_group, float* C, int ldc, float* group_max,
-                                int M, int N, int K, int act, float slope, void* stream) {
+static int gemm_launch(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias, int rows_per_group,
+                       const int32_t* row_group, float* C, int ldc, float* group_max, int M, int N, int K, int act, float slope,
+                       void* stream) {
   SV_CHECK_ARG(A && W && (C || group_max), "gemm_bias_act: null pointer");
   SV_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0, "gemm_bias_act: K=%d must be a positive multiple of %d", K, BK);
   SV_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= K, "gemm_bias_act: lda/ldw must be >= K and multiples of 4");
   SV_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "gemm_bias_act: A/W must be 16-byte aligned");
   SV_CHECK_ARG(rows_per_group >= 1, "gemm_bias_act: rows_per_group must be >= 1");
   SV_CHECK_ARG(act >= 0 && act <= 2, "gemm_bias_act: unknown activation %d", act);
-  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, C, ldc, group_max, M, N, K, act, slope};
+  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, row_group, C, ldc, group_max, M, N, K, act, slope};
   dim3 grid(sv_div_up(N, BN), sv_div_up(M, BM));
   hipStream_t st = sv_stream(stream);
   if (C && group_max)
@@ -201,6 +202,19 @@ extern "C" int sv_gemm_bias_act(const float* A, int lda, const float* W, int ldw
     hipLaunchKernelGGL(k_gemm_f32<EPI_MAX>, grid, dim3(256), 0, st, g);
   SV_LAUNCH_CHECK();
   return SV_OK;
+}
+
+extern "C" int sv_gemm_bias_act(const float* A, int lda, const float* W, int ldw, const float* bias,
+                                const float* group_bias, int rows_per_group, float* C, int ldc, float* group_max,
+                                int M, int N, int K, int act, float slope, void* stream) {
+  return gemm_launch(A, lda, W, ldw, bias, group_bias, rows_per_group, nullptr, C, ldc, group_max, M, N, K, act, slope, stream);
+}
+
+extern "C" int sv_gemm_bias_act_ragged(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias,
+                                       const int32_t* row_group, float* C, int ldc, float* group_max, int M, int N, int K, int act,
+                                       float slope, void* stream) {
+  SV_CHECK_ARG(row_group, "gemm_bias_act_ragged: row_group is required");
+  return gemm_launch(A, lda, W, ldw, bias, group_bias, 1, row_group, C, ldc, group_max, M, N, K, act, slope, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

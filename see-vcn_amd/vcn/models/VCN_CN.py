@@ -18,6 +18,7 @@ class VCN_CN(nn.Module):
         self.encoder = L.FeatureEncoder([3, 128, 256, 512, 512, self.number_coarse])
         self.shape_fc = L.fc_layers([1024, 1024, 1024, 3 * self.number_coarse], last_as_linear=True)
         self._prepared = L.PreparedCache(self, lambda: dict(enc=L.prepare_encoder(self.encoder), shape_fc=L.prepare_fc(self.shape_fc)))
+        self.dedup_points = True     # run the per-point layers on each object's distinct rows only (bit-identical output)
 
     def get_loss(self, ret_dict, in_dict):
         raise NotImplementedError("VCN training loss (VCN_CN.py:125-140) is outside the built hot path")
@@ -37,7 +38,11 @@ class VCN_CN(nn.Module):
         st = _lib.stream()
         pc = torch.empty_like(x)
         _lib.check(lib.sv_vcn_cn_transform(_lib.ptr(x), bs, n, _lib.ptr(boxes), 0, _lib.ptr(pc), st), "sv_vcn_cn_transform")
-        feat = L.encode(p["enc"], pc.view(bs * n, 3), bs, n)
+        pts, rg = pc.view(bs * n, 3), None
+        if self.dedup_points and n > 1:
+            sel, rg = L.distinct_rows(x)
+            pts = pts[sel]
+        feat = L.encode(p["enc"], pts, bs, n, row_group=rg)
         coarse_cn = L.run_fc(p["shape_fc"], feat, L.ACT_RELU)
         nc = self.number_coarse
         coarse = torch.empty((bs, nc, 3), dtype=torch.float32, device=x.device)

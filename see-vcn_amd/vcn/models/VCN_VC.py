@@ -54,6 +54,7 @@ class VCN_VC(nn.Module):
             nn.Conv1d(1024 + 3 + 2, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True), nn.Conv1d(512, 512, 1),
             nn.BatchNorm1d(512), nn.ReLU(inplace=True), nn.Conv1d(512, 3, 1))
         self._prepared = L.PreparedCache(self, self._prepare)
+        self.dedup_points = True     # eval: run the per-point layers on each object's distinct rows only (bit-identical output)
         self.build_loss_func()
 
     def _prepare(self):
@@ -131,14 +132,19 @@ class VCN_VC(nn.Module):
         _lib.check(lib.sv_vcn_vc_prep(_lib.ptr(x), bs, n, _lib.ptr(fview), _lib.ptr(centred), _lib.ptr(state), st), "sv_vcn_vc_prep")
         # pose encoder: 3->64 LReLU, 64->128 LReLU, 128->1024, max over n   (VCN_VC.py:116-123,193)
         (w0, b0), (w1, b1), (w2, b2) = p["pose"]
-        h = L.pointwise3(centred.view(bs * n, 3), w0, b0, L.ACT_LRELU)
+        sel = rg = None
+        if self.dedup_points and n > 1:
+            sel, rg = L.distinct_rows(x)
+        pts = centred.view(bs * n, 3)
+        h = L.pointwise3(pts if sel is None else pts[sel], w0, b0, L.ACT_LRELU)
         h = L.gemm(h, w1, b1, L.ACT_LRELU)
         pose_feat = L.neg_inf((bs, w2.shape[0]), dev)
-        L.gemm(h, w2, b2, L.ACT_NONE, rows_per_group=n, store=False, group_max=pose_feat)
+        L.gemm(h, w2, b2, L.ACT_NONE, rows_per_group=n, store=False, group_max=pose_feat, row_group=rg)
         rel_pose = L.run_fc(p["pose_fc"], pose_feat, L.ACT_LRELU)                     # (B, 9)   :194
         pc_cn = torch.empty_like(x)
         _lib.check(lib.sv_vcn_vc_pose(_lib.ptr(fview), bs, n, _lib.ptr(rel_pose), _lib.ptr(state), _lib.ptr(pc_cn), st), "sv_vcn_vc_pose")
-        feat = L.encode(p["enc"], pc_cn.view(bs * n, 3), bs, n)                       # (B, 1024) :203
+        pts = pc_cn.view(bs * n, 3)
+        feat = L.encode(p["enc"], pts if sel is None else pts[sel], bs, n, row_group=rg)   # (B, 1024) :203
         coarse_cn = L.run_fc(p["shape_fc"], feat, L.ACT_RELU)                         # (B, 3072) :204
         nc = self.number_coarse
         coarse = torch.empty((bs, nc, 3), dtype=torch.float32, device=dev)

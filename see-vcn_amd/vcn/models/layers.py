@@ -64,19 +64,43 @@ class PreparedCache:
         return self.value
 
 
-def gemm(a, w, bias=None, act=ACT_NONE, group_bias=None, rows_per_group=1, store=True, group_max=None, slope=LRELU_SLOPE):
-    """act(a @ w.T + bias + group_bias[row // rows_per_group]) via sv_gemm_bias_act (fp32 MFMA).
+def gemm(a, w, bias=None, act=ACT_NONE, group_bias=None, rows_per_group=1, store=True, group_max=None, slope=LRELU_SLOPE, row_group=None):
+    """act(a @ w.T + bias + group_bias[group(row)]) via sv_gemm_bias_act (fp32 MFMA); group(row) = row // rows_per_group, or
+    row_group[row] (int32, non-decreasing) for ragged groups.
 
-    Returns the (M,N) output (or None when store=False); `group_max` (M/rows_per_group, N) must be pre-filled with -inf."""
+    Returns the (M,N) output (or None when store=False); `group_max` (groups, N) must be pre-filled with -inf."""
     lib = _lib.load()
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and a.is_contiguous() and w.is_contiguous()
     out = torch.empty((M, N), dtype=torch.float32, device=a.device) if store else None
-    rc = lib.sv_gemm_bias_act(_lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(bias), _lib.ptr(group_bias), int(rows_per_group),
-                              _lib.ptr(out), N, _lib.ptr(group_max), M, N, K, int(act), float(slope), _lib.stream())
+    if row_group is None:
+        rc = lib.sv_gemm_bias_act(_lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(bias), _lib.ptr(group_bias), int(rows_per_group),
+                                  _lib.ptr(out), N, _lib.ptr(group_max), M, N, K, int(act), float(slope), _lib.stream())
+    else:
+        assert row_group.dtype == torch.int32 and row_group.shape[0] == M
+        rc = lib.sv_gemm_bias_act_ragged(_lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(bias), _lib.ptr(group_bias), _lib.ptr(row_group),
+                                         _lib.ptr(out), N, _lib.ptr(group_max), M, N, K, int(act), float(slope), _lib.stream())
     _lib.check(rc, "sv_gemm_bias_act")
     return out
+
+
+def distinct_rows(x):
+    """x (B,n,3) -> (sel (U,) int64 flat row indices into x.view(B*n,3), row_group (U,) int32 object of each kept row).
+
+    ResamplePoints (vcn/datasets/data_transforms.py:254-262) tiles an object's Ni points to n = 1024, so a cloud holds only
+    Ni distinct rows; the per-point layers (Conv1d k=1, eval-mode BatchNorm folded) and the max-pools over points give
+    bit-identical results on the distinct rows alone.  One host sync (the number of kept rows)."""
+    lib = _lib.load()
+    B, n, _ = x.shape
+    idx = torch.empty((B, n), dtype=torch.int32, device=x.device)
+    cnt = torch.empty((B,), dtype=torch.int32, device=x.device)
+    _lib.check(lib.sv_unique_rows(_lib.ptr(x), B, n, _lib.ptr(idx), _lib.ptr(cnt), _lib.stream()), "sv_unique_rows")
+    keep = torch.arange(n, device=x.device, dtype=torch.int32).unsqueeze(0) < cnt.unsqueeze(1)               # (B,n)
+    flat = idx.long() + torch.arange(B, device=x.device, dtype=torch.int64).unsqueeze(1) * n
+    sel = flat[keep]                                                                                          # sync: U rows
+    row_group = torch.arange(B, device=x.device, dtype=torch.int32).unsqueeze(1).expand(B, n)[keep].contiguous()
+    return sel, row_group
 
 
 def pointwise3(xyz, w, b, act, slope=LRELU_SLOPE):
@@ -108,16 +132,17 @@ def prepare_encoder(enc):
                 b2a=b2a, w2b=w2b, b2b=b2b)
 
 
-def encode(p, pts, batch, n):
-    """FeatureEncoder.forward (VCN_VC.py:97-106) on channel-last activations. pts: (B*n, 3) -> (B, 1024)."""
+def encode(p, pts, batch, n, row_group=None):
+    """FeatureEncoder.forward (VCN_VC.py:97-106) on channel-last activations. pts: (B*n, 3) or, with row_group, the (U, 3)
+    distinct rows -> (B, 1024)."""
     dev = pts.device
     f1 = pointwise3(pts, p["w1a"], p["b1a"], ACT_RELU)                               # conv 3->128 + BN + ReLU
     g1 = neg_inf((batch, p["w1b"].shape[0]), dev)
-    local = gemm(f1, p["w1b"], p["b1b"], ACT_NONE, rows_per_group=n, group_max=g1)  # conv 128->256, max over n
+    local = gemm(f1, p["w1b"], p["b1b"], ACT_NONE, rows_per_group=n, group_max=g1, row_group=row_group)  # conv 128->256, max over n
     gb = gemm(g1, p["w2a_g"], None, ACT_NONE)                                        # global half of conv 512->512
-    f2 = gemm(local, p["w2a_l"], p["b2a"], ACT_RELU, group_bias=gb, rows_per_group=n)  # + BN + ReLU
+    f2 = gemm(local, p["w2a_l"], p["b2a"], ACT_RELU, group_bias=gb, rows_per_group=n, row_group=row_group)  # + BN + ReLU
     g2 = neg_inf((batch, p["w2b"].shape[0]), dev)
-    gemm(f2, p["w2b"], p["b2b"], ACT_NONE, rows_per_group=n, store=False, group_max=g2)  # conv 512->1024, max over n
+    gemm(f2, p["w2b"], p["b2b"], ACT_NONE, rows_per_group=n, store=False, group_max=g2, row_group=row_group)  # conv 512->1024, max over n
     return g2
 
 

@@ -173,3 +173,31 @@ def test_hip_vcn_inference_wrapper_chunking(cuda, hip_lib):
     np.random.seed(3)
     single = vcn.inference(objs[0])
     assert np.array_equal(single["input"][0], out["input"][0]) and _rel_err(single["coarse"][0], ref[0]) < RTOL
+
+
+@pytest.mark.gpu
+def test_hip_vcn_distinct_row_path_is_bit_identical(cuda, hip_lib):
+    """ResamplePoints tiles Ni points to 1024: the per-point layers run on the distinct rows only (sv_unique_rows +
+    sv_gemm_bias_act_ragged).  Output must equal the full 1024-row execution bit for bit, for VCN_VC and VCN_CN, including an
+    all-zero padding object (one distinct row) and an object with 1024 distinct points."""
+    import seevcn_amd.synth as synth
+    V = _models()
+    clouds, boxes = synth.make_object_batch(6, seed=1000)
+    clouds[4] = 0.0
+    clouds[5] = np.random.default_rng(0).normal(size=(1024, 3)).astype(np.float32) + np.array([20, 3, -1], np.float32)
+    x, bx = torch.from_numpy(clouds).to(cuda), torch.from_numpy(boxes).to(cuda)
+    for name, extra in (("VCN_VC", {}), ("VCN_CN", {"gt_boxes": bx})):
+        m = V.MODELS.build({"NAME": name})
+        m.load_state_dict(seeded_state_dict(m, seed=0))
+        m = m.to(cuda).eval()
+        m.dedup_points = True
+        a = m({"input": x, **extra})
+        m.dedup_points = False
+        b = m({"input": x, **extra})
+        for k in a:
+            assert torch.equal(a[k], b[k]), (name, k)
+    from seevcn_amd.vcn.models import layers as L
+    sel, rg = L.distinct_rows(x)
+    counts = torch.bincount(rg.long(), minlength=6).cpu().numpy()
+    want = [len(np.unique(clouds[i], axis=0)) for i in range(6)]
+    assert counts.tolist() == want and counts[4] == 1 and counts[5] == 1024
