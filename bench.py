@@ -319,6 +319,16 @@ def main():
                            "launches_per_step": c_launches, "avg_launch_ms": round(c_ms, 4), "ms_per_step": round(c_step_ms, 3),
                            "algorithmic_flop_per_launch": round(c_flop), "algorithmic_bytes_per_launch": round(c_bytes),
                            "algorithmic_GBps": round(c_bytes / (c_ms * 1e-3) / 1e9, 1)}
+        # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the newest committed PMC pass over this
+        # same command (tools/traffic.sh -> profiles/*_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, x2 on reads for gfx950)
+        import glob
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1:]:
+            with open(tf) as fh:
+                kernels = json.load(fh).get("kernels", {})
+            hit = [v for k, v in kernels.items() if name in k]
+            if hit:
+                out["roofline"]["traffic"] = round(hit[0]["hbm_bytes_per_dispatch"])
+                out["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
         out["roofline_vcn_gemm"] = vcn_roof
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pts_np, objs_np, scene_np)
