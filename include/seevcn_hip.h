@@ -247,6 +247,32 @@ int sv_center_assign_targets(const float* gt_boxes, int batch, int max_gt, int b
                              int num_max_objs, float gaussian_overlap, int min_radius, float* heatmaps, float* target_boxes,
                              int64_t* inds, int64_t* masks, void* stream);
 
+/* ---- pointnet2_batch_cuda wrappers (detector3d/pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:12-27; kernels in
+ * ball_query_gpu.cu, group_points_gpu.cu, sampling_gpu.cu, interpolate_gpu.cu) and the stacked 3-NN interpolation
+ * (pointnet2_stack/src/interpolate_gpu.cu:16-195).  Same argument order as the pybind wrappers, raw device pointers.
+ * ball query: idx (B,m,nsample) must be zero-filled by the caller like the reference's Python does (queries without a hit
+ * keep it).  Gradient entries zero-fill their output.  Batch farthest point sampling = sv_farthest_point_sampling. */
+int sv_ball_query_batch(int batch, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int32_t* idx,
+                        void* stream);
+int sv_group_points_batch(int batch, int c, int n, int npoints, int nsample, const float* points, const int32_t* idx, float* out,
+                          void* stream);
+int sv_group_points_grad_batch(int batch, int c, int n, int npoints, int nsample, const float* grad_out, const int32_t* idx,
+                               float* grad_points, void* stream);
+int sv_gather_points_batch(int batch, int c, int n, int npoints, const float* points, const int32_t* idx, float* out, void* stream);
+int sv_gather_points_grad_batch(int batch, int c, int n, int npoints, const float* grad_out, const int32_t* idx, float* grad_points,
+                                void* stream);
+int sv_three_nn_batch(int batch, int n, int m, const float* unknown, const float* known, float* dist2, int32_t* idx, void* stream);
+int sv_three_interpolate_batch(int batch, int c, int m, int n, const float* points, const int32_t* idx, const float* weight, float* out,
+                               void* stream);
+int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float* grad_out, const int32_t* idx, const float* weight,
+                                    float* grad_points, void* stream);
+int sv_three_nn_stack(int batch, int64_t n_unknown, const float* unknown, const int32_t* unknown_batch_cnt, const float* known,
+                      const int32_t* known_batch_cnt, float* dist2, int32_t* idx, void* stream);
+int sv_three_interpolate_stack(int64_t n, int channels, const float* features, const int32_t* idx, const float* weight, float* out,
+                               void* stream);
+int sv_three_interpolate_grad_stack(int64_t n, int channels, int64_t m, const float* grad_out, const int32_t* idx, const float* weight,
+                                    float* grad_features, void* stream);
+
 /* ---- BatchNorm1d (+ReLU) on (N,C) voxel features: the norm_fn -> ReLU tail of post_act_block
  * (detector3d/pcdet/models/backbones_3d/spconv_backbone.py:9-27,73; torch.nn.BatchNorm1d semantics: biased batch variance for
  * normalisation, unbiased for running_var, running = (1-momentum)*running + momentum*batch).  C multiple of 4, C/4 divides 256.

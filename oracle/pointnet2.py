@@ -80,3 +80,42 @@ def group_points_grad(grad_out, idx, idx_batch_cnt, features_batch_cnt, n):
     rows = (row_start[:, None] + idx)                                # (M, ns)
     np.add.at(g, rows.reshape(-1), np.transpose(grad_out, (0, 2, 1)).reshape(-1, grad_out.shape[1]))
     return g
+
+
+# ------------------------------------------------------------------------------------------ batch layout + 3-NN interpolation
+def ball_query_batch(radius, nsample, xyz, new_xyz):
+    """pointnet2_batch/src/ball_query_gpu.cu:13-48.  xyz (B,N,3), new_xyz (B,M,3) -> idx (B,M,nsample) int32 (zeros when no hit)."""
+    B, M = new_xyz.shape[:2]
+    idx = np.zeros((B, M, nsample), np.int32)
+    r2 = F(radius) * F(radius)
+    for b in range(B):
+        for q in range(M):
+            d = new_xyz[b, q].astype(F) - xyz[b].astype(F)
+            d2 = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]
+            hit = np.nonzero(d2 < r2)[0][:nsample]
+            if len(hit):
+                idx[b, q, :] = hit[0]
+                idx[b, q, :len(hit)] = hit
+    return idx
+
+
+def three_nn(unknown, known):
+    """interpolate_gpu.cu three_nn_kernel: float squared distances, strict '<' cascade -> (dist2 (N,3) float32, idx (N,3))."""
+    u, k = np.asarray(unknown, F), np.asarray(known, F)
+    dist2, idx = np.empty((len(u), 3), F), np.zeros((len(u), 3), np.int32)
+    for i in range(len(u)):
+        d = u[i] - k
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(F)
+        order = np.argsort(d2, kind='stable')[:3]                  # first-come wins among equal distances, like the cascade
+        best = np.full(3, 1e40)
+        bi = np.zeros(3, np.int32)
+        best[:len(order)] = d2[order]
+        bi[:len(order)] = order
+        dist2[i], idx[i] = best.astype(F), bi
+    return dist2, idx
+
+
+def three_interpolate(features_mc, idx, weight):
+    """stack layout: features (M,C) -> (N,C) = w0 f[i0] + w1 f[i1] + w2 f[i2] in fp32, left to right."""
+    f, w = np.asarray(features_mc, F), np.asarray(weight, F)
+    return (w[:, 0:1] * f[idx[:, 0]] + w[:, 1:2] * f[idx[:, 1]]) + w[:, 2:3] * f[idx[:, 2]]

@@ -69,6 +69,17 @@ SIGNATURES = {
     "sv_points_near_set": (c_i, [c_p, c_i64, c_p, c_i64, c_i, c_d, c_p, c_p]),
     "sv_gemm_bias_act_ragged": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "sv_unique_rows": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
+    "sv_ball_query_batch": (c_i, [c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p]),
+    "sv_group_points_batch": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "sv_group_points_grad_batch": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "sv_gather_points_batch": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "sv_gather_points_grad_batch": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "sv_three_nn_batch": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sv_three_interpolate_batch": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sv_three_interpolate_grad_batch": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sv_three_nn_stack": (c_i, [c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sv_three_interpolate_stack": (c_i, [c_i64, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sv_three_interpolate_grad_stack": (c_i, [c_i64, c_i, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "sv_chamfer_forward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_chamfer_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_batchnorm_scratch_bytes": (c_sz, [c_i]),

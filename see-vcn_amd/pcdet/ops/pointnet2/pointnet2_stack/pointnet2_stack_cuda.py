@@ -71,3 +71,31 @@ def stack_farthest_point_sampling(points, xyz_batch_cnt, npoint, max_n=None):
                                               _lib.ptr(temp), _lib.ptr(idx), _lib.stream())
     _lib.check(rc, "sv_stack_farthest_point_sampling")
     return idx
+
+
+def three_nn_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx):
+    """pointnet2_stack/src/interpolate.cpp three_nn_wrapper_stack: idx are GLOBAL rows of `known`."""
+    lib = _lib.load()
+    _lib.require_cuda(unknown, known, dist2, idx)
+    rc = lib.sv_three_nn_stack(int(unknown_batch_cnt.shape[0]), int(unknown.shape[0]), _lib.ptr(unknown), _lib.ptr(unknown_batch_cnt.int().contiguous()),
+                               _lib.ptr(known), _lib.ptr(known_batch_cnt.int().contiguous()), _lib.ptr(dist2), _lib.ptr(idx), _lib.stream())
+    _lib.check(rc, "sv_three_nn_stack")
+    return 1
+
+
+def three_interpolate_wrapper(features, idx, weight, out):
+    lib = _lib.load()
+    _lib.require_cuda(features, idx, weight, out)
+    rc = lib.sv_three_interpolate_stack(int(idx.shape[0]), int(features.shape[1]), _lib.ptr(features), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(out),
+                                        _lib.stream())
+    _lib.check(rc, "sv_three_interpolate_stack")
+    return 1
+
+
+def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
+    lib = _lib.load()
+    _lib.require_cuda(grad_out, idx, weight, grad_features)
+    rc = lib.sv_three_interpolate_grad_stack(int(idx.shape[0]), int(grad_out.shape[1]), int(grad_features.shape[0]), _lib.ptr(grad_out), _lib.ptr(idx),
+                                             _lib.ptr(weight), _lib.ptr(grad_features), _lib.stream())
+    _lib.check(rc, "sv_three_interpolate_grad_stack")
+    return 1

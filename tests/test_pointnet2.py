@@ -120,3 +120,80 @@ def test_hip_ball_query_group_vs_oracle(cuda, hip_lib, radius, nsample):
     go_f = go[:, 3:].copy()
     go_f[empty] = 0
     np.testing.assert_allclose(f.grad.cpu().numpy(), op2.group_points_grad(go_f, ref0, qcnt, counts, len(xyz)), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ batch layout + 3-NN interpolation
+@pytest.mark.gpu
+def test_hip_pointnet2_batch_ops_vs_oracle(cuda, hip_lib):
+    """pointnet2_batch wrappers (ball query, grouping, gather, FPS, three_nn, three_interpolate and their gradients) against the
+    numpy restatement of the reference kernels / torch indexing."""
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as PB
+    rng = np.random.default_rng(12)
+    B, N, M, C = 2, 700, 90, 5
+    xyz = rng.uniform(-3, 3, (B, N, 3)).astype(np.float32)
+    txyz = torch.from_numpy(xyz).to(cuda)
+    fidx = PB.farthest_point_sample(txyz, M)
+    assert np.array_equal(fidx.cpu().numpy(), np.stack([op2.farthest_point_sampling(xyz[b], M) for b in range(B)]))
+    new_xyz = PB.gather_operation(txyz.transpose(1, 2).contiguous(), fidx).transpose(1, 2).contiguous()
+    assert np.array_equal(new_xyz.cpu().numpy(), np.stack([xyz[b][fidx[b].cpu().numpy()] for b in range(B)]))
+    far = new_xyz.clone()
+    far[0, 0] = 100.0                                                              # a query with no neighbour keeps zeros
+    for radius, ns in [(0.6, 16), (1.5, 8), (0.05, 4)]:
+        idx = PB.ball_query(radius, ns, txyz, far)
+        assert np.array_equal(idx.cpu().numpy(), op2.ball_query_batch(radius, ns, xyz, far.cpu().numpy()))
+    feats = torch.from_numpy(rng.normal(size=(B, C, N)).astype(np.float32)).to(cuda).requires_grad_(True)
+    idx = PB.ball_query(0.6, 16, txyz, new_xyz)
+    grouped = PB.grouping_operation(feats, idx)
+    want = torch.gather(feats.unsqueeze(2).expand(B, C, M, N), 3, idx.long().unsqueeze(1).expand(B, C, M, 16))
+    assert torch.equal(grouped, want)
+    w = torch.from_numpy(rng.normal(size=tuple(grouped.shape)).astype(np.float32)).to(cuda)
+    (g1,) = torch.autograd.grad((grouped * w).sum(), feats)
+    (g2,) = torch.autograd.grad((want * w).sum(), feats)
+    torch.testing.assert_close(g1, g2, rtol=1e-5, atol=1e-5)
+    qa = PB.QueryAndGroup(0.6, 16)(txyz, new_xyz, feats.detach())
+    assert qa.shape == (B, 3 + C, M, 16)
+    # three_nn / three_interpolate (batch layout)
+    unknown = torch.from_numpy(rng.uniform(-3, 3, (B, 333, 3)).astype(np.float32)).to(cuda)
+    dist, idx3 = PB.three_nn(unknown, new_xyz)
+    for b in range(B):
+        d2, i3 = op2.three_nn(unknown[b].cpu().numpy(), new_xyz[b].cpu().numpy())
+        assert np.array_equal(idx3[b].cpu().numpy(), i3) and np.array_equal(dist[b].cpu().numpy(), np.sqrt(d2))
+    weight = torch.softmax(-dist, dim=2).contiguous()
+    known_f = torch.from_numpy(rng.normal(size=(B, C, M)).astype(np.float32)).to(cuda).requires_grad_(True)
+    out = PB.three_interpolate(known_f, idx3, weight)
+    for b in range(B):
+        want_b = op2.three_interpolate(known_f[b].detach().cpu().numpy().T.copy(), idx3[b].cpu().numpy(), weight[b].cpu().numpy()).T
+        assert np.array_equal(out[b].detach().cpu().numpy(), want_b)
+    gw = torch.from_numpy(rng.normal(size=tuple(out.shape)).astype(np.float32)).to(cuda)
+    (g1,) = torch.autograd.grad((out * gw).sum(), known_f)
+    ref = torch.zeros_like(known_f)
+    for j in range(3):
+        ref.scatter_add_(2, idx3[:, :, j].long().unsqueeze(1).expand(B, C, -1), gw * weight[:, :, j].unsqueeze(1))
+    torch.testing.assert_close(g1, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_three_nn_interpolate_stack_vs_oracle(cuda, hip_lib):
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as PS
+    rng = np.random.default_rng(13)
+    ucnt, kcnt = [300, 0, 451], [120, 40, 77]
+    unknown = rng.uniform(-3, 3, (sum(ucnt), 3)).astype(np.float32)
+    known = rng.uniform(-3, 3, (sum(kcnt), 3)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    dist, idx = PS.three_nn(t(unknown), torch.tensor(ucnt, dtype=torch.int32, device=cuda), t(known), torch.tensor(kcnt, dtype=torch.int32, device=cuda))
+    u0 = k0 = 0
+    for nu, nk in zip(ucnt, kcnt):
+        if nu:
+            d2, i3 = op2.three_nn(unknown[u0:u0 + nu], known[k0:k0 + nk])
+            assert np.array_equal(idx[u0:u0 + nu].cpu().numpy(), i3 + k0) and np.array_equal(dist[u0:u0 + nu].cpu().numpy(), np.sqrt(d2))
+        u0, k0 = u0 + nu, k0 + nk
+    feats = t(rng.normal(size=(sum(kcnt), 24)).astype(np.float32)).requires_grad_(True)
+    weight = torch.softmax(-dist, dim=1).contiguous()
+    out = PS.three_interpolate(feats, idx, weight)
+    assert np.array_equal(out.detach().cpu().numpy(), op2.three_interpolate(feats.detach().cpu().numpy(), idx.cpu().numpy(), weight.cpu().numpy()))
+    gw = t(rng.normal(size=tuple(out.shape)).astype(np.float32))
+    (g1,) = torch.autograd.grad((out * gw).sum(), feats)
+    ref = torch.zeros_like(feats)
+    for j in range(3):
+        ref.index_add_(0, idx[:, j].long(), gw * weight[:, j:j + 1])
+    torch.testing.assert_close(g1, ref, rtol=1e-4, atol=1e-5)
