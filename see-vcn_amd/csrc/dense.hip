@@ -43,6 +43,31 @@ __global__ __launch_bounds__(DN_THREADS) void k_dense_write(const float* __restr
   }
 }
 
+// 4 consecutive cells per thread, one 16-byte store per channel plane and thread (the tensor is > 99 % zeros: the kernel is a
+// 577 MB streaming write at the bench geometry; 4-byte stores reached 3.65 TB/s).  Needs spatial % 4 == 0.
+__global__ __launch_bounds__(DN_THREADS) void k_dense_write4(const float* __restrict__ feat, const int32_t* __restrict__ cellmap, int B, int C,
+                                                             int64_t spatial, float* __restrict__ out) {
+  const int64_t total4 = (int64_t)B * spatial / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cell = q * 4;
+    const int4 rows = *reinterpret_cast<const int4*>(cellmap + cell);
+    const int64_t b = cell / spatial, s = cell - b * spatial;
+    float* o = out + (b * C) * spatial + s;
+    if ((rows.x & rows.y & rows.z & rows.w) < 0 && rows.x < 0 && rows.y < 0 && rows.z < 0 && rows.w < 0) {
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < C; ++c) __builtin_nontemporal_store(z, reinterpret_cast<f32x4_t*>(o + (int64_t)c * spatial));
+    } else {
+      const float* f0 = rows.x >= 0 ? feat + (int64_t)rows.x * C : nullptr;
+      const float* f1 = rows.y >= 0 ? feat + (int64_t)rows.y * C : nullptr;
+      const float* f2 = rows.z >= 0 ? feat + (int64_t)rows.z * C : nullptr;
+      const float* f3 = rows.w >= 0 ? feat + (int64_t)rows.w * C : nullptr;
+      for (int c = 0; c < C; ++c)
+        *reinterpret_cast<float4*>(o + (int64_t)c * spatial) = make_float4(f0 ? f0[c] : 0.f, f1 ? f1[c] : 0.f, f2 ? f2[c] : 0.f, f3 ? f3[c] : 0.f);
+    }
+  }
+}
+
 extern "C" size_t sv_sparse_to_dense_scratch_bytes(int batch, int D, int H, int W) { return (size_t)batch * D * H * W * sizeof(int32_t); }
 
 extern "C" int sv_sparse_to_dense(const float* features, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W,
@@ -57,8 +82,12 @@ extern "C" int sv_sparse_to_dense(const float* features, const int32_t* coords, 
   if (n > 0)
     hipLaunchKernelGGL(k_cellmap_scatter, dim3(sv_grid_1d(n, DN_THREADS)), dim3(DN_THREADS), 0, st, reinterpret_cast<const int4*>(coords), n,
                        batch, D, H, W, cellmap);
-  hipLaunchKernelGGL(k_dense_write, dim3(sv_grid_1d(batch * spatial, DN_THREADS, 256 * 16)), dim3(DN_THREADS), 0, st, features, cellmap, batch,
-                     C, spatial, out);
+  if (spatial % 4 == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)cellmap % 16 == 0))
+    hipLaunchKernelGGL(k_dense_write4, dim3(sv_grid_1d(batch * spatial / 4, DN_THREADS, 256 * 16)), dim3(DN_THREADS), 0, st, features, cellmap,
+                       batch, C, spatial, out);
+  else
+    hipLaunchKernelGGL(k_dense_write, dim3(sv_grid_1d(batch * spatial, DN_THREADS, 256 * 16)), dim3(DN_THREADS), 0, st, features, cellmap, batch,
+                       C, spatial, out);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -18,8 +18,10 @@
 //   stride class) through a power-of-two tree that keeps the LOWER slot on ties (sampling_gpu.cu:16-21,55-134),
 //   i.e. among equal maxima the winner minimises (bitreverse(k mod T), k div T), T = 2^floor(log2 n) <= 1024.
 // ------------------------------------------------------------------------------------------------
-constexpr int FPS_THREADS = 1024;
-constexpr int FPS_MAXP = 24;   // points per thread held in registers -> n <= 24576 on the register path
+constexpr int FPS_THREADS = 512;   // 8 waves = 2 per SIMD: 256 VGPRs per lane, so 48 points per thread stay in registers (1024 threads
+                                   // capped the kernel at 128 VGPRs: the 16- and 24-point variants spilled ~700 / ~2500 registers to scratch
+                                   // and a round took 39 us instead of ~2)
+constexpr int FPS_MAXP = 48;       // points per thread held in registers -> n <= 24576 on the register path
 
 __device__ __forceinline__ unsigned long long fps_key(float d, int k, int log2t) {
   // larger key wins: distance first (non-negative floats order as their bit patterns), then the tie rule
@@ -69,20 +71,26 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_reg(const float* __restrict
   float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];                  // first pick is index 0 (sampling_gpu.cu:44-46)
   for (int j = 1; j < m; ++j) {
     const int par = j & 1;
-    unsigned long long best = 0ull;
-    float bx = 0.f, by = 0.f, bz = 0.f;
+    // per-thread winner by distance; the tie rule is only evaluated on an exact distance tie, so nothing per point is kept in
+    // registers beyond x, y, z and the running minimum distance (hoisted tie keys cost 5 more registers per point and spilled)
+    float bd = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
+    int bk = -1;
+    int tid_r = tid, l2 = log2t;
+    asm volatile("" : "+v"(tid_r), "+s"(l2));      // opaque per round: keeps hipcc from hoisting P point indices / tie keys into registers
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-      const int k = tid + i * FPS_THREADS;
+      const int k = tid_r + i * FPS_THREADS;
       // same expression order as the reference (sampling_gpu.cu:62); fp contraction is off for this library
       const float d = (px[i] - x1) * (px[i] - x1) + (py[i] - y1) * (py[i] - y1) + (pz[i] - z1) * (pz[i] - z1);
       const float d2 = fminf(d, pt[i]);
       pt[i] = d2;
-      const unsigned long long key = k < n ? fps_key(d2, k, log2t) : 0ull;
-      const bool up = key > best;
-      best = up ? key : best;
+      bool up = k < n && d2 > bd;
+      if (k < n && d2 == bd) up = fps_key(d2, k, l2) > fps_key(bd, bk, l2);
+      bd = up ? d2 : bd;
+      bk = up ? k : bk;
       bx = up ? px[i] : bx; by = up ? py[i] : by; bz = up ? pz[i] : bz;
     }
+    const unsigned long long best = bk >= 0 ? fps_key(bd, bk, l2) : 0ull;
     const unsigned long long wbest = wave_max_u64(best);
     // the lane that holds the wave's winner publishes key + coordinates (keys are unique per point)
     if (best == wbest && best != 0ull) {
@@ -161,6 +169,8 @@ static int fps_launch(const float* xyz, const int32_t* starts, const int32_t* co
   if (p <= 4) hipLaunchKernelGGL(k_fps_reg<4>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
   else if (p <= 8) hipLaunchKernelGGL(k_fps_reg<8>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
   else if (p <= 16) hipLaunchKernelGGL(k_fps_reg<16>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
+  else if (p <= 32) hipLaunchKernelGGL(k_fps_reg<32>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
+  else if (p <= 40) hipLaunchKernelGGL(k_fps_reg<40>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
   else if (p <= FPS_MAXP) hipLaunchKernelGGL(k_fps_reg<FPS_MAXP>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
   else {
     SV_CHECK_ARG(temp, "farthest_point_sampling: scenes with more than %d points need the temp buffer", FPS_MAXP * FPS_THREADS);
