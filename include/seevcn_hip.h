@@ -136,6 +136,16 @@ int sv_rulebook_pair_counts(const int32_t* nbr, int64_t n_out, int K, int32_t* c
 int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
                                int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
                                const float* residual, int relu, void* stream);
+/* Work-balanced tile order of a rulebook table (spconv has no counterpart: its gather/scatter GEMMs are per-offset launches).
+ * tile_order (sv_conv_tile_order_bytes(n_rows)) maps [wave*4 + slot] to a 16-row tile or -1: tiles counting-sorted by their number
+ * of active kernel offsets and dealt to the waves in snake order.  Compute once per table, pass to every gather-GEMM that uses it
+ * (results are identical with or without it). */
+size_t sv_conv_tile_order_scratch_bytes(int64_t n_rows);
+size_t sv_conv_tile_order_bytes(int64_t n_rows);
+int sv_conv_tile_order(const int32_t* nbr, int64_t n_rows, int K, void* scratch, int32_t* tile_order, void* stream);
+int sv_sparse_conv_gather_gemm_ordered(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows, int K,
+                                       int Kd, int Nc, const float* bias, const float* scale, const float* shift, const float* residual,
+                                       int relu, const int32_t* tile_order, void* stream);
 /* dW (K, C_in, C_out) = sum_o X[nbr[k][o]]^T dY[o]; deterministic two-stage reduction */
 size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout);
 int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,

@@ -38,6 +38,7 @@ struct ConvArgs {
   int relu;
   int64_t n_rows;
   int K, Kd, Nc;
+  const int32_t* tile_order;  // [wave * 4 + slot] -> 16-row tile (sv_conv_tile_order) or null: tiles by position
 };
 
 __device__ __forceinline__ float conv_epilogue(float v, int col, int64_t row, const ConvArgs& a) {
@@ -242,6 +243,307 @@ __global__ __launch_bounds__(256) void k_spconv_rs(ConvArgs a) {
       }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Three-stage variant of k_spconv_rs.  PMC on k_spconv_rs: matrix core busy 38 %, waves waiting for operands that were requested
+// only one 64-MFMA step (~2000 cycles) earlier, less than the gather latency under load; hipcc additionally sinks its own
+// prefetch loads towards their first use.  Here every operand load of the loop is an inline-asm buffer_load_dwordx4 (hipcc can
+// neither move it nor wait for it), issued TWO steps ahead into a 3-deep register ring, and retired with a counted
+// s_waitcnt vmcnt(2 x loads-per-step) that names the stage's registers ("+v", form (ii) of cdna_hip_programming.md 5.7).
+// Every step issues exactly RS_G + NT loads: rows without a neighbour use an out-of-range buffer offset (the range check
+// returns zeros without a memory access), steps past the end issue out-of-range dummies.  The wave's neighbour indices are parked
+// in LDS once, so the loop contains no compiler-visible VMEM load.  Same ownership, skipping and summation order as k_spconv_rs.
+// ------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 make_srd(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffffu));      // stride 0
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ f32x4 buf_load_b128(i32x4 srd, uint32_t voff) {
+  f32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(srd) : "memory");
+  return v;
+}
+
+constexpr int RS3_KMAX = 27;
+
+// weights re-laid in MFMA fragment order, one contiguous KiB per (offset, 16-channel step, column tile): the B-operand load of
+// a wave then touches 8 whole cache lines instead of 16 half lines at 16 different rows.  Rewritten by every call (<= 442 KB);
+// calls on one device are serialised on one stream ("Error behaviour and streams").
+__device__ __attribute__((aligned(256))) float g_wfrag[RS3_KMAX * 64 * 64];
+
+__global__ __launch_bounds__(256) void k_weight_fragments(const float* __restrict__ wt, int K, int Nc, int Kd, float* __restrict__ wf) {
+  const int total = K * Nc * Kd / 4;                      // float4 units
+  const int KQ = Kd / 16, NT = Nc / 16;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int lane = i & 63, t = (i >> 6) % NT, q = ((i >> 6) / NT) % KQ, k = (i >> 6) / (NT * KQ);
+    const int li = lane & 15, kk = lane >> 4;
+    reinterpret_cast<float4*>(wf)[i] = *reinterpret_cast<const float4*>(wt + ((size_t)(k * Nc + t * 16 + li)) * Kd + q * 16 + kk * 4);
+  }
+}
+
+// Work-balanced tile assignment.  A 16-row tile costs as many MFMA steps as it has kernel offsets with at least one neighbour
+// (9 / 18 / 27 for the bench layers, depending on how many z-slices it spans); with tiles dealt to waves by position the
+// busiest wave had 1.8x the mean work and set the kernel time.  Tiles are counting-sorted by cost and dealt to the waves in
+// snake order (max / mean 1.05).  Order inside a cost bucket is arbitrary: every output row is still produced by one wave with
+// the same summation order, so results do not depend on it.
+// The order is a property of the rulebook table: sv_conv_tile_order computes it once (two small launches), the conv launches
+// that use the table pass it in.
+struct TileOrderArgs {
+  const int32_t* nbr;
+  int64_t n_rows, n_tiles, n_waves;
+  int K;
+  uint8_t* cost;        // scratch: (n_tiles)
+  int32_t* hist;        // scratch: [0][32] tiles per cost, [1][32] running fill per cost
+  int32_t* tile_of;     // out: [wave * 4 + slot] -> tile or -1
+};
+
+constexpr int TO_WGS = 128;
+
+__global__ __launch_bounds__(256) void k_tile_cost(TileOrderArgs a) {
+  __shared__ int s_hist[32];
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t n_groups = (a.n_tiles + 3) / 4;                      // one wave per 4 tiles (64 rows)
+  for (int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; w < n_groups; w += (int64_t)gridDim.x * 4) {
+    const int64_t row = w * 64 + lane;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int k = 0; k < a.K; ++k) {
+      const int32_t j = row < a.n_rows ? a.nbr[(int64_t)k * a.n_rows + row] : -1;
+      const unsigned long long v = __ballot(j >= 0);
+      c0 += (v & 0xffffull) != 0, c1 += ((v >> 16) & 0xffffull) != 0, c2 += ((v >> 32) & 0xffffull) != 0, c3 += (v >> 48) != 0;
+    }
+    if (lane < 4) {
+      const int64_t t = w * 4 + lane;
+      int c = lane == 0 ? c0 : (lane == 1 ? c1 : (lane == 2 ? c2 : c3));
+      c = c > 31 ? 31 : c;
+      if (t < a.n_tiles) {
+        a.cost[t] = (uint8_t)c;
+        atomicAdd(&s_hist[c], 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32 && s_hist[threadIdx.x]) atomicAdd(&a.hist[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_tile_deal(TileOrderArgs a) {
+  __shared__ int s_start[32], s_cnt[32], s_base[32];
+  if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) {                 // descending cost: the most expensive bucket first
+    int acc = 0;
+    for (int c = 31; c >= 0; --c) s_start[c] = acc, acc += a.hist[c];
+  }
+  __syncthreads();
+  // this workgroup's contiguous slice of tiles: count per bucket, reserve one range per bucket, then place
+  const int64_t per = (a.n_tiles + gridDim.x - 1) / gridDim.x, t0 = blockIdx.x * per, t1 = min(a.n_tiles, t0 + per);
+  for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) atomicAdd(&s_cnt[a.cost[t]], 1);
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    s_base[threadIdx.x] = s_cnt[threadIdx.x] ? s_start[threadIdx.x] + atomicAdd(&a.hist[32 + threadIdx.x], s_cnt[threadIdx.x]) : 0;
+    s_cnt[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) {
+    const int c = a.cost[t];
+    const int64_t p = s_base[c] + atomicAdd(&s_cnt[c], 1);
+    const int64_t r = p / a.n_waves, i = p - r * a.n_waves;
+    const int64_t wv = (r & 1) ? a.n_waves - 1 - i : i;          // snake: dense and sparse tiles alternate per wave
+    a.tile_of[wv * 4 + r] = (int32_t)t;
+  }
+}
+
+static size_t tile_order_scratch_bytes(int64_t n_rows) { return (size_t)((n_rows + 15) / 16) + 256 + 64 * sizeof(int32_t); }
+
+extern "C" size_t sv_conv_tile_order_scratch_bytes(int64_t n_rows) { return tile_order_scratch_bytes(n_rows < 0 ? 0 : n_rows); }
+extern "C" size_t sv_conv_tile_order_bytes(int64_t n_rows) {
+  const int64_t n_tiles = ((n_rows < 0 ? 0 : n_rows) + 15) / 16;
+  return (size_t)(((n_tiles + 3) / 4) * 4 + 4) * sizeof(int32_t);
+}
+
+extern "C" int sv_conv_tile_order(const int32_t* nbr, int64_t n_rows, int K, void* scratch, int32_t* tile_order, void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && K > 0, "sv_conv_tile_order: bad sizes");
+  if (n_rows == 0) return SV_OK;
+  SV_CHECK_ARG(nbr && scratch && tile_order, "sv_conv_tile_order: null pointer");
+  TileOrderArgs a{};
+  a.nbr = nbr, a.n_rows = n_rows, a.K = K;
+  a.n_tiles = (n_rows + 15) / 16;
+  a.n_waves = (a.n_tiles + 3) / 4;
+  a.hist = reinterpret_cast<int32_t*>(scratch);
+  a.cost = reinterpret_cast<uint8_t*>(scratch) + 64 * sizeof(int32_t);
+  a.tile_of = tile_order;
+  hipStream_t st = sv_stream(stream);
+  SV_HIP(hipMemsetAsync(a.hist, 0, 64 * sizeof(int32_t), st));
+  SV_HIP(hipMemsetAsync(tile_order, 0xFF, (size_t)a.n_waves * 4 * sizeof(int32_t), st));
+  const int wgs = (int)((a.n_tiles + 15) / 16 < TO_WGS ? (a.n_tiles + 15) / 16 : TO_WGS);
+  hipLaunchKernelGGL(k_tile_cost, dim3(wgs), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_tile_deal, dim3(wgs), dim3(256), 0, st, a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+template <int NT, int KQ, int RS_G>
+__global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_bytes, uint32_t w_bytes) {
+  constexpr int Kd = KQ * 16, Nc = NT * 16, NLOAD = RS_G + NT;
+  __shared__ int32_t s_idx_all[4][RS3_KMAX][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int li = lane & 15, kk = lane >> 4;
+  const int64_t n_tiles = (a.n_rows + 15) / 16;
+  const int64_t n_waves = (n_tiles + RS_G - 1) / RS_G;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid;
+  if (wave_id >= n_waves) return;
+  int32_t(*s_idx)[64] = s_idx_all[wid];
+  // rows past the end for an empty slot
+  auto tile_row0 = [&](int g) {
+    if (!a.tile_order) return (wave_id + (int64_t)g * n_waves) * 16;         // by position (strided)
+    const int32_t t = a.tile_order[wave_id * 4 + g];
+    return t >= 0 ? (int64_t)t * 16 : a.n_rows;
+  };
+
+  // neighbour indices of the wave's rows -> LDS (lane = (tile lane>>4, row lane&15)); per-offset tile masks in lane k of maskreg
+  unsigned maskreg = 0;
+  {
+    const int g = (lane >> 4) % RS_G;
+    const int64_t r = tile_row0(g) + li;
+    const bool valid = (lane >> 4) < RS_G && r < a.n_rows;
+    for (int k = 0; k < a.K; ++k) {
+      const int32_t j = valid ? a.nbr[(int64_t)k * a.n_rows + r] : -1;
+      s_idx[k][lane] = j;
+      const unsigned long long vote = __ballot(j >= 0);
+      unsigned m = 0;
+#pragma unroll
+      for (int t = 0; t < RS_G; ++t) m |= ((vote >> (16 * t)) & 0xffffull) ? (1u << t) : 0u;
+      if (lane == k) maskreg = m;
+    }
+  }
+  const unsigned long long active = __ballot(maskreg != 0);
+
+  f32x4 acc[RS_G][NT];
+#pragma unroll
+  for (int g = 0; g < RS_G; ++g)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (active) {
+    const i32x4 srd_x = make_srd(a.X, x_bytes), srd_w = make_srd(g_wfrag, w_bytes);
+    f32x4 A[3][RS_G], B[3][NT];
+    // load iterator (two steps ahead of the compute iterator)
+    unsigned long long la = active;
+    int kl = __ffsll((long long)la) - 1, ql = 0;
+    int32_t jl[RS_G];
+    auto read_j = [&]() {
+#pragma unroll
+      for (int g = 0; g < RS_G; ++g) jl[g] = s_idx[kl][g * 16 + li];
+    };
+    read_j();
+    auto issue = [&](f32x4 (&As)[RS_G], f32x4 (&Bs)[NT]) {       // exactly NLOAD loads, always
+      const bool live = kl >= 0;
+#pragma unroll
+      for (int g = 0; g < RS_G; ++g) {
+        const uint32_t off = (live && jl[g] >= 0) ? (uint32_t)((jl[g] * Kd + ql * 16 + kk * 4) * 4) : 0xfffffff0u;
+        As[g] = buf_load_b128(srd_x, off);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const uint32_t off = live ? (uint32_t)(((((kl * KQ + ql) * NT + t) * 64 + lane) * 4) * 4) : 0xfffffff0u;
+        Bs[t] = buf_load_b128(srd_w, off);
+      }
+      if (live && ++ql == KQ) {
+        ql = 0;
+        la &= la - 1;
+        kl = la ? __ffsll((long long)la) - 1 : -1;
+        if (kl >= 0) read_j();
+      }
+    };
+    // compute iterator
+    unsigned long long ca = active;
+    int kc = __ffsll((long long)ca) - 1, qc = 0;
+    unsigned mc = (unsigned)__builtin_amdgcn_readlane((int)maskreg, kc);
+    auto compute = [&](f32x4 (&As)[RS_G], f32x4 (&Bs)[NT]) {
+      // the stage's loads are the oldest NLOAD in flight: everything issued later (2 steps) may stay outstanding
+      if constexpr (NLOAD == 8) {
+        asm volatile("s_waitcnt vmcnt(16)" : "+v"(As[0]), "+v"(As[1]), "+v"(As[2]), "+v"(As[3]), "+v"(Bs[0]), "+v"(Bs[1]), "+v"(Bs[2]), "+v"(Bs[3]));
+      } else if constexpr (NLOAD == 6 && RS_G == 4) {
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(As[0]), "+v"(As[1]), "+v"(As[2]), "+v"(As[3]), "+v"(Bs[0]), "+v"(Bs[1]));
+      } else {
+        asm volatile("s_waitcnt vmcnt(10)" : "+v"(As[0]), "+v"(As[1]), "+v"(As[2]), "+v"(As[3]), "+v"(Bs[0]));
+      }
+      // per tile: 4 passes over the NT column tiles, so that consecutive MFMAs never share an accumulator (a dependent
+      // v_mfma_f32_16x16x4_f32 issues 47 cycles after its producer, an independent one after 32)
+#pragma unroll
+      for (int g = 0; g < RS_G; ++g)
+        if ((mc >> g) & 1u) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g].x, Bs[t].x, acc[g][t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g].y, Bs[t].y, acc[g][t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g].z, Bs[t].z, acc[g][t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g].w, Bs[t].w, acc[g][t], 0, 0, 0);
+        }
+      if (++qc == KQ) {
+        qc = 0;
+        ca &= ca - 1;
+        kc = ca ? __ffsll((long long)ca) - 1 : -1;
+        if (kc >= 0) mc = (unsigned)__builtin_amdgcn_readlane((int)maskreg, kc);
+      }
+    };
+    issue(A[0], B[0]);
+    issue(A[1], B[1]);
+    while (true) {
+      issue(A[2], B[2]);
+      compute(A[0], B[0]);
+      if (kc < 0) break;
+      issue(A[0], B[0]);
+      compute(A[1], B[1]);
+      if (kc < 0) break;
+      issue(A[1], B[1]);
+      compute(A[2], B[2]);
+      if (kc < 0) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // retire the dummy loads before the registers are reused
+  }
+  // D layout (16x16): col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+  for (int g = 0; g < RS_G; ++g)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = tile_row0(g) + kk * 4 + r;
+        const int col = t * 16 + li;
+        if (row < a.n_rows) a.Y[row * Nc + col] = conv_epilogue(acc[g][t][r], col, row, a);
+      }
+}
+
+static int try_launch_rs3(const ConvArgs& a, int64_t n_src, hipStream_t st) {
+  if (a.K > RS3_KMAX || a.Kd % 16 || a.Nc % 16 || a.Kd > 64 || a.Nc > 64) return -1;
+  const uint64_t xb = (uint64_t)n_src * a.Kd * 4, wb = (uint64_t)a.K * a.Nc * a.Kd * 4;
+  if (xb >= 0xfffffff0ull || wb >= 0xfffffff0ull) return -1;
+  const int64_t n_tiles = (a.n_rows + 15) / 16;
+  const int64_t n_waves = (n_tiles + 3) / 4;
+  const dim3 grid((unsigned)((n_waves + 3) / 4));
+  const int nt = a.Nc / 16, kq = a.Kd / 16;
+  float* wf = nullptr;
+  if (hipGetSymbolAddress(reinterpret_cast<void**>(&wf), HIP_SYMBOL(g_wfrag)) != hipSuccess) return -1;
+  hipLaunchKernelGGL(k_weight_fragments, dim3(sv_grid_1d((int64_t)a.K * a.Nc * a.Kd / 4, 256)), dim3(256), 0, st, a.Wt, a.K, a.Nc, a.Kd, wf);
+#define RS3_CASE(NTV, KQV)                                                                                              \
+  if (nt == NTV && kq == KQV) {                                                                                         \
+    hipLaunchKernelGGL((k_spconv_rs3<NTV, KQV, 4>), grid, dim3(256), 0, st, a, (uint32_t)xb, (uint32_t)wb);             \
+    return 0;                                                                                                           \
+  }
+  RS3_CASE(4, 4) RS3_CASE(4, 2) RS3_CASE(2, 4) RS3_CASE(2, 2) RS3_CASE(2, 1) RS3_CASE(1, 2) RS3_CASE(1, 1)
+#undef RS3_CASE
+  return -1;
+}
+
 template <int NT, int G>
 static int launch_rs_kq(const ConvArgs& a, int kq, hipStream_t st) {
   const int64_t n_tiles = (a.n_rows + 15) / 16;
@@ -292,19 +594,41 @@ __global__ __launch_bounds__(256) void k_spconv_valu(ConvArgs a) {
   }
 }
 
+static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows, int K, int Kd, int Nc,
+                            const float* bias, const float* scale, const float* shift, const float* residual, int relu,
+                            const int32_t* tile_order, void* stream);
+
 extern "C" int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
                                           int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
                                           const float* residual, int relu, void* stream) {
+  return gather_gemm_impl(X, n_src, nbr, Wt, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, nullptr, stream);
+}
+
+extern "C" int sv_sparse_conv_gather_gemm_ordered(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
+                                                  int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale,
+                                                  const float* shift, const float* residual, int relu, const int32_t* tile_order,
+                                                  void* stream) {
+  return gather_gemm_impl(X, n_src, nbr, Wt, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, tile_order, stream);
+}
+
+static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows, int K, int Kd, int Nc,
+                            const float* bias, const float* scale, const float* shift, const float* residual, int relu,
+                            const int32_t* tile_order, void* stream) {
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Kd > 0 && Nc > 0, "sparse_conv: bad sizes");
   if (n_rows == 0) return SV_OK;
   SV_CHECK_ARG(X && nbr && Wt && Y, "sparse_conv: null pointer");
   SV_CHECK_ARG((scale == nullptr) == (shift == nullptr), "sparse_conv: scale and shift go together");
-  ConvArgs a{X, nbr, Wt, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc};
+  ConvArgs a{X, nbr, Wt, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc, tile_order};
   hipStream_t st = sv_stream(stream);
   const int nt = Nc / 16;
   const bool mfma_ok = (Kd % 16 == 0) && (Nc % 16 == 0) && (nt == 1 || nt == 2 || nt == 4 || nt == 8) &&
                        ((uintptr_t)X % 16 == 0) && ((uintptr_t)Wt % 16 == 0);
   static const bool force_v1 = getenv("SEEVCN_SPCONV_V1") != nullptr;
+  static const bool use_rs3 = getenv("SEEVCN_SPCONV_NORS3") == nullptr;
+  if (mfma_ok && !force_v1 && use_rs3 && try_launch_rs3(a, n_src, st) == 0) {
+    SV_LAUNCH_CHECK();
+    return SV_OK;
+  }
   if (mfma_ok && !force_v1 && try_launch_rs(a, st) == 0) {
     SV_LAUNCH_CHECK();
     return SV_OK;

@@ -27,6 +27,7 @@ class Rulebook:
         self.out_indices, self.out_shape = out_indices, out_shape
         self.n_in, self.n_out, self.subm, self.ksize = n_in, n_out, subm, ksize
         self._nbr_in_subm = None
+        self._orders = {}
 
     @property
     def K(self):
@@ -40,6 +41,21 @@ class Rulebook:
         if self._nbr_in_subm is None:
             self._nbr_in_subm = torch.flip(self.nbr_out, dims=[0]).contiguous()
         return self._nbr_in_subm
+
+    def tile_order(self, table):
+        """Work-balanced tile order of one of this rulebook's tables (sv_conv_tile_order), computed once and reused by every
+        gather-GEMM launch on that table."""
+        key = table.data_ptr()
+        if key not in self._orders:
+            lib = _lib.load()
+            n_rows, K = table.shape[1], table.shape[0]
+            if n_rows == 0:
+                return None
+            order = torch.empty((lib.sv_conv_tile_order_bytes(n_rows) // 4,), dtype=torch.int32, device=table.device)
+            scratch = _lib.workspace.scratch("tile_order", lib.sv_conv_tile_order_scratch_bytes(n_rows), table.device)
+            _lib.check(lib.sv_conv_tile_order(_lib.ptr(table), n_rows, K, _lib.ptr(scratch), _lib.ptr(order), _lib.stream()), "sv_conv_tile_order")
+            self._orders[key] = (order, table)       # keep the table alive with its order
+        return self._orders[key][0]
 
     def pair_counts(self):
         lib = _lib.load()
@@ -99,16 +115,16 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
     return Rulebook(nbr_out, nbr_in, out_coords, oshape, n_in, n_out, False, list(ksize))
 
 
-def gather_gemm(x, nbr, wt, n_rows, bias=None, scale=None, shift=None, residual=None, relu=False):
-    """Y (n_rows, Nc) = epi(sum_k X[nbr[k]] @ wt[k].T); wt is (K, Nc, Kd) contiguous."""
+def gather_gemm(x, nbr, wt, n_rows, bias=None, scale=None, shift=None, residual=None, relu=False, tile_order=None):
+    """Y (n_rows, Nc) = epi(sum_k X[nbr[k]] @ wt[k].T); wt is (K, Nc, Kd) contiguous.  tile_order: Rulebook.tile_order(nbr)."""
     lib = _lib.load()
     K, Nc, Kd = wt.shape
     assert x.shape[1] == Kd and nbr.shape[0] == K
     x = x.contiguous()
     y = torch.empty((n_rows, Nc), dtype=torch.float32, device=x.device)
-    rc = lib.sv_sparse_conv_gather_gemm(_lib.ptr(x) if x.numel() else None, x.shape[0], _lib.ptr(nbr) if nbr.numel() else None, _lib.ptr(wt),
-                                        _lib.ptr(y) if n_rows else None, n_rows, K, Kd, Nc, _lib.ptr(bias), _lib.ptr(scale),
-                                        _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), _lib.stream())
+    rc = lib.sv_sparse_conv_gather_gemm_ordered(_lib.ptr(x) if x.numel() else None, x.shape[0], _lib.ptr(nbr) if nbr.numel() else None, _lib.ptr(wt),
+                                                _lib.ptr(y) if n_rows else None, n_rows, K, Kd, Nc, _lib.ptr(bias), _lib.ptr(scale),
+                                                _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), _lib.ptr(tile_order), _lib.stream())
     _lib.check(rc, "sv_sparse_conv_gather_gemm")
     return y
 
@@ -133,7 +149,7 @@ class SparseConvFunction(torch.autograd.Function):
         _lib.require_cuda(features, weight_kio)
         features = features.contiguous().float()
         wt = weight_kio.detach().permute(0, 2, 1).contiguous()  # (K, C_out, C_in)
-        out = gather_gemm(features, rulebook.nbr_out, wt, rulebook.n_out)
+        out = gather_gemm(features, rulebook.nbr_out, wt, rulebook.n_out, tile_order=rulebook.tile_order(rulebook.nbr_out))
         ctx.rulebook = rulebook
         ctx.save_for_backward(features, weight_kio)
         return out
@@ -147,7 +163,8 @@ class SparseConvFunction(torch.autograd.Function):
         gf = gw = None
         if ctx.needs_input_grad[0]:
             # dX[i] = sum_k dY[nbr_in[k][i]] @ W[k]^T  -> Wt[k][n=c_in][c=c_out] = W[k][c_in][c_out]: weight_kio itself
-            gf = gather_gemm(grad_out, rb.table_for_backward_data(), weight_kio.detach().contiguous(), rb.n_in)
+            tb = rb.table_for_backward_data()
+            gf = gather_gemm(grad_out, tb, weight_kio.detach().contiguous(), rb.n_in, tile_order=rb.tile_order(tb))
         if ctx.needs_input_grad[1]:
             gw = wgrad(features, rb.nbr_out, grad_out, K, cin, cout)
         return gf, gw, None
