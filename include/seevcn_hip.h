@@ -137,12 +137,13 @@ int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr
                                int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
                                const float* residual, int relu, void* stream);
 /* Work-balanced tile order of a rulebook table (spconv has no counterpart: its gather/scatter GEMMs are per-offset launches).
- * tile_order (sv_conv_tile_order_bytes(n_rows)) maps [wave*4 + slot] to a 16-row tile or -1: tiles counting-sorted by their number
+ * tile_order (sv_conv_tile_order_bytes(n_rows)) maps [wave*G + slot] to a 16-row tile or -1 (G = tiles_per_wave = sv_conv_tiles_per_wave(n_rows, Kd, Nc) of the conv that will use it): tiles counting-sorted by their number
  * of active kernel offsets and dealt to the waves in snake order.  Compute once per table, pass to every gather-GEMM that uses it
  * (results are identical with or without it). */
+int sv_conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc);   /* the G the gather-GEMM uses for this shape (2, 3 or 4) */
 size_t sv_conv_tile_order_scratch_bytes(int64_t n_rows);
 size_t sv_conv_tile_order_bytes(int64_t n_rows);
-int sv_conv_tile_order(const int32_t* nbr, int64_t n_rows, int K, void* scratch, int32_t* tile_order, void* stream);
+int sv_conv_tile_order(const int32_t* nbr, int64_t n_rows, int K, int tiles_per_wave, void* scratch, int32_t* tile_order, void* stream);
 int sv_sparse_conv_gather_gemm_ordered(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows, int K,
                                        int Kd, int Nc, const float* bias, const float* scale, const float* shift, const float* residual,
                                        int relu, const int32_t* tile_order, void* stream);

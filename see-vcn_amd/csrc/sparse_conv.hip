@@ -297,10 +297,10 @@ __global__ __launch_bounds__(256) void k_weight_fragments(const float* __restric
 struct TileOrderArgs {
   const int32_t* nbr;
   int64_t n_rows, n_tiles, n_waves;
-  int K;
+  int K, G;             // G = tiles per wave of the conv kernel that will use the order
   uint8_t* cost;        // scratch: (n_tiles)
   int32_t* hist;        // scratch: [0][32] tiles per cost, [1][32] running fill per cost
-  int32_t* tile_of;     // out: [wave * 4 + slot] -> tile or -1
+  int32_t* tile_of;     // out: [wave * G + slot] -> tile or -1
 };
 
 constexpr int TO_WGS = 128;
@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) void k_tile_deal(TileOrderArgs a) {
   __syncthreads();
   // this workgroup's contiguous slice of tiles: count per bucket, reserve one range per bucket, then place
   const int64_t per = (a.n_tiles + gridDim.x - 1) / gridDim.x, t0 = blockIdx.x * per, t1 = min(a.n_tiles, t0 + per);
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.tile_of[0] = a.G;
   for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) atomicAdd(&s_cnt[a.cost[t]], 1);
   __syncthreads();
   if (threadIdx.x < 32) {
@@ -355,32 +356,55 @@ __global__ __launch_bounds__(256) void k_tile_deal(TileOrderArgs a) {
     const int64_t p = s_base[c] + atomicAdd(&s_cnt[c], 1);
     const int64_t r = p / a.n_waves, i = p - r * a.n_waves;
     const int64_t wv = (r & 1) ? a.n_waves - 1 - i : i;          // snake: dense and sparse tiles alternate per wave
-    a.tile_of[wv * 4 + r] = (int32_t)t;
+    a.tile_of[4 + wv * a.G + r] = (int32_t)t;      // 4-int header: [0] = G
   }
 }
+
+// Tiles per wave.  All workgroups (4 waves) of a launch are resident at once, so the kernel lasts as long as the fullest CU:
+// 526 workgroups on 256 CUs put 3 on 14 of them and 2 on the rest, 1.46x the mean.  Pick G in {4, 3, 2} for the smallest
+// ceil(WGs / 256) / (WGs / 256); larger G (fewer weight loads per tile) wins ties and near-ties.
+static int conv_tiles_per_wave(int64_t n_rows) {
+  const int64_t n_tiles = (n_rows + 15) / 16;
+  int best = 4;
+  double best_score = 1e30;
+  for (int g = 4; g >= 2; --g) {
+    const int64_t wgs = ((n_tiles + g - 1) / g + 3) / 4;
+    if (wgs <= 0) continue;
+    const double per_cu = (double)wgs / 256.0;
+    const double imbalance = wgs <= 256 ? 1.0 : (double)((wgs + 255) / 256) / per_cu;
+    const double score = imbalance * (1.0 + 0.04 * (4 - g));       // a smaller G re-reads the weight slab more often
+    if (score < best_score - 1e-9) best_score = score, best = g;
+  }
+  return best;
+}
+// layers with fewer than 32x32 channel products per tile are bound by their operand loads, not by matrix-core time: keep G = 4
+static int conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc) { return (Kd / 16) * (Nc / 16) < 4 ? 4 : conv_tiles_per_wave(n_rows); }
+extern "C" int sv_conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc) { return conv_tiles_per_wave(n_rows < 0 ? 0 : n_rows, Kd, Nc); }
 
 static size_t tile_order_scratch_bytes(int64_t n_rows) { return (size_t)((n_rows + 15) / 16) + 256 + 64 * sizeof(int32_t); }
 
 extern "C" size_t sv_conv_tile_order_scratch_bytes(int64_t n_rows) { return tile_order_scratch_bytes(n_rows < 0 ? 0 : n_rows); }
 extern "C" size_t sv_conv_tile_order_bytes(int64_t n_rows) {
   const int64_t n_tiles = ((n_rows < 0 ? 0 : n_rows) + 15) / 16;
-  return (size_t)(((n_tiles + 3) / 4) * 4 + 4) * sizeof(int32_t);
+  return (size_t)(((n_tiles + 1) / 2) * 2 + 16) * sizeof(int32_t);     // 4-int header + enough slots for any G in {2, 3, 4}
 }
 
-extern "C" int sv_conv_tile_order(const int32_t* nbr, int64_t n_rows, int K, void* scratch, int32_t* tile_order, void* stream) {
-  SV_CHECK_ARG(n_rows >= 0 && K > 0, "sv_conv_tile_order: bad sizes");
+extern "C" int sv_conv_tile_order(const int32_t* nbr, int64_t n_rows, int K, int tiles_per_wave, void* scratch, int32_t* tile_order,
+                                  void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && K > 0 && tiles_per_wave >= 2 && tiles_per_wave <= 4, "sv_conv_tile_order: bad sizes (tiles_per_wave %d)", tiles_per_wave);
   if (n_rows == 0) return SV_OK;
   SV_CHECK_ARG(nbr && scratch && tile_order, "sv_conv_tile_order: null pointer");
   TileOrderArgs a{};
   a.nbr = nbr, a.n_rows = n_rows, a.K = K;
   a.n_tiles = (n_rows + 15) / 16;
-  a.n_waves = (a.n_tiles + 3) / 4;
+  a.G = tiles_per_wave;
+  a.n_waves = (a.n_tiles + a.G - 1) / a.G;
   a.hist = reinterpret_cast<int32_t*>(scratch);
   a.cost = reinterpret_cast<uint8_t*>(scratch) + 64 * sizeof(int32_t);
   a.tile_of = tile_order;
   hipStream_t st = sv_stream(stream);
   SV_HIP(hipMemsetAsync(a.hist, 0, 64 * sizeof(int32_t), st));
-  SV_HIP(hipMemsetAsync(tile_order, 0xFF, (size_t)a.n_waves * 4 * sizeof(int32_t), st));
+  SV_HIP(hipMemsetAsync(tile_order, 0xFF, (size_t)(4 + a.n_waves * a.G) * sizeof(int32_t), st));
   const int wgs = (int)((a.n_tiles + 15) / 16 < TO_WGS ? (a.n_tiles + 15) / 16 : TO_WGS);
   hipLaunchKernelGGL(k_tile_cost, dim3(wgs), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_tile_deal, dim3(wgs), dim3(256), 0, st, a);
@@ -401,9 +425,9 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_by
   int32_t(*s_idx)[64] = s_idx_all[wid];
   // rows past the end for an empty slot
   auto tile_row0 = [&](int g) {
-    if (!a.tile_order) return (wave_id + (int64_t)g * n_waves) * 16;         // by position (strided)
-    const int32_t t = a.tile_order[wave_id * 4 + g];
-    return t >= 0 ? (int64_t)t * 16 : a.n_rows;
+    if (!a.tile_order || a.tile_order[0] != RS_G) return (wave_id + (int64_t)g * n_waves) * 16;   // by position (strided)
+    const int32_t t = a.tile_order[4 + wave_id * RS_G + g];
+    return (t >= 0 && t < n_tiles) ? (int64_t)t * 16 : a.n_rows;
   };
 
   // neighbour indices of the wave's rows -> LDS (lane = (tile lane>>4, row lane&15)); per-offset tile masks in lane k of maskreg
@@ -467,13 +491,19 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_by
     unsigned mc = (unsigned)__builtin_amdgcn_readlane((int)maskreg, kc);
     auto compute = [&](f32x4 (&As)[RS_G], f32x4 (&Bs)[NT]) {
       // the stage's loads are the oldest NLOAD in flight: everything issued later (2 steps) may stay outstanding
-      if constexpr (NLOAD == 8) {
-        asm volatile("s_waitcnt vmcnt(16)" : "+v"(As[0]), "+v"(As[1]), "+v"(As[2]), "+v"(As[3]), "+v"(Bs[0]), "+v"(Bs[1]), "+v"(Bs[2]), "+v"(Bs[3]));
-      } else if constexpr (NLOAD == 6 && RS_G == 4) {
-        asm volatile("s_waitcnt vmcnt(12)" : "+v"(As[0]), "+v"(As[1]), "+v"(As[2]), "+v"(As[3]), "+v"(Bs[0]), "+v"(Bs[1]));
-      } else {
-        asm volatile("s_waitcnt vmcnt(10)" : "+v"(As[0]), "+v"(As[1]), "+v"(As[2]), "+v"(As[3]), "+v"(Bs[0]));
-      }
+#define RS3_WAIT(N, ...) asm volatile("s_waitcnt vmcnt(" #N ")" : __VA_ARGS__)
+#define V(x) "+v"(x)
+      if constexpr (RS_G == 4 && NT == 4) RS3_WAIT(16, V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3]));
+      else if constexpr (RS_G == 4 && NT == 2) RS3_WAIT(12, V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]), V(Bs[1]));
+      else if constexpr (RS_G == 4 && NT == 1) RS3_WAIT(10, V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]));
+      else if constexpr (RS_G == 3 && NT == 4) RS3_WAIT(14, V(As[0]), V(As[1]), V(As[2]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3]));
+      else if constexpr (RS_G == 3 && NT == 2) RS3_WAIT(10, V(As[0]), V(As[1]), V(As[2]), V(Bs[0]), V(Bs[1]));
+      else if constexpr (RS_G == 3 && NT == 1) RS3_WAIT(8, V(As[0]), V(As[1]), V(As[2]), V(Bs[0]));
+      else if constexpr (RS_G == 2 && NT == 4) RS3_WAIT(12, V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3]));
+      else if constexpr (RS_G == 2 && NT == 2) RS3_WAIT(8, V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1]));
+      else RS3_WAIT(6, V(As[0]), V(As[1]), V(Bs[0]));
+#undef V
+#undef RS3_WAIT
       // per tile: 4 passes over the NT column tiles, so that consecutive MFMAs never share an accumulator (a dependent
       // v_mfma_f32_16x16x4_f32 issues 47 cycles after its producer, an independent one after 32)
 #pragma unroll
@@ -528,16 +558,19 @@ static int try_launch_rs3(const ConvArgs& a, int64_t n_src, hipStream_t st) {
   const uint64_t xb = (uint64_t)n_src * a.Kd * 4, wb = (uint64_t)a.K * a.Nc * a.Kd * 4;
   if (xb >= 0xfffffff0ull || wb >= 0xfffffff0ull) return -1;
   const int64_t n_tiles = (a.n_rows + 15) / 16;
-  const int64_t n_waves = (n_tiles + 3) / 4;
+  const int G = conv_tiles_per_wave(a.n_rows, a.Kd, a.Nc);   // the value the caller passed to sv_conv_tile_order for a.tile_order
+  const int64_t n_waves = (n_tiles + G - 1) / G;
   const dim3 grid((unsigned)((n_waves + 3) / 4));
   const int nt = a.Nc / 16, kq = a.Kd / 16;
   float* wf = nullptr;
   if (hipGetSymbolAddress(reinterpret_cast<void**>(&wf), HIP_SYMBOL(g_wfrag)) != hipSuccess) return -1;
   hipLaunchKernelGGL(k_weight_fragments, dim3(sv_grid_1d((int64_t)a.K * a.Nc * a.Kd / 4, 256)), dim3(256), 0, st, a.Wt, a.K, a.Nc, a.Kd, wf);
-#define RS3_CASE(NTV, KQV)                                                                                              \
-  if (nt == NTV && kq == KQV) {                                                                                         \
-    hipLaunchKernelGGL((k_spconv_rs3<NTV, KQV, 4>), grid, dim3(256), 0, st, a, (uint32_t)xb, (uint32_t)wb);             \
-    return 0;                                                                                                           \
+#define RS3_CASE(NTV, KQV)                                                                                                       \
+  if (nt == NTV && kq == KQV) {                                                                                                  \
+    if (G == 4) hipLaunchKernelGGL((k_spconv_rs3<NTV, KQV, 4>), grid, dim3(256), 0, st, a, (uint32_t)xb, (uint32_t)wb);          \
+    else if (G == 3) hipLaunchKernelGGL((k_spconv_rs3<NTV, KQV, 3>), grid, dim3(256), 0, st, a, (uint32_t)xb, (uint32_t)wb);     \
+    else hipLaunchKernelGGL((k_spconv_rs3<NTV, KQV, 2>), grid, dim3(256), 0, st, a, (uint32_t)xb, (uint32_t)wb);                 \
+    return 0;                                                                                                                    \
   }
   RS3_CASE(4, 4) RS3_CASE(4, 2) RS3_CASE(2, 4) RS3_CASE(2, 2) RS3_CASE(2, 1) RS3_CASE(1, 2) RS3_CASE(1, 1)
 #undef RS3_CASE

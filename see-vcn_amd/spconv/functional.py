@@ -42,18 +42,19 @@ class Rulebook:
             self._nbr_in_subm = torch.flip(self.nbr_out, dims=[0]).contiguous()
         return self._nbr_in_subm
 
-    def tile_order(self, table):
-        """Work-balanced tile order of one of this rulebook's tables (sv_conv_tile_order), computed once and reused by every
-        gather-GEMM launch on that table."""
-        key = table.data_ptr()
+    def tile_order(self, table, kd, nc):
+        """Work-balanced tile order of one of this rulebook's tables (sv_conv_tile_order) for a (kd -> nc)-channel gather-GEMM,
+        computed once and reused by every launch with the same tiles-per-wave on that table."""
+        lib = _lib.load()
+        n_rows, K = table.shape[1], table.shape[0]
+        if n_rows == 0:
+            return None
+        g = lib.sv_conv_tiles_per_wave(n_rows, int(kd), int(nc))
+        key = (table.data_ptr(), g)
         if key not in self._orders:
-            lib = _lib.load()
-            n_rows, K = table.shape[1], table.shape[0]
-            if n_rows == 0:
-                return None
             order = torch.empty((lib.sv_conv_tile_order_bytes(n_rows) // 4,), dtype=torch.int32, device=table.device)
             scratch = _lib.workspace.scratch("tile_order", lib.sv_conv_tile_order_scratch_bytes(n_rows), table.device)
-            _lib.check(lib.sv_conv_tile_order(_lib.ptr(table), n_rows, K, _lib.ptr(scratch), _lib.ptr(order), _lib.stream()), "sv_conv_tile_order")
+            _lib.check(lib.sv_conv_tile_order(_lib.ptr(table), n_rows, K, g, _lib.ptr(scratch), _lib.ptr(order), _lib.stream()), "sv_conv_tile_order")
             self._orders[key] = (order, table)       # keep the table alive with its order
         return self._orders[key][0]
 
@@ -149,7 +150,7 @@ class SparseConvFunction(torch.autograd.Function):
         _lib.require_cuda(features, weight_kio)
         features = features.contiguous().float()
         wt = weight_kio.detach().permute(0, 2, 1).contiguous()  # (K, C_out, C_in)
-        out = gather_gemm(features, rulebook.nbr_out, wt, rulebook.n_out, tile_order=rulebook.tile_order(rulebook.nbr_out))
+        out = gather_gemm(features, rulebook.nbr_out, wt, rulebook.n_out, tile_order=rulebook.tile_order(rulebook.nbr_out, wt.shape[2], wt.shape[1]))
         ctx.rulebook = rulebook
         ctx.save_for_backward(features, weight_kio)
         return out
@@ -164,7 +165,7 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dX[i] = sum_k dY[nbr_in[k][i]] @ W[k]^T  -> Wt[k][n=c_in][c=c_out] = W[k][c_in][c_out]: weight_kio itself
             tb = rb.table_for_backward_data()
-            gf = gather_gemm(grad_out, tb, weight_kio.detach().contiguous(), rb.n_in, tile_order=rb.tile_order(tb))
+            gf = gather_gemm(grad_out, tb, weight_kio.detach().contiguous(), rb.n_in, tile_order=rb.tile_order(tb, cout, cin))
         if ctx.needs_input_grad[1]:
             gw = wgrad(features, rb.nbr_out, grad_out, K, cin, cout)
         return gf, gw, None

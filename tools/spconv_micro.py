@@ -79,11 +79,11 @@ def main():
             continue
         tf = td = tw = float("nan")
         if mode in ("all", "fwd"):
-            order = rb.tile_order(rb.nbr_out) if os.environ.get("ORDER", "1") == "1" else None
+            order = rb.tile_order(rb.nbr_out, cin, cout) if os.environ.get("ORDER", "1") == "1" else None
             tf = timeit(lambda: Fsp.gather_gemm(x, rb.nbr_out, wt, rb.n_out, tile_order=order))
         if mode in ("all", "bwd"):
             tb_ = rb.table_for_backward_data()
-            order_b = rb.tile_order(tb_) if os.environ.get("ORDER", "1") == "1" else None
+            order_b = rb.tile_order(tb_, cout, cin) if os.environ.get("ORDER", "1") == "1" else None
             td = timeit(lambda: Fsp.gather_gemm(dy, tb_, w, rb.n_in, tile_order=order_b))
         if mode in ("all", "wgrad"):
             tw = timeit(lambda: Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout))
