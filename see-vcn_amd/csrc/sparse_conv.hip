@@ -360,9 +360,13 @@ __global__ __launch_bounds__(256) void k_tile_deal(TileOrderArgs a) {
   }
 }
 
-// Tiles per wave.  All workgroups (4 waves) of a launch are resident at once, so the kernel lasts as long as the fullest CU:
-// 526 workgroups on 256 CUs put 3 on 14 of them and 2 on the rest, 1.46x the mean.  Pick G in {4, 3, 2} for the smallest
-// ceil(WGs / 256) / (WGs / 256); larger G (fewer weight loads per tile) wins ties and near-ties.
+// Tiles per wave.  A launch lasts as long as its fullest CU: 526 workgroups (4 waves each) on 256 CUs put 3 on 14 CUs and 2 on
+// the rest (1.46x the mean), and a launch with fewer workgroups than CUs leaves one wave per SIMD with nothing to hide its
+// operand latency behind.  Model: time ~ ceil(WGs / 256) * G / eff(waves per SIMD), eff = 0.45 / 0.75 / 0.9 for 1 / 2 / >= 3
+// resident workgroups per CU (measured shape of the curve on the bench layers), + 4 % per step of G below 4 for the extra
+// weight-slab loads.  Measured on the 64->64 layers: 8412 tiles G = 4 230 us, G = 3 183 us; 4012 tiles G = 4 130 us, G = 2 105 us.
+// (The same whole-rounds idea applied to the weight-gradient grid made it slower: its workgroups are unequal, dispatch order
+// already balances them.)
 static int conv_tiles_per_wave(int64_t n_rows) {
   const int64_t n_tiles = (n_rows + 15) / 16;
   int best = 4;
@@ -370,9 +374,9 @@ static int conv_tiles_per_wave(int64_t n_rows) {
   for (int g = 4; g >= 2; --g) {
     const int64_t wgs = ((n_tiles + g - 1) / g + 3) / 4;
     if (wgs <= 0) continue;
-    const double per_cu = (double)wgs / 256.0;
-    const double imbalance = wgs <= 256 ? 1.0 : (double)((wgs + 255) / 256) / per_cu;
-    const double score = imbalance * (1.0 + 0.04 * (4 - g));       // a smaller G re-reads the weight slab more often
+    const int64_t per_cu = (wgs + 255) / 256;
+    const double eff = per_cu >= 3 ? 0.9 : (per_cu == 2 ? 0.75 : 0.45);
+    const double score = (double)per_cu * g / eff * (1.0 + 0.04 * (4 - g));
     if (score < best_score - 1e-9) best_score = score, best = g;
   }
   return best;
