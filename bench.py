@@ -325,9 +325,10 @@ def main():
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1:]:
             with open(tf) as fh:
                 kernels = json.load(fh).get("kernels", {})
-            hit = [v for k, v in kernels.items() if name in k]
+            hit = [v for k, v in kernels.items() if name in k]          # the G = 2 / 3 / 4 instances of this channel shape
             if hit:
-                out["roofline"]["traffic"] = round(hit[0]["hbm_bytes_per_dispatch"])
+                n_disp = sum(v["dispatches"] for v in hit)
+                out["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in hit) / n_disp)
                 out["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
         out["roofline_vcn_gemm"] = vcn_roof
         if not args.no_cpu_baseline:

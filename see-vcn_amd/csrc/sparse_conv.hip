@@ -303,7 +303,7 @@ struct TileOrderArgs {
   int32_t* tile_of;     // out: [wave * G + slot] -> tile or -1
 };
 
-constexpr int TO_WGS = 128;
+constexpr int TO_WGS = 512;
 
 __global__ __launch_bounds__(256) void k_tile_cost(TileOrderArgs a) {
   __shared__ int s_hist[32];
@@ -314,10 +314,15 @@ __global__ __launch_bounds__(256) void k_tile_cost(TileOrderArgs a) {
   for (int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; w < n_groups; w += (int64_t)gridDim.x * 4) {
     const int64_t row = w * 64 + lane;
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    for (int k = 0; k < a.K; ++k) {
-      const int32_t j = row < a.n_rows ? a.nbr[(int64_t)k * a.n_rows + row] : -1;
-      const unsigned long long v = __ballot(j >= 0);
-      c0 += (v & 0xffffull) != 0, c1 += ((v >> 16) & 0xffffull) != 0, c2 += ((v >> 32) & 0xffffull) != 0, c3 += (v >> 48) != 0;
+    for (int k0 = 0; k0 < a.K; k0 += 9) {               // 9 independent loads in flight per lane (27 = 3 x 9)
+      int32_t j[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) j[u] = (row < a.n_rows && k0 + u < a.K) ? a.nbr[(int64_t)(k0 + u) * a.n_rows + row] : -1;
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const unsigned long long v = __ballot(j[u] >= 0);
+        c0 += (v & 0xffffull) != 0, c1 += ((v >> 16) & 0xffffull) != 0, c2 += ((v >> 32) & 0xffffull) != 0, c3 += (v >> 48) != 0;
+      }
     }
     if (lane < 4) {
       const int64_t t = w * 4 + lane;

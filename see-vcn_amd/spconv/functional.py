@@ -47,8 +47,8 @@ class Rulebook:
         computed once and reused by every launch with the same tiles-per-wave on that table."""
         lib = _lib.load()
         n_rows, K = table.shape[1], table.shape[0]
-        if n_rows == 0:
-            return None
+        if n_rows == 0 or (int(kd) // 16) * (int(nc) // 16) < 4 or kd % 16 or nc % 16:
+            return None              # load-bound small-channel layers: the order does not pay for its own launch
         g = lib.sv_conv_tiles_per_wave(n_rows, int(kd), int(nc))
         key = (table.data_ptr(), g)
         if key not in self._orders:

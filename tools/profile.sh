@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/profile.sh <tag> [steps]
+# rocprofv3 --kernel-trace --stats over the bench command (no PMC in this pass); leaves gpurun_out/<tag>_kernel_stats.csv
+TAG=$1
+STEPS=${2:-20}
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+cd $R
+rm -rf gpurun_out/prof_$TAG
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --steps $STEPS --warmup 5 --no-cpu-baseline > gpurun_out/prof_$TAG.log 2>&1
+F=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
+cp "$F" gpurun_out/${TAG}_kernel_stats.csv
+tail -1 gpurun_out/prof_$TAG.log | cut -c1-200
+python3 - <<PY
+import csv
+rows = list(csv.DictReader(open("gpurun_out/${TAG}_kernel_stats.csv")))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+steps = $STEPS + 5
+print("GPU busy ms/step (incl. warmup steps): %.3f" % (tot / steps / 1e6))
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:28]:
+    print("%-78s %7.1f calls/step %8.1f us -> %.3f ms/step" % (r["Name"][:78], int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / steps / 1e6))
+PY
+rm -rf gpurun_out/prof_$TAG
