@@ -335,6 +335,36 @@ int sv_vcn_largest_cluster(const float* points, int batch, int n, double eps, in
 int sv_points_near_set(const float* query, int64_t n_query, const float* ref, int64_t n_ref, int row_dim, double thresh,
                        uint8_t* near, void* stream);
 
+/* ---- point isolation: the CPU step in front of VCN --------------------------------------------------
+ * isolate_gt_pts (see/surface_completion/SEE_VCN.py:61-82): open3d `pcd.crop(OrientedBoundingBox)` for every box of a scene.
+ * boxes (G,15) float64 host-or-device rows [centre(3), R row-major(9), extent(3)] (device pointer); a point is inside iff
+ * |(p - c) . R[:,a]| <= extent[a]/2 for a = 0,1,2 (float64, like open3d's GetPointIndicesWithinBoundingBox).
+ * out_index (G,cap): ascending point indices of box g (first cap of them); out_count (G): their number (may exceed cap). */
+int sv_crop_points_in_boxes(const float* points, int64_t n_points, int row_stride, const double* boxes, int n_boxes, int64_t cap,
+                            int32_t* out_index, int32_t* out_count, void* stream);
+/* KittiObjects.map_pointcloud_to_image (datasets/kitti/kitti_objects.py:153-176) with Calibration.project_velo_to_imageuv /
+ * project_velo_to_rect (datasets/kitti/kitti_utils.py:69-114), float64.  v2c (3x4), r0 (3x3), p (3x4): HOST pointers, row-major.
+ * fov[i] = 0 <= u < img_w and 0 <= v < img_h and x > min_dist; uv (n,2) = floor(u,v) (-1 outside the FOV); rect (n,3) optional. */
+int sv_project_lidar_to_image_kitti(const float* points, int64_t n_points, int row_stride, const double* v2c, const double* r0,
+                                    const double* p, int img_w, int img_h, double min_dist, int32_t* uv, uint8_t* fov, float* rect,
+                                    void* stream);
+/* get_pts_in_mask (datasets/shared_utils.py:36-106): per instance the FOV points with mask[v,u] set.  Give either masks
+ * (I,img_h,img_w) uint8 or rects (I,4) int32 [x0,y0,x1,y1] (use_bbox, :56-60).  Lists as in sv_crop_points_in_boxes. */
+int sv_points_in_masks(const int32_t* uv, const uint8_t* fov, int64_t n_points, const uint8_t* masks, const int32_t* rects,
+                       int n_instances, int img_w, int img_h, int64_t cap, int32_t* out_index, int32_t* out_count, void* stream);
+/* isolate_det_pts (SEE_VCN.py:144-181) and db_scan(..., return_largest_cluster=True) (shared_utils.py:395-409), one workgroup
+ * per instance: eps = clip(eps_scaling * (|mean(xyz)| * tan_vres), min_eps, max_eps) unless fixed_eps >= 0; open3d
+ * cluster_dbscan(eps, min_points) incl. border points; first largest cluster.  Instance g = counts[g] points: rows
+ * point_index[starts[g]+r] of `points` (or rows starts[g]+r when point_index is null).  out_local[starts[g]+r] = position within
+ * the instance of the r-th member (ascending), out_count[g] = members (0: instance has <= min_cluster points or is all noise;
+ * -1: counts[g] > max_points), out_eps[g] = eps used.  Instances above 4096 points need
+ * sv_isolate_cluster_scratch_bytes(n_instances, max_points) bytes of scratch. */
+int64_t sv_isolate_cluster_scratch_bytes(int n_instances, int64_t max_points);
+int sv_isolate_largest_cluster(const float* points, int row_stride, const int32_t* point_index, const int64_t* starts,
+                               const int32_t* counts, int n_instances, int64_t max_points, double tan_vres, double eps_scaling,
+                               double min_eps, double max_eps, double fixed_eps, int min_points, int min_cluster, void* scratch,
+                               int32_t* out_local, int32_t* out_count, double* out_eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,11 @@ SIGNATURES = {
     "sv_vcn_surface_select": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_vcn_largest_cluster": (c_i, [c_p, c_i, c_i, c_d, c_i, c_i, c_p, c_p, c_p]),
     "sv_points_near_set": (c_i, [c_p, c_i64, c_p, c_i64, c_i, c_d, c_p, c_p]),
+    "sv_crop_points_in_boxes": (c_i, [c_p, c_i64, c_i, c_p, c_i, c_i64, c_p, c_p, c_p]),
+    "sv_project_lidar_to_image_kitti": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p]),
+    "sv_points_in_masks": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i, c_i, c_i, c_i64, c_p, c_p, c_p]),
+    "sv_isolate_cluster_scratch_bytes": (c_i64, [c_i, c_i64]),
+    "sv_isolate_largest_cluster": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i64, c_d, c_d, c_d, c_d, c_d, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_gemm_bias_act_ragged": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "sv_unique_rows": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "sv_ball_query_batch": (c_i, [c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p]),

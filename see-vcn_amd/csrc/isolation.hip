@@ -1,0 +1,344 @@
+// Point isolation on the GPU: the step in front of VCN.  The reference does all of it on the CPU
+// with numpy / open3d (see/surface_completion/SEE_VCN.py:61-82,144-181, datasets/shared_utils.py:36-106,
+// datasets/kitti/kitti_objects.py:153-176, datasets/kitti/kitti_utils.py:58-114):
+//   k_crop_boxes       : open3d PointCloud.crop(OrientedBoundingBox) for every ground-truth box of a scene (isolate_gt_pts)
+//   k_project_kitti    : lidar -> reference camera -> rectified -> image plane, image-FOV test (map_pointcloud_to_image)
+//   k_mask_select      : mask[v,u] lookup per instance (get_pts_in_mask)
+//   k_isolate_cluster  : per instance range-adaptive DBSCAN (min_points >= 1, border points included), largest cluster
+// Index lists come out in ascending point order (numpy boolean indexing / np.argwhere order); all geometry in float64 like
+// numpy / Eigen.  One workgroup per box / instance.
+#include "common.h"
+
+#define ISO_THREADS 1024
+#define ISO_WAVES (ISO_THREADS / SV_WAVE)
+#define ISO_LDS_N 4096    // instances up to this many points are clustered entirely in LDS, larger ones in caller scratch
+
+// Ascending list of the i in [0,n) with pred(i): out[r] = r-th such i (written while r < cap); returns their number.
+// Whole workgroup must call; uses 17 ints of LDS.
+template <class Pred>
+__device__ __forceinline__ int iso_ordered_select(int64_t n, Pred pred, int32_t* out, int64_t cap) {
+  __shared__ int s_wcnt[ISO_WAVES];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __syncthreads();
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int64_t start = 0; start < n; start += ISO_THREADS) {
+    const int64_t i = start + tid;
+    const bool p = i < n && pred(i);
+    const unsigned long long vote = __ballot(p);
+    if (lane == 0) s_wcnt[wave] = __popcll(vote);
+    __syncthreads();
+    int pos = s_base + __popcll(vote & ((1ull << lane) - 1));
+    for (int w = 0; w < wave; ++w) pos += s_wcnt[w];
+    if (p && pos < cap) out[pos] = (int32_t)i;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < ISO_WAVES; ++w) t += s_wcnt[w];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  return s_base;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// open3d OrientedBoundingBox::GetPointIndicesWithinBoundingBox: d = p - center; inside iff |d . R[:,a]| <= extent[a]/2 for
+// the three box axes a (float64).  box row = [cx,cy,cz, R row-major (9), ex,ey,ez].
+__global__ __launch_bounds__(ISO_THREADS) void k_crop_boxes(const float* __restrict__ points, int64_t n, int row_stride,
+                                                            const double* __restrict__ boxes, int64_t cap,
+                                                            int32_t* __restrict__ out_index, int32_t* __restrict__ out_count) {
+  const int g = blockIdx.x;
+  const double* B = boxes + (size_t)g * 15;
+  const double cx = B[0], cy = B[1], cz = B[2];
+  const double ax0 = B[3], ax1 = B[6], ax2 = B[9];      // R (1,0,0)
+  const double ay0 = B[4], ay1 = B[7], ay2 = B[10];     // R (0,1,0)
+  const double az0 = B[5], az1 = B[8], az2 = B[11];     // R (0,0,1)
+  const double hx = B[12] / 2, hy = B[13] / 2, hz = B[14] / 2;
+  const int total = iso_ordered_select(
+      n,
+      [&](int64_t i) {
+        const float* p = points + i * row_stride;
+        const double d0 = (double)p[0] - cx, d1 = (double)p[1] - cy, d2 = (double)p[2] - cz;
+        return fabs(d0 * ax0 + d1 * ax1 + d2 * ax2) <= hx && fabs(d0 * ay0 + d1 * ay1 + d2 * ay2) <= hy &&
+               fabs(d0 * az0 + d1 * az1 + d2 * az2) <= hz;
+      },
+      out_index + (size_t)g * cap, cap);
+  if (threadIdx.x == 0) out_count[g] = total;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// KITTI projection chain (kitti_utils.py:69-114) and FOV test (kitti_objects.py:160-173), float64:
+//   ref = [x y z 1] . V2C^T ; rect = R0 . ref ; img = [rect 1] . P^T ; (u,v) = img[:2] / img[2]
+//   fov = 0 <= u < W and 0 <= v < H and x > min_dist ; pts_img = floor(u,v)
+struct ProjectArgs {
+  const float* points;
+  int64_t n;
+  int row_stride;
+  double v2c[12], r0[9], p[12];
+  int img_w, img_h;
+  double min_dist;
+  int32_t* uv;        // (n,2), written for every point (undefined outside the FOV)
+  uint8_t* fov;       // (n)
+  float* rect;        // (n,3) or null: project_velo_to_rect of every point
+};
+
+__global__ __launch_bounds__(256) void k_project_kitti(ProjectArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const float* q = a.points + i * a.row_stride;
+  const double x = q[0], y = q[1], z = q[2];
+  double ref[3], rc[3], im[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ref[c] = x * a.v2c[c * 4] + y * a.v2c[c * 4 + 1] + z * a.v2c[c * 4 + 2] + a.v2c[c * 4 + 3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rc[c] = a.r0[c * 3] * ref[0] + a.r0[c * 3 + 1] * ref[1] + a.r0[c * 3 + 2] * ref[2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) im[c] = rc[0] * a.p[c * 4] + rc[1] * a.p[c * 4 + 1] + rc[2] * a.p[c * 4 + 2] + a.p[c * 4 + 3];
+  const double u = im[0] / im[2], v = im[1] / im[2];
+  const bool in = u < (double)a.img_w && u >= 0.0 && v < (double)a.img_h && v >= 0.0 && x > a.min_dist;
+  a.fov[i] = in ? 1 : 0;
+  a.uv[i * 2] = in ? (int32_t)floor(u) : -1;
+  a.uv[i * 2 + 1] = in ? (int32_t)floor(v) : -1;
+  if (a.rect) a.rect[i * 3] = (float)rc[0], a.rect[i * 3 + 1] = (float)rc[1], a.rect[i * 3 + 2] = (float)rc[2];
+}
+
+// get_pts_in_mask (shared_utils.py:36-106): for instance g, the FOV points whose pixel is set in mask g (masks (I,H,W) uint8)
+// or, with rects (I,4) = [x0,y0,x1,y1] already truncated to int, inside the box (use_bbox, :56-60).
+__global__ __launch_bounds__(ISO_THREADS) void k_mask_select(const int32_t* __restrict__ uv, const uint8_t* __restrict__ fov, int64_t n,
+                                                             const uint8_t* __restrict__ masks, const int32_t* __restrict__ rects,
+                                                             int img_w, int img_h, int64_t cap, int32_t* __restrict__ out_index,
+                                                             int32_t* __restrict__ out_count) {
+  const int g = blockIdx.x;
+  const uint8_t* M = masks ? masks + (size_t)g * img_w * img_h : nullptr;
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  if (rects) x0 = rects[g * 4], y0 = rects[g * 4 + 1], x1 = rects[g * 4 + 2], y1 = rects[g * 4 + 3];
+  const int total = iso_ordered_select(
+      n,
+      [&](int64_t i) {
+        if (!fov[i]) return false;
+        const int u = uv[i * 2], v = uv[i * 2 + 1];
+        if (M) return M[(size_t)v * img_w + u] != 0;
+        return v >= y0 && v < y1 && u >= x0 && u < x1;
+      },
+      out_index + (size_t)g * cap, cap);
+  if (threadIdx.x == 0) out_count[g] = total;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// isolate_det_pts (SEE_VCN.py:144-181) / db_scan(..., return_largest_cluster) (shared_utils.py:395-409) for one instance:
+//   eps = clip(eps_scaling * (|mean(xyz)| * tan(vres)), min_eps, max_eps)      (or a fixed eps)
+//   labels = open3d cluster_dbscan(eps, min_points); members of the first largest cluster, ascending.
+// open3d's sequential DBSCAN reduces to: core = at least min_points points with d^2 < eps^2 (itself included); clusters =
+// connected components of the cores, numbered by their smallest core index; a non-core point within eps of a core takes the
+// smallest cluster number among those cores (the first cluster that reaches it); the rest is noise.
+struct IsoArgs {
+  const float* points;
+  int row_stride;
+  const int32_t* point_index;   // rows of `points`, or null: the instance's points are rows starts[g] .. starts[g]+counts[g]-1
+  const int64_t* starts;        // (I) first slot of instance g in point_index / out_local
+  const int32_t* counts;        // (I)
+  int32_t* out_local;           // slot starts[g]+r <- position (within the instance) of the r-th member of the selected cluster
+  int32_t* out_count;           // (I)
+  double* out_eps;              // (I)
+  int32_t* scratch;             // I * scratch_stride ints, used by instances with more than ISO_LDS_N points
+  int64_t scratch_stride;
+  double tan_vres, eps_scaling, min_eps, max_eps, fixed_eps;
+  int min_points, min_cluster;
+  int64_t max_points;
+};
+
+__device__ __forceinline__ int iso_find(volatile int* parent, int x) {
+  int p = parent[x];
+  while (p != x) {
+    const int g = parent[p];
+    if (g != p) parent[x] = g;       // path halving (parents only ever decrease)
+    x = p, p = g;
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(ISO_THREADS) void k_isolate_cluster(IsoArgs a) {
+  __shared__ float s_xyz[ISO_LDS_N * 3];
+  __shared__ int s_parent[ISO_LDS_N], s_aux[ISO_LDS_N], s_lab[ISO_LDS_N];
+  __shared__ double s_eps2;
+  __shared__ unsigned long long s_best;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int n = a.counts[g];
+  const int64_t start = a.starts[g];
+  if (n <= a.min_cluster || n <= 0) {          // `if xyz.shape[0] > min_cluster` (SEE_VCN.py:158)
+    if (tid == 0) a.out_count[g] = 0, a.out_eps[g] = 0.0;
+    return;
+  }
+  if (n > a.max_points) {                      // caller's bound violated: report, touch nothing
+    if (tid == 0) a.out_count[g] = -1, a.out_eps[g] = 0.0;
+    return;
+  }
+  float* xyz = s_xyz;
+  int *parent = s_parent, *aux = s_aux, *lab = s_lab;
+  if (n > ISO_LDS_N) {
+    int32_t* sc = a.scratch + (size_t)g * a.scratch_stride;
+    xyz = reinterpret_cast<float*>(sc), parent = sc + (size_t)3 * n, aux = sc + (size_t)4 * n, lab = sc + (size_t)5 * n;
+  }
+  for (int i = tid; i < n; i += ISO_THREADS) {
+    const int64_t row = a.point_index ? (int64_t)a.point_index[start + i] : start + i;
+    const float* p = a.points + row * a.row_stride;
+    xyz[i * 3] = p[0], xyz[i * 3 + 1] = p[1], xyz[i * 3 + 2] = p[2];
+    parent[i] = i;
+  }
+  if (tid == 0) s_best = 0ull;
+  __syncthreads();
+  if (tid == 0) {
+    double eps = a.fixed_eps;
+    if (!(eps >= 0.0)) {
+      double sx = 0.0, sy = 0.0, sz = 0.0;     // open3d get_center(): sequential float64 accumulate, then / n
+      for (int i = 0; i < n; ++i) sx += (double)xyz[i * 3], sy += (double)xyz[i * 3 + 1], sz += (double)xyz[i * 3 + 2];
+      const double cx = sx / n, cy = sy / n, cz = sz / n;
+      const double dist = sqrt(cx * cx + cy * cy + cz * cz);
+      const double ring_height = dist * a.tan_vres;
+      eps = a.eps_scaling * ring_height;
+      eps = eps < a.min_eps ? a.min_eps : (eps > a.max_eps ? a.max_eps : eps);   // np.clip
+    }
+    a.out_eps[g] = eps;
+    s_eps2 = eps * eps;
+  }
+  __syncthreads();
+  const double eps2 = s_eps2;
+
+  // neighbour counts (the point itself included) -> core flags
+  for (int i = tid; i < n; i += ISO_THREADS) {
+    const double x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+    int c = 0;
+#pragma unroll 4
+    for (int j = 0; j < n; ++j) {
+      const double dx = (double)xyz[j * 3] - x, dy = (double)xyz[j * 3 + 1] - y, dz = (double)xyz[j * 3 + 2] - z;
+      c += (dx * dx + dy * dy + dz * dz < eps2) ? 1 : 0;
+    }
+    aux[i] = c;
+  }
+  __syncthreads();
+  // union the cores that are within eps of each other; roots are the smallest index of a component
+  for (int i = tid; i < n; i += ISO_THREADS) {
+    if (aux[i] < a.min_points) continue;
+    const double x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+    int my_parent = i;
+    for (int j = i + 1; j < n; ++j) {
+      const double dx = (double)xyz[j * 3] - x, dy = (double)xyz[j * 3 + 1] - y, dz = (double)xyz[j * 3 + 2] - z;
+      if (dx * dx + dy * dy + dz * dz < eps2 && aux[j] >= a.min_points && parent[j] != my_parent) {
+        int ra = i, rb = j;
+        while (true) {
+          ra = iso_find(parent, ra), rb = iso_find(parent, rb);
+          if (ra == rb) break;
+          if (ra > rb) { const int t = ra; ra = rb; rb = t; }
+          if (atomicCAS(&parent[rb], rb, ra) == rb) break;
+        }
+        my_parent = iso_find(parent, i);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += ISO_THREADS) {
+    int l = -1;
+    if (aux[i] >= a.min_points) {
+      l = iso_find(parent, i);
+    } else if (aux[i] >= 2) {                 // border candidate: the smallest cluster among the cores within eps
+      const double x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+      int best = 0x7fffffff;
+      for (int j = 0; j < n; ++j) {
+        if (aux[j] < a.min_points) continue;
+        const double dx = (double)xyz[j * 3] - x, dy = (double)xyz[j * 3 + 1] - y, dz = (double)xyz[j * 3 + 2] - z;
+        if (dx * dx + dy * dy + dz * dz < eps2) {
+          const int r = iso_find(parent, j);
+          best = r < best ? r : best;
+        }
+      }
+      l = best == 0x7fffffff ? -1 : best;
+    }
+    lab[i] = l;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += ISO_THREADS) aux[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += ISO_THREADS)
+    if (lab[i] >= 0) atomicAdd(&aux[lab[i]], 1);
+  __syncthreads();
+  for (int i = tid; i < n; i += ISO_THREADS)
+    if (aux[i] > 0) atomicMax(&s_best, ((unsigned long long)aux[i] << 32) | (unsigned)(0x7fffffff - i));   // ties: first label
+  __syncthreads();
+  const unsigned long long best = s_best;
+  if (best == 0ull) {                          // every point is noise (`if len(y) > 0`, SEE_VCN.py:173)
+    if (tid == 0) a.out_count[g] = 0;
+    return;
+  }
+  const int best_root = 0x7fffffff - (int)(best & 0xffffffffu);
+  const int total = iso_ordered_select(n, [&](int64_t i) { return lab[i] == best_root; }, a.out_local + start, n);
+  if (tid == 0) a.out_count[g] = total;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int sv_crop_points_in_boxes(const float* points, int64_t n_points, int row_stride, const double* boxes, int n_boxes,
+                                       int64_t cap, int32_t* out_index, int32_t* out_count, void* stream) {
+  SV_CHECK_ARG(n_points >= 0 && n_boxes >= 0 && cap >= 0 && row_stride >= 3, "sv_crop_points_in_boxes: bad sizes");
+  if (n_boxes == 0) return SV_OK;
+  SV_CHECK_ARG((points || n_points == 0) && boxes && out_count && (out_index || cap == 0), "sv_crop_points_in_boxes: null pointer");
+  hipLaunchKernelGGL(k_crop_boxes, dim3(n_boxes), dim3(ISO_THREADS), 0, sv_stream(stream), points, n_points, row_stride, boxes, cap,
+                     out_index, out_count);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_project_lidar_to_image_kitti(const float* points, int64_t n_points, int row_stride, const double* v2c, const double* r0,
+                                               const double* p, int img_w, int img_h, double min_dist, int32_t* uv, uint8_t* fov,
+                                               float* rect, void* stream) {
+  SV_CHECK_ARG(n_points >= 0 && row_stride >= 3 && img_w > 0 && img_h > 0, "sv_project_lidar_to_image_kitti: bad sizes");
+  if (n_points == 0) return SV_OK;
+  SV_CHECK_ARG(points && v2c && r0 && p && uv && fov, "sv_project_lidar_to_image_kitti: null pointer");
+  ProjectArgs a;
+  a.points = points, a.n = n_points, a.row_stride = row_stride;
+  for (int i = 0; i < 12; ++i) a.v2c[i] = v2c[i], a.p[i] = p[i];      // host pointers: 33 doubles of calibration
+  for (int i = 0; i < 9; ++i) a.r0[i] = r0[i];
+  a.img_w = img_w, a.img_h = img_h, a.min_dist = min_dist, a.uv = uv, a.fov = fov, a.rect = rect;
+  hipLaunchKernelGGL(k_project_kitti, dim3(sv_div_up(n_points, 256)), dim3(256), 0, sv_stream(stream), a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_points_in_masks(const int32_t* uv, const uint8_t* fov, int64_t n_points, const uint8_t* masks, const int32_t* rects,
+                                  int n_instances, int img_w, int img_h, int64_t cap, int32_t* out_index, int32_t* out_count,
+                                  void* stream) {
+  SV_CHECK_ARG(n_points >= 0 && n_instances >= 0 && cap >= 0 && img_w > 0 && img_h > 0, "sv_points_in_masks: bad sizes");
+  SV_CHECK_ARG((masks != nullptr) != (rects != nullptr) || n_instances == 0, "sv_points_in_masks: give masks or rects, not both");
+  if (n_instances == 0) return SV_OK;
+  SV_CHECK_ARG((uv && fov) || n_points == 0, "sv_points_in_masks: null pointer");
+  SV_CHECK_ARG(out_count && (out_index || cap == 0), "sv_points_in_masks: null output");
+  hipLaunchKernelGGL(k_mask_select, dim3(n_instances), dim3(ISO_THREADS), 0, sv_stream(stream), uv, fov, n_points, masks, rects, img_w,
+                     img_h, cap, out_index, out_count);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int64_t sv_isolate_cluster_scratch_bytes(int n_instances, int64_t max_points) {
+  if (max_points <= ISO_LDS_N) return 0;
+  return (int64_t)n_instances * 6 * max_points * 4;
+}
+
+extern "C" int sv_isolate_largest_cluster(const float* points, int row_stride, const int32_t* point_index, const int64_t* starts,
+                                          const int32_t* counts, int n_instances, int64_t max_points, double tan_vres,
+                                          double eps_scaling, double min_eps, double max_eps, double fixed_eps, int min_points,
+                                          int min_cluster, void* scratch, int32_t* out_local, int32_t* out_count, double* out_eps,
+                                          void* stream) {
+  SV_CHECK_ARG(n_instances >= 0 && row_stride >= 3 && min_points >= 1 && max_points >= 0, "sv_isolate_largest_cluster: bad sizes");
+  if (n_instances == 0) return SV_OK;
+  SV_CHECK_ARG(points && starts && counts && out_local && out_count && out_eps, "sv_isolate_largest_cluster: null pointer");
+  SV_CHECK_ARG(max_points <= ISO_LDS_N || scratch, "sv_isolate_largest_cluster: instances above %d points need scratch", ISO_LDS_N);
+  IsoArgs a;
+  a.points = points, a.row_stride = row_stride, a.point_index = point_index, a.starts = starts, a.counts = counts;
+  a.out_local = out_local, a.out_count = out_count, a.out_eps = out_eps;
+  a.scratch = static_cast<int32_t*>(scratch), a.scratch_stride = 6 * max_points;
+  a.tan_vres = tan_vres, a.eps_scaling = eps_scaling, a.min_eps = min_eps, a.max_eps = max_eps, a.fixed_eps = fixed_eps;
+  a.min_points = min_points, a.min_cluster = min_cluster, a.max_points = max_points;
+  hipLaunchKernelGGL(k_isolate_cluster, dim3(n_instances), dim3(ISO_THREADS), 0, sv_stream(stream), a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -1,0 +1,202 @@
+"""Point isolation: image projection + FOV, mask lookup, range-adaptive DBSCAN, oriented-box crops, multi-camera
+merge.  Pinned to the reference's own code through tests/golden/isolation.npz (make_isolation_golden.py); the open3d calls inside
+are parity-unpinned (served by the oracle when the fixture was made) and cross-checked here against sklearn / scipy."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from isolation_inputs import CLASSES, IMG_SHAPE, MIN_LIDAR_PTS, PC_ISOLATION, make_inputs, multi_camera_instances
+from oracle import isolation as oiso
+from oracle.postprocess import dbscan_labels
+
+
+def _split(g, prefix):
+    rows, counts = g[prefix + "_rows"], g[prefix + "_counts"]
+    return np.split(rows, np.cumsum(counts)[:-1]) if len(counts) else []
+
+
+@pytest.fixture(scope="module")
+def inputs():
+    return make_inputs()
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "isolation.npz"))
+
+
+def _oracle_imgfov(inp):
+    c = inp['calib']
+    fov, pts_img, rect = oiso.project_velo_to_image_kitti(inp['points'], c['Tr_velo2cam'], c['R0'], c['P2'], IMG_SHAPE[0], IMG_SHAPE[1], 1.0)
+    return fov, pts_img, rect
+
+
+def test_oracle_projection_matches_reference_golden(inputs, golden):
+    fov, pts_img, rect = _oracle_imgfov(inputs)
+    assert np.array_equal(fov, golden["fov_inds"]) and 0 < fov.sum() < len(fov)
+    assert np.array_equal(pts_img, golden["pts_img"])                       # floor(u,v): bit-exact pixels
+    np.testing.assert_allclose(rect, golden["pc_cam"], rtol=0, atol=1e-12)  # BLAS summation order
+
+
+def test_oracle_mask_lookup_matches_reference_golden(inputs, golden):
+    fov, pts_img, _ = _oracle_imgfov(inputs)
+    lidar = inputs['points'][fov]
+    kept = [i for i in inputs['instances'] if i['segmentation']]
+    for mode in ("mask", "bbox"):
+        if mode == "mask":
+            lists = oiso.pts_in_masks(pts_img, masks=[i['bin_mask'] for i in kept])
+        else:
+            rects = []
+            for i in kept:
+                b = np.array(i['bbox'])
+                b[2:4] = b[0:2] + b[2:4]
+                rects.append([max(int(b[0]), 0), max(int(b[1]), 0), min(int(b[2]), IMG_SHAPE[1]), min(int(b[3]), IMG_SHAPE[0])])
+            lists = oiso.pts_in_masks(pts_img, rects=rects)
+        got = [(lidar[l], pts_img[l], i['box_id']) for l, i in zip(lists, kept) if len(l)]
+        want_l, want_uv = _split(golden, f"inmask_{mode}_lidar"), _split(golden, f"inmask_{mode}_uv")
+        assert [g[2] for g in got] == list(golden[f"inmask_{mode}_box_id"]) and len(got) >= 5
+        for (l, uv, _), wl, wuv in zip(got, want_l, want_uv):
+            assert np.array_equal(l, wl) and np.array_equal(uv, wuv)
+
+
+def test_oracle_isolate_det_and_gt_match_reference_golden(inputs, golden):
+    clouds = _split(golden, "inmask_mask_lidar")
+    got = oiso.isolate_det_pts(clouds, PC_ISOLATION['VRES'], PC_ISOLATION['EPS_SCALING'], PC_ISOLATION['MIN_EPS'], PC_ISOLATION['MAX_EPS'], 10)
+    want = _split(golden, "det_instances")
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert sum(len(w) for w in want) < sum(len(c) for c in clouds)          # the clustering removed background points
+    boxes = [b for b, n in zip(inputs['sample_infos']['annos']['gt_boxes_lidar'], inputs['sample_infos']['annos']['name']) if n in CLASSES]
+    crops, labels = oiso.isolate_gt_pts(inputs['points'], boxes, MIN_LIDAR_PTS)
+    want = _split(golden, "gt_crops")
+    assert len(crops) == len(want) >= 3 and all(np.array_equal(a, b) for a, b in zip(crops, want))
+    assert np.array_equal(np.stack(labels), golden["gt_labels"])
+    merged = oiso.merge_multi_camera_detections(multi_camera_instances())
+    want = _split(golden, "merged")
+    assert len(merged) == len(want) == 4 and all(np.array_equal(a, b) for a, b in zip(merged, want))
+
+
+def _cluster_case(rng, n, spread=0.25):
+    centres = rng.uniform(-6, 6, (5, 3))
+    sizes = rng.multinomial(n - n // 10, [0.45, 0.25, 0.15, 0.1, 0.05])
+    pts = [rng.normal(0, spread, (s, 3)) + c for s, c in zip(sizes, centres)]
+    pts.append(rng.uniform(-8, 8, (n - sum(sizes), 3)))
+    return rng.permutation(np.vstack(pts)).astype(np.float32)
+
+
+def test_oracle_dbscan_min_points_3_vs_sklearn():
+    from sklearn.cluster import DBSCAN
+    rng = np.random.default_rng(3)
+    for n, eps, mp in [(300, 0.3, 3), (700, 0.22, 5), (150, 0.5, 3)]:
+        x = _cluster_case(rng, n)
+        mine = dbscan_labels(x, eps, mp)
+        sk = DBSCAN(eps=eps, min_samples=mp).fit(x.astype(np.float64))
+        core = np.zeros(n, bool)
+        core[sk.core_sample_indices_] = True
+        assert np.array_equal(mine >= 0, sk.labels_ >= 0)
+        # same partition of the core points (labels are numbered differently; border ties may go to different clusters)
+        pairs = set(zip(mine[core].tolist(), sk.labels_[core].tolist()))
+        assert len(pairs) == len(set(mine[core].tolist())) == len(set(sk.labels_[core].tolist()))
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_projection_and_masks_bitexact_vs_reference_golden(inputs, golden, cuda, hip_lib):
+    from seevcn_amd.vcn import isolation as I
+    calib = I.Calibration(inputs['calib'])
+    imgfov = I.map_pointcloud_to_image(inputs['points'], calib, IMG_SHAPE, min_dist=1.0)
+    assert np.array_equal(imgfov["fov_inds"], golden["fov_inds"])
+    assert np.array_equal(imgfov["pts_img"], golden["pts_img"])
+    assert np.array_equal(imgfov["pc_lidar"], inputs['points'][golden["fov_inds"]])
+    np.testing.assert_allclose(imgfov["pc_cam"], golden["pc_cam"], rtol=1e-6, atol=1e-5)     # float32 storage of the rectified coordinates
+    for mode, use_bbox in (("mask", False), ("bbox", True)):
+        proj = I.get_pts_in_mask(None, inputs['instances'], imgfov, shrink_percentage=0, use_bbox=use_bbox)
+        want_l, want_uv = _split(golden, f"inmask_{mode}_lidar"), _split(golden, f"inmask_{mode}_uv")
+        assert [l['box_id'] for l in proj["img_labels"]] == list(golden[f"inmask_{mode}_box_id"])
+        assert len(proj["lidar_xyz"]) == len(want_l) == len(proj["cam_xyz"])
+        for l, uv, wl, wuv in zip(proj["lidar_xyz"], proj["img_uv"], want_l, want_uv):
+            assert np.array_equal(l, wl) and np.array_equal(uv, wuv)
+
+
+@pytest.mark.gpu
+def test_hip_isolate_det_gt_merge_bitexact_vs_reference_golden(inputs, golden, cuda, hip_lib):
+    from seevcn_amd.vcn import isolation as I
+    proj = {"lidar_xyz": _split(golden, "inmask_mask_lidar"), "img_uv": _split(golden, "inmask_mask_uv")}
+    got = I.isolate_det_pts([proj], PC_ISOLATION['VRES'], PC_ISOLATION['EPS_SCALING'], PC_ISOLATION['MIN_EPS'], PC_ISOLATION['MAX_EPS'], min_cluster=10)
+    want = _split(golden, "det_instances")
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    pcd_gtboxes = I.populate_gtboxes(inputs['sample_infos'], 'kitti', CLASSES, add_ground_lift=True, ground_lift_height=0.1)
+    pcd_gtboxes['pcd'] = inputs['points']
+    crops, labels = I.isolate_gt_pts(pcd_gtboxes, MIN_LIDAR_PTS)
+    want = _split(golden, "gt_crops")
+    assert len(crops) == len(want) and all(a.dtype == np.float64 and np.array_equal(a, b) for a, b in zip(crops, want))
+    assert np.array_equal(np.stack(labels), golden["gt_labels"])
+    merged = I.merge_multi_camera_detections(multi_camera_instances())
+    want = _split(golden, "merged")
+    assert len(merged) == len(want) and all(np.array_equal(a, b) for a, b in zip(merged, want))
+
+
+@pytest.mark.gpu
+def test_hip_largest_cluster_vs_oracle_edge_cases(cuda, hip_lib):
+    """Instances of every size class in ONE launch: <= min_cluster points, all noise, LDS path, > 4096 points (scratch path),
+    min_points 1..5, fixed and range-adaptive eps; indices bit-exact against the oracle."""
+    from seevcn_amd.vcn import isolation as I
+    rng = np.random.default_rng(11)
+    clouds = [_cluster_case(rng, n) + np.float32(off) for n, off in [(400, 10), (1500, 25), (9, 5), (64, 40), (4500, 15), (4096, 30)]]
+    clouds.append((np.arange(60, dtype=np.float32).reshape(20, 3) * 7 + 3))                  # all noise
+    counts = np.array([len(c) for c in clouds], np.int32)
+    starts = np.concatenate([[0], np.cumsum(counts[:-1])]).astype(np.int64)
+    pts = torch.from_numpy(np.vstack(clouds)).to(cuda)
+    for mp, fixed in [(3, None), (1, 0.2), (2, 0.3), (5, 0.35)]:
+        kw = dict(fixed_eps=fixed) if fixed is not None else dict(vres=0.4, eps_scaling=4, min_eps=0.0, max_eps=1.0)
+        out_local, out_count, out_eps = I.largest_clusters_device(pts, torch.from_numpy(starts).to(cuda), torch.from_numpy(counts).to(cuda),
+                                                                  int(counts.max()), min_points=mp, min_cluster=10, **kw)
+        out_local, out_count, out_eps = out_local.cpu().numpy(), out_count.cpu().numpy(), out_eps.cpu().numpy()
+        for g, c in enumerate(clouds):
+            if len(c) <= 10:
+                assert out_count[g] == 0
+                continue
+            eps = fixed if fixed is not None else oiso.instance_eps(c, 0.4, 4, 0.0, 1.0)
+            assert out_eps[g] == eps
+            idx = oiso.largest_cluster_indices(c, eps, mp)
+            if idx is None:
+                assert out_count[g] == 0
+            else:
+                assert out_count[g] == len(idx) and np.array_equal(out_local[starts[g]:starts[g] + len(idx)], idx), (g, mp)
+    # point_index indirection + the caller's bound
+    perm = rng.permutation(len(pts)).astype(np.int32)
+    inv = np.argsort(perm).astype(np.int32)
+    out_local2, out_count2, _ = I.largest_clusters_device(pts[torch.from_numpy(perm).to(cuda)].contiguous(), torch.from_numpy(starts).to(cuda),
+                                                          torch.from_numpy(counts).to(cuda), int(counts.max()), point_index=torch.from_numpy(inv).to(cuda),
+                                                          fixed_eps=0.35, min_points=5, min_cluster=10)
+    assert np.array_equal(out_count2.cpu().numpy(), out_count)
+    _, bad, _ = I.largest_clusters_device(pts, torch.from_numpy(starts).to(cuda), torch.from_numpy(counts).to(cuda), 1000, fixed_eps=0.3)
+    assert list(bad.cpu().numpy() == -1) == [bool(c > 1000) for c in counts]
+
+
+@pytest.mark.gpu
+def test_hip_crop_boxes_vs_oracle_random(cuda, hip_lib):
+    from seevcn_amd.vcn import isolation as I
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-20, 20, (30000, 4)).astype(np.float32)
+    boxes = [I.OrientedBox(rng.uniform(-15, 15, 3), I.gtbox_to_corners([0, 0, 0, 1, 1, 1, rng.uniform(-3, 3)])[1], rng.uniform(0.5, 12, 3))
+             for _ in range(9)]
+    boxes.append(I.OrientedBox([1, -2, 0], I.gtbox_to_corners([0, 0, 0, 1, 1, 1, 0.7])[1], [30, 25, 38]))   # > 1024 points: several select rounds
+    boxes.append(I.OrientedBox([100, 100, 100], np.eye(3), [1, 1, 1]))                     # empty crop
+    dev = torch.from_numpy(pts).to(cuda)
+    index, count = I.crop_boxes_device(dev, boxes)                                          # row stride 4
+    small_index, small_count = I.crop_boxes_device(dev, boxes, cap=16)
+    index, count = index.cpu().numpy(), count.cpu().numpy()
+    assert np.array_equal(small_count.cpu().numpy(), count)
+    for g, b in enumerate(boxes):
+        want = oiso.crop_oriented_box(pts, b.center, b.R, b.extent)
+        assert count[g] == len(want) and np.array_equal(index[g, :count[g]], want)
+        assert np.array_equal(small_index.cpu().numpy()[g, :min(16, len(want))], want[:16])
+    assert count[-1] == 0 and count[:-1].max() > 1024
+
+
+def test_isolation_refuses_cpu(hip_lib):
+    from seevcn_amd.vcn import isolation as I
+    with pytest.raises((RuntimeError, AssertionError, ValueError)):
+        I.crop_boxes_device(torch.zeros((10, 3)), [I.OrientedBox([0, 0, 0], np.eye(3), [1, 1, 1])])
