@@ -2,6 +2,10 @@ import torch
 import torch.nn as nn
 
 from ... import _lib
+from ..extensions.chamfer_dist import ChamferDistanceL2
+from ..utils import misc
+from ..utils.sampling import get_partial_mesh_batch_device
+from ..utils.transform import cn_to_vc, normalize_scale, restore_scale, vc_to_cn
 from . import layers as L
 from .build import MODELS
 
@@ -20,13 +24,46 @@ class VCN_CN(nn.Module):
         self._prepared = L.PreparedCache(self, lambda: dict(enc=L.prepare_encoder(self.encoder), shape_fc=L.prepare_fc(self.shape_fc)))
         self.dedup_points = True     # run the per-point layers on each object's distinct rows only (bit-identical output)
 
-    def get_loss(self, ret_dict, in_dict):
-        raise NotImplementedError("VCN training loss (VCN_CN.py:125-140) is outside the built hot path")
+        self.build_loss_func()
 
-    @torch.no_grad()
+    def build_loss_func(self):
+        self.loss_coarse = ChamferDistanceL2()
+        self.loss_partial = ChamferDistanceL2()
+        self.loss_translation = nn.SmoothL1Loss(reduction='none')
+        self.loss_dims = nn.SmoothL1Loss(reduction='none')
+
+    def get_loss(self, ret_dict, in_dict):
+        """coarse (Chamfer vs the FPS-downsampled complete cloud) and partial (Chamfer between the surfaces selected around the
+        input) -- reference VCN_CN.py:125-140; HIP Chamfer distance, farthest point sampling and surface selection."""
+        loss_dict = {}
+        if in_dict['training']:
+            ds_complete = misc.fps(in_dict['complete'], ret_dict['coarse'].shape[1])
+            loss_dict['coarse'] = self.loss_coarse(ret_dict['coarse'], ds_complete)
+            pred_surface, _ = get_partial_mesh_batch_device(in_dict['input'], ret_dict['coarse'], k=self.sel_k)
+            gt_surface, _ = get_partial_mesh_batch_device(in_dict['input'], ds_complete, k=self.sel_k)
+            loss_dict['partial'] = self.loss_partial(pred_surface, gt_surface)
+        return loss_dict
+
+    def _forward_train(self, in_dict):
+        """The reference forward (VCN_CN.py:142-156) on torch ops, differentiable (batch-statistics BatchNorm)."""
+        x, boxes = in_dict['input'], in_dict['gt_boxes']
+        n = x.shape[1]
+        pc = normalize_scale(vc_to_cn(x, boxes), boxes)
+        enc = self.encoder
+        feature = enc.mlp_conv1(pc.permute(0, 2, 1))
+        feature_global = torch.max(feature, dim=2, keepdim=True)[0]
+        feature = enc.mlp_conv2(torch.cat([feature_global.expand(-1, -1, n), feature], dim=1))
+        feature_global = torch.max(feature, dim=2)[0]
+        coarse = self.shape_fc(feature_global).reshape(-1, self.number_coarse, 3)
+        return {'coarse': cn_to_vc(restore_scale(coarse.contiguous(), boxes), boxes)}
+
     def forward(self, in_dict):
         if self.training:
-            raise RuntimeError("seevcn_amd VCN_CN implements the eval-mode forward (BatchNorm folded); call .eval()")
+            return self._forward_train(in_dict)
+        with torch.no_grad():
+            return self._forward_eval(in_dict)
+
+    def _forward_eval(self, in_dict):
         lib = _lib.load()
         x, boxes = in_dict['input'], in_dict['gt_boxes']
         _lib.require_cuda(x, boxes)

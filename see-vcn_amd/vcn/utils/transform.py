@@ -15,3 +15,29 @@ def rotate_points_along_z(points, angle):
     rot = rot_from_heading(angle)
     points_rot = torch.matmul(points[:, :, 0:3], rot)
     return torch.cat((points_rot, points[:, :, 3:]), dim=-1)
+
+
+def vc_to_cn(points, gt_label):
+    """view-centric -> canonical frame of the gt box: (points - centre) rotated by -heading (transform.py:91-113)."""
+    assert gt_label.shape[1] == 7, f'gt_label wrong shape, should be (B 7) but given shape is {gt_label.shape}'
+    assert points.shape[2] == 3, f'points wrong shape, should be (B N 3) but given shape is {points.shape}.'
+    return rotate_points_along_z(points - gt_label[:, :3].unsqueeze(1), -gt_label[:, -1])
+
+
+def cn_to_vc(points, gt_label):
+    """canonical -> view-centric (transform.py:115-137)."""
+    assert gt_label.shape[1] == 7, f'gt_label wrong shape, should be (B 7) but given shape is {gt_label.shape}'
+    assert points.shape[2] == 3, f'points wrong shape, should be (B N 3) but given shape is {points.shape}.'
+    return rotate_points_along_z(points, gt_label[:, -1]) + gt_label[:, :3].unsqueeze(1)
+
+
+def normalize_scale(points, gt_label):
+    """divide by the box length (transform.py:139-151)."""
+    assert gt_label.shape[1] == 7 and points.shape[2] == 3
+    return points / gt_label[:, 3].view(-1, 1, 1)
+
+
+def restore_scale(points, gt_label):
+    """multiply by the box length (transform.py:153-165)."""
+    assert gt_label.shape[1] == 7 and points.shape[2] == 3
+    return points * gt_label[:, 3].view(-1, 1, 1)

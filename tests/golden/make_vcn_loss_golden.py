@@ -1,5 +1,5 @@
-"""Generate tests/golden/vcn_loss.npz: the REFERENCE's own VCN_VC (see/surface_completion/models/vcn/models/VCN_VC.py:110-214) in
-train mode (batch-statistics BatchNorm) and its get_loss terms (:150-171).  The reference's CUDA-only ops are served by the
+"""Generate tests/golden/vcn_loss.npz: the REFERENCE's own VCN_VC (see/surface_completion/models/vcn/models/VCN_VC.py:110-214) and
+VCN_CN (VCN_CN.py:110-156) in train mode (batch-statistics BatchNorm) and its get_loss terms (:150-171).  The reference's CUDA-only ops are served by the
 oracle: `chamfer.forward/backward` -> oracle/chamfer.py, `pointnet2_ops.furthest_point_sample / gather_operation` ->
 oracle/pointnet2.py.  get_loss is called with training=False for dims / translation / rotation; the 'coarse' term is evaluated
 with the reference's own misc.fps + ChamferDistanceL2 (the 'partial' term of the reference passes numpy arrays to the Chamfer
@@ -46,5 +46,16 @@ coarse_loss = ChamferDistanceL2()(ret["coarse"], ds)
 out = {k: ret[k].detach().numpy() for k in ("coarse", "reg_rot", "reg_centre")}
 out.update({"loss_" + k: np.float32(float(v)) for k, v in ld.items()})
 out["loss_coarse"] = np.float32(float(coarse_loss))
+
+# VCN_CN (models/VCN_CN.py:110-156): train-mode forward with gt boxes and the 'coarse' loss term
+from models.vcn.models.VCN_CN import VCN_CN  # noqa: E402
+cn = VCN_CN({})
+cn.load_state_dict(R.seeded_state_dict(cn, seed=1))
+cn.train()
+ret_cn = cn({"input": torch.from_numpy(inp), "gt_boxes": torch.from_numpy(gt)})
+assert cn.get_loss(ret_cn, {"gt_boxes": torch.from_numpy(gt), "training": False}) == {}
+ds_cn = misc.fps(torch.from_numpy(complete), ret_cn["coarse"].shape[1])
+out["cn_coarse"] = ret_cn["coarse"].detach().numpy()
+out["cn_loss_coarse"] = np.float32(float(ChamferDistanceL2()(ret_cn["coarse"], ds_cn)))
 np.savez_compressed(os.path.join(HERE, "vcn_loss.npz"), **out)
 print({k: (float(v) if v.ndim == 0 else v.shape) for k, v in out.items()})

@@ -43,7 +43,37 @@ def test_vcn_train_forward_and_loss_match_reference_golden_cpu(golden_dir):
         assert abs(float(ld[k]) - float(g["loss_" + k])) <= 1e-3 * abs(float(g["loss_" + k])) + 1e-6, k
 
 
+def test_vcn_cn_train_forward_matches_reference_golden_cpu(golden_dir):
+    import seevcn_amd.vcn as V
+    g = np.load(os.path.join(golden_dir, "vcn_loss.npz"))
+    inp, complete, gt = make_batch()
+    m = V.MODELS.build({"NAME": "VCN_CN"})
+    m.load_state_dict(seeded_state_dict(m, seed=1))
+    m.train()
+    ret = m({"input": torch.from_numpy(inp), "gt_boxes": torch.from_numpy(gt)})
+    assert np.abs(ret["coarse"].detach().numpy() - g["cn_coarse"]).max() <= 1e-3 * np.abs(g["cn_coarse"]).max() + 1e-5
+    assert m.get_loss(ret, {"gt_boxes": torch.from_numpy(gt), "training": False}) == {}
+
+
 # ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_vcn_cn_get_loss_matches_reference_golden(golden_dir, cuda, hip_lib):
+    import seevcn_amd.vcn as V
+    g = np.load(os.path.join(golden_dir, "vcn_loss.npz"))
+    inp, complete, gt = make_batch()
+    m = V.MODELS.build({"NAME": "VCN_CN"})
+    m.load_state_dict(seeded_state_dict(m, seed=1))
+    m = m.to(cuda).train()
+    dev = lambda a: torch.from_numpy(a).to(cuda)
+    ret = m({"input": dev(inp), "gt_boxes": dev(gt)})
+    assert np.abs(ret["coarse"].detach().cpu().numpy() - g["cn_coarse"]).max() <= 1e-3 * np.abs(g["cn_coarse"]).max() + 1e-5
+    ld = m.get_loss(ret, {"gt_boxes": dev(gt), "training": True, "complete": dev(complete), "input": dev(inp)})
+    assert abs(float(ld["coarse"]) - float(g["cn_loss_coarse"])) <= 1e-3 * abs(float(g["cn_loss_coarse"]))
+    assert torch.isfinite(ld["partial"]) and float(ld["partial"]) >= 0
+    ld["coarse"].backward()
+    assert float(m.shape_fc[0].weight.grad.abs().sum()) > 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,n,m", [(3, 700, 1300), (2, 1024, 1024), (1, 1, 5), (4, 513, 512)])
 def test_hip_chamfer_forward_backward_vs_oracle(cuda, hip_lib, B, n, m):
