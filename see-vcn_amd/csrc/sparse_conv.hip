@@ -20,6 +20,7 @@
 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SC_THREADS = 256;
 constexpr int SC_ROWS_PER_WAVE = 32;  // two 16-row MFMA tiles
@@ -698,13 +699,16 @@ static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, c
 //          fixed order -> bitwise reproducible, no atomics.
 // ------------------------------------------------------------------------------------------------
 constexpr int WG_CHUNK_MAX = 4096;  // rows per stage-1 workgroup (upper bound; sized per launch to fill the chip)
+constexpr int WG_SUB = 4;           // 64-row blocks a wave compacts per pass
+constexpr int WG_DEPTH = 4;         // operand ring depth (MFMA steps)
 
 struct WgradArgs;
 static int wgrad_chunk_rows(int64_t n_rows, int K, int groups) {
-  // aim at ~2048 workgroups: chunk = n_rows*K*groups/2048 rounded up to 256 rows, within [256, WG_CHUNK_MAX]
+  // aim at ~2048 workgroups: chunk = n_rows*K*groups/2048 rounded up to one pass of the four waves (4 x WG_SUB x 64 rows)
+  constexpr int64_t pass = 256 * WG_SUB;
   int64_t c = (n_rows * K * groups + 2047) / 2048;
-  c = (c + 255) / 256 * 256;
-  if (c < 256) c = 256;
+  c = (c + pass - 1) / pass * pass;
+  if (c < pass) c = pass;
   if (c > WG_CHUNK_MAX) c = WG_CHUNK_MAX;
   return (int)c;
 }
@@ -718,13 +722,24 @@ struct WgradArgs {
   int K, Cin, Cout, nchunks, chunk_rows;
 };
 
+template <int N> struct WgVec;
+template <> struct WgVec<4> { using type = f32x4; };
+template <> struct WgVec<2> { using type = f32x2; };
+template <> struct WgVec<1> { using type = float; };
+__device__ __forceinline__ void wg_gload(f32x4& v, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void wg_gload(f32x2& v, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void wg_gload(float& v, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ float wg_elem(const f32x4& v, int i) { return v[i]; }
+__device__ __forceinline__ float wg_elem(const f32x2& v, int i) { return v[i]; }
+__device__ __forceinline__ float wg_elem(const float& v, int) { return v; }
+
 // grid = (nchunks, K, tile groups).  Each wave walks its share of the chunk 64 rows at a time: one coalesced read of the
 // neighbour table, ballot + prefix popcount compaction of the valid (row, source) pairs into a wave-private LDS list,
 // then MFMAs over the COMPACTED pairs only (4 pairs per 16x16x4 step) with the next step's operands requested first.
 // The four waves' accumulators are summed through LDS in a fixed order and one slab per (chunk, k) is stored.
 template <int CT, int NTL>  // register tile grid: CT x NTL tiles of 16x16 (rows = c_in, cols = c_out)
 __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {
-  __shared__ int32_t pj[4][64], pr[4][64];
+  __shared__ int32_t pj[4][64 * WG_SUB], pr[4][64 * WG_SUB];
   __shared__ float red[CT * NTL * 256];
   const int k = blockIdx.y, chunk = blockIdx.x;
   const int ngroups_n = (a.Cout / 16) / NTL;
@@ -739,45 +754,81 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {
   const int64_t r_begin = (int64_t)chunk * a.chunk_rows, r_end = min(r_begin + (int64_t)a.chunk_rows, a.n_rows);
   const int32_t* nb = a.nbr + (int64_t)k * a.n_rows;
 
-  auto load_ops = [&](int p, int cnt, float (&xa)[CT], float (&yb)[NTL]) {
-    const bool ok = p < cnt;
-    const int32_t j = ok ? pj[wid][p] : 0;
-    const int32_t r = ok ? pr[wid][p] : 0;
+  // Operand fetch for one MFMA step (4 pairs): lane (li, kk) needs X[j_kk][.] for CT tiles and dY[r_kk][.] for NTL tiles.
+  // Tile c holds the channels c_base + CT*i + c (i = 0..15), so the CT values of a lane are CONTIGUOUS: one 4*CT-byte load per
+  // operand instead of CT scalar loads, and the 16 lanes of a pair read its whole 64*CT-byte row segment.
+  // The loads are inline asm: hipcc sinks a plain prefetch load into the block of its first use (measured: load, vmcnt(0), MFMA),
+  // an asm load stays where it is written and is retired by the counted s_waitcnt in `consume`.  Steps past the end of the list
+  // re-read its last pair (a cache hit); their operands are zeroed after the wait.
+  using XV = typename WgVec<CT>::type;
+  using YV = typename WgVec<NTL>::type;
+  const bool x_in = CT > 1 || c_base + li < a.Cin;           // the 3-channel input layer runs with zero-padded rows
+  auto issue = [&](int p, int cnt, XV& xs, YV& ys) {
+    const int pc = p < cnt ? p : cnt - 1;
+    const int32_t j = pj[wid][pc];
+    const int32_t r = pr[wid][pc];
+    wg_gload(xs, a.X + (int64_t)j * a.Cin + (x_in ? c_base + CT * li : 0));
+    wg_gload(ys, a.dY + ((int64_t)r_begin + r) * a.Cout + n_base + NTL * li);
+  };
+  // waits for the two loads of this step (the 3 younger steps stay in flight), then 16 x CT x NTL MFMAs
+  auto consume = [&](int p0, int cnt, XV& xs, YV& ys) {
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(xs), "+v"(ys));
+    if (p0 >= cnt) return;                                   // wave-uniform: a dummy step of the ring's tail
+    const bool ok = p0 + kk < cnt;
+    float xa[CT], yb[NTL];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) xa[c] = (ok && c_base + c * 16 + li < a.Cin) ? a.X[(int64_t)j * a.Cin + c_base + c * 16 + li] : 0.f;
+    for (int c = 0; c < CT; ++c) xa[c] = (ok && x_in) ? wg_elem(xs, c) : 0.f;
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) yb[t] = ok ? a.dY[((int64_t)r_begin + r) * a.Cout + n_base + t * 16 + li] : 0.f;
+    for (int t = 0; t < NTL; ++t) yb[t] = ok ? wg_elem(ys, t) : 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[c], yb[t], acc[c][t], 0, 0, 0);
   };
 
-  for (int64_t base = r_begin + wid * 64; base < r_end; base += 256) {
-    const int64_t r = base + lane;
-    const int32_t j = r < r_end ? nb[r] : -1;
-    const unsigned long long m = __ballot(j >= 0);
-    const int cnt = __popcll(m);
-    if (cnt == 0) continue;
-    if (j >= 0) {
-      const int pos = __popcll(m & ((1ull << lane) - 1ull));
-      pj[wid][pos] = j;
-      pr[wid][pos] = (int32_t)(r - r_begin);
+  for (int64_t base = r_begin + wid * (64 * WG_SUB); base < r_end; base += 256 * WG_SUB) {
+    // WG_SUB x 64 rows per wave and pass: the neighbour reads are in flight together and the start-up latency of a pass
+    // (table read -> compaction -> first operand loads) is paid once per ~80 pairs instead of once per ~20
+    int32_t jv[WG_SUB];
+#pragma unroll
+    for (int s = 0; s < WG_SUB; ++s) {
+      const int64_t r = base + s * 64 + lane;
+      jv[s] = r < r_end ? nb[r] : -1;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private list: LDS ops of one wave complete in order
-    float xa[CT], yb[NTL], xn[CT], yn[NTL];
-    load_ops(kk, cnt, xa, yb);
-    for (int g = 0; g < cnt; g += 4) {
-      if (g + 4 < cnt) load_ops(g + 4 + kk, cnt, xn, yn);
-      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMA block
+    int cnt = 0;
 #pragma unroll
-      for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[c], yb[t], acc[c][t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g + 4 < cnt) {
-#pragma unroll
-        for (int c = 0; c < CT; ++c) xa[c] = xn[c];
-#pragma unroll
-        for (int t = 0; t < NTL; ++t) yb[t] = yn[t];
+    for (int s = 0; s < WG_SUB; ++s) {
+      const unsigned long long m = __ballot(jv[s] >= 0);
+      if (jv[s] >= 0) {
+        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        pj[wid][pos] = jv[s];
+        pr[wid][pos] = (int32_t)(base + s * 64 + lane - r_begin);
       }
+      cnt += __popcll(m);
     }
+    if (cnt == 0) continue;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private list: LDS ops of one wave complete in order
+    // operand ring, 4 steps deep: step s uses stage s % 4 while the loads of steps s+1 .. s+3 are in flight (a gathered row
+    // takes ~2 us under load, a step's MFMAs 0.2 us).  EVERY ring slot issues exactly two loads and every consume waits for
+    // vmcnt(6): no conditional issue, so each stage register has one definition per slot and hipcc never copies a stage whose
+    // load is still in flight (a copied stage lets the late load land in a register that has been handed to something else).
+    static_assert(WG_DEPTH == 4, "the wait count in consume() is written for a 4-deep ring");
+    XV x0, x1, x2, x3;
+    YV y0, y1, y2, y3;
+    issue(kk, cnt, x0, y0);
+    issue(4 + kk, cnt, x1, y1);
+    issue(8 + kk, cnt, x2, y2);
+    for (int p0 = 0; p0 < cnt; p0 += 16) {
+      issue(p0 + 12 + kk, cnt, x3, y3);
+      consume(p0, cnt, x0, y0);
+      issue(p0 + 16 + kk, cnt, x0, y0);
+      consume(p0 + 4, cnt, x1, y1);
+      issue(p0 + 20 + kk, cnt, x1, y1);
+      consume(p0 + 8, cnt, x2, y2);
+      issue(p0 + 24 + kk, cnt, x2, y2);
+      consume(p0 + 12, cnt, x3, y3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2));   // retire the tail's dummy loads
   }
   // fixed-order reduction over the 4 waves (wave 0 stores, waves 1..3 add in turn), then one slab per (chunk, k)
   for (int w = 0; w < 4; ++w) {
@@ -794,13 +845,14 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {
     }
     __syncthreads();
   }
-  // D layout: col = lane&15 (c_out), row = 4*(lane>>4) + reg (c_in)
+  // D layout of tile (c,t): col = lane&15, row = 4*(lane>>4) + reg; tile row i is channel c_base + CT*i + c, tile col i is
+  // column n_base + NTL*i + t (the interleaved tiles of load_ops)
   float* out = a.partial + (((int64_t)chunk * a.K + k) * a.Cin) * a.Cout;
   for (int e = tid; e < CT * NTL * 256; e += 256) {
     const int ln = e & 63, r = (e >> 6) & 3, tile = e >> 8;
     const int c = tile / NTL, t = tile - c * NTL;
-    const int crow = c_base + c * 16 + (ln >> 4) * 4 + r;
-    if (crow < a.Cin) out[(int64_t)crow * a.Cout + n_base + t * 16 + (ln & 15)] = red[e];
+    const int crow = c_base + CT * ((ln >> 4) * 4 + r) + c;
+    if (crow < a.Cin) out[(int64_t)crow * a.Cout + n_base + NTL * (ln & 15) + t] = red[e];
   }
 }
 
