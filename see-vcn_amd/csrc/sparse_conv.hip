@@ -654,6 +654,48 @@ extern "C" int sv_sparse_conv_gather_gemm_ordered(const float* X, int64_t n_src,
   return gather_gemm_impl(X, n_src, nbr, Wt, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, tile_order, stream);
 }
 
+// Input layer (C_in = 3 or 4 point features -> 16 channels, spconv_backbone.py:77-81): HBM-bound -- 4*K bytes of neighbour table and
+// 4*Nc bytes of output per row against 2*K*Kd*Nc flops.  Same thread mapping and summation order as k_spconv_valu (bit-identical
+// results); the weights (K*Nc*Kd floats, 5 KB) are staged in LDS and the K table reads of a row are issued 9 at a time.
+constexpr int SC_SMALL_KD = 4, SC_SMALL_LDS = 27 * 32 * SC_SMALL_KD;
+template <int KD>
+__global__ __launch_bounds__(256) void k_spconv_small_cin(ConvArgs a) {
+  __shared__ float s_w[SC_SMALL_LDS];
+  for (int i = threadIdx.x; i < a.K * a.Nc * KD; i += 256) s_w[i] = a.Wt[i];
+  __syncthreads();
+  const int nq = (a.Nc + 3) / 4;
+  const int64_t total = a.n_rows * nq;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / nq;
+    const int n0 = (int)(idx - row * nq) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < a.K; k0 += 9) {
+      int32_t j[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) j[u] = k0 + u < a.K ? a.nbr[(int64_t)(k0 + u) * a.n_rows + row] : -1;
+      float x[9][KD];
+#pragma unroll
+      for (int u = 0; u < 9; ++u)
+#pragma unroll
+        for (int c = 0; c < KD; ++c) x[u][c] = j[u] >= 0 ? a.X[(int64_t)j[u] * KD + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        if (j[u] < 0) continue;
+        const float* w = s_w + (size_t)((k0 + u) * a.Nc + n0) * KD;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          if (n0 + v >= a.Nc) break;
+          float t = acc[v];
+#pragma unroll
+          for (int c = 0; c < KD; ++c) t = fmaf(x[u][c], w[v * KD + c], t);
+          acc[v] = t;
+        }
+      }
+    }
+    for (int v = 0; v < 4 && n0 + v < a.Nc; ++v) a.Y[row * a.Nc + n0 + v] = conv_epilogue(acc[v], n0 + v, row, a);
+  }
+}
+
 static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows, int K, int Kd, int Nc,
                             const float* bias, const float* scale, const float* shift, const float* residual, int relu,
                             const int32_t* tile_order, void* stream) {
@@ -685,6 +727,10 @@ static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, c
       case 4: hipLaunchKernelGGL(k_spconv_mfma<4>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
       default: hipLaunchKernelGGL(k_spconv_mfma<8>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
     }
+  } else if ((Kd == 3 || Kd == 4) && K * Nc * Kd <= SC_SMALL_LDS) {
+    const dim3 grid(sv_grid_1d(n_rows * ((Nc + 3) / 4), 256, 256 * 8));
+    if (Kd == 3) hipLaunchKernelGGL(k_spconv_small_cin<3>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_spconv_small_cin<4>, grid, dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL(k_spconv_valu, dim3(sv_grid_1d(n_rows * ((Nc + 3) / 4), 256, 256 * 16)), dim3(256), 0, st, a);
   }

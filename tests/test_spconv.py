@@ -161,7 +161,7 @@ def test_hip_subm_rulebook_bit_exact(cuda, hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cin,cout", [(3, 16), (16, 16), (16, 32), (32, 64), (64, 64), (64, 128), (128, 128), (5, 7)])
+@pytest.mark.parametrize("cin,cout", [(3, 16), (4, 16), (16, 16), (16, 32), (32, 64), (64, 64), (64, 128), (128, 128), (5, 7)])
 def test_hip_conv_forward_backward_vs_oracle(cuda, hip_lib, cin, cout):
     import seevcn_amd.spconv as spconv
     rng = np.random.default_rng(5)
