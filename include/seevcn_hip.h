@@ -306,6 +306,10 @@ int sv_gemm_bias_act_ragged(const float* A, int lda, const float* W, int ldw, co
 /* x (B,n,3), n <= 1024 -> uniq_idx (B,n): the first counts[b] entries of row b index one copy of each distinct point of object b
  * (exact float equality, -0.0 == 0.0), lexicographic order. */
 int sv_unique_rows(const float* x, int batch, int n, int32_t* uniq_idx, int32_t* counts, void* stream);
+/* Packs sv_unique_rows' per-object lists: sel (>= sum(counts)) int64 flat row b*n + uniq_idx[b][r], row_group int32 = b, object
+ * after object; *total (device int32) = sum(counts).  Replaces ~25 torch indexing kernels in the VCN eval forward. */
+int sv_unique_rows_compact(const int32_t* uniq_idx, const int32_t* counts, int batch, int n, int64_t* sel, int32_t* row_group,
+                           int32_t* total, void* stream);
 
 /* ---- Chamfer distance of the VCN training loss: the reference's `chamfer` extension,
  * see/surface_completion/models/vcn/extensions/chamfer_dist/chamfer_cuda.cpp:36-39 (forward -> [dist1, dist2, idx1, idx2],

@@ -88,6 +88,7 @@ SIGNATURES = {
     "sv_isolate_largest_cluster": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i64, c_d, c_d, c_d, c_d, c_d, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_gemm_bias_act_ragged": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "sv_unique_rows": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
+    "sv_unique_rows_compact": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_ball_query_batch": (c_i, [c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p]),
     "sv_group_points_batch": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_group_points_grad_batch": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),

@@ -519,6 +519,38 @@ extern "C" int sv_unique_rows(const float* x, int batch, int n, int32_t* uniq_id
   return SV_OK;
 }
 
+// Packs the per-object lists of sv_unique_rows behind each other: sel[off_b + r] = b*n + uniq_idx[b][r], row_group[off_b + r] = b
+// with off_b = counts[0] + .. + counts[b-1]; *total = all kept rows.  One workgroup per object (it sums the counts before it).
+__global__ __launch_bounds__(256) void k_unique_compact(const int32_t* __restrict__ uniq_idx, const int32_t* __restrict__ counts, int batch,
+                                                        int n, int64_t* __restrict__ sel, int32_t* __restrict__ row_group,
+                                                        int32_t* __restrict__ total) {
+  __shared__ int s_part[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int acc = 0;
+  for (int i = tid; i < b; i += 256) acc += counts[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) s_part[wave] = acc;
+  __syncthreads();
+  const int first = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  const int cnt = counts[b];
+  for (int r = tid; r < cnt; r += 256) {
+    sel[first + r] = (int64_t)b * n + uniq_idx[(size_t)b * n + r];
+    row_group[first + r] = b;
+  }
+  if (b == batch - 1 && tid == 0) *total = first + cnt;
+}
+
+extern "C" int sv_unique_rows_compact(const int32_t* uniq_idx, const int32_t* counts, int batch, int n, int64_t* sel, int32_t* row_group,
+                                      int32_t* total, void* stream) {
+  SV_CHECK_ARG(batch >= 0 && n >= 1, "sv_unique_rows_compact: bad sizes");
+  if (batch == 0) return SV_OK;
+  SV_CHECK_ARG(uniq_idx && counts && sel && row_group && total, "sv_unique_rows_compact: null pointer");
+  hipLaunchKernelGGL(k_unique_compact, dim3(batch), dim3(256), 0, sv_stream(stream), uniq_idx, counts, batch, n, sel, row_group, total);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 extern "C" size_t sv_vcn_surface_select_scratch_bytes(int batch) {
   return (size_t)(batch < 1 ? 1 : batch) * (PP_MAXN * (sizeof(int) + sizeof(unsigned short)) + 2 * sizeof(int));
 }

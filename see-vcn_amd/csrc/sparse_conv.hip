@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void k_tile_cost(TileOrderArgs a) {
     }
   }
   __syncthreads();
-  if (threadIdx.x < 32 && s_hist[threadIdx.x]) atomicAdd(&a.hist[threadIdx.x], s_hist[threadIdx.x]);
+  if (a.hist && threadIdx.x < 32 && s_hist[threadIdx.x]) atomicAdd(&a.hist[threadIdx.x], s_hist[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void k_tile_deal(TileOrderArgs a) {
@@ -363,6 +363,40 @@ __global__ __launch_bounds__(256) void k_tile_deal(TileOrderArgs a) {
     const int64_t r = p / a.n_waves, i = p - r * a.n_waves;
     const int64_t wv = (r & 1) ? a.n_waves - 1 - i : i;          // snake: dense and sparse tiles alternate per wave
     a.tile_of[4 + wv * a.G + r] = (int32_t)t;      // 4-int header: [0] = G
+  }
+}
+
+// Same result class as k_tile_deal for up to TO_ONE_WG_TILES tiles, in ONE workgroup and without the two fills: the histogram lives
+// in LDS, every slot of the order (header, tiles, -1 padding) is written here.
+constexpr int TO_ONE_WG_TILES = 65536;
+__global__ __launch_bounds__(1024) void k_tile_deal_one(TileOrderArgs a) {
+  __shared__ int s_cnt[32], s_start[32];
+  const int tid = threadIdx.x;
+  if (tid < 32) s_cnt[tid] = 0;
+  __syncthreads();
+  for (int64_t t = tid; t < a.n_tiles; t += 1024) atomicAdd(&s_cnt[a.cost[t]], 1);
+  __syncthreads();
+  if (tid == 0) {                          // descending cost: the most expensive bucket first
+    int acc = 0;
+    for (int c = 31; c >= 0; --c) s_start[c] = acc, acc += s_cnt[c];
+  }
+  __syncthreads();
+  if (tid < 32) s_cnt[tid] = 0;
+  if (tid < 4) a.tile_of[tid] = tid == 0 ? a.G : -1;
+  __syncthreads();
+  const int64_t slots = a.n_waves * a.G;
+  for (int64_t t = tid; t < slots; t += 1024) {
+    if (t < a.n_tiles) {
+      const int c = a.cost[t];
+      const int64_t p = s_start[c] + atomicAdd(&s_cnt[c], 1);
+      const int64_t r = p / a.n_waves, i = p - r * a.n_waves;
+      const int64_t wv = (r & 1) ? a.n_waves - 1 - i : i;          // snake: dense and sparse tiles alternate per wave
+      a.tile_of[4 + wv * a.G + r] = (int32_t)t;
+    } else {                                                        // positions n_tiles .. slots-1 of the snake stay empty
+      const int64_t r = t / a.n_waves, i = t - r * a.n_waves;
+      const int64_t wv = (r & 1) ? a.n_waves - 1 - i : i;
+      a.tile_of[4 + wv * a.G + r] = -1;
+    }
   }
 }
 
@@ -413,11 +447,17 @@ extern "C" int sv_conv_tile_order(const int32_t* nbr, int64_t n_rows, int K, int
   a.cost = reinterpret_cast<uint8_t*>(scratch) + 64 * sizeof(int32_t);
   a.tile_of = tile_order;
   hipStream_t st = sv_stream(stream);
-  SV_HIP(hipMemsetAsync(a.hist, 0, 64 * sizeof(int32_t), st));
-  SV_HIP(hipMemsetAsync(tile_order, 0xFF, (size_t)(4 + a.n_waves * a.G) * sizeof(int32_t), st));
   const int wgs = (int)((a.n_tiles + 15) / 16 < TO_WGS ? (a.n_tiles + 15) / 16 : TO_WGS);
-  hipLaunchKernelGGL(k_tile_cost, dim3(wgs), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_tile_deal, dim3(wgs), dim3(256), 0, st, a);
+  if (a.n_tiles <= TO_ONE_WG_TILES) {
+    a.hist = nullptr;
+    hipLaunchKernelGGL(k_tile_cost, dim3(wgs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_tile_deal_one, dim3(1), dim3(1024), 0, st, a);
+  } else {
+    SV_HIP(hipMemsetAsync(a.hist, 0, 64 * sizeof(int32_t), st));
+    SV_HIP(hipMemsetAsync(tile_order, 0xFF, (size_t)(4 + a.n_waves * a.G) * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_tile_cost, dim3(wgs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_tile_deal, dim3(wgs), dim3(256), 0, st, a);
+  }
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -927,6 +967,24 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   }
 }
 
+// slab % 4 == 0: 64 float4 columns x 4 quarters of the chunk range per workgroup -- four times the loads in flight of the scalar
+// kernel, partial sums combined in a fixed order ((q0 + q1) + (q2 + q3)): still bitwise reproducible
+__global__ __launch_bounds__(256) void k_wgrad_reduce4(const float* __restrict__ partial, int nchunks, int64_t slab4, float* __restrict__ dW) {
+  __shared__ f32x4 s_q[4][64];
+  const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + col;
+  const int c0 = (int)((int64_t)nchunks * q / 4), c1 = (int)((int64_t)nchunks * (q + 1) / 4);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (e < slab4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(partial) + e;
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) s += __builtin_nontemporal_load(p + (int64_t)c * slab4);
+  }
+  s_q[q][col] = s;
+  __syncthreads();
+  if (q == 0 && e < slab4) reinterpret_cast<f32x4*>(dW)[e] = (s_q[0][col] + s_q[1][col]) + (s_q[2][col] + s_q[3][col]);
+}
+
 extern "C" size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout) {
   const int64_t nchunks = (n_rows + 255) / 256;   // worst case: smallest chunk
   return (size_t)(nchunks > 0 ? nchunks : 1) * K * Cin * Cout * sizeof(float);
@@ -972,7 +1030,10 @@ extern "C" int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const fl
     hipLaunchKernelGGL(k_spconv_wgrad_valu, dim3(a.nchunks, K), dim3(256), 0, st, a);
     nslabs = a.nchunks;
   }
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(sv_grid_1d(slab, 256)), dim3(256), 0, st, a.partial, nslabs, slab, dW);
+  if (slab % 4 == 0 && (uintptr_t)dW % 16 == 0 && (uintptr_t)a.partial % 16 == 0)
+    hipLaunchKernelGGL(k_wgrad_reduce4, dim3(sv_div_up(slab / 4, 64)), dim3(256), 0, st, a.partial, nslabs, slab / 4, dW);
+  else
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(sv_grid_1d(slab, 256)), dim3(256), 0, st, a.partial, nslabs, slab, dW);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

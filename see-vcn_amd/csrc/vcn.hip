@@ -182,6 +182,58 @@ extern "C" int sv_fill_f32(float* dst, int64_t n, float value, void* stream) {
   return SV_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// M <= 64 rows (the per-object layers: pose_fc, shape_fc, the folded global half of mlp_conv2[0]; VCN_VC.py:124-131,200-204).
+// These are weight-streaming: 2*N*K*4 bytes against 2*M*N*K flops.  The 128x128 tile kernel gives them N/128 workgroups that
+// each walk all of K alone (85 us for a 4 MB weight matrix).  Here a workgroup owns 16 output columns and all rows; its four
+// waves split K into quarters (16x16x4 MFMA, one 16-byte load per operand and 16 k), partial sums meet in LDS in a fixed order.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs g) {
+  __shared__ float s_red[4][4][4][64];                      // [wave][row tile][reg][lane]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int li = lane & 15, kk = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int kq = g.K / 4, kbeg = wid * kq;                  // K % 32 == 0 -> kq % 8 == 0
+  f32x4v acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  const int wn = n0 + li;
+  const float* wrow = g.W + (int64_t)(wn < g.N ? wn : g.N - 1) * g.ldw + 4 * kk;
+  const float* arow[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int m = t * 16 + li;
+    arow[t] = g.A + (int64_t)(m < g.M ? m : g.M - 1) * g.lda + 4 * kk;
+  }
+  for (int k0 = kbeg; k0 < kbeg + kq; k0 += 16) {           // lane (li, kk) holds k = k0 + 4*kk + s in MFMA s, for A and W alike
+    const f32x4v b = *reinterpret_cast<const f32x4v*>(wrow + k0);
+    f32x4v a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const f32x4v*>(arow[t] + k0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], b[s], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_red[wid][t][r][lane] = acc[t][r];
+  __syncthreads();
+  // D layout (16x16): col = lane & 15, row = 4 * (lane >> 4) + reg.  Thread (wid = row tile, lane) finishes 4 outputs.
+  const int col = n0 + li;
+  if (col >= g.N) return;
+  const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = wid * 16 + 4 * kk + r;
+    if (row >= g.M) continue;
+    float v = ((s_red[0][wid][r][lane] + s_red[1][wid][r][lane]) + (s_red[2][wid][r][lane] + s_red[3][wid][r][lane])) + bv;
+    g.C[(int64_t)row * g.ldc + col] = apply_act(v, g.act, g.slope);
+  }
+}
+
 static int gemm_launch(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias, int rows_per_group,
                        const int32_t* row_group, float* C, int ldc, float* group_max, int M, int N, int K, int act, float slope,
                        void* stream) {
@@ -194,6 +246,11 @@ static int gemm_launch(const float* A, int lda, const float* W, int ldw, const f
   GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, row_group, C, ldc, group_max, M, N, K, act, slope};
   dim3 grid(sv_div_up(N, BN), sv_div_up(M, BM));
   hipStream_t st = sv_stream(stream);
+  if (M <= 64 && C && !group_max && !group_bias && !row_group) {
+    hipLaunchKernelGGL(k_gemm_small_m, dim3(sv_div_up(N, 16)), dim3(256), 0, st, g);
+    SV_LAUNCH_CHECK();
+    return SV_OK;
+  }
   if (C && group_max)
     hipLaunchKernelGGL(k_gemm_f32<EPI_STORE | EPI_MAX>, grid, dim3(256), 0, st, g);
   else if (C)

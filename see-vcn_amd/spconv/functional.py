@@ -50,6 +50,8 @@ class Rulebook:
         if n_rows == 0 or (int(kd) // 16) * (int(nc) // 16) < 4 or kd % 16 or nc % 16:
             return None              # load-bound small-channel layers: the order does not pay for its own launch
         g = lib.sv_conv_tiles_per_wave(n_rows, int(kd), int(nc))
+        if self.subm and self._nbr_in_subm is not None and table.data_ptr() == self._nbr_in_subm.data_ptr():
+            table = self.nbr_out     # the flipped table has the same number of active offsets per tile: one order serves both directions
         key = (table.data_ptr(), g)
         if key not in self._orders:
             order = torch.empty((lib.sv_conv_tile_order_bytes(n_rows) // 4,), dtype=torch.int32, device=table.device)

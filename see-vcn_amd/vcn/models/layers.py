@@ -96,10 +96,13 @@ def distinct_rows(x):
     idx = torch.empty((B, n), dtype=torch.int32, device=x.device)
     cnt = torch.empty((B,), dtype=torch.int32, device=x.device)
     _lib.check(lib.sv_unique_rows(_lib.ptr(x), B, n, _lib.ptr(idx), _lib.ptr(cnt), _lib.stream()), "sv_unique_rows")
-    keep = torch.arange(n, device=x.device, dtype=torch.int32).unsqueeze(0) < cnt.unsqueeze(1)               # (B,n)
-    flat = idx.long() + torch.arange(B, device=x.device, dtype=torch.int64).unsqueeze(1) * n
-    sel = flat[keep]                                                                                          # sync: U rows
-    row_group = torch.arange(B, device=x.device, dtype=torch.int32).unsqueeze(1).expand(B, n)[keep].contiguous()
+    sel = torch.empty((B * n,), dtype=torch.int64, device=x.device)
+    row_group = torch.empty((B * n,), dtype=torch.int32, device=x.device)
+    total = torch.empty((1,), dtype=torch.int32, device=x.device)
+    _lib.check(lib.sv_unique_rows_compact(_lib.ptr(idx), _lib.ptr(cnt), B, n, _lib.ptr(sel), _lib.ptr(row_group), _lib.ptr(total), _lib.stream()),
+               "sv_unique_rows_compact")
+    u = int(total.item())                                                                                     # sync: U rows
+    sel, row_group = sel[:u], row_group[:u]
     return sel, row_group
 
 
