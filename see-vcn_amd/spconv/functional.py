@@ -1,5 +1,6 @@
 """Host wrappers + autograd Functions over the rulebook / sparse-conv entry points of libseevcn_hip.so."""
 import ctypes
+import os
 
 import torch
 
@@ -68,6 +69,10 @@ class Rulebook:
         return counts
 
 
+# dense cell -> row maps (4 B per cell) up to this size replace the rank dictionary in submanifold rulebooks (MI355X: 288 GB of HBM)
+CELLMAP_MAX_BYTES = int(os.environ.get("SEEVCN_CELLMAP_MAX_BYTES", 24 << 30))
+
+
 def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1)):
     lib = _lib.load()
     _lib.require_cuda(indices)
@@ -77,9 +82,15 @@ def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 
     dev = indices.device
     K = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
     ncells = int(batch_size) * int(spatial_shape[0]) * int(spatial_shape[1]) * int(spatial_shape[2])
+    nbr = torch.empty((K, n), dtype=torch.int32, device=dev)
+    if lib.sv_cellmap_persistent_bytes(ncells) <= CELLMAP_MAX_BYTES:
+        cellmap = _lib.workspace.persistent(f"rb_cellmap_{tuple(spatial_shape)}_{batch_size}", lib.sv_cellmap_persistent_bytes(ncells), dev)
+        rc = lib.sv_rulebook_subm_cellmap(_lib.ptr(indices), n, int(batch_size), _i3(spatial_shape), _i3(ksize), _i3(dilation),
+                                          _lib.ptr(cellmap), _lib.ptr(nbr), _lib.stream())
+        _lib.check(rc, "sv_rulebook_subm_cellmap")
+        return Rulebook(nbr, None, indices, list(spatial_shape), n, n, True, list(ksize))
     ws = _lib.workspace.persistent(f"rb_index_{tuple(spatial_shape)}_{batch_size}", lib.sv_index_persistent_bytes(ncells), dev)
     scratch = _lib.workspace.scratch("rb_scratch", lib.sv_rulebook_scratch_bytes(n, ncells), dev)
-    nbr = torch.empty((K, n), dtype=torch.int32, device=dev)
     rc = lib.sv_rulebook_subm(_lib.ptr(indices), n, int(batch_size), _i3(spatial_shape), _i3(ksize), _i3(dilation),
                               _lib.ptr(ws), _lib.ptr(scratch), _lib.ptr(nbr), _lib.stream())
     _lib.check(rc, "sv_rulebook_subm")

@@ -149,9 +149,15 @@ def test_hip_subm_rulebook_bit_exact(cuda, hip_lib):
     for batch, shape, n, ks in [(2, (41, 160, 140), 6000, (3, 3, 3)), (1, (5, 30, 30), 900, (3, 3, 3)), (2, (9, 20, 20), 500, (1, 3, 3))]:
         coords = _rand_coords(rng, n, batch, shape)          # random row order (like the voxeliser's (b,x,y,z) order)
         nbr = osp.rulebook_subm(coords, shape, ks)
-        rb = Fsp.build_subm_rulebook(torch.from_numpy(coords).to(cuda), batch, shape, list(ks))
-        torch.cuda.synchronize()
-        assert np.array_equal(rb.nbr_out.cpu().numpy(), nbr)
+        for cap in (Fsp.CELLMAP_MAX_BYTES, 0):               # dense cell map, then the rank dictionary (grids too large for a map)
+            saved, Fsp.CELLMAP_MAX_BYTES = Fsp.CELLMAP_MAX_BYTES, cap
+            try:
+                for _ in range(2):                            # twice: the persistent workspace must come back clean
+                    rb = Fsp.build_subm_rulebook(torch.from_numpy(coords).to(cuda), batch, shape, list(ks))
+                    torch.cuda.synchronize()
+                    assert np.array_equal(rb.nbr_out.cpu().numpy(), nbr)
+            finally:
+                Fsp.CELLMAP_MAX_BYTES = saved
         assert np.array_equal(rb.table_for_backward_data().cpu().numpy(), nbr[::-1])
     # empty input
     rb = Fsp.build_subm_rulebook(torch.zeros((0, 4), dtype=torch.int32, device=cuda), 1, (4, 4, 4), [3, 3, 3])
