@@ -45,6 +45,7 @@ SIGNATURES = {
     "sv_rulebook_pair_counts": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
     "sv_sparse_conv_gather_gemm": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p]),
     "sv_sparse_conv_gather_gemm_ordered": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "sv_sparse_conv_gather_gemm_strided": (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     "sv_conv_tiles_per_wave": (c_i, [c_i64, c_i, c_i]),
     "sv_conv_tile_order_scratch_bytes": (c_sz, [c_i64]),
     "sv_conv_tile_order_bytes": (c_sz, [c_i64]),
@@ -105,7 +106,7 @@ SIGNATURES = {
     "sv_chamfer_forward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_chamfer_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_batchnorm_scratch_bytes": (c_sz, [c_i]),
-    "sv_batchnorm_relu_forward": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sv_batchnorm_relu_forward": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_batchnorm_relu_backward": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_anchor_decode": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p]),
     "sv_assign_targets_axis_aligned": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

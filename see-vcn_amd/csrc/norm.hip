@@ -25,6 +25,7 @@ struct BnArgs {
   int64_t n;
   int C, relu, wgs;
   float momentum, eps;
+  int64_t* num_batches_tracked;   // nn.BatchNorm1d's counter, incremented by the training forward (may be null)
 };
 
 // per-thread: channels c4*4..c4*4+3 of rows (row0 + tid / C4) + k * R
@@ -83,6 +84,7 @@ template <bool BWD>
 __global__ __launch_bounds__(BN_THREADS) void k_bn_finalize(BnArgs a) {
   __shared__ double s0[BN_THREADS], s1[BN_THREADS];
   const int c = blockIdx.x, tid = threadIdx.x;
+  if (!BWD && c == 0 && tid == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
   double t0 = 0.0, t1 = 0.0;
   for (int w = tid; w < a.wgs; w += BN_THREADS) {
     t0 += (double)a.partial[(size_t)w * 2 * a.C + c];
@@ -192,7 +194,8 @@ static void bn_scratch(BnArgs& a, void* scratch) {
 
 extern "C" int sv_batchnorm_relu_forward(const float* x, int64_t n, int channels, const float* gamma, const float* beta,
                                          float* running_mean, float* running_var, float momentum, float eps, int training, int relu,
-                                         void* scratch, float* y, float* save_mean, float* save_invstd, void* stream) {
+                                         void* scratch, float* y, float* save_mean, float* save_invstd, int64_t* num_batches_tracked,
+                                         void* stream) {
   if (int rc = bn_common_check("sv_batchnorm_relu_forward", n, channels)) return rc;
   SV_CHECK_ARG(x && y && scratch, "sv_batchnorm_relu_forward: null pointer");
   SV_CHECK_ARG(training ? (save_mean && save_invstd) : (running_mean && running_var),
@@ -201,6 +204,7 @@ extern "C" int sv_batchnorm_relu_forward(const float* x, int64_t n, int channels
   a.x = x, a.out = y, a.gamma = gamma, a.beta = beta, a.running_mean = running_mean, a.running_var = running_var;
   a.save_mean = save_mean, a.save_invstd = save_invstd, a.n = n, a.C = channels, a.relu = relu, a.momentum = momentum, a.eps = eps;
   a.wgs = bn_wgs(n, channels);
+  a.num_batches_tracked = training ? num_batches_tracked : nullptr;
   bn_scratch(a, scratch);
   hipStream_t st = sv_stream(stream);
   if (training) {

@@ -278,13 +278,30 @@ constexpr int RS3_KMAX = 27;
 // calls on one device are serialised on one stream ("Error behaviour and streams").
 __device__ __attribute__((aligned(256))) float g_wfrag[RS3_KMAX * 64 * 64];
 
-__global__ __launch_bounds__(256) void k_weight_fragments(const float* __restrict__ wt, int K, int Nc, int Kd, float* __restrict__ wf) {
+struct WStride {
+  int64_t k, n, c;     // element strides of the (K, Nc, Kd) weight view
+};
+__global__ __launch_bounds__(256) void k_weight_fragments(const float* __restrict__ wt, WStride ws, int K, int Nc, int Kd, float* __restrict__ wf) {
   const int total = K * Nc * Kd / 4;                      // float4 units
   const int KQ = Kd / 16, NT = Nc / 16;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int lane = i & 63, t = (i >> 6) % NT, q = ((i >> 6) / NT) % KQ, k = (i >> 6) / (NT * KQ);
     const int li = lane & 15, kk = lane >> 4;
-    reinterpret_cast<float4*>(wf)[i] = *reinterpret_cast<const float4*>(wt + ((size_t)(k * Nc + t * 16 + li)) * Kd + q * 16 + kk * 4);
+    const float* src = wt + k * ws.k + (t * 16 + li) * ws.n + (q * 16 + kk * 4) * ws.c;
+    float4 v;
+    if (ws.c == 1 && (((uintptr_t)src) & 15) == 0) v = *reinterpret_cast<const float4*>(src);
+    else v = make_float4(src[0], src[ws.c], src[2 * ws.c], src[3 * ws.c]);
+    reinterpret_cast<float4*>(wf)[i] = v;
+  }
+}
+// any weight view -> contiguous (K, Nc, Kd) for the kernels that read the weights in place
+constexpr int64_t WPACK_FLOATS = 27 * 128 * 128;
+__device__ __attribute__((aligned(256))) float g_wpack[WPACK_FLOATS];
+__global__ __launch_bounds__(256) void k_weight_pack(const float* __restrict__ wt, WStride ws, int K, int Nc, int Kd, float* __restrict__ out) {
+  const int64_t total = (int64_t)K * Nc * Kd;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % Kd), n = (int)((i / Kd) % Nc), k = (int)(i / ((int64_t)Kd * Nc));
+    out[i] = wt[k * ws.k + n * ws.n + c * ws.c];
   }
 }
 
@@ -603,7 +620,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_by
       }
 }
 
-static int try_launch_rs3(const ConvArgs& a, int64_t n_src, hipStream_t st) {
+static int try_launch_rs3(const ConvArgs& a, const WStride& ws, int64_t n_src, hipStream_t st) {
   if (a.K > RS3_KMAX || a.Kd % 16 || a.Nc % 16 || a.Kd > 64 || a.Nc > 64) return -1;
   const uint64_t xb = (uint64_t)n_src * a.Kd * 4, wb = (uint64_t)a.K * a.Nc * a.Kd * 4;
   if (xb >= 0xfffffff0ull || wb >= 0xfffffff0ull) return -1;
@@ -614,7 +631,7 @@ static int try_launch_rs3(const ConvArgs& a, int64_t n_src, hipStream_t st) {
   const int nt = a.Nc / 16, kq = a.Kd / 16;
   float* wf = nullptr;
   if (hipGetSymbolAddress(reinterpret_cast<void**>(&wf), HIP_SYMBOL(g_wfrag)) != hipSuccess) return -1;
-  hipLaunchKernelGGL(k_weight_fragments, dim3(sv_grid_1d((int64_t)a.K * a.Nc * a.Kd / 4, 256)), dim3(256), 0, st, a.Wt, a.K, a.Nc, a.Kd, wf);
+  hipLaunchKernelGGL(k_weight_fragments, dim3(sv_grid_1d((int64_t)a.K * a.Nc * a.Kd / 4, 256)), dim3(256), 0, st, a.Wt, ws, a.K, a.Nc, a.Kd, wf);
 #define RS3_CASE(NTV, KQV)                                                                                                       \
   if (nt == NTV && kq == KQV) {                                                                                                  \
     if (G == 4) hipLaunchKernelGGL((k_spconv_rs3<NTV, KQV, 4>), grid, dim3(256), 0, st, a, (uint32_t)xb, (uint32_t)wb);          \
@@ -677,21 +694,29 @@ __global__ __launch_bounds__(256) void k_spconv_valu(ConvArgs a) {
   }
 }
 
-static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows, int K, int Kd, int Nc,
-                            const float* bias, const float* scale, const float* shift, const float* residual, int relu,
+static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, const int64_t* w_strides, float* Y, int64_t n_rows,
+                            int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift, const float* residual, int relu,
                             const int32_t* tile_order, void* stream);
 
 extern "C" int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
                                           int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
                                           const float* residual, int relu, void* stream) {
-  return gather_gemm_impl(X, n_src, nbr, Wt, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, nullptr, stream);
+  return gather_gemm_impl(X, n_src, nbr, Wt, nullptr, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, nullptr, stream);
 }
 
 extern "C" int sv_sparse_conv_gather_gemm_ordered(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
                                                   int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale,
                                                   const float* shift, const float* residual, int relu, const int32_t* tile_order,
                                                   void* stream) {
-  return gather_gemm_impl(X, n_src, nbr, Wt, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, tile_order, stream);
+  return gather_gemm_impl(X, n_src, nbr, Wt, nullptr, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, tile_order, stream);
+}
+
+extern "C" int sv_sparse_conv_gather_gemm_strided(const float* X, int64_t n_src, const int32_t* nbr, const float* W, int64_t w_stride_k,
+                                                  int64_t w_stride_n, int64_t w_stride_c, float* Y, int64_t n_rows, int K, int Kd, int Nc,
+                                                  const float* bias, const float* scale, const float* shift, const float* residual, int relu,
+                                                  const int32_t* tile_order, void* stream) {
+  const int64_t ws[3] = {w_stride_k, w_stride_n, w_stride_c};
+  return gather_gemm_impl(X, n_src, nbr, W, ws, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, tile_order, stream);
 }
 
 // Input layer (C_in = 3 or 4 point features -> 16 channels, spconv_backbone.py:77-81): HBM-bound -- 4*K bytes of neighbour table and
@@ -736,8 +761,8 @@ __global__ __launch_bounds__(256) void k_spconv_small_cin(ConvArgs a) {
   }
 }
 
-static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows, int K, int Kd, int Nc,
-                            const float* bias, const float* scale, const float* shift, const float* residual, int relu,
+static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, const int64_t* w_strides, float* Y, int64_t n_rows,
+                            int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift, const float* residual, int relu,
                             const int32_t* tile_order, void* stream) {
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Kd > 0 && Nc > 0, "sparse_conv: bad sizes");
   if (n_rows == 0) return SV_OK;
@@ -746,14 +771,26 @@ static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, c
   ConvArgs a{X, nbr, Wt, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc, tile_order};
   hipStream_t st = sv_stream(stream);
   const int nt = Nc / 16;
-  const bool mfma_ok = (Kd % 16 == 0) && (Nc % 16 == 0) && (nt == 1 || nt == 2 || nt == 4 || nt == 8) &&
-                       ((uintptr_t)X % 16 == 0) && ((uintptr_t)Wt % 16 == 0);
+  WStride ws{(int64_t)Nc * Kd, (int64_t)Kd, 1};
+  if (w_strides) ws = WStride{w_strides[0], w_strides[1], w_strides[2]};
+  const bool w_packed = ws.k == (int64_t)Nc * Kd && ws.n == Kd && ws.c == 1;
   static const bool force_v1 = getenv("SEEVCN_SPCONV_V1") != nullptr;
   static const bool use_rs3 = getenv("SEEVCN_SPCONV_NORS3") == nullptr;
-  if (mfma_ok && !force_v1 && use_rs3 && try_launch_rs3(a, n_src, st) == 0) {
+  // the rs3 path re-lays the weights into fragment order anyway: it reads any (K, Nc, Kd) view through its strides
+  if ((Kd % 16 == 0) && (Nc % 16 == 0) && ((uintptr_t)X % 16 == 0) && !force_v1 && use_rs3 && try_launch_rs3(a, ws, n_src, st) == 0) {
     SV_LAUNCH_CHECK();
     return SV_OK;
   }
+  if (!w_packed) {                          // the other kernels read a contiguous (K, Nc, Kd) array
+    const int64_t total = (int64_t)K * Nc * Kd;
+    SV_CHECK_ARG(total <= WPACK_FLOATS, "sparse_conv: a strided weight view of %lld floats does not fit the pack buffer; pass it contiguous", (long long)total);
+    float* wp = nullptr;
+    SV_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&wp), HIP_SYMBOL(g_wpack)));
+    hipLaunchKernelGGL(k_weight_pack, dim3(sv_grid_1d(total, 256)), dim3(256), 0, st, Wt, ws, K, Nc, Kd, wp);
+    a.Wt = Wt = wp;
+  }
+  const bool mfma_ok = (Kd % 16 == 0) && (Nc % 16 == 0) && (nt == 1 || nt == 2 || nt == 4 || nt == 8) &&
+                       ((uintptr_t)X % 16 == 0) && ((uintptr_t)Wt % 16 == 0);
   if (mfma_ok && !force_v1 && try_launch_rs(a, st) == 0) {
     SV_LAUNCH_CHECK();
     return SV_OK;

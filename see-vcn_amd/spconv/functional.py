@@ -130,14 +130,16 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
 
 
 def gather_gemm(x, nbr, wt, n_rows, bias=None, scale=None, shift=None, residual=None, relu=False, tile_order=None):
-    """Y (n_rows, Nc) = epi(sum_k X[nbr[k]] @ wt[k].T); wt is (K, Nc, Kd) contiguous.  tile_order: Rulebook.tile_order(nbr)."""
+    """Y (n_rows, Nc) = epi(sum_k X[nbr[k]] @ wt[k].T); wt is ANY (K, Nc, Kd) float32 view (its strides go to the kernel: no
+    transposing copy of the parameter per call).  tile_order: Rulebook.tile_order(nbr)."""
     lib = _lib.load()
     K, Nc, Kd = wt.shape
-    assert x.shape[1] == Kd and nbr.shape[0] == K
+    assert x.shape[1] == Kd and nbr.shape[0] == K and wt.dtype == torch.float32
     x = x.contiguous()
     y = torch.empty((n_rows, Nc), dtype=torch.float32, device=x.device)
-    rc = lib.sv_sparse_conv_gather_gemm_ordered(_lib.ptr(x) if x.numel() else None, x.shape[0], _lib.ptr(nbr) if nbr.numel() else None, _lib.ptr(wt),
-                                                _lib.ptr(y) if n_rows else None, n_rows, K, Kd, Nc, _lib.ptr(bias), _lib.ptr(scale),
+    sk, sn, sc = wt.stride()
+    rc = lib.sv_sparse_conv_gather_gemm_strided(_lib.ptr(x) if x.numel() else None, x.shape[0], _lib.ptr(nbr) if nbr.numel() else None, ctypes.c_void_p(wt.data_ptr()),
+                                                sk, sn, sc, _lib.ptr(y) if n_rows else None, n_rows, K, Kd, Nc, _lib.ptr(bias), _lib.ptr(scale),
                                                 _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), _lib.ptr(tile_order), _lib.stream())
     _lib.check(rc, "sv_sparse_conv_gather_gemm")
     return y
@@ -162,7 +164,7 @@ class SparseConvFunction(torch.autograd.Function):
     def forward(ctx, features, weight_kio, rulebook):
         _lib.require_cuda(features, weight_kio)
         features = features.contiguous().float()
-        wt = weight_kio.detach().permute(0, 2, 1).contiguous()  # (K, C_out, C_in)
+        wt = weight_kio.detach().permute(0, 2, 1)               # (K, C_out, C_in) view
         out = gather_gemm(features, rulebook.nbr_out, wt, rulebook.n_out, tile_order=rulebook.tile_order(rulebook.nbr_out, wt.shape[2], wt.shape[1]))
         ctx.rulebook = rulebook
         ctx.save_for_backward(features, weight_kio)
@@ -178,7 +180,7 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dX[i] = sum_k dY[nbr_in[k][i]] @ W[k]^T  -> Wt[k][n=c_in][c=c_out] = W[k][c_in][c_out]: weight_kio itself
             tb = rb.table_for_backward_data()
-            gf = gather_gemm(grad_out, tb, weight_kio.detach().contiguous(), rb.n_in, tile_order=rb.tile_order(tb, cout, cin))
+            gf = gather_gemm(grad_out, tb, weight_kio.detach(), rb.n_in, tile_order=rb.tile_order(tb, cout, cin))
         if ctx.needs_input_grad[1]:
             gw = wgrad(features, rb.nbr_out, grad_out, K, cin, cout)
         return gf, gw, None

@@ -14,7 +14,7 @@ def _scratch(channels, device):
 
 class _BatchNormReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, num_batches_tracked=None):
         lib = _lib.load()
         x = x.contiguous()
         n, c = x.shape
@@ -26,7 +26,7 @@ class _BatchNormReLU(torch.autograd.Function):
             mean = invstd = None
         _lib.check(lib.sv_batchnorm_relu_forward(_lib.ptr(x), n, c, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var),
                                                  float(momentum), float(eps), int(training), int(relu), _lib.ptr(_scratch(c, x.device)), _lib.ptr(y),
-                                                 _lib.ptr(mean), _lib.ptr(invstd), _lib.stream()), "sv_batchnorm_relu_forward")
+                                                 _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(num_batches_tracked), _lib.stream()), "sv_batchnorm_relu_forward")
         ctx.relu, ctx.training = relu, training
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         return y
@@ -44,7 +44,7 @@ class _BatchNormReLU(torch.autograd.Function):
         _lib.check(lib.sv_batchnorm_relu_backward(_lib.ptr(x), _lib.ptr(dy), n, c, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(invstd),
                                                   int(ctx.relu), _lib.ptr(_scratch(c, x.device)), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta),
                                                   _lib.stream()), "sv_batchnorm_relu_backward")
-        return dx, (dgamma if gamma is not None else None), (dbeta if beta is not None else None), None, None, None, None, None, None
+        return dx, (dgamma if gamma is not None else None), (dbeta if beta is not None else None), None, None, None, None, None, None, None
 
 
 def fusable(bn, x):
@@ -59,8 +59,7 @@ def batch_norm_relu(bn, x, relu):
     training = bn.training or not bn.track_running_stats
     if training and x.shape[0] == 1:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    nbt = bn.num_batches_tracked if (training and bn.track_running_stats) else None   # incremented inside the kernel chain
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, training, relu)
+    return _BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, training, relu, nbt)
