@@ -68,6 +68,69 @@ __global__ __launch_bounds__(DN_THREADS) void k_dense_write4(const float* __rest
   }
 }
 
+// 64 consecutive cells per workgroup.  The rows of the occupied cells are read once, coalesced, into LDS; then wave w writes the
+// channel planes c = w, w+4, ...: 64 lanes x 4 bytes = two full cache lines per store, zeros and values alike.  No lane ever walks
+// a feature row with a 4-byte stride (k_dense_write4's slow path, which its whole wave waits for).  spatial % 64 == 0.
+constexpr int DT_CELLS = 64;
+__global__ __launch_bounds__(DN_THREADS) void k_dense_write_t(const float* __restrict__ feat, const int32_t* __restrict__ cellmap, int C,
+                                                              int64_t spatial, float* __restrict__ out) {
+  extern __shared__ float s_f[];                       // [slot][C + 1]
+  __shared__ int s_slot[DT_CELLS];
+  __shared__ int s_row[DT_CELLS];
+  __shared__ int s_n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t cell0 = (int64_t)blockIdx.x * DT_CELLS;
+  const int64_t b = cell0 / spatial, s0 = cell0 - b * spatial;
+  if (wave == 0) {
+    const int32_t row = cellmap[cell0 + lane];
+    const unsigned long long occ = __ballot(row >= 0);
+    const int slot = __popcll(occ & ((1ull << lane) - 1));
+    s_slot[lane] = row >= 0 ? slot : -1;
+    if (row >= 0) s_row[slot] = row;
+    if (lane == 0) s_n = __popcll(occ);
+  }
+  __syncthreads();
+  const int n_occ = s_n;
+  const int pitch = C + 1;
+  // rows -> LDS: half a wave per row, float4 per lane
+  for (int slot = tid >> 5; slot < n_occ; slot += DN_THREADS / 32) {
+    const float* f = feat + (int64_t)s_row[slot] * C;
+    for (int c = (tid & 31) * 4; c < C; c += 128) {
+      const float4 v = *reinterpret_cast<const float4*>(f + c);
+      float* d = s_f + slot * pitch + c;
+      d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    }
+  }
+  if (n_occ) __syncthreads();
+  const int slot = s_slot[lane];
+  float* o = out + (b * C) * spatial + s0 + lane;
+  for (int c = wave; c < C; c += DN_THREADS / 64) __builtin_nontemporal_store(slot >= 0 ? s_f[slot * pitch + c] : 0.f, o + (int64_t)c * spatial);
+}
+
+// backward twin: 64 rows per workgroup; reads walk one channel plane at a time (lanes = consecutive sorted cells), the rows leave
+// through LDS as whole 4*C-byte segments instead of 4-byte writes with a 4*C-byte stride.
+__global__ __launch_bounds__(DN_THREADS) void k_dense_gather_t(const float* __restrict__ dense, const int4* __restrict__ coords, int64_t n, int B,
+                                                               int C, int D, int H, int W, float* __restrict__ out) {
+  extern __shared__ float s_f[];                       // [row][C + 1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t spatial = (int64_t)D * H * W;
+  const int64_t i0 = (int64_t)blockIdx.x * 64, i = i0 + lane;
+  const int pitch = C + 1;
+  int64_t base = -1;
+  if (i < n) {
+    const int4 p = coords[i];
+    if (p.x >= 0 && p.x < B && p.y >= 0 && p.y < D && p.z >= 0 && p.z < H && p.w >= 0 && p.w < W)
+      base = (int64_t)p.x * C * spatial + ((int64_t)p.y * H + p.z) * W + p.w;
+  }
+  for (int c = wave; c < C; c += DN_THREADS / 64) s_f[lane * pitch + c] = base >= 0 ? dense[base + (int64_t)c * spatial] : 0.f;
+  __syncthreads();
+  const int rows = (int)((n - i0) < 64 ? (n - i0) : 64);
+  for (int e = tid; e < rows * C; e += DN_THREADS) {
+    const int r = e / C, c = e - r * C;
+    out[(i0 + r) * C + c] = s_f[r * pitch + c];
+  }
+}
+
 extern "C" size_t sv_sparse_to_dense_scratch_bytes(int batch, int D, int H, int W) { return (size_t)batch * D * H * W * sizeof(int32_t); }
 
 extern "C" int sv_sparse_to_dense(const float* features, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W,
@@ -82,7 +145,11 @@ extern "C" int sv_sparse_to_dense(const float* features, const int32_t* coords, 
   if (n > 0)
     hipLaunchKernelGGL(k_cellmap_scatter, dim3(sv_grid_1d(n, DN_THREADS)), dim3(DN_THREADS), 0, st, reinterpret_cast<const int4*>(coords), n,
                        batch, D, H, W, cellmap);
-  if (spatial % 4 == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)cellmap % 16 == 0))
+  const size_t lds_t = (size_t)DT_CELLS * (C + 1) * sizeof(float);
+  if (spatial % DT_CELLS == 0 && C % 4 == 0 && lds_t <= 60 * 1024)
+    hipLaunchKernelGGL(k_dense_write_t, dim3((unsigned)(batch * spatial / DT_CELLS)), dim3(DN_THREADS), lds_t, st, features, cellmap, C, spatial,
+                       out);
+  else if (spatial % 4 == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)cellmap % 16 == 0))
     hipLaunchKernelGGL(k_dense_write4, dim3(sv_grid_1d(batch * spatial / 4, DN_THREADS, 256 * 16)), dim3(DN_THREADS), 0, st, features, cellmap,
                        batch, C, spatial, out);
   else
@@ -113,8 +180,13 @@ extern "C" int sv_dense_to_sparse(const float* dense, const int32_t* coords, int
   SV_CHECK_ARG(n >= 0 && batch > 0 && C > 0 && D > 0 && H > 0 && W > 0, "dense_to_sparse: bad arguments");
   if (n == 0) return SV_OK;
   SV_CHECK_ARG(dense && coords && out, "dense_to_sparse: null pointer");
-  hipLaunchKernelGGL(k_dense_gather, dim3(sv_grid_1d(n * C, DN_THREADS, 256 * 16)), dim3(DN_THREADS), 0, sv_stream(stream), dense,
-                     reinterpret_cast<const int4*>(coords), n, batch, C, D, H, W, out);
+  const size_t lds_t = (size_t)64 * (C + 1) * sizeof(float);
+  if (lds_t <= 60 * 1024)
+    hipLaunchKernelGGL(k_dense_gather_t, dim3((unsigned)sv_div_up(n, 64)), dim3(DN_THREADS), lds_t, sv_stream(stream), dense,
+                       reinterpret_cast<const int4*>(coords), n, batch, C, D, H, W, out);
+  else
+    hipLaunchKernelGGL(k_dense_gather, dim3(sv_grid_1d(n * C, DN_THREADS, 256 * 16)), dim3(DN_THREADS), 0, sv_stream(stream), dense,
+                       reinterpret_cast<const int4*>(coords), n, batch, C, D, H, W, out);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

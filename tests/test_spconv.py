@@ -220,20 +220,23 @@ def test_hip_dense_and_height_compression(cuda, hip_lib):
     import seevcn_amd.spconv as spconv
     from seevcn_amd.pcdet.models.backbones_2d import map_to_bev
     rng = np.random.default_rng(7)
-    batch, shape, c = 3, (2, 50, 44), 128
-    coords = _rand_coords(rng, 1500, batch, shape, clustered=False)
-    feats = rng.normal(size=(len(coords), c)).astype(np.float32)
-    f = torch.from_numpy(feats).to(cuda).requires_grad_(True)
-    t = spconv.SparseConvTensor(f, torch.from_numpy(coords).to(cuda), shape, batch)
-    hc = map_to_bev.__all__["HeightCompression"]({"NUM_BEV_FEATURES": 256})
-    bd = hc({"encoded_spconv_tensor": t, "encoded_spconv_tensor_stride": 8})
-    ref = osp.dense(feats, coords, batch, shape).reshape(batch, c * shape[0], shape[1], shape[2])
-    assert bd["spatial_features"].shape == ref.shape and bd["spatial_features_stride"] == 8
-    assert np.array_equal(bd["spatial_features"].detach().cpu().numpy(), ref)
-    g = rng.normal(size=ref.shape).astype(np.float32)
-    bd["spatial_features"].backward(torch.from_numpy(g).to(cuda))
-    gd = g.reshape(batch, c, *shape)
-    assert np.array_equal(f.grad.cpu().numpy(), gd[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]])
+    # (2,50,44): cells per scene not a multiple of 64 -> 16-byte-store kernel; (2,32,24) -> the transposing 64-cell kernel, sparse and
+    # nearly full; 6 channels -> scalar kernel; 300 channels -> beyond the LDS tile of the transposing kernels
+    for batch, shape, c, n in [(3, (2, 50, 44), 128, 1500), (2, (2, 32, 24), 128, 400), (1, (2, 32, 24), 64, 1500), (2, (1, 16, 16), 6, 40),
+                               (1, (2, 32, 24), 300, 200)]:
+        coords = _rand_coords(rng, n, batch, shape, clustered=False)
+        feats = rng.normal(size=(len(coords), c)).astype(np.float32)
+        f = torch.from_numpy(feats).to(cuda).requires_grad_(True)
+        t = spconv.SparseConvTensor(f, torch.from_numpy(coords).to(cuda), shape, batch)
+        hc = map_to_bev.__all__["HeightCompression"]({"NUM_BEV_FEATURES": c * shape[0]})
+        bd = hc({"encoded_spconv_tensor": t, "encoded_spconv_tensor_stride": 8})
+        ref = osp.dense(feats, coords, batch, shape).reshape(batch, c * shape[0], shape[1], shape[2])
+        assert bd["spatial_features"].shape == ref.shape and bd["spatial_features_stride"] == 8
+        assert np.array_equal(bd["spatial_features"].detach().cpu().numpy(), ref)
+        g = rng.normal(size=ref.shape).astype(np.float32)
+        bd["spatial_features"].backward(torch.from_numpy(g).to(cuda))
+        gd = g.reshape(batch, c, *shape)
+        assert np.array_equal(f.grad.cpu().numpy(), gd[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]])
 
 
 @pytest.mark.gpu
