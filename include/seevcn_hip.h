@@ -116,10 +116,10 @@ size_t sv_rulebook_scratch_bytes(int64_t n_in, int64_t ncells);
 int sv_rulebook_subm(const int32_t* coords, int64_t n, int batch, const int32_t* shape_host,
                      const int32_t* ksize_host, const int32_t* dilation_host, void* index_ws, void* scratch,
                      int32_t* nbr, void* stream);
-/* Same table through a dense cell -> row map (int32 per cell, sv_cellmap_persistent_bytes(batch*Z*Y*X) bytes, ALL ZERO on entry and
- * on return): 3 launches instead of 8, no atomics.  For grids whose map fits comfortably in the 288 GB of HBM (16 KITTI scenes at
+/* Same table through a dense cell -> row map (int32 per cell in 4x4x8-cell tiles, sv_cellmap_persistent_bytes(batch, shape) bytes,
+ * ALL ZERO on entry and on return): 3 launches instead of 8, no atomics.  For grids whose map fits comfortably in the 288 GB of HBM (16 KITTI scenes at
  * 5 cm: 5.9 GB); callers fall back to sv_rulebook_subm for larger grids. */
-size_t sv_cellmap_persistent_bytes(int64_t ncells);
+size_t sv_cellmap_persistent_bytes(int batch, const int32_t* spatial_shape);
 int sv_rulebook_subm_cellmap(const int32_t* coords, int64_t n, int batch, const int32_t* spatial_shape, const int32_t* ksize,
                              const int32_t* dilation, void* cellmap, int32_t* nbr, void* stream);
 /* SparseConv3d rulebook, phase 1: output coordinates in canonical (ascending ((b*Z+z)*Y+y)*X+x) order and the

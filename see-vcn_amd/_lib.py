@@ -38,7 +38,7 @@ SIGNATURES = {
     "sv_conv_out_shape": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_rulebook_scratch_bytes": (c_sz, [c_i64, c_i64]),
     "sv_rulebook_subm": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "sv_cellmap_persistent_bytes": (c_sz, [c_i64]),
+    "sv_cellmap_persistent_bytes": (c_sz, [c_i, c_p]),
     "sv_rulebook_subm_cellmap": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_rulebook_sparse": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "sv_rulebook_invert": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p]),

@@ -83,8 +83,9 @@ def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 
     K = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
     ncells = int(batch_size) * int(spatial_shape[0]) * int(spatial_shape[1]) * int(spatial_shape[2])
     nbr = torch.empty((K, n), dtype=torch.int32, device=dev)
-    if lib.sv_cellmap_persistent_bytes(ncells) <= CELLMAP_MAX_BYTES:
-        cellmap = _lib.workspace.persistent(f"rb_cellmap_{tuple(spatial_shape)}_{batch_size}", lib.sv_cellmap_persistent_bytes(ncells), dev)
+    map_bytes = lib.sv_cellmap_persistent_bytes(int(batch_size), _i3(spatial_shape))
+    if map_bytes <= CELLMAP_MAX_BYTES:
+        cellmap = _lib.workspace.persistent(f"rb_cellmap_{tuple(spatial_shape)}_{batch_size}", map_bytes, dev)
         rc = lib.sv_rulebook_subm_cellmap(_lib.ptr(indices), n, int(batch_size), _i3(spatial_shape), _i3(ksize), _i3(dilation),
                                           _lib.ptr(cellmap), _lib.ptr(nbr), _lib.stream())
         _lib.check(rc, "sv_rulebook_subm_cellmap")
