@@ -155,11 +155,25 @@ int sv_sparse_conv_gather_gemm_ordered(const float* X, int64_t n_src, const int3
                                        int relu, const int32_t* tile_order, void* stream);
 /* Same, with the weights given as ANY (K, Nc, Kd) view of a tensor: element strides (w_stride_k, w_stride_n, w_stride_c).  The
  * parameter of spconv-2.x layout (C_out, kz, ky, kx, C_in) serves the forward (Nc = C_out: strides K*C_in... see
- * seevcn_amd/spconv/functional.py) and the data gradient (Nc = C_in) without a transposing copy per call. */
+ * seevcn_amd/spconv/functional.py) and the data gradient (Nc = C_in) without a transposing copy per call.
+ * row_perm (n_rows int32, may be null): tile position p stands for row row_perm[p] of the table and of the output -- 16
+ * consecutive positions share their neighbour mask (sv_conv_group_rows); table_k_reversed: offset k reads table
+ * row K-1-k (a submanifold table serving its own data gradient, no flipped copy).  Only the rs3 kernel (C_in, C_out multiples of 16
+ * up to 64, K <= 27) takes these two. */
 int sv_sparse_conv_gather_gemm_strided(const float* X, int64_t n_src, const int32_t* nbr, const float* W, int64_t w_stride_k,
                                        int64_t w_stride_n, int64_t w_stride_c, float* Y, int64_t n_rows, int K, int Kd, int Nc,
                                        const float* bias, const float* scale, const float* shift, const float* residual, int relu,
-                                       const int32_t* tile_order, void* stream);
+                                       const int32_t* tile_order, const int32_t* row_perm, int table_k_reversed, void* stream);
+/* masks[row] = bit k set iff nbr[k][row] >= 0 (K <= 31): the sort key of the grouping above. */
+int sv_conv_row_masks(const int32_t* nbr, int64_t n_rows, int K, int32_t* masks, void* stream);
+/* Groups a table's columns by neighbour-mask class (counting sort, 3 launches): masks (n_rows) and row_perm (n_rows), position p
+ * of the grouped order is row row_perm[p].  The table is not rewritten: the conv kernel reads it through row_perm.  persistent:
+ * sv_conv_group_persistent_bytes() bytes, all zero before the first call and left consistent by every call.
+ * sv_conv_tile_order_grouped: the work-balanced tile order of the grouped tiles from the masks alone (no pass over the table). */
+size_t sv_conv_group_persistent_bytes(void);
+int sv_conv_group_rows(const int32_t* nbr, int64_t n_rows, int K, void* persistent, int32_t* masks, int32_t* row_perm, void* stream);
+int sv_conv_tile_order_grouped(const int32_t* masks, const int32_t* row_perm, int64_t n_rows, int tiles_per_wave, void* scratch,
+                               int32_t* tile_order, void* stream);
 /* dW (K, C_in, C_out) = sum_o X[nbr[k][o]]^T dY[o]; deterministic two-stage reduction */
 size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout);
 int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,

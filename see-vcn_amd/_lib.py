@@ -45,7 +45,11 @@ SIGNATURES = {
     "sv_rulebook_pair_counts": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
     "sv_sparse_conv_gather_gemm": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p]),
     "sv_sparse_conv_gather_gemm_ordered": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
-    "sv_sparse_conv_gather_gemm_strided": (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "sv_sparse_conv_gather_gemm_strided": (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p]),
+    "sv_conv_group_persistent_bytes": (c_sz, []),
+    "sv_conv_group_rows": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p]),
+    "sv_conv_tile_order_grouped": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),
+    "sv_conv_row_masks": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
     "sv_conv_tiles_per_wave": (c_i, [c_i64, c_i, c_i]),
     "sv_conv_tile_order_scratch_bytes": (c_sz, [c_i64]),
     "sv_conv_tile_order_bytes": (c_sz, [c_i64]),

@@ -40,6 +40,8 @@ struct ConvArgs {
   int64_t n_rows;
   int K, Kd, Nc;
   const int32_t* tile_order;  // [wave * 4 + slot] -> 16-row tile (sv_conv_tile_order) or null: tiles by position
+  const int32_t* row_perm;    // table column p produces output row row_perm[p] (sv_conv_group_rows), or null: p itself
+  int k_flip;                 // read table row K-1-k for offset k (a submanifold table serving its own data gradient)
 };
 
 __device__ __forceinline__ float conv_epilogue(float v, int col, int64_t row, const ConvArgs& a) {
@@ -305,6 +307,158 @@ __global__ __launch_bounds__(256) void k_weight_pack(const float* __restrict__ w
   }
 }
 
+// Neighbour mask of every row of a table: bit k set iff nbr[k][row] >= 0 (K <= 32).  Rows with equal masks make 16-row tiles whose
+// every executed (tile, offset) step is useful; tiles of consecutive rows waste 40-80 % of them.
+__global__ __launch_bounds__(256) void k_row_masks(const int32_t* __restrict__ nbr, int64_t n_rows, int K, int32_t* __restrict__ masks) {
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n_rows; row += (int64_t)gridDim.x * 256) {
+    unsigned m = 0;
+    for (int k0 = 0; k0 < K; k0 += 9) {
+      int32_t j[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) j[u] = k0 + u < K ? nbr[(int64_t)(k0 + u) * n_rows + row] : -1;
+#pragma unroll
+      for (int u = 0; u < 9; ++u) m |= j[u] >= 0 ? (1u << (k0 + u)) : 0u;
+    }
+    masks[row] = (int32_t)m;
+  }
+}
+
+extern "C" int sv_conv_row_masks(const int32_t* nbr, int64_t n_rows, int K, int32_t* masks, void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && K > 0 && K <= 31, "sv_conv_row_masks: 1 <= K <= 31 (got %d)", K);
+  if (n_rows == 0) return SV_OK;
+  SV_CHECK_ARG(nbr && masks, "sv_conv_row_masks: null pointer");
+  hipLaunchKernelGGL(k_row_masks, dim3(sv_grid_1d(n_rows, 256)), dim3(256), 0, sv_stream(stream), nbr, n_rows, K, masks);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// Regrouping of a table's columns by neighbour mask without a sort: a counting sort over GR_BUCKETS classes of the mask
+// (group_key).  Three launches: masks + class histogram, an exclusive scan over the classes, and the placement row_perm[p] = row.
+// The table itself is NOT rewritten: the conv kernel reads its 16 x 27 entries per tile through row_perm (a 2 us start-up per
+// wave instead of a 50 MB pass per table).  Histogram and cursors are bumped once per (wave, class) -- lanes with equal keys are
+// found with ballots -- so the hot classes (one mask covers ~20 % of the rows) do not serialise on one address.
+// `hist` is persistent and all-zero between calls.
+constexpr int GR_BUCKETS = 4096, GR_THREADS = 256;
+__device__ __forceinline__ int group_key(unsigned mask) {
+  // equal masks -> equal class; classes ordered by the number of active offsets first (neighbouring tiles then cost the same and
+  // mixed tiles at class borders waste little), a 7-bit hash of the mask inside one count
+  return (__popc(mask) << 7) | (int)((mask * 2654435761u) >> 25);
+}
+struct GroupArgs {
+  const int32_t* nbr;
+  int64_t n_rows;
+  int K;
+  int32_t* masks;     // out (n_rows)
+  int32_t* hist;      // [0..B): class counts (zero on entry, zeroed again by the scan); [B..2B): class starts; [2B..3B): cursors
+  int32_t* perm;      // out (n_rows)
+};
+
+// "for every distinct key among the live lanes": this lane's rank inside its key group, the group's size and its first lane
+__device__ __forceinline__ void wave_key_groups(int key, bool live, int& rank, int& size, int& first_lane) {
+  unsigned long long todo = __ballot(live);
+  const int lane = threadIdx.x & 63;
+  rank = 0, size = 0, first_lane = lane;
+  while (todo) {
+    const int first = __ffsll((long long)todo) - 1;
+    const int k0 = __shfl(key, first);
+    const unsigned long long same = __ballot(live && key == k0);
+    if (live && key == k0) {
+      rank = __popcll(same & ((1ull << lane) - 1));
+      size = __popcll(same);
+      first_lane = first;
+    }
+    todo &= ~same;
+  }
+}
+
+__global__ __launch_bounds__(GR_THREADS) void k_group_masks(GroupArgs a) {
+  const int64_t row = (int64_t)blockIdx.x * GR_THREADS + threadIdx.x;
+  const bool live = row < a.n_rows;
+  unsigned m = 0;
+  if (live) {
+    for (int k0 = 0; k0 < a.K; k0 += 9) {
+      int32_t j[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) j[u] = k0 + u < a.K ? a.nbr[(int64_t)(k0 + u) * a.n_rows + row] : -1;
+#pragma unroll
+      for (int u = 0; u < 9; ++u) m |= j[u] >= 0 ? (1u << (k0 + u)) : 0u;
+    }
+    a.masks[row] = (int32_t)m;
+  }
+  int rank, size, first_lane;
+  const int key = group_key(m);
+  wave_key_groups(key, live, rank, size, first_lane);
+  if (live && rank == 0) atomicAdd(&a.hist[key], size);
+}
+
+__global__ __launch_bounds__(1024) void k_group_scan(GroupArgs a) {
+  __shared__ int s_part[1024];
+  const int tid = threadIdx.x;
+  int v[4], sum = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] = a.hist[tid * 4 + u], sum += v[u];
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan of the 1024 partial sums
+    const int t = tid >= d ? s_part[tid - d] : 0;
+    __syncthreads();
+    s_part[tid] += t;
+    __syncthreads();
+  }
+  int run = s_part[tid] - sum;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    a.hist[GR_BUCKETS + tid * 4 + u] = run;
+    a.hist[2 * GR_BUCKETS + tid * 4 + u] = 0;
+    a.hist[tid * 4 + u] = 0;
+    run += v[u];
+  }
+}
+
+__global__ __launch_bounds__(GR_THREADS) void k_group_place(GroupArgs a) {
+  const int64_t row = (int64_t)blockIdx.x * GR_THREADS + threadIdx.x;
+  const bool live = row < a.n_rows;
+  const int key = live ? group_key((unsigned)a.masks[row]) : 0;
+  int rank, size, first_lane;
+  wave_key_groups(key, live, rank, size, first_lane);
+  int base = 0;
+  if (live && rank == 0) base = a.hist[GR_BUCKETS + key] + atomicAdd(&a.hist[2 * GR_BUCKETS + key], size);
+  base = __shfl(base, first_lane);                 // the group's first lane holds its range
+  if (live) a.perm[base + rank] = (int32_t)row;
+}
+
+// cost of the regrouped tiles from the masks alone: active offsets of tile t = popcount(OR of its 16 rows' masks)
+__global__ __launch_bounds__(256) void k_tile_cost_masks(const int32_t* __restrict__ masks, const int32_t* __restrict__ perm, int64_t n_rows,
+                                                         int64_t n_tiles, uint8_t* __restrict__ cost) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned m = p < n_rows ? (unsigned)masks[perm[p]] : 0u;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) m |= __shfl_xor(m, off);
+  const int64_t t = p >> 4;
+  if ((threadIdx.x & 15) == 0 && t < n_tiles) {
+    const int c = __popc(m);
+    cost[t] = (uint8_t)(c > 31 ? 31 : c);
+  }
+}
+
+extern "C" size_t sv_conv_group_persistent_bytes(void) { return (size_t)3 * GR_BUCKETS * sizeof(int32_t); }
+
+extern "C" int sv_conv_group_rows(const int32_t* nbr, int64_t n_rows, int K, void* persistent, int32_t* masks, int32_t* row_perm,
+                                  void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && K > 0 && K <= 27, "sv_conv_group_rows: 1 <= K <= 27 (got %d)", K);
+  if (n_rows == 0) return SV_OK;
+  SV_CHECK_ARG(nbr && persistent && masks && row_perm, "sv_conv_group_rows: null pointer");
+  GroupArgs a;
+  a.nbr = nbr, a.n_rows = n_rows, a.K = K, a.masks = masks, a.hist = static_cast<int32_t*>(persistent), a.perm = row_perm;
+  const int wgs = sv_div_up(n_rows, GR_THREADS);
+  hipStream_t st = sv_stream(stream);
+  hipLaunchKernelGGL(k_group_masks, dim3(wgs), dim3(GR_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(k_group_place, dim3(wgs), dim3(GR_THREADS), 0, st, a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 // Work-balanced tile assignment.  A 16-row tile costs as many MFMA steps as it has kernel offsets with at least one neighbour
 // (9 / 18 / 27 for the bench layers, depending on how many z-slices it spans); with tiles dealt to waves by position the
 // busiest wave had 1.8x the mean work and set the kernel time.  Tiles are counting-sorted by cost and dealt to the waves in
@@ -479,6 +633,24 @@ extern "C" int sv_conv_tile_order(const int32_t* nbr, int64_t n_rows, int K, int
   return SV_OK;
 }
 
+extern "C" int sv_conv_tile_order_grouped(const int32_t* masks, const int32_t* row_perm, int64_t n_rows, int tiles_per_wave, void* scratch,
+                                          int32_t* tile_order, void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && tiles_per_wave >= 2 && tiles_per_wave <= 4, "sv_conv_tile_order_grouped: bad sizes");
+  if (n_rows == 0) return SV_OK;
+  SV_CHECK_ARG(masks && row_perm && scratch && tile_order, "sv_conv_tile_order_grouped: null pointer");
+  TileOrderArgs a{};
+  a.n_rows = n_rows, a.n_tiles = (n_rows + 15) / 16, a.G = tiles_per_wave;
+  SV_CHECK_ARG(a.n_tiles <= TO_ONE_WG_TILES, "sv_conv_tile_order_grouped: at most %d tiles", TO_ONE_WG_TILES);
+  a.n_waves = (a.n_tiles + a.G - 1) / a.G;
+  a.cost = reinterpret_cast<uint8_t*>(scratch) + 64 * sizeof(int32_t);
+  a.tile_of = tile_order;
+  hipStream_t st = sv_stream(stream);
+  hipLaunchKernelGGL(k_tile_cost_masks, dim3(sv_div_up(a.n_tiles * 16, 256)), dim3(256), 0, st, masks, row_perm, n_rows, a.n_tiles, a.cost);
+  hipLaunchKernelGGL(k_tile_deal_one, dim3(1), dim3(1024), 0, st, a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 template <int NT, int KQ, int RS_G>
 __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_bytes, uint32_t w_bytes) {
   constexpr int Kd = KQ * 16, Nc = NT * 16, NLOAD = RS_G + NT;
@@ -501,10 +673,11 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_by
   unsigned maskreg = 0;
   {
     const int g = (lane >> 4) % RS_G;
-    const int64_t r = tile_row0(g) + li;
-    const bool valid = (lane >> 4) < RS_G && r < a.n_rows;
+    const int64_t p = tile_row0(g) + li;
+    const bool valid = (lane >> 4) < RS_G && p < a.n_rows;
+    const int64_t r = (valid && a.row_perm) ? (int64_t)a.row_perm[p] : p;     // regrouped tiles: 16 arbitrary rows
     for (int k = 0; k < a.K; ++k) {
-      const int32_t j = valid ? a.nbr[(int64_t)k * a.n_rows + r] : -1;
+      const int32_t j = valid ? a.nbr[(int64_t)(a.k_flip ? a.K - 1 - k : k) * a.n_rows + r] : -1;
       s_idx[k][lane] = j;
       const unsigned long long vote = __ballot(j >= 0);
       unsigned m = 0;
@@ -614,9 +787,12 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_by
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t row = tile_row0(g) + kk * 4 + r;
+        const int64_t p = tile_row0(g) + kk * 4 + r;
         const int col = t * 16 + li;
-        if (row < a.n_rows) a.Y[row * Nc + col] = conv_epilogue(acc[g][t][r], col, row, a);
+        if (p < a.n_rows) {
+          const int64_t row = a.row_perm ? (int64_t)a.row_perm[p] : p;
+          a.Y[row * Nc + col] = conv_epilogue(acc[g][t][r], col, row, a);
+        }
       }
 }
 
@@ -696,27 +872,28 @@ __global__ __launch_bounds__(256) void k_spconv_valu(ConvArgs a) {
 
 static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, const int64_t* w_strides, float* Y, int64_t n_rows,
                             int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift, const float* residual, int relu,
-                            const int32_t* tile_order, void* stream);
+                            const int32_t* tile_order, const int32_t* row_perm, int table_k_reversed, void* stream);
 
 extern "C" int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
                                           int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
                                           const float* residual, int relu, void* stream) {
-  return gather_gemm_impl(X, n_src, nbr, Wt, nullptr, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, nullptr, stream);
+  return gather_gemm_impl(X, n_src, nbr, Wt, nullptr, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int sv_sparse_conv_gather_gemm_ordered(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
                                                   int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale,
                                                   const float* shift, const float* residual, int relu, const int32_t* tile_order,
                                                   void* stream) {
-  return gather_gemm_impl(X, n_src, nbr, Wt, nullptr, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, tile_order, stream);
+  return gather_gemm_impl(X, n_src, nbr, Wt, nullptr, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, tile_order, nullptr, 0, stream);
 }
 
 extern "C" int sv_sparse_conv_gather_gemm_strided(const float* X, int64_t n_src, const int32_t* nbr, const float* W, int64_t w_stride_k,
                                                   int64_t w_stride_n, int64_t w_stride_c, float* Y, int64_t n_rows, int K, int Kd, int Nc,
                                                   const float* bias, const float* scale, const float* shift, const float* residual, int relu,
-                                                  const int32_t* tile_order, void* stream) {
+                                                  const int32_t* tile_order, const int32_t* row_perm, int table_k_reversed, void* stream) {
   const int64_t ws[3] = {w_stride_k, w_stride_n, w_stride_c};
-  return gather_gemm_impl(X, n_src, nbr, W, ws, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, tile_order, stream);
+  return gather_gemm_impl(X, n_src, nbr, W, ws, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, tile_order, row_perm,
+                          table_k_reversed, stream);
 }
 
 // Input layer (C_in = 3 or 4 point features -> 16 channels, spconv_backbone.py:77-81): HBM-bound -- 4*K bytes of neighbour table and
@@ -763,12 +940,12 @@ __global__ __launch_bounds__(256) void k_spconv_small_cin(ConvArgs a) {
 
 static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, const int64_t* w_strides, float* Y, int64_t n_rows,
                             int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift, const float* residual, int relu,
-                            const int32_t* tile_order, void* stream) {
+                            const int32_t* tile_order, const int32_t* row_perm, int table_k_reversed, void* stream) {
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Kd > 0 && Nc > 0, "sparse_conv: bad sizes");
   if (n_rows == 0) return SV_OK;
   SV_CHECK_ARG(X && nbr && Wt && Y, "sparse_conv: null pointer");
   SV_CHECK_ARG((scale == nullptr) == (shift == nullptr), "sparse_conv: scale and shift go together");
-  ConvArgs a{X, nbr, Wt, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc, tile_order};
+  ConvArgs a{X, nbr, Wt, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc, tile_order, row_perm, table_k_reversed};
   hipStream_t st = sv_stream(stream);
   const int nt = Nc / 16;
   WStride ws{(int64_t)Nc * Kd, (int64_t)Kd, 1};
@@ -781,6 +958,7 @@ static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, c
     SV_LAUNCH_CHECK();
     return SV_OK;
   }
+  SV_CHECK_ARG(!row_perm && !table_k_reversed, "sparse_conv: row_perm / table_k_reversed (grouped table) need the rs3 kernel: C_in, C_out multiples of 16 up to 64, K <= %d", RS3_KMAX);
   if (!w_packed) {                          // the other kernels read a contiguous (K, Nc, Kd) array
     const int64_t total = (int64_t)K * Nc * Kd;
     SV_CHECK_ARG(total <= WPACK_FLOATS, "sparse_conv: a strided weight view of %lld floats does not fit the pack buffer; pass it contiguous", (long long)total);

@@ -29,6 +29,7 @@ class Rulebook:
         self.n_in, self.n_out, self.subm, self.ksize = n_in, n_out, subm, ksize
         self._nbr_in_subm = None
         self._orders = {}
+        self._groups = {}
 
     @property
     def K(self):
@@ -61,6 +62,43 @@ class Rulebook:
             self._orders[key] = (order, table)       # keep the table alive with its order
         return self._orders[key][0]
 
+    def plan(self, direction, kd, nc):
+        """(table, tile_order, row_perm, table_k_reversed) for a (kd -> nc)-channel gather-GEMM over this rulebook; direction 'fwd' (output-major
+        table) or 'bwd' (input-major table).  When the MFMA kernel applies (channels multiples of 16 up to 64, K <= 27) the
+        table's columns are regrouped by neighbour mask: row_perm[p] is the row that column p of the returned table produces.
+        A 16-row tile executes an offset when ANY of its rows has that neighbour; tiles of consecutive rows waste 40-80 % of
+        those steps (70 % on a strided conv's input-major table, whose masks are a function of coordinate parity), tiles of
+        equal-mask rows almost none.  Computed once per table and reused by every launch on it."""
+        assert direction in ("fwd", "bwd")
+        kd, nc = int(kd), int(nc)
+        n_rows = self.n_out if direction == "fwd" else self.n_in
+        groupable = (GROUP_ROWS and kd % 16 == 0 and nc % 16 == 0 and kd <= 64 and nc <= 64 and self.K <= 27 and 64 <= n_rows <= 16 * 65536)
+        if not groupable:
+            table = self.nbr_out if direction == "fwd" else self.table_for_backward_data()
+            return table, self.tile_order(table, kd, nc), None, False
+        key = "fwd" if (direction == "fwd" or self.subm) else "bwd"    # a submanifold table serves its own data gradient reversed
+        lib = _lib.load()
+        base = self.nbr_out if key == "fwd" else self.nbr_in
+        if key not in self._groups:
+            perm = torch.empty((n_rows,), dtype=torch.int32, device=base.device)
+            masks = torch.empty((n_rows,), dtype=torch.int32, device=base.device)
+            hist = _lib.workspace.persistent("conv_group_hist", lib.sv_conv_group_persistent_bytes(), base.device)
+            _lib.check(lib.sv_conv_group_rows(_lib.ptr(base), n_rows, self.K, _lib.ptr(hist), _lib.ptr(masks), _lib.ptr(perm), _lib.stream()),
+                       "sv_conv_group_rows")
+            self._groups[key] = (perm, masks)
+        perm, masks = self._groups[key]
+        if (kd // 16) * (nc // 16) < 4:
+            return base, None, perm, (direction == "bwd" and self.subm)       # load-bound layers: equal-mask tiles already cost the same
+        g = lib.sv_conv_tiles_per_wave(n_rows, kd, nc)
+        okey = ("grouped", key, g)
+        if okey not in self._orders:
+            order = torch.empty((lib.sv_conv_tile_order_bytes(n_rows) // 4,), dtype=torch.int32, device=base.device)
+            scratch = _lib.workspace.scratch("tile_order", lib.sv_conv_tile_order_scratch_bytes(n_rows), base.device)
+            _lib.check(lib.sv_conv_tile_order_grouped(_lib.ptr(masks), _lib.ptr(perm), n_rows, g, _lib.ptr(scratch), _lib.ptr(order), _lib.stream()),
+                       "sv_conv_tile_order_grouped")
+            self._orders[okey] = (order, base)
+        return base, self._orders[okey][0], perm, (direction == "bwd" and self.subm)
+
     def pair_counts(self):
         lib = _lib.load()
         counts = torch.empty((self.K,), dtype=torch.int32, device=self.nbr_out.device)
@@ -71,6 +109,11 @@ class Rulebook:
 
 # dense cell -> row maps (4 B per cell) up to this size replace the rank dictionary in submanifold rulebooks (MI355X: 288 GB of HBM)
 CELLMAP_MAX_BYTES = int(os.environ.get("SEEVCN_CELLMAP_MAX_BYTES", 24 << 30))
+# Group table rows by neighbour mask before the MFMA gather-GEMM (Rulebook.plan).  OFF by default: measured on the bench workload the
+# conv kernels get 15-45 % faster (64->64 submanifold layer 185 -> 143 us with an exact sort by mask, 152-158 us with the
+# counting-sort classes built here) but the grouping passes (40 + 33 us per table, hot-class atomics) cost more than that saves
+# per step (7.67 vs 7.25 ms).  DESIGN.md 3 has the numbers; the path is kept correct by tests/test_spconv.py.
+GROUP_ROWS = os.environ.get("SEEVCN_GROUP_ROWS", "0") == "1"
 
 
 def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1)):
@@ -130,7 +173,8 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
     return Rulebook(nbr_out, nbr_in, out_coords, oshape, n_in, n_out, False, list(ksize))
 
 
-def gather_gemm(x, nbr, wt, n_rows, bias=None, scale=None, shift=None, residual=None, relu=False, tile_order=None):
+def gather_gemm(x, nbr, wt, n_rows, bias=None, scale=None, shift=None, residual=None, relu=False, tile_order=None, row_perm=None,
+                table_k_reversed=False):
     """Y (n_rows, Nc) = epi(sum_k X[nbr[k]] @ wt[k].T); wt is ANY (K, Nc, Kd) float32 view (its strides go to the kernel: no
     transposing copy of the parameter per call).  tile_order: Rulebook.tile_order(nbr)."""
     lib = _lib.load()
@@ -141,7 +185,7 @@ def gather_gemm(x, nbr, wt, n_rows, bias=None, scale=None, shift=None, residual=
     sk, sn, sc = wt.stride()
     rc = lib.sv_sparse_conv_gather_gemm_strided(_lib.ptr(x) if x.numel() else None, x.shape[0], _lib.ptr(nbr) if nbr.numel() else None, ctypes.c_void_p(wt.data_ptr()),
                                                 sk, sn, sc, _lib.ptr(y) if n_rows else None, n_rows, K, Kd, Nc, _lib.ptr(bias), _lib.ptr(scale),
-                                                _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), _lib.ptr(tile_order), _lib.stream())
+                                                _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), _lib.ptr(tile_order), _lib.ptr(row_perm), int(bool(table_k_reversed)), _lib.stream())
     _lib.check(rc, "sv_sparse_conv_gather_gemm")
     return y
 
@@ -166,7 +210,8 @@ class SparseConvFunction(torch.autograd.Function):
         _lib.require_cuda(features, weight_kio)
         features = features.contiguous().float()
         wt = weight_kio.detach().permute(0, 2, 1)               # (K, C_out, C_in) view
-        out = gather_gemm(features, rulebook.nbr_out, wt, rulebook.n_out, tile_order=rulebook.tile_order(rulebook.nbr_out, wt.shape[2], wt.shape[1]))
+        table, order, perm, rev = rulebook.plan("fwd", wt.shape[2], wt.shape[1])
+        out = gather_gemm(features, table, wt, rulebook.n_out, tile_order=order, row_perm=perm, table_k_reversed=rev)
         ctx.rulebook = rulebook
         ctx.save_for_backward(features, weight_kio)
         return out
@@ -180,8 +225,8 @@ class SparseConvFunction(torch.autograd.Function):
         gf = gw = None
         if ctx.needs_input_grad[0]:
             # dX[i] = sum_k dY[nbr_in[k][i]] @ W[k]^T  -> Wt[k][n=c_in][c=c_out] = W[k][c_in][c_out]: weight_kio itself
-            tb = rb.table_for_backward_data()
-            gf = gather_gemm(grad_out, tb, weight_kio.detach(), rb.n_in, tile_order=rb.tile_order(tb, cout, cin))
+            table, order, perm, rev = rb.plan("bwd", cout, cin)
+            gf = gather_gemm(grad_out, table, weight_kio.detach(), rb.n_in, tile_order=order, row_perm=perm, table_k_reversed=rev)
         if ctx.needs_input_grad[1]:
             gw = wgrad(features, rb.nbr_out, grad_out, K, cin, cout)
         return gf, gw, None

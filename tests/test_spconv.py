@@ -167,6 +167,35 @@ def test_hip_subm_rulebook_bit_exact(cuda, hip_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64)])
+def test_hip_conv_with_mask_grouped_tiles_is_bit_identical(cuda, hip_lib, cin, cout):
+    """Rulebook.plan with GROUP_ROWS: 16-row tiles of equal neighbour mask, table read through row_perm, submanifold data gradient on the
+    reversed table -- same summation order per output row, so outputs and gradients must equal the ungrouped run bit for bit."""
+    import seevcn_amd.spconv as spconv
+    from seevcn_amd.spconv import functional as Fsp
+    rng = np.random.default_rng(9)
+    batch, shape = 2, (9, 48, 40)
+    coords = _rand_coords(rng, 2500, batch, shape)
+    feats = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    for subm in (True, False):
+        res = []
+        for grouped in (False, True):
+            saved, Fsp.GROUP_ROWS = Fsp.GROUP_ROWS, grouped
+            try:
+                torch.manual_seed(0)
+                conv = (spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="k") if subm
+                        else spconv.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False)).to(cuda)
+                f = torch.from_numpy(feats).to(cuda).requires_grad_(True)
+                out = conv(spconv.SparseConvTensor(f, torch.from_numpy(coords).to(cuda), list(shape), batch)).features
+                out.square().sum().backward()
+                res.append((out.detach().cpu().numpy(), f.grad.cpu().numpy(), conv.weight.grad.cpu().numpy()))
+            finally:
+                Fsp.GROUP_ROWS = saved
+        for a, b in zip(*res):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout", [(3, 16), (4, 16), (16, 16), (16, 32), (32, 64), (64, 64), (64, 128), (128, 128), (5, 7)])
 def test_hip_conv_forward_backward_vs_oracle(cuda, hip_lib, cin, cout):
     import seevcn_amd.spconv as spconv

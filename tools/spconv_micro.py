@@ -78,13 +78,13 @@ def main():
             c, shape = rb.out_indices, rb.out_shape
             continue
         tf = td = tw = float("nan")
+        plain = os.environ.get("ORDER", "1") != "1"
         if mode in ("all", "fwd"):
-            order = rb.tile_order(rb.nbr_out, cin, cout) if os.environ.get("ORDER", "1") == "1" else None
-            tf = timeit(lambda: Fsp.gather_gemm(x, rb.nbr_out, wt, rb.n_out, tile_order=order))
+            table, order, perm, rev = (rb.nbr_out, None, None, False) if plain else rb.plan("fwd", cin, cout)
+            tf = timeit(lambda: Fsp.gather_gemm(x, table, wt, rb.n_out, tile_order=order, row_perm=perm, table_k_reversed=rev))
         if mode in ("all", "bwd"):
-            tb_ = rb.table_for_backward_data()
-            order_b = rb.tile_order(tb_, cout, cin) if os.environ.get("ORDER", "1") == "1" else None
-            td = timeit(lambda: Fsp.gather_gemm(dy, tb_, w, rb.n_in, tile_order=order_b))
+            table_b, order_b, perm_b, rev_b = (rb.table_for_backward_data(), None, None, False) if plain else rb.plan("bwd", cout, cin)
+            td = timeit(lambda: Fsp.gather_gemm(dy, table_b, w, rb.n_in, tile_order=order_b, row_perm=perm_b, table_k_reversed=rev_b))
         if mode in ("all", "wgrad"):
             tw = timeit(lambda: Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout))
         fl = 2.0 * pairs * cin * cout
