@@ -71,6 +71,7 @@ def loss_fn(bd):
 def allreduce_grads(params, world):
     if world == 1:
         return
+    params = [p for p in params if p.grad is not None]
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat)                       # RCCL ring over xGMI; 0.71 M fp32 = one 2.8 MB bucket
     flat.div_(world)
