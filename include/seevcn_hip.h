@@ -380,6 +380,13 @@ int sv_crop_points_in_boxes(const float* points, int64_t n_points, int row_strid
 int sv_project_lidar_to_image_kitti(const float* points, int64_t n_points, int row_stride, const double* v2c, const double* r0,
                                     const double* p, int img_w, int img_h, double min_dist, int32_t* uv, uint8_t* fov, float* rect,
                                     void* stream);
+/* CustomDatasetObjects.map_pointcloud_to_image (datasets/custom_dataset/custom_dataset_objects.py:141-192): extrinsic (3x4), intrinsic
+ * (3x3), distcoeff (5) HOST pointers row-major; camera_model 0 = "pinhole" (k1,k2,p1,p2,k3), 1 = "equidistant" (4 coefficients).
+ * uvd_int (n,3) = round-half-even [u, v, depth] (-1 outside), uvd (n,3) float64 optional, fov[i] = z_cam > 0 and |x/z| < atan(W/H) and
+ * 0 < u < W-1 and 0 < v < H-1. */
+int sv_project_lidar_to_image_camera(const float* points, int64_t n_points, int row_stride, const double* extrinsic, const double* intrinsic,
+                                     const double* distcoeff, int camera_model, int img_w, int img_h, int32_t* uvd_int, double* uvd,
+                                     uint8_t* fov, void* stream);
 /* get_pts_in_mask (datasets/shared_utils.py:36-106): per instance the FOV points with mask[v,u] set.  Give either masks
  * (I,img_h,img_w) uint8 or rects (I,4) int32 [x0,y0,x1,y1] (use_bbox, :56-60).  Lists as in sv_crop_points_in_boxes. */
 int sv_points_in_masks(const int32_t* uv, const uint8_t* fov, int64_t n_points, const uint8_t* masks, const int32_t* rects,

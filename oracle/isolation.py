@@ -5,11 +5,12 @@ CPU restatement of the reference's point isolation, the CPU step in front of VCN
   gt_box_to_obb / crop_oriented_box  <- datasets/shared_utils.py:11-34,201-231,274-292 (populate_gtboxes, gtbox_to_corners,
                                         get_o3dbox) + open3d PointCloud.crop(OrientedBoundingBox), SEE_VCN.py:61-82
   project_velo_to_image_kitti        <- datasets/kitti/kitti_utils.py:58-114, datasets/kitti/kitti_objects.py:153-176
+  project_custom_camera              <- datasets/custom_dataset/custom_dataset_objects.py:141-192 (pinhole / equidistant distortion)
   pts_in_masks                       <- datasets/shared_utils.py:36-106 (get_pts_in_mask)
   isolate_det_pts                    <- SEE_VCN.py:144-181
   merge_multi_camera_detections      <- SEE_VCN.py:183-209
 
-Pinning: project_velo_to_image_kitti and pts_in_masks are pinned bit-exactly against tests/golden/isolation.npz, produced by the
+Pinning: project_velo_to_image_kitti, project_custom_camera and pts_in_masks are pinned bit-exactly against tests/golden/isolation.npz, produced by the
 reference's own Calibration / get_pts_in_mask (numpy only) in the build container (tests/golden/make_isolation_golden.py).
 isolate_det_pts / isolate_gt_pts / merge_multi_camera_detections are pinned at the glue level by the same fixture: the
 reference's own SEE_VCN methods were run with the open3d calls they make (get_center, cluster_dbscan, crop) served by this
@@ -97,6 +98,37 @@ def project_velo_to_image_kitti(pc_velo, V2C, R0, P, img_h, img_w, min_dist=1.0)
     fov = (u < img_w) & (u >= 0) & (v < img_h) & (v >= 0) & (np.asarray(pc_velo)[:, 0] > min_dist)
     pts_img = np.floor(np.stack([u[fov], v[fov]], 1)).astype(int)
     return fov, pts_img, np.stack([r[fov] for r in rect], 1)
+
+
+def project_custom_camera(points, intrinsic, extrinsic, distcoeff, img_h, img_w, camera_model="pinhole"):
+    """custom_dataset_objects.py:141-192 per element in float64.  Returns fov (N) bool, pts_img (Nf,3) int [u,v,depth] rounded
+    half-to-even, uv (Nf,3) float64."""
+    p = np.asarray(points, np.float64)[:, :3]
+    E, K, d = np.asarray(extrinsic, np.float64), np.asarray(intrinsic, np.float64), np.asarray(distcoeff, np.float64).reshape(-1)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    cam = [E[c, 0] * x + E[c, 1] * y + E[c, 2] * z + E[c, 3] for c in range(3)]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xn, yn = cam[0] / cam[2], cam[1] / cam[2]
+        pre = (cam[2] > 0) & (np.abs(xn) < np.arctan(img_w / img_h))
+        r2 = xn * xn + yn * yn
+        if camera_model == "equidistant":
+            r1 = np.sqrt(r2)
+            a0 = np.arctan(r1)
+            a2 = a0 * a0
+            a4 = a2 * a2
+            a1 = a0 * (1 + d[0] * a2 + d[1] * a4 + d[2] * (a4 * a2) + d[3] * (a4 * a4))
+            u, v = (a1 / r1) * xn, (a1 / r1) * yn
+        elif camera_model == "pinhole":
+            td = 1 + d[0] * r2 + d[1] * (r2 * r2) + d[4] * (r2 * r2 * r2)
+            u = xn * td + 2 * d[2] * xn * yn + d[3] * (r2 + 2 * (xn * xn))
+            v = yn * td + d[2] * (r2 + 2 * (yn * yn)) + 2 * d[3] * xn * yn
+        else:
+            raise NotImplementedError
+        u = K[0, 0] * u + K[0, 2]
+        v = K[1, 1] * v + K[1, 2]
+        fov = pre & (u > 0) & (u < img_w - 1) & (v > 0) & (v < img_h - 1)
+    uv = np.stack([u[fov], v[fov], cam[2][fov]], 1)
+    return fov, np.round(uv, 0).astype(int), uv
 
 
 def pts_in_masks(pts_img, masks=None, rects=None):

@@ -104,6 +104,53 @@ __global__ __launch_bounds__(256) void k_project_kitti(ProjectArgs a) {
   if (a.rect) a.rect[i * 3] = (float)rc[0], a.rect[i * 3 + 1] = (float)rc[1], a.rect[i * 3 + 2] = (float)rc[2];
 }
 
+// CustomDatasetObjects.map_pointcloud_to_image (datasets/custom_dataset/custom_dataset_objects.py:141-192): one 3x4 extrinsic, a
+// pinhole (radial k1,k2,k3 + tangential p1,p2) or equidistant (fisheye, 4 coefficients) distortion model, intrinsics, float64.
+//   cam = E . [x y z 1]; (xn, yn) = cam.xy / cam.z; pre = cam.z > 0 and |xn| < atan(W / H)
+//   fov = pre and 0 < u < W-1 and 0 < v < H-1; pts_img = round-half-even(u, v, depth)
+struct CameraArgs {
+  const float* points;
+  int64_t n;
+  int row_stride;
+  double e[12], kmat[9], dist[5];
+  int model, img_w, img_h;     // model 0 pinhole, 1 equidistant
+  int32_t* uvd_int;            // (n,3) rounded [u, v, depth] (-1 outside the FOV)
+  double* uvd;                 // (n,3) or null
+  uint8_t* fov;
+};
+
+__global__ __launch_bounds__(256) void k_project_camera(CameraArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const float* q = a.points + i * a.row_stride;
+  const double x = q[0], y = q[1], z = q[2];
+  double cam[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) cam[c] = a.e[c * 4] * x + a.e[c * 4 + 1] * y + a.e[c * 4 + 2] * z + a.e[c * 4 + 3];
+  const double xn = cam[0] / cam[2], yn = cam[1] / cam[2];
+  const bool pre = cam[2] > 0.0 && fabs(xn) < atan((double)a.img_w / (double)a.img_h);
+  const double r2 = xn * xn + yn * yn;
+  double u, v;
+  if (a.model == 1) {
+    const double r1 = sqrt(r2), a0 = atan(r1);
+    const double a2 = a0 * a0, a4 = a2 * a2;
+    const double a1 = a0 * (1 + a.dist[0] * a2 + a.dist[1] * a4 + a.dist[2] * (a4 * a2) + a.dist[3] * (a4 * a4));
+    u = (a1 / r1) * xn, v = (a1 / r1) * yn;
+  } else {
+    const double td = 1 + a.dist[0] * r2 + a.dist[1] * (r2 * r2) + a.dist[4] * (r2 * r2 * r2);
+    u = xn * td + 2 * a.dist[2] * xn * yn + a.dist[3] * (r2 + 2 * (xn * xn));
+    v = yn * td + a.dist[2] * (r2 + 2 * (yn * yn)) + 2 * a.dist[3] * xn * yn;
+  }
+  u = a.kmat[0] * u + a.kmat[2];
+  v = a.kmat[4] * v + a.kmat[5];
+  const bool in = pre && u > 0.0 && u < (double)(a.img_w - 1) && v > 0.0 && v < (double)(a.img_h - 1);
+  a.fov[i] = in ? 1 : 0;
+  a.uvd_int[i * 3] = in ? (int32_t)rint(u) : -1;
+  a.uvd_int[i * 3 + 1] = in ? (int32_t)rint(v) : -1;
+  a.uvd_int[i * 3 + 2] = in ? (int32_t)rint(cam[2]) : -1;
+  if (a.uvd) a.uvd[i * 3] = u, a.uvd[i * 3 + 1] = v, a.uvd[i * 3 + 2] = cam[2];
+}
+
 // get_pts_in_mask (shared_utils.py:36-106): for instance g, the FOV points whose pixel is set in mask g (masks (I,H,W) uint8)
 // or, with rects (I,4) = [x0,y0,x1,y1] already truncated to int, inside the box (use_bbox, :56-60).
 __global__ __launch_bounds__(ISO_THREADS) void k_mask_select(const int32_t* __restrict__ uv, const uint8_t* __restrict__ fov, int64_t n,
@@ -300,6 +347,24 @@ extern "C" int sv_project_lidar_to_image_kitti(const float* points, int64_t n_po
   for (int i = 0; i < 9; ++i) a.r0[i] = r0[i];
   a.img_w = img_w, a.img_h = img_h, a.min_dist = min_dist, a.uv = uv, a.fov = fov, a.rect = rect;
   hipLaunchKernelGGL(k_project_kitti, dim3(sv_div_up(n_points, 256)), dim3(256), 0, sv_stream(stream), a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_project_lidar_to_image_camera(const float* points, int64_t n_points, int row_stride, const double* extrinsic,
+                                                const double* intrinsic, const double* distcoeff, int camera_model, int img_w, int img_h,
+                                                int32_t* uvd_int, double* uvd, uint8_t* fov, void* stream) {
+  SV_CHECK_ARG(n_points >= 0 && row_stride >= 3 && img_w > 0 && img_h > 0, "sv_project_lidar_to_image_camera: bad sizes");
+  SV_CHECK_ARG(camera_model == 0 || camera_model == 1, "sv_project_lidar_to_image_camera: camera_model 0 (pinhole) or 1 (equidistant)");
+  if (n_points == 0) return SV_OK;
+  SV_CHECK_ARG(points && extrinsic && intrinsic && distcoeff && uvd_int && fov, "sv_project_lidar_to_image_camera: null pointer");
+  CameraArgs a;
+  a.points = points, a.n = n_points, a.row_stride = row_stride;
+  for (int i = 0; i < 12; ++i) a.e[i] = extrinsic[i];                 // host pointers: 26 doubles of calibration
+  for (int i = 0; i < 9; ++i) a.kmat[i] = intrinsic[i];
+  for (int i = 0; i < 5; ++i) a.dist[i] = distcoeff[i];
+  a.model = camera_model, a.img_w = img_w, a.img_h = img_h, a.uvd_int = uvd_int, a.uvd = uvd, a.fov = fov;
+  hipLaunchKernelGGL(k_project_camera, dim3(sv_div_up(n_points, 256)), dim3(256), 0, sv_stream(stream), a);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -84,6 +84,34 @@ def map_pointcloud_to_image(pc_velo, calib, img_shape, min_dist=1.0, device='cud
             "fov_inds": fov_np, "img_shape": (img_h, img_w), "_device": (pts, uv, fov)}
 
 
+def map_pointcloud_to_image_custom(points, calib, img_shape, camera_model="pinhole", device='cuda'):
+    """CustomDatasetObjects.map_pointcloud_to_image (custom_dataset_objects.py:141-192): calib = {'intrinsic' (3,3), 'extrinsic'
+    (>=3,4), 'distcoeff' (5)}, camera_model "pinhole" | "equidistant".  pts_img / pc_cam carry three columns [u, v, depth] like the
+    reference's (rounded half-to-even / float64)."""
+    if camera_model not in ("pinhole", "equidistant"):
+        raise NotImplementedError
+    lib = _lib.load()
+    img_h, img_w = int(img_shape[0]), int(img_shape[1])
+    pts = _dev_points(points, device)
+    n = pts.shape[0]
+    uvd_int = torch.empty((n, 3), dtype=torch.int32, device=pts.device)
+    uvd = torch.empty((n, 3), dtype=torch.float64, device=pts.device)
+    fov = torch.empty((n,), dtype=torch.uint8, device=pts.device)
+    e = np.ascontiguousarray(np.asarray(calib['extrinsic'], dtype=np.float64)[:3, :])
+    k = np.ascontiguousarray(calib['intrinsic'], dtype=np.float64)
+    d = np.zeros(5, np.float64)
+    dc = np.asarray(calib['distcoeff'], dtype=np.float64).reshape(-1)
+    d[:min(5, len(dc))] = dc[:5]
+    _lib.check(lib.sv_project_lidar_to_image_camera(_lib.ptr(pts), n, pts.stride(0), e.ctypes.data, k.ctypes.data, d.ctypes.data,
+                                                    1 if camera_model == "equidistant" else 0, img_w, img_h, _lib.ptr(uvd_int), _lib.ptr(uvd),
+                                                    _lib.ptr(fov), _lib.stream()), "sv_project_lidar_to_image_camera")
+    fovb = fov.bool()
+    fov_np = fovb.cpu().numpy()
+    src = points if isinstance(points, np.ndarray) else points.cpu().numpy()
+    return {"pc_lidar": src[fov_np, :], "pc_cam": uvd[fovb].cpu().numpy(), "pts_img": uvd_int[fovb].cpu().numpy().astype(int),
+            "fov_inds": fov_np, "img_shape": (img_h, img_w), "_device": (pts, uvd_int[:, :2].contiguous(), fovb)}
+
+
 def points_in_masks_device(uv, fov, masks=None, rects=None, cap=None):
     """uv (N,2) int32, fov (N) bool/uint8, masks (I,H,W) uint8 or rects (I,4) int32 -> index (I,cap) int32 ascending point
     indices, count (I) int32 (CUDA tensors)."""

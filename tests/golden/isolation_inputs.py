@@ -83,3 +83,20 @@ def multi_camera_instances(seed=5):
     c = blob([20.0, 8.0, -0.9], 50)
     c2 = np.vstack([c[:2], blob([21.5, 8.0, -0.9], 40)])
     return [a, b, c, a2, c2]
+
+
+def custom_calibration(model):
+    """A front camera looking along +x of the lidar (x forward, y left, z up -> camera z forward, x right, y down), lifted 0.3 m, with
+    mild distortion; the shapes CustomDatasetObjects.get_calibration returns (intrinsic 3x3, extrinsic 4x4, distcoeff 1x5)."""
+    R = np.array([[0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]])
+    yaw = 0.03
+    Rz = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+    E = np.eye(4)
+    E[:3, :3] = R @ Rz
+    E[:3, 3] = [0.05, 0.3, -0.2]
+    K = np.array([[960.0, 0.0, 958.3], [0.0, 955.0, 601.7], [0.0, 0.0, 1.0]])
+    dist = np.array([[-0.21, 0.07, 0.0012, -0.0007, -0.011]]) if model == "pinhole" else np.array([[0.041, -0.013, 0.0042, -0.0009, 0.0]])
+    return {"intrinsic": K, "extrinsic": E, "distcoeff": dist.reshape(-1)}
+
+
+CUSTOM_IMG_SHAPE = (1208, 1920)

@@ -19,7 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import _refimport as R  # noqa: E402
-from isolation_inputs import CLASSES, IMG_SHAPE, MIN_LIDAR_PTS, PC_ISOLATION, make_inputs, multi_camera_instances  # noqa: E402
+from isolation_inputs import (CLASSES, CUSTOM_IMG_SHAPE, IMG_SHAPE, MIN_LIDAR_PTS, PC_ISOLATION, custom_calibration, make_inputs,  # noqa: E402
+                              multi_camera_instances)
 from oracle import isolation as oiso  # noqa: E402
 from oracle.postprocess import dbscan_labels  # noqa: E402
 
@@ -111,5 +112,24 @@ out["gt_labels"] = np.stack(labels) if labels else np.zeros((0, 7))
 merged = see.SEE_VCN.merge_multi_camera_detections(types.SimpleNamespace(), multi_camera_instances())
 _pack("merged", merged)
 
+
+# CustomDatasetObjects.map_pointcloud_to_image (custom_dataset_objects.py:141-192): pinhole and equidistant camera models
+R._mod("datasets.custom_dataset.custom_dataset_objects_real")
+import importlib.util  # noqa: E402
+spec = importlib.util.spec_from_file_location("custom_dataset_objects_real",
+                                              os.path.join(R.REF, "see", "surface_completion", "datasets", "custom_dataset", "custom_dataset_objects.py"))
+cdo = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(cdo)
+for model in ("pinhole", "equidistant"):
+    co = object.__new__(cdo.CustomDatasetObjects)
+    co.camera_model = model
+    co.get_pointcloud = lambda idx: pts
+    co.get_image = lambda idx, channel=None: np.zeros(CUSTOM_IMG_SHAPE + (3,), np.uint8)
+    co.get_calibration = lambda idx, model=model: custom_calibration(model)
+    fovd = co.map_pointcloud_to_image(0, camera_channel="front")
+    out[f"custom_{model}_fov_inds"] = fovd["fov_inds"]
+    out[f"custom_{model}_pts_img"] = fovd["pts_img"].astype(np.int32)
+    out[f"custom_{model}_pc_cam"] = fovd["pc_cam"]
+    assert np.array_equal(fovd["pc_lidar"], pts[fovd["fov_inds"]])
 np.savez_compressed(os.path.join(HERE, "isolation.npz"), **out)
 print({k: v.shape for k, v in out.items()}, os.path.getsize(os.path.join(HERE, "isolation.npz")))

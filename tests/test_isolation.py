@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from isolation_inputs import CLASSES, IMG_SHAPE, MIN_LIDAR_PTS, PC_ISOLATION, make_inputs, multi_camera_instances
+from isolation_inputs import (CLASSES, CUSTOM_IMG_SHAPE, IMG_SHAPE, MIN_LIDAR_PTS, PC_ISOLATION, custom_calibration, make_inputs,
+                              multi_camera_instances)
 from oracle import isolation as oiso
 from oracle.postprocess import dbscan_labels
 
@@ -38,6 +39,15 @@ def test_oracle_projection_matches_reference_golden(inputs, golden):
     assert np.array_equal(fov, golden["fov_inds"]) and 0 < fov.sum() < len(fov)
     assert np.array_equal(pts_img, golden["pts_img"])                       # floor(u,v): bit-exact pixels
     np.testing.assert_allclose(rect, golden["pc_cam"], rtol=0, atol=1e-12)  # BLAS summation order
+
+
+@pytest.mark.parametrize("model", ["pinhole", "equidistant"])
+def test_oracle_custom_camera_projection_matches_reference_golden(inputs, golden, model):
+    c = custom_calibration(model)
+    fov, pts_img, uv = oiso.project_custom_camera(inputs['points'], c['intrinsic'], c['extrinsic'], c['distcoeff'], *CUSTOM_IMG_SHAPE, camera_model=model)
+    assert np.array_equal(fov, golden[f"custom_{model}_fov_inds"]) and 0 < (~fov).sum() < len(fov)
+    assert np.array_equal(pts_img, golden[f"custom_{model}_pts_img"])              # rounded pixels and depth: bit-exact
+    np.testing.assert_allclose(uv, golden[f"custom_{model}_pc_cam"], rtol=0, atol=1e-9)
 
 
 def test_oracle_mask_lookup_matches_reference_golden(inputs, golden):
@@ -117,6 +127,19 @@ def test_hip_projection_and_masks_bitexact_vs_reference_golden(inputs, golden, c
         assert len(proj["lidar_xyz"]) == len(want_l) == len(proj["cam_xyz"])
         for l, uv, wl, wuv in zip(proj["lidar_xyz"], proj["img_uv"], want_l, want_uv):
             assert np.array_equal(l, wl) and np.array_equal(uv, wuv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["pinhole", "equidistant"])
+def test_hip_custom_camera_projection_vs_reference_golden(inputs, golden, cuda, hip_lib, model):
+    from seevcn_amd.vcn import isolation as I
+    imgfov = I.map_pointcloud_to_image_custom(inputs['points'], custom_calibration(model), CUSTOM_IMG_SHAPE, camera_model=model)
+    assert np.array_equal(imgfov["fov_inds"], golden[f"custom_{model}_fov_inds"])
+    assert np.array_equal(imgfov["pts_img"], golden[f"custom_{model}_pts_img"])
+    assert np.array_equal(imgfov["pc_lidar"], inputs['points'][golden[f"custom_{model}_fov_inds"]])
+    np.testing.assert_allclose(imgfov["pc_cam"], golden[f"custom_{model}_pc_cam"], rtol=0, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        I.map_pointcloud_to_image_custom(inputs['points'], custom_calibration(model), CUSTOM_IMG_SHAPE, camera_model="spherical")
 
 
 @pytest.mark.gpu
