@@ -49,7 +49,7 @@ class Rulebook:
         computed once and reused by every launch with the same tiles-per-wave on that table."""
         lib = _lib.load()
         n_rows, K = table.shape[1], table.shape[0]
-        if n_rows == 0 or (int(kd) // 16) * (int(nc) // 16) < 4 or kd % 16 or nc % 16:
+        if not TILE_ORDER or n_rows == 0 or (int(kd) // 16) * (int(nc) // 16) < 4 or kd % 16 or nc % 16:
             return None              # load-bound small-channel layers: the order does not pay for its own launch
         g = lib.sv_conv_tiles_per_wave(n_rows, int(kd), int(nc))
         if self.subm and self._nbr_in_subm is not None and table.data_ptr() == self._nbr_in_subm.data_ptr():
@@ -109,6 +109,7 @@ class Rulebook:
 
 # dense cell -> row maps (4 B per cell) up to this size replace the rank dictionary in submanifold rulebooks (MI355X: 288 GB of HBM)
 CELLMAP_MAX_BYTES = int(os.environ.get("SEEVCN_CELLMAP_MAX_BYTES", 24 << 30))
+TILE_ORDER = os.environ.get("SEEVCN_TILE_ORDER", "1") != "0"      # work-balanced tile order (sv_conv_tile_order); 0: tiles by position
 # Group table rows by neighbour mask before the MFMA gather-GEMM (Rulebook.plan).  OFF by default: measured on the bench workload the
 # conv kernels get 15-45 % faster (64->64 submanifold layer 185 -> 143 us with an exact sort by mask, 152-158 us with the
 # counting-sort classes built here) but the grouping passes (40 + 33 us per table, hot-class atomics) cost more than that saves
