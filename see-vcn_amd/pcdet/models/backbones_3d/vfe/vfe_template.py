@@ -1,15 +1,19 @@
+"""Base class of the voxel feature encoders; contract of the reference's VFETemplate (backbones_3d/vfe/vfe_template.py:4-22):
+constructed with `model_cfg` plus keyword geometry, reports its channel count, maps batch_dict -> batch_dict."""
+import abc
+
 import torch.nn as nn
 
 
-class VFETemplate(nn.Module):
-    """Same base contract as the reference's VFETemplate (backbones_3d/vfe/vfe_template.py:4-22)."""
-
-    def __init__(self, model_cfg, **kwargs):
-        super().__init__()
+class VFETemplate(nn.Module, metaclass=abc.ABCMeta):
+    def __init__(self, model_cfg, **_geometry):
+        nn.Module.__init__(self)
         self.model_cfg = model_cfg
 
+    @abc.abstractmethod
     def get_output_feature_dim(self):
-        raise NotImplementedError
+        """number of channels of `voxel_features` / `pillar_features`"""
 
-    def forward(self, **kwargs):
-        raise NotImplementedError
+    @abc.abstractmethod
+    def forward(self, batch_dict, **kwargs):
+        """adds `voxel_features` (or `pillar_features`) to batch_dict and returns it"""

@@ -10,14 +10,6 @@ class CenterPoint(Detector3DTemplate):
         super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
         self.module_list = self.build_networks()
 
-    def forward(self, batch_dict):
-        for cur_module in self.module_list:
-            batch_dict = cur_module(batch_dict)
-        if self.training:
-            loss_rpn, tb_dict = self.dense_head.get_loss()
-            return {'loss': loss_rpn}, {'loss_rpn': loss_rpn.item(), **tb_dict}, {}
-        return self.post_processing(batch_dict)
-
     def post_processing(self, batch_dict):
         final = batch_dict['final_box_dicts']
         recall_dict = {}

@@ -136,8 +136,32 @@ class Detector3DTemplate(nn.Module):
         model_info_dict['module_list'].append(m)
         return m, model_info_dict
 
-    def forward(self, **kwargs):
-        raise NotImplementedError
+    # heads whose get_loss() terms are summed in training, in call order; every head after the first receives the running tb_dict
+    LOSS_HEADS = ('dense_head',)
+
+    def run_modules(self, batch_dict):
+        for module in self.module_list:
+            batch_dict = module(batch_dict)
+        return batch_dict
+
+    def get_training_loss(self):
+        """sum of the LOSS_HEADS' losses -> (loss, tb_dict, disp_dict), the reference detectors' return convention"""
+        total, tb_dict = None, None
+        for name in self.LOSS_HEADS:
+            head = getattr(self, name)
+            term, tb_dict = head.get_loss() if tb_dict is None else head.get_loss(tb_dict)
+            total = term if total is None else total + term
+        if len(self.LOSS_HEADS) == 1:
+            tb_dict = {'loss_rpn': total.item(), **tb_dict}
+        return total, tb_dict, {}
+
+    def forward(self, batch_dict):
+        """train: ({'loss': loss}, tb_dict, disp_dict); eval: post_processing(batch_dict) = (pred_dicts, recall_dict)"""
+        batch_dict = self.run_modules(batch_dict)
+        if not self.training:
+            return self.post_processing(batch_dict)
+        loss, tb_dict, disp_dict = self.get_training_loss()
+        return {'loss': loss}, tb_dict, disp_dict
 
     def post_processing(self, batch_dict):
         """Per scene: sigmoid scores, max over classes, class-agnostic NMS, recall bookkeeping

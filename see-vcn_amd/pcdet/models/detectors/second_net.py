@@ -2,22 +2,9 @@ from .detector3d_template import Detector3DTemplate
 
 
 class SECONDNet(Detector3DTemplate):
-    """VFE -> sparse 3-D backbone -> HeightCompression -> BEV backbone -> anchor head (reference detectors/second_net.py:4-37)."""
+    """VFE -> sparse 3-D backbone -> HeightCompression -> BEV backbone -> anchor head (reference detectors/second_net.py:4-37).
+    One loss head (the template's default): tb_dict carries 'loss_rpn'."""
 
     def __init__(self, model_cfg, num_class, dataset):
         super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
         self.module_list = self.build_networks()
-
-    def forward(self, batch_dict):
-        for cur_module in self.module_list:
-            batch_dict = cur_module(batch_dict)
-        if self.training:
-            loss, tb_dict, disp_dict = self.get_training_loss()
-            return {'loss': loss}, tb_dict, disp_dict
-        pred_dicts, recall_dicts = self.post_processing(batch_dict)
-        return pred_dicts, recall_dicts
-
-    def get_training_loss(self):
-        loss_rpn, tb_dict = self.dense_head.get_loss()
-        tb_dict = {'loss_rpn': loss_rpn.item(), **tb_dict}
-        return loss_rpn, tb_dict, {}

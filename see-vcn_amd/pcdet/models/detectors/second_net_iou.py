@@ -13,15 +13,11 @@ class SECONDNetIoU(Detector3DTemplate):
         super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
         self.module_list = self.build_networks()
 
+    LOSS_HEADS = ('dense_head', 'roi_head')
+
     def forward(self, batch_dict):
         batch_dict['dataset_cfg'] = self.dataset.dataset_cfg
-        for cur_module in self.module_list:
-            batch_dict = cur_module(batch_dict)
-        if self.training:
-            loss_rpn, tb_dict = self.dense_head.get_loss()
-            loss_rcnn, tb_dict = self.roi_head.get_loss(tb_dict)
-            return {'loss': loss_rpn + loss_rcnn}, tb_dict, {}
-        return self.post_processing(batch_dict)
+        return super().forward(batch_dict)
 
     @staticmethod
     def cal_scores_by_npoints(cls_scores, iou_scores, num_points_in_gt, cls_thresh=10, iou_thresh=100):
