@@ -1,6 +1,4 @@
 """Autograd functions / modules of the reference's pointnet2_batch/pointnet2_utils.py (same names), on the HIP wrappers."""
-from typing import Tuple
-
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -8,19 +6,26 @@ from torch.autograd import Function
 from . import pointnet2_batch_cuda as pointnet2
 
 
-class FarthestPointSampling(Function):
+class _IndexOp:
+    """Index-producing ops carry no gradient: plain functions run without autograd, exposed with the `.apply` surface the
+    reference's autograd.Function classes have (pointnet2_utils.py:10-40,87-123,228-260)."""
+
+    @classmethod
+    def apply(cls, *args):
+        with torch.no_grad():
+            return cls.run(*args)
+
+
+class FarthestPointSampling(_IndexOp):
     @staticmethod
-    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+    def run(xyz, npoint):
+        """xyz (B,N,3) -> (B,npoint) int32 indices; start index 0, the reference kernel's tie rule"""
         assert xyz.is_contiguous()
         B, N, _ = xyz.size()
-        output = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-        temp = torch.empty((B, N), dtype=torch.float32, device=xyz.device)
-        pointnet2.farthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
-        return output
-
-    @staticmethod
-    def backward(xyz, a=None):
-        return None, None
+        idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+        scratch = torch.empty((B, N), dtype=torch.float32, device=xyz.device)
+        pointnet2.farthest_point_sampling_wrapper(B, N, npoint, xyz, scratch, idx)
+        return idx
 
 
 farthest_point_sample = furthest_point_sample = FarthestPointSampling.apply
@@ -49,20 +54,16 @@ class GatherOperation(Function):
 gather_operation = GatherOperation.apply
 
 
-class ThreeNN(Function):
+class ThreeNN(_IndexOp):
     @staticmethod
-    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def run(unknown, known):
+        """unknown (B,n,3), known (B,m,3) -> (distances (B,n,3), indices (B,n,3)) of the three nearest known points"""
         assert unknown.is_contiguous() and known.is_contiguous()
-        B, N, _ = unknown.size()
-        m = known.size(1)
-        dist2 = torch.empty((B, N, 3), dtype=torch.float32, device=unknown.device)
-        idx = torch.empty((B, N, 3), dtype=torch.int32, device=unknown.device)
-        pointnet2.three_nn_wrapper(B, N, m, unknown, known, dist2, idx)
-        return torch.sqrt(dist2), idx
-
-    @staticmethod
-    def backward(ctx, a=None, b=None):
-        return None, None
+        B, n, _ = unknown.size()
+        d2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
+        idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
+        pointnet2.three_nn_wrapper(B, n, known.size(1), unknown, known, d2, idx)
+        return d2.sqrt_(), idx
 
 
 three_nn = ThreeNN.apply
@@ -114,19 +115,15 @@ class GroupingOperation(Function):
 grouping_operation = GroupingOperation.apply
 
 
-class BallQuery(Function):
+class BallQuery(_IndexOp):
     @staticmethod
-    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+    def run(radius, nsample, xyz, new_xyz):
+        """first nsample points of xyz (B,N,3) within radius of each new_xyz (B,npoint,3) -> (B,npoint,nsample) int32"""
         assert new_xyz.is_contiguous() and xyz.is_contiguous()
         B, N, _ = xyz.size()
-        npoint = new_xyz.size(1)
-        idx = torch.zeros((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
-        pointnet2.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx)
+        idx = torch.zeros((B, new_xyz.size(1), nsample), dtype=torch.int32, device=xyz.device)
+        pointnet2.ball_query_wrapper(B, N, new_xyz.size(1), radius, nsample, new_xyz, xyz, idx)
         return idx
-
-    @staticmethod
-    def backward(ctx, a=None):
-        return None, None, None, None
 
 
 ball_query = BallQuery.apply
