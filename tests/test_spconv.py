@@ -334,3 +334,75 @@ def test_hip_fused_batchnorm_relu_matches_torch(cuda, hip_lib, n, c, relu):
         ye = ref(x0)
         ye = torch.relu(ye) if relu else ye
         torch.testing.assert_close(norm.batch_norm_relu(mine, x0, relu), ye, **tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["kitti16", "nuscenes_stress"])
+def test_hip_sparse_conv_full_size_properties(cuda, hip_lib, config):
+    """BASELINE sizes (config 3: 16 KITTI scenes, ~213 k voxels; config 5: 300 k points / scene on the 1440 x 1440 x 40 grid) through
+    size-independent properties: rulebook symmetry / inverse tables / sorted unique outputs, linearity of the conv, and the adjoint
+    identities <conv(X; W), dY> = <X, bwd_data(dY; W)> = <W, wgrad(X, dY)> that tie forward, data gradient and weight gradient."""
+    import seevcn_amd.synth as synth
+    from seevcn_amd.pcdet.ops import voxel_ops
+    from seevcn_amd.spconv import functional as Fsp
+    if config == "kitti16":
+        bs = 16
+        pts, _ = synth.make_scene_batch(bs, seed=2000)
+        pc_range, vs, grid = [0, -40, -3, 70.4, 40, 1], [0.05, 0.05, 0.1], [1408, 1600, 40]
+    else:
+        bs = 3
+        pts, _ = synth.make_scene_batch(bs, seed=4000, n_beams=32, elev=(-30.0, 10.0), az=(-180.0, 180.0), n_az=940, n_sweeps=10,
+                                        box_area=((-50.0, 50.0), (-50.0, 50.0)), max_range=54.0, z_shift=0.0)
+        pc_range, vs, grid = [-54, -54, -5, 54, 54, 3], [0.075, 0.075, 0.2], [1440, 1440, 40]
+    p = torch.from_numpy(pts).to(cuda)
+    feats, coords, _ = voxel_ops.voxelize_dynamic(p, pc_range, vs, grid, bs)
+    shape = [grid[2] + 1, grid[1], grid[0]]
+    n = coords.shape[0]
+    assert n > (150000 if config == "kitti16" else 100000)
+    gen = torch.Generator(device=cuda).manual_seed(0)
+    # --- submanifold rulebook: centre = identity, table symmetric under offset reversal
+    rb = Fsp.build_subm_rulebook(coords, bs, shape, [3, 3, 3])
+    nbr = rb.nbr_out
+    rows = torch.arange(n, device=cuda, dtype=torch.int32)
+    assert torch.equal(nbr[13], rows)
+    for k in (0, 5, 12):
+        j = nbr[k].long()
+        ok = j >= 0
+        assert torch.equal(nbr[26 - k][j[ok]], rows[ok])
+    # --- strided rulebook: outputs sorted by key and unique, the two tables are inverses of each other
+    rs = Fsp.build_sparse_rulebook(coords, bs, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    oc = rs.out_indices.long()
+    key = ((oc[:, 0] * rs.out_shape[0] + oc[:, 1]) * rs.out_shape[1] + oc[:, 2]) * rs.out_shape[2] + oc[:, 3]
+    assert bool((key[1:] > key[:-1]).all())
+    assert int((rs.nbr_out >= 0).sum()) == int((rs.nbr_in >= 0).sum())
+    for k in (0, 13, 26):
+        o = rs.nbr_in[k].long()
+        ok = o >= 0
+        assert torch.equal(rs.nbr_out[k][o[ok]], rows[ok])
+    # --- conv: linearity and adjointness on both rulebooks (64 -> 64 channels: the dominant kernel)
+    for book, n_in, n_out in ((rb, n, n), (rs, n, rs.n_out)):
+        cin = cout = 64
+        x1, x2 = (torch.randn((n_in, cin), device=cuda, generator=gen) for _ in range(2))
+        w = torch.randn((book.K, cin, cout), device=cuda, generator=gen) * 0.1
+        wt = w.permute(0, 2, 1)
+        dy = torch.randn((n_out, cout), device=cuda, generator=gen)
+        table, order, perm, rev = book.plan("fwd", cin, cout)
+        conv = lambda x: Fsp.gather_gemm(x, table, wt, n_out, tile_order=order, row_perm=perm, table_k_reversed=rev)
+        y1, y2, y12 = conv(x1), conv(x2), conv(2.0 * x1 - 3.0 * x2)
+        scale = float(y12.abs().max())
+        assert float((y12 - (2.0 * y1 - 3.0 * y2)).abs().max()) <= 1e-4 * scale
+        tb, ob, pb, rvb = book.plan("bwd", cout, cin)
+        dx = Fsp.gather_gemm(dy, tb, w, n_in, tile_order=ob, row_perm=pb, table_k_reversed=rvb)
+        dw = Fsp.wgrad(x1, book.nbr_out, dy, book.K, cin, cout)
+        lhs = float((y1.double() * dy.double()).sum())
+        assert abs(lhs - float((x1.double() * dx.double()).sum())) <= 1e-4 * abs(lhs) + 1e-3
+        assert abs(lhs - float((w.double() * dw.double()).sum())) <= 1e-4 * abs(lhs) + 1e-3
+    # --- dense scatter / gather round trip on the backbone's last grid
+    last = Fsp.build_sparse_rulebook(coords, bs, shape, [3, 3, 3], [8, 8, 8], [1, 1, 1])
+    f = torch.randn((last.n_out, 128), device=cuda, generator=gen)
+    import seevcn_amd.spconv as spconv
+    t = spconv.SparseConvTensor(f.clone().requires_grad_(True), last.out_indices, last.out_shape, bs)
+    d = t.dense()
+    assert int((d != 0).sum()) == int((f != 0).sum())
+    d.backward(d.detach())
+    assert torch.equal(t.features.grad, f)
