@@ -186,7 +186,7 @@ extern "C" int sv_fill_f32(float* dst, int64_t n, float value, void* stream) {
 // M <= 64 rows (the per-object layers: pose_fc, shape_fc, the folded global half of mlp_conv2[0]; VCN_VC.py:124-131,200-204).
 // These are weight-streaming: 2*N*K*4 bytes against 2*M*N*K flops.  The 128x128 tile kernel gives them N/128 workgroups that
 // each walk all of K alone (85 us for a 4 MB weight matrix).  Here a workgroup owns 16 output columns and all rows; its four
-// waves split K into quarters (16x16x4 MFMA, one 16-byte load per operand and 16 k), partial sums meet in LDS in a fixed order.
+// waves share K in interleaved 16-wide steps (16x16x4 MFMA, one 16-byte load per operand and 16 k), partial sums meet in LDS in a fixed order.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs g) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs g) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int li = lane & 15, kk = lane >> 4;
   const int n0 = blockIdx.x * 16;
-  const int kq = g.K / 4, kbeg = wid * kq;                  // K % 32 == 0 -> kq % 8 == 0
+  // K % 32 == 0 (checked by the launcher): the four waves take the 16-wide k-steps round-robin
   f32x4v acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs g) {
     const int m = t * 16 + li;
     arow[t] = g.A + (int64_t)(m < g.M ? m : g.M - 1) * g.lda + 4 * kk;
   }
-  for (int k0 = kbeg; k0 < kbeg + kq; k0 += 16) {           // lane (li, kk) holds k = k0 + 4*kk + s in MFMA s, for A and W alike
+  for (int k0 = wid * 16; k0 < g.K; k0 += 64) {             // lane (li, kk) holds k = k0 + 4*kk + s in MFMA s, for A and W alike
     const f32x4v b = *reinterpret_cast<const f32x4v*>(wrow + k0);
     f32x4v a[4];
 #pragma unroll

@@ -91,6 +91,30 @@ def test_hip_gemm_epilogues(cuda, hip_lib):
 
 
 @pytest.mark.gpu
+def test_hip_gemm_small_m_kernel(cuda, hip_lib):
+    """M <= 64 without group options runs k_gemm_small_m (16 columns per workgroup, K split over the waves): every M / N / K edge,
+    bias or not, all activations, against float64; and the same rows through the 128x128-tile kernel agree to fp32 rounding."""
+    from seevcn_amd.vcn.models import layers as L
+    g = torch.Generator().manual_seed(1)
+    for (M, N, K) in [(64, 1024, 1024), (1, 9, 512), (5, 3072, 1024), (64, 9, 32), (33, 40, 64), (17, 512, 256)]:
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        for bias in (b, None):
+            ref = a.double() @ w.double().t() + (bias.double() if bias is not None else 0)
+            for act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU):
+                r = ref.clamp_min(0) if act == L.ACT_RELU else (torch.where(ref >= 0, ref, ref * 0.01) if act == L.ACT_LRELU else ref)
+                out = L.gemm(a.to(cuda), w.to(cuda), bias.to(cuda) if bias is not None else None, act)
+                np.testing.assert_allclose(out.cpu().numpy(), r.numpy(), rtol=1e-4, atol=1e-4)
+        # 65 rows take the tile kernel: its first 64 rows must match the small-M result closely (different summation order)
+        a65 = torch.cat([a, a[:1]], 0) if M == 64 else None
+        if a65 is not None:
+            big = L.gemm(a65.to(cuda), w.to(cuda), b.to(cuda), L.ACT_NONE)[:64]
+            small = L.gemm(a.to(cuda), w.to(cuda), b.to(cuda), L.ACT_NONE)
+            np.testing.assert_allclose(big.cpu().numpy(), small.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
 def test_hip_vcn_vc_matches_reference_golden(golden_dir, cuda, hip_lib):
     V = _models()
     g = np.load(os.path.join(golden_dir, "vcn_vc.npz"))
