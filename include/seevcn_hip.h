@@ -38,7 +38,9 @@ const char* sv_last_error(void);
 /* ------------------------------------------------------------------------------------------------
  * Coordinate index (persistent workspace shared by voxelisation and rulebook builds)
  * ---------------------------------------------------------------------------------------------- */
-/* bytes of persistent (zero-initialised) workspace indexing `ncells` grid cells */
+/* bytes of persistent (zero-initialised) workspace indexing `ncells` grid cells.  A workspace belongs to ONE cell count: its layout
+ * (occupancy words | chunk counts | chunk bases) depends on ncells and a call returns only the words and counts to zero, so reusing
+ * it with another ncells needs a memset in between. */
 size_t sv_index_persistent_bytes(int64_t ncells);
 /* bytes of per-call scratch used by the chunk scan for `ncells` cells */
 size_t sv_index_scratch_bytes(int64_t ncells);

@@ -31,7 +31,9 @@ def voxelize_dynamic(points, pc_range, voxel_size, grid_size, batch_size, num_fe
     cap = max(int(P if capacity is None else capacity), 1)
     dev = points.device
     ncells = int(batch_size) * int(grid_size[0]) * int(grid_size[1]) * int(grid_size[2])
-    ws = _lib.workspace.persistent("vox_index", lib.sv_index_persistent_bytes(ncells), dev)
+    # one persistent index per grid size: the layout (words | chunk counts | chunk bases) depends on the cell count, and only the
+    # words and counts are returned to zero by a call -- the scan output of a call on another grid would alias them
+    ws = _lib.workspace.persistent(f"vox_index_{ncells}", lib.sv_index_persistent_bytes(ncells), dev)
     scratch = _lib.workspace.scratch("vox_scratch", lib.sv_voxelize_dynamic_scratch_bytes(P, ncells, cap), dev)
     coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     feats = torch.empty((cap, C), dtype=torch.float32, device=dev)

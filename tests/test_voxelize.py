@@ -122,3 +122,13 @@ def test_hip_mean_vfe(golden_dir, cuda, hip_lib):
     m = vfe.__all__["MeanVFE"](model_cfg={}, num_point_features=3)
     bd = m({"voxels": torch.from_numpy(g["voxels"]).to(cuda), "voxel_num_points": torch.from_numpy(g["voxel_num_points"]).to(cuda)})
     np.testing.assert_allclose(bd["voxel_features"].cpu().numpy(), g["voxel_features"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_alternating_grids_keep_their_indices_clean(golden_dir, cuda, hip_lib):
+    """Calls on different grids in one process (each grid size owns a persistent index): results stay bit-exact in any order."""
+    names = list(CASES)
+    for name in names + names[::-1] + names:
+        g = _load(golden_dir, name)
+        _, coords, _ = _run_hip(g["points"], g["pc_range"], g["voxel_size"], g["grid_size"], int(g["batch_size"]), cuda)
+        assert np.array_equal(coords.cpu().numpy(), g["voxel_coords"]), name
