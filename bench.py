@@ -69,17 +69,19 @@ def loss_fn(bd):
 
 
 def allreduce_grads(params, world):
+    """The one exchange step of the data-parallel path: every gradient in ONE flat fp32 bucket (0.71 M values = 2.8 MB), one RCCL
+    all-reduce over xGMI, averaged, copied back with one multi-tensor kernel (not one launch per parameter)."""
     if world == 1:
         return
-    params = [p for p in params if p.grad is not None]
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    dist.all_reduce(flat)                       # RCCL ring over xGMI; 0.71 M fp32 = one 2.8 MB bucket
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
     flat.div_(world)
-    off = 0
-    for p in params:
-        n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
+    views, off = [], 0
+    for g in grads:
+        views.append(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+    torch._foreach_copy_(grads, views)
 
 
 def run_step(model, opt, params, inputs, world):

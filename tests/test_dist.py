@@ -40,3 +40,44 @@ def test_flat_bucket_allreduce_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _gpu_worker(rank, world, port, out):
+    """Two ranks on ONE GPU over gloo (RCCL refuses two ranks on a device): everything of bench.py's N > 1 path except the
+    transport -- per-rank inputs, the step, the flat-bucket exchange on CUDA gradients, the optimiser."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    bench.SCENES_PER_GPU, bench.OBJECTS_PER_GPU = 2, 8                      # small per-rank batch: this is a plumbing test
+    device = torch.device("cuda", 0)
+    points, objects, scene, *_ = bench.make_inputs(rank, device)
+    model = bench.build_model(device).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, fused=True)
+    for _ in range(2):
+        loss = bench.run_step(model, opt, params, (points, objects, scene), world)
+    torch.cuda.synchronize()
+    grads = torch.cat([p.grad.reshape(-1) for p in params if p.grad is not None]).cpu()
+    weights = torch.cat([p.detach().reshape(-1) for p in params]).cpu()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (float(loss), grads, weights))
+    same_grads = all(torch.equal(gathered[0][1], g[1]) for g in gathered)
+    same_weights = all(torch.equal(gathered[0][2], g[2]) for g in gathered)
+    out[rank] = (bool(same_grads), bool(same_weights), bool(torch.isfinite(grads).all()), gathered[0][0] != gathered[1][0])
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_rank_step_keeps_replicas_in_sync_on_one_gpu():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gpu_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    # averaged gradients and updated weights identical on both ranks, finite, while the ranks saw different scenes (different loss)
+    assert dict(out) == {0: (True, True, True, True), 1: (True, True, True, True)}
