@@ -676,14 +676,25 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_by
     const int64_t p = tile_row0(g) + li;
     const bool valid = (lane >> 4) < RS_G && p < a.n_rows;
     const int64_t r = (valid && a.row_perm) ? (int64_t)a.row_perm[p] : p;     // regrouped tiles: 16 arbitrary rows
-    for (int k = 0; k < a.K; ++k) {
-      const int32_t j = valid ? a.nbr[(int64_t)(a.k_flip ? a.K - 1 - k : k) * a.n_rows + r] : -1;
-      s_idx[k][lane] = j;
-      const unsigned long long vote = __ballot(j >= 0);
-      unsigned m = 0;
+    for (int k0 = 0; k0 < a.K; k0 += 9) {                  // 9 table reads in flight: 3 load latencies before the first MFMA, not 27
+      int32_t jv[9];
 #pragma unroll
-      for (int t = 0; t < RS_G; ++t) m |= ((vote >> (16 * t)) & 0xffffull) ? (1u << t) : 0u;
-      if (lane == k) maskreg = m;
+      for (int u = 0; u < 9; ++u) {
+        const int k = k0 + u;
+        jv[u] = (valid && k < a.K) ? a.nbr[(int64_t)(a.k_flip ? a.K - 1 - k : k) * a.n_rows + r] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const int k = k0 + u;
+        if (k < a.K) {
+          s_idx[k][lane] = jv[u];
+          const unsigned long long vote = __ballot(jv[u] >= 0);
+          unsigned m = 0;
+#pragma unroll
+          for (int t = 0; t < RS_G; ++t) m |= ((vote >> (16 * t)) & 0xffffull) ? (1u << t) : 0u;
+          if (lane == k) maskreg = m;
+        }
+      }
     }
   }
   const unsigned long long active = __ballot(maskreg != 0);
