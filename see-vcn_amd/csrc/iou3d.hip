@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_points_in_boxes(int T, int M, const flo
     if (fabsf(z - s[2]) > s[5] / 2.0) continue;              // double-precision compare like the reference (:28)
     const float sx = x - s[0], sy = y - s[1];
     const float lx = sx * s[6] + sy * (-s[7]), ly = sx * s[7] + sy * s[6];
-    if ((fabs(lx) < s[3] / 2.0 + (double)1e-5f) & (fabs(ly) < s[4] / 2.0 + (double)1e-5f)) { found = k; break; }
+    if (fabs(lx) < s[3] / 2.0 + (double)1e-5f && fabs(ly) < s[4] / 2.0 + (double)1e-5f) { found = k; break; }
   }
   out[(int64_t)b * M + m] = found;
 }

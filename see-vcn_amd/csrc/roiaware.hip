@@ -29,7 +29,7 @@ __device__ __forceinline__ int ra_voxel_of(const float* p, const float* b, float
   if (fabsf(z - cz) > dz / 2.0) return -1;
   const float sx = x - b[0], sy = y - b[1];
   const float lx = sx * cosa + sy * (-sina), ly = sx * sina + sy * cosa;
-  if (!((fabs(lx) < dx / 2.0 + (double)1e-5f) & (fabs(ly) < dy / 2.0 + (double)1e-5f))) return -1;
+  if (!(fabs(lx) < dx / 2.0 + (double)1e-5f && fabs(ly) < dy / 2.0 + (double)1e-5f)) return -1;
   const float lz = z - cz;
   const float xr = dx / ox, yr = dy / oy, zr = dz / oz;
   unsigned xi = (unsigned)(int)((lx + dx / 2) / xr), yi = (unsigned)(int)((ly + dy / 2) / yr), zi = (unsigned)(int)((lz + dz / 2) / zr);
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_points_in_boxes_matrix(int N, int M, co
     const float cosa = cosf(-b[6]), sina = sinf(-b[6]);
     const float sx = x - b[0], sy = y - b[1];
     const float lx = sx * cosa + sy * (-sina), ly = sx * sina + sy * cosa;
-    in = (fabs(lx) < b[3] / 2.0 + (double)1e-2f) & (fabs(ly) < b[4] / 2.0 + (double)1e-2f);
+    in = (fabs(lx) < b[3] / 2.0 + (double)1e-2f && fabs(ly) < b[4] / 2.0 + (double)1e-2f) ? 1 : 0;
   }
   out[(size_t)i * M + j] = in;
 }

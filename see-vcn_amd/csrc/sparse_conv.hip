@@ -653,7 +653,7 @@ extern "C" int sv_conv_tile_order_grouped(const int32_t* masks, const int32_t* r
 
 template <int NT, int KQ, int RS_G>
 __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_bytes, uint32_t w_bytes) {
-  constexpr int Kd = KQ * 16, Nc = NT * 16, NLOAD = RS_G + NT;
+  constexpr int Kd = KQ * 16, Nc = NT * 16;
   __shared__ int32_t s_idx_all[4][RS3_KMAX][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int li = lane & 15, kk = lane >> 4;

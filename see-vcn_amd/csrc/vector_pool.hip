@@ -28,7 +28,7 @@ __device__ __forceinline__ StackBatch stack_batch_of(int q, int batch, const int
 
 __device__ __forceinline__ bool vp_in_range(float lx, float ly, float lz, float dist, float radius2, int neighbor_type) {
   if (neighbor_type == 1) return !(lx * lx + ly * ly + lz * lz > radius2);
-  return !((fabs(lx) > dist) | (fabs(ly) > dist) | (fabs(lz) > dist));
+  return !(fabs(lx) > dist || fabs(ly) > dist || fabs(lz) > dist);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
