@@ -21,7 +21,8 @@ class SparseConvolution(SparseModule):
     def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
                  bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None, **kwargs):
         super().__init__()
-        assert ndim == 3 and groups == 1 and not transposed and not inverse, "only 3-D forward (sub)manifold convs are built"
+        assert ndim == 3 and groups == 1 and not transposed, "only 3-D (sub)manifold, strided and inverse convs are built"
+        self.inverse = inverse
         self.ndim = ndim
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride = _triple(kernel_size), _triple(stride)
@@ -57,6 +58,7 @@ class SparseConvolution(SparseModule):
         else:
             rb = Fsp.build_sparse_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding,
                                            self.dilation)
+        rb.in_indices, rb.in_shape = x.indices, list(x.spatial_shape)      # what SparseInverseConv3d restores
         if self.indice_key is not None:
             x.indice_dict[self.indice_key] = rb
         return rb
@@ -83,3 +85,23 @@ class SparseConv3d(SparseConvolution):
                  indice_key=None, **kwargs):
         super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, False,
                          indice_key=indice_key, **kwargs)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    """Undoes the sparsity change of the strided SparseConv3d that registered `indice_key` (spconv_backbone.py:16-18, the UNet
+    decoders): the output sites are that conv's INPUT sites and every (input row, output row, offset) pair of its rulebook is used
+    the other way round -- out[i] = sum over pairs (i, o, k) of W[k] . x[o].  No rulebook is built: the original's input-major
+    table is this layer's output-major table."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True, **kwargs):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, subm=False, inverse=True, indice_key=indice_key, **kwargs)
+
+    def forward(self, x):
+        assert isinstance(x, SparseConvTensor)
+        rb = x.find_indice_pair(self.indice_key)
+        assert rb is not None and not rb.subm, f"SparseInverseConv3d needs the rulebook of a strided conv under indice_key {self.indice_key!r}"
+        assert rb.ksize == self.kernel_size and rb.n_out == x.features.shape[0], "inverse conv applied to a tensor of another level"
+        feats = Fsp.SparseConvFunction.apply(x.features, self.weight_kio(), rb.inverse_view())
+        if self.bias is not None:
+            feats = feats + self.bias
+        return SparseConvTensor(feats, rb.in_indices, rb.in_shape, x.batch_size, x.grid, x.indice_dict)

@@ -30,10 +30,19 @@ class Rulebook:
         self._nbr_in_subm = None
         self._orders = {}
         self._groups = {}
+        self._inverse = None
+        self.in_indices = self.in_shape = None      # set by the conv that built the rulebook
 
     @property
     def K(self):
         return self.nbr_out.shape[0]
+
+    def inverse_view(self):
+        """The same pairs read the other way round (SparseInverseConv3d): the input-major table becomes the output-major one."""
+        assert not self.subm and self.nbr_in is not None
+        if self._inverse is None:
+            self._inverse = Rulebook(self.nbr_in, self.nbr_out, self.in_indices, self.in_shape, self.n_out, self.n_in, False, self.ksize)
+        return self._inverse
 
     def table_for_backward_data(self):
         """Input-major table. For SubM it is the output-major table with the offsets reversed
