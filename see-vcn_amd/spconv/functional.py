@@ -81,8 +81,12 @@ class Rulebook:
         assert direction in ("fwd", "bwd")
         kd, nc = int(kd), int(nc)
         n_rows = self.n_out if direction == "fwd" else self.n_in
-        groupable = (GROUP_ROWS and kd % 16 == 0 and nc % 16 == 0 and kd <= 64 and nc <= 64 and self.K <= 27 and 64 <= n_rows <= 16 * 65536)
+        mfma_kernel = kd % 16 == 0 and nc % 16 == 0 and kd <= 64 and nc <= 64 and self.K <= 27        # k_spconv_rs3 takes the layer
+        groupable = GROUP_ROWS and mfma_kernel and 64 <= n_rows <= 16 * 65536
         if not groupable:
+            if direction == "bwd" and self.subm and mfma_kernel:
+                # the submanifold table read with its offsets reversed IS its input-major table: no flipped copy, same tile order
+                return self.nbr_out, self.tile_order(self.nbr_out, kd, nc), None, True
             table = self.nbr_out if direction == "fwd" else self.table_for_backward_data()
             return table, self.tile_order(table, kd, nc), None, False
         key = "fwd" if (direction == "fwd" or self.subm) else "bwd"    # a submanifold table serves its own data gradient reversed
