@@ -48,7 +48,7 @@ class SceneStep(nn.Module):
         # VCN.inference's post-processing (models/VCN.py:89-93) and the scene merge (SEE_VCN.py:115,247-265), all on the GPU
         surface, _ = get_partial_mesh_batch_device(objects, coarse, k=self.sel_k)
         clustered, _ = get_largest_cluster_batch_device(surface, eps=self.cluster_eps, min_points=2, total_pts=coarse.shape[1])
-        return complete_scene_batch_device(points, clustered, object_scene, 0.1)
+        return complete_scene_batch_device(points, clustered, object_scene, 0.1, compact=False)   # replaced points: scene id -1, dropped by the VFE
 
     def forward(self, points, objects, object_scene, batch_size):
         pts = self.complete_and_paste(points, objects, object_scene)

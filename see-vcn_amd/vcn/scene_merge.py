@@ -44,11 +44,17 @@ def replace_with_completed_pts(points, sc_instances, point_dist_thresh=0.1, devi
     return replace_with_completed_pts_device(p, r, point_dist_thresh).cpu().numpy().astype(np.float64)
 
 
-def complete_scene_batch_device(points, clustered, object_scene, point_dist_thresh=0.1):
+def complete_scene_batch_device(points, clustered, object_scene, point_dist_thresh=0.1, compact=True):
     """Batched tail of SEE_VCN.complete_*_pts + replace_with_completed_pts for a whole batch of scenes in one pass:
     points (SP,4) [b,x,y,z], clustered (B_o,N,3) completed objects, object_scene (B_o,) scene id of each object ->
-    (SP',4) rows [b,x,y,z]: per-scene unique completed points first, then the scene points not within the threshold of them."""
+    (SP',4) rows [b,x,y,z]: per-scene unique completed points first, then the scene points not within the threshold of them.
+    compact=False keeps the replaced scene points in place with scene id -1 (every consumer downstream -- the voxelisers -- drops
+    rows whose scene id is out of range): no boolean-mask compaction, hence no host sync, when the cloud only feeds voxelisation."""
     bcol = object_scene.to(clustered.dtype).view(-1, 1, 1).expand(-1, clustered.shape[1], 1)
     inst = torch.unique(torch.cat([bcol, clustered], dim=2).view(-1, 4), dim=0)        # row-sorted: scene id first, like one np.unique per scene
     near = points_near_set(points, inst, point_dist_thresh)
-    return torch.cat([inst, points[~near]], dim=0)
+    if compact:
+        return torch.cat([inst, points[~near]], dim=0)
+    out = torch.cat([inst, points], dim=0)
+    out[inst.shape[0]:, 0].masked_fill_(near, -1.0)
+    return out

@@ -129,3 +129,14 @@ def test_hip_batched_scene_completion_vs_per_scene_oracle(golden_dir, cuda, hip_
         scene_xyz = pts[pts[:, 0] == sc][:, 1:4]
         want = opp.replace_with_completed_pts(scene_xyz, opp.merge_instances(objs), 0.1)[0] if objs else scene_xyz
         assert np.array_equal(mine.astype(np.float64), np.asarray(want, np.float64)), sc
+    # compact=False: same rows, the replaced scene points stay in place with scene id -1; the voxeliser sees the same scene
+    from seevcn_amd.pcdet.ops import voxel_ops
+    raw = M.complete_scene_batch_device(torch.from_numpy(pts).to(cuda), torch.from_numpy(world).to(cuda), torch.from_numpy(obj_scene).to(cuda), 0.1,
+                                        compact=False)
+    kept = raw[raw[:, 0] >= 0].cpu().numpy()
+    assert np.array_equal(kept, out) and raw.shape[0] > out.shape[0]
+    geo = ([0, -40, -3, 70.4, 40, 1], [0.05, 0.05, 0.1], [1408, 1600, 40])
+    fa, ca, _ = voxel_ops.voxelize_dynamic(raw.contiguous(), *geo, 3)
+    fb, cb, _ = voxel_ops.voxelize_dynamic(torch.from_numpy(out).to(cuda), *geo, 3)
+    assert torch.equal(ca, cb)
+    np.testing.assert_allclose(fa.cpu().numpy(), fb.cpu().numpy(), rtol=1e-5, atol=1e-5)
