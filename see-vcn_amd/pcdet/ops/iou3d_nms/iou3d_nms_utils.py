@@ -16,6 +16,20 @@ def _pairs(boxes_a, boxes_b, iou):
     return out
 
 
+def boxes_iou_bev_cpu(boxes_a, boxes_b, device='cuda'):
+    """(N,7),(M,7) numpy arrays or CPU tensors -> (N,M) rotated BEV IoU of the same type (reference iou3d_nms_utils.py:11-28, a host
+    loop over iou3d_cpu.cpp there).  Keeps the name and the CPU-side interface; the pairs are evaluated by the same kernel as
+    boxes_iou_bev -- this build has no CPU code path."""
+    import numpy as np
+    is_numpy = isinstance(boxes_a, np.ndarray)
+    a = torch.from_numpy(boxes_a) if is_numpy else boxes_a
+    b = torch.from_numpy(boxes_b) if isinstance(boxes_b, np.ndarray) else boxes_b
+    assert not (a.is_cuda or b.is_cuda), 'Only support CPU tensors'
+    assert a.shape[1] == 7 and b.shape[1] == 7
+    out = _pairs(a.float().to(device), b.float().to(device), True).cpu()
+    return out.numpy() if is_numpy else out
+
+
 def boxes_iou_bev(boxes_a, boxes_b):
     """(N,7),(M,7) -> (N,M) rotated BEV IoU (reference iou3d_nms_utils.py:33-45)."""
     assert boxes_a.shape[1] == boxes_b.shape[1] == 7

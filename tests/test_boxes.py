@@ -89,6 +89,11 @@ def test_hip_overlap_iou_iou3d(cuda, hip_lib):
     np.testing.assert_allclose(u.boxes_iou_bev(ta, tb).cpu().numpy(), ob.boxes_iou_bev(a, b), rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(u.boxes_iou3d_gpu(ta, tb).cpu().numpy(), ob.boxes_iou3d(a, b), rtol=1e-3, atol=1e-4)
     assert u.boxes_iou_bev(ta[:0], tb).shape == (0, 77)
+    cpu = u.boxes_iou_bev_cpu(a, b)                                   # numpy in / numpy out, like the reference's CPU entry point
+    assert isinstance(cpu, np.ndarray) and np.array_equal(cpu, u.boxes_iou_bev(ta, tb).cpu().numpy())
+    assert isinstance(u.boxes_iou_bev_cpu(torch.from_numpy(a), torch.from_numpy(b)), torch.Tensor)
+    with pytest.raises(AssertionError):
+        u.boxes_iou_bev_cpu(ta, tb)
 
 
 @pytest.mark.gpu
