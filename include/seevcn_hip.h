@@ -166,6 +166,9 @@ int sv_sparse_conv_gather_gemm_strided(const float* X, int64_t n_src, const int3
                                        int64_t w_stride_n, int64_t w_stride_c, float* Y, int64_t n_rows, int K, int Kd, int Nc,
                                        const float* bias, const float* scale, const float* shift, const float* residual, int relu,
                                        const int32_t* tile_order, const int32_t* row_perm, int table_k_reversed, void* stream);
+/* 1 iff the MFMA kernel that takes tile_order / row_perm / table_k_reversed is built for this layer shape (K offsets, Kd input and
+ * Nc output channels: multiples of 16 in {16, 32, 64}, K <= 27); other shapes run on the earlier kernels and accept neither. */
+int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc);
 /* masks[row] = bit k set iff nbr[k][row] >= 0 (K <= 31): the sort key of the grouping above. */
 int sv_conv_row_masks(const int32_t* nbr, int64_t n_rows, int K, int32_t* masks, void* stream);
 /* Groups a table's columns by neighbour-mask class (counting sort, 3 launches): masks (n_rows) and row_perm (n_rows), position p

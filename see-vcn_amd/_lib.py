@@ -49,6 +49,7 @@ SIGNATURES = {
     "sv_conv_group_persistent_bytes": (c_sz, []),
     "sv_conv_group_rows": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p]),
     "sv_conv_tile_order_grouped": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),
+    "sv_conv_mfma_kernel_applies": (c_i, [c_i, c_i, c_i]),
     "sv_conv_row_masks": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
     "sv_conv_tiles_per_wave": (c_i, [c_i64, c_i, c_i]),
     "sv_conv_tile_order_scratch_bytes": (c_sz, [c_i64]),

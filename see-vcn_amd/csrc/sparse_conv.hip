@@ -338,7 +338,7 @@ extern "C" int sv_conv_row_masks(const int32_t* nbr, int64_t n_rows, int K, int3
 // wave instead of a 50 MB pass per table).  Histogram and cursors are bumped once per (wave, class) -- lanes with equal keys are
 // found with ballots -- so the hot classes (one mask covers ~20 % of the rows) do not serialise on one address.
 // `hist` is persistent and all-zero between calls.
-constexpr int GR_BUCKETS = 4096, GR_THREADS = 256;
+constexpr int GR_BUCKETS = 4096;
 __device__ __forceinline__ int group_key(unsigned mask) {
   // equal masks -> equal class; classes ordered by the number of active offsets first (neighbouring tiles then cost the same and
   // mixed tiles at class borders waste little), a 7-bit hash of the mask inside one count
@@ -371,8 +371,14 @@ __device__ __forceinline__ void wave_key_groups(int key, bool live, int& rank, i
   }
 }
 
-__global__ __launch_bounds__(GR_THREADS) void k_group_masks(GroupArgs a) {
-  const int64_t row = (int64_t)blockIdx.x * GR_THREADS + threadIdx.x;
+// 1024 rows per workgroup, one per thread.  Class counts go wave -> LDS (one atomic per (wave, class)) -> global (one atomic per
+// (workgroup, class) that occurs): the hottest class sees ~n_rows / 1024 global atomics instead of one per wave.
+constexpr int GR_WG = 1024;
+__global__ __launch_bounds__(GR_WG) void k_group_masks(GroupArgs a) {
+  __shared__ int s_hist[GR_BUCKETS];
+  for (int i = threadIdx.x; i < GR_BUCKETS; i += GR_WG) s_hist[i] = 0;
+  __syncthreads();
+  const int64_t row = (int64_t)blockIdx.x * GR_WG + threadIdx.x;
   const bool live = row < a.n_rows;
   unsigned m = 0;
   if (live) {
@@ -388,7 +394,10 @@ __global__ __launch_bounds__(GR_THREADS) void k_group_masks(GroupArgs a) {
   int rank, size, first_lane;
   const int key = group_key(m);
   wave_key_groups(key, live, rank, size, first_lane);
-  if (live && rank == 0) atomicAdd(&a.hist[key], size);
+  if (live && rank == 0) atomicAdd(&s_hist[key], size);
+  __syncthreads();
+  for (int i = threadIdx.x; i < GR_BUCKETS; i += GR_WG)
+    if (s_hist[i]) atomicAdd(&a.hist[i], s_hist[i]);
 }
 
 __global__ __launch_bounds__(1024) void k_group_scan(GroupArgs a) {
@@ -415,16 +424,25 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupArgs a) {
   }
 }
 
-__global__ __launch_bounds__(GR_THREADS) void k_group_place(GroupArgs a) {
-  const int64_t row = (int64_t)blockIdx.x * GR_THREADS + threadIdx.x;
+__global__ __launch_bounds__(GR_WG) void k_group_place(GroupArgs a) {
+  __shared__ int s_cnt[GR_BUCKETS];          // rows of this workgroup per class, then the workgroup's first position in the class
+  for (int i = threadIdx.x; i < GR_BUCKETS; i += GR_WG) s_cnt[i] = 0;
+  __syncthreads();
+  const int64_t row = (int64_t)blockIdx.x * GR_WG + threadIdx.x;
   const bool live = row < a.n_rows;
   const int key = live ? group_key((unsigned)a.masks[row]) : 0;
   int rank, size, first_lane;
   wave_key_groups(key, live, rank, size, first_lane);
-  int base = 0;
-  if (live && rank == 0) base = a.hist[GR_BUCKETS + key] + atomicAdd(&a.hist[2 * GR_BUCKETS + key], size);
-  base = __shfl(base, first_lane);                 // the group's first lane holds its range
-  if (live) a.perm[base + rank] = (int32_t)row;
+  int wave_off = 0;
+  if (live && rank == 0) wave_off = atomicAdd(&s_cnt[key], size);      // this wave's offset inside the workgroup's share of the class
+  wave_off = __shfl(wave_off, first_lane);
+  __syncthreads();
+  for (int i = threadIdx.x; i < GR_BUCKETS; i += GR_WG) {
+    const int c = s_cnt[i];
+    if (c) s_cnt[i] = a.hist[GR_BUCKETS + i] + atomicAdd(&a.hist[2 * GR_BUCKETS + i], c);
+  }
+  __syncthreads();
+  if (live) a.perm[s_cnt[key] + wave_off + rank] = (int32_t)row;
 }
 
 // cost of the regrouped tiles from the masks alone: active offsets of tile t = popcount(OR of its 16 rows' masks)
@@ -450,11 +468,11 @@ extern "C" int sv_conv_group_rows(const int32_t* nbr, int64_t n_rows, int K, voi
   SV_CHECK_ARG(nbr && persistent && masks && row_perm, "sv_conv_group_rows: null pointer");
   GroupArgs a;
   a.nbr = nbr, a.n_rows = n_rows, a.K = K, a.masks = masks, a.hist = static_cast<int32_t*>(persistent), a.perm = row_perm;
-  const int wgs = sv_div_up(n_rows, GR_THREADS);
+  const int wgs = sv_div_up(n_rows, GR_WG);
   hipStream_t st = sv_stream(stream);
-  hipLaunchKernelGGL(k_group_masks, dim3(wgs), dim3(GR_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_group_masks, dim3(wgs), dim3(GR_WG), 0, st, a);
   hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(k_group_place, dim3(wgs), dim3(GR_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_group_place, dim3(wgs), dim3(GR_WG), 0, st, a);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -807,8 +825,16 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_by
       }
 }
 
+// shapes the rs3 kernel is instantiated for (the only kernel that takes row_perm / table_k_reversed)
+static bool rs3_applies(int K, int Kd, int Nc) {
+  if (K > RS3_KMAX || Kd % 16 || Nc % 16 || Kd > 64 || Nc > 64 || Kd < 16 || Nc < 16) return false;
+  const int nt = Nc / 16, kq = Kd / 16;
+  return nt != 3 && kq != 3 && !(nt == 4 && kq == 3) && !(nt == 3 && kq == 4);
+}
+extern "C" int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc) { return rs3_applies(K, Kd, Nc) ? 1 : 0; }
+
 static int try_launch_rs3(const ConvArgs& a, const WStride& ws, int64_t n_src, hipStream_t st) {
-  if (a.K > RS3_KMAX || a.Kd % 16 || a.Nc % 16 || a.Kd > 64 || a.Nc > 64) return -1;
+  if (!rs3_applies(a.K, a.Kd, a.Nc)) return -1;
   const uint64_t xb = (uint64_t)n_src * a.Kd * 4, wb = (uint64_t)a.K * a.Nc * a.Kd * 4;
   if (xb >= 0xfffffff0ull || wb >= 0xfffffff0ull) return -1;
   const int64_t n_tiles = (a.n_rows + 15) / 16;
@@ -826,7 +852,7 @@ static int try_launch_rs3(const ConvArgs& a, const WStride& ws, int64_t n_src, h
     else hipLaunchKernelGGL((k_spconv_rs3<NTV, KQV, 2>), grid, dim3(256), 0, st, a, (uint32_t)xb, (uint32_t)wb);                 \
     return 0;                                                                                                                    \
   }
-  RS3_CASE(4, 4) RS3_CASE(4, 2) RS3_CASE(2, 4) RS3_CASE(2, 2) RS3_CASE(2, 1) RS3_CASE(1, 2) RS3_CASE(1, 1)
+  RS3_CASE(4, 4) RS3_CASE(4, 2) RS3_CASE(2, 4) RS3_CASE(2, 2) RS3_CASE(2, 1) RS3_CASE(1, 2) RS3_CASE(1, 1) RS3_CASE(4, 1) RS3_CASE(1, 4)
 #undef RS3_CASE
   return -1;
 }

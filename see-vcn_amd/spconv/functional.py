@@ -81,8 +81,9 @@ class Rulebook:
         assert direction in ("fwd", "bwd")
         kd, nc = int(kd), int(nc)
         n_rows = self.n_out if direction == "fwd" else self.n_in
-        mfma_kernel = kd % 16 == 0 and nc % 16 == 0 and kd <= 64 and nc <= 64 and self.K <= 27        # k_spconv_rs3 takes the layer
-        groupable = GROUP_ROWS and mfma_kernel and 64 <= n_rows <= 16 * 65536
+        mfma_kernel = bool(_lib.load().sv_conv_mfma_kernel_applies(int(self.K), kd, nc))              # k_spconv_rs3 takes the layer
+        # narrow layers are bound by their loads, and reading the table through the permutation costs them more than equal-mask tiles save
+        groupable = GROUP_ROWS and mfma_kernel and max(kd, nc) >= 64 and 64 <= n_rows <= 16 * 65536
         if not groupable:
             if direction == "bwd" and self.subm and mfma_kernel:
                 # the submanifold table read with its offsets reversed IS its input-major table: no flipped copy, same tile order
@@ -123,11 +124,10 @@ class Rulebook:
 # dense cell -> row maps (4 B per cell) up to this size replace the rank dictionary in submanifold rulebooks (MI355X: 288 GB of HBM)
 CELLMAP_MAX_BYTES = int(os.environ.get("SEEVCN_CELLMAP_MAX_BYTES", 24 << 30))
 TILE_ORDER = os.environ.get("SEEVCN_TILE_ORDER", "1") != "0"      # work-balanced tile order (sv_conv_tile_order); 0: tiles by position
-# Group table rows by neighbour mask before the MFMA gather-GEMM (Rulebook.plan).  OFF by default: measured on the bench workload the
-# conv kernels get 15-45 % faster (64->64 submanifold layer 185 -> 143 us with an exact sort by mask, 152-158 us with the
-# counting-sort classes built here) but the grouping passes (40 + 33 us per table, hot-class atomics) cost more than that saves
-# per step (7.67 vs 7.25 ms).  DESIGN.md 3 has the numbers; the path is kept correct by tests/test_spconv.py.
-GROUP_ROWS = os.environ.get("SEEVCN_GROUP_ROWS", "0") == "1"
+# Group table rows by neighbour mask before the MFMA gather-GEMM (Rulebook.plan): 16-row tiles of equal mask waste almost none of
+# their MFMA steps.  Applied to the layers with >= 64 channels on one side (the narrow ones are load-bound and lose more to the
+# permuted table reads than they gain); same-box A/B on the bench: GPU time 7.81 -> 7.63 ms per step, the 64->64 kernel 177 -> 145 us.
+GROUP_ROWS = os.environ.get("SEEVCN_GROUP_ROWS", "1") != "0"
 
 
 def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1)):
