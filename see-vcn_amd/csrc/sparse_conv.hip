@@ -442,7 +442,8 @@ __global__ __launch_bounds__(GR_WG) void k_group_place(GroupArgs a) {
     if (c) s_cnt[i] = a.hist[GR_BUCKETS + i] + atomicAdd(&a.hist[2 * GR_BUCKETS + i], c);
   }
   __syncthreads();
-  if (live) a.perm[s_cnt[key] + wave_off + rank] = (int32_t)row;
+  const int64_t pos = (int64_t)s_cnt[key] + wave_off + rank;
+  if (live && pos >= 0 && pos < a.n_rows) a.perm[pos] = (int32_t)row;      // the range check only matters if the persistent counters were clobbered
 }
 
 // cost of the regrouped tiles from the masks alone: active offsets of tile t = popcount(OR of its 16 rows' masks)
