@@ -7,10 +7,16 @@ VoxelBackBone8x (sparse 3-D conv) + HeightCompression forward, loss, backward, S
 HBM before the timed region.  Scenes shard data-parallel (weak scaling); gradients are all-reduced over RCCL.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the process is only a launcher: it starts N rank processes (one GPU each,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches the GPU and exits with their status -- the role of
+`python -m torch.distributed.launch` in the reference's tools/scripts/dist_train.sh:17.  Under torchrun (WORLD_SIZE set) it is a rank.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +29,7 @@ import torch.distributed as dist
 
 SCENES_PER_GPU = 16
 OBJECTS_PER_GPU = 64
+SCENE_N_AZ = 384                   # azimuth steps of the 64-beam ray cast: 20.9 k returns per scene inside the KITTI range
 VCN_FLOP_PER_OBJECT = 1.976e9      # 987.8 M MAC / object, reference formulation
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 PEAK_HBM_GBS = 8000.0
@@ -30,7 +37,7 @@ PEAK_HBM_GBS = 8000.0
 
 def make_inputs(rank, device):
     import seevcn_amd.synth as synth
-    pts, _ = synth.make_scene_batch(SCENES_PER_GPU, seed=2000 + 1000 * rank)
+    pts, _ = synth.make_scene_batch(SCENES_PER_GPU, seed=2000 + 1000 * rank, n_az=SCENE_N_AZ)
     objs, _ = synth.make_object_batch(OBJECTS_PER_GPU, seed=1000 + 1000 * rank)
     # put the objects inside the KITTI range of their scene (x>0 half-plane) so their completed points voxelise
     objs = objs.copy()
@@ -164,9 +171,10 @@ def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
     return f"k_spconv_rs3<{nt}, {kq}, ", ms / n, flop / n, byt / n, n // reps, ms / reps
 
 
-def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1):
-    """Oracle (CPU port) on a bounded sample of the same workload: VCN on n_objects objects + one scene's
-    voxelise -> backbone forward/backward (numpy sparse conv inside torch-CPU autograd for BN/ReLU)."""
+def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1, warmup=3, timed=5):
+    """Oracle (CPU port) on a bounded sample of the same workload: VCN + post-processing on n_objects objects and one scene's
+    merge -> voxelise -> VoxelBackBone8x forward/backward (numpy sparse conv inside torch-CPU autograd for BN/ReLU).
+    SURVEY 8(d): warm-up passes, then the median of the timed passes (each pass = the whole sample)."""
     from oracle import vcn as ovcn, voxelize as ovox, spconv as osp, postprocess as opp
     from seevcn_amd.pipeline import KITTI
     from seevcn_amd.pcdet.models import backbones_3d
@@ -175,29 +183,10 @@ def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1):
     import seevcn_amd.vcn as V
     threads = torch.get_num_threads()
     vsd = seeded_state_dict(V.MODELS.build({'NAME': 'VCN_VC'}), seed=0)
-    t0 = time.perf_counter()
-    coarse = ovcn.vcn_vc_forward(vsd, torch.from_numpy(objs_np[:n_objects]))['coarse'].numpy()
-    surface = opp.get_partial_mesh_batch(objs_np[:n_objects], coarse, k=30)
-    coarse = opp.get_largest_cluster_batch(surface, eps=0.4, min_points=2).astype(np.float32)      # 'clustered'
-    t_vcn = (time.perf_counter() - t0) / n_objects            # s / object
-    per_scene_objs = OBJECTS_PER_GPU // SCENES_PER_GPU
-    t1 = time.perf_counter()
-    sel = pts_np[pts_np[:, 0] < n_scenes]
-    paste = np.concatenate([np.repeat(scene_np[:n_objects, None, None], 1024, 1), coarse], axis=2).reshape(-1, 4)
-    paste = paste[paste[:, 0] < n_scenes]
-    if len(paste):
-        inst = np.unique(paste.astype(np.float32), axis=0)
-        near = np.zeros(len(sel), bool)
-        for b in np.unique(inst[:, 0]):
-            qm = sel[:, 0] == b
-            near[qm] = opp.replace_with_completed_pts(sel[qm, 1:4], inst[inst[:, 0] == b, 1:4], 0.1)[1]
-        allp = np.concatenate([inst, sel[~near]], 0)
-    else:
-        allp = sel
     g = KITTI
-    feats, coords, _ = ovox.dynamic_mean_vfe(allp, g['point_cloud_range'], g['voxel_size'], g['grid_size'])
     m = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size'])
     sd = {k: v.numpy() for k, v in seeded_state_dict(m, seed=0).items()}
+    per_scene_objs = OBJECTS_PER_GPU // SCENES_PER_GPU
 
     class Conv(torch.autograd.Function):
         @staticmethod
@@ -218,30 +207,119 @@ def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1):
     def W(key):
         return torch.from_numpy(osp.weight_to_kio(sd[key])).requires_grad_(True)
 
-    shape = tuple(m.sparse_shape)
-    x = torch.from_numpy(feats)
-    nb = osp.rulebook_subm(coords, shape, 3)
-    x = bn_relu(Conv.apply(x, W('conv_input.0.weight'), nb), 16)
-    x = bn_relu(Conv.apply(x, W('conv1.0.0.weight'), nb), 16)
-    c = coords
-    for name, pad, ch in (('conv2', 1, 32), ('conv3', 1, 64), ('conv4', (0, 1, 1), 64)):
-        oc, nbo, _, oshape = osp.rulebook_sparse(c, shape, 3, 2, pad)
-        x = bn_relu(Conv.apply(x, W(f'{name}.0.0.weight'), nbo), ch)
-        c, shape = oc, oshape
-        nb = osp.rulebook_subm(c, shape, 3)
-        for i in (1, 2):
-            x = bn_relu(Conv.apply(x, W(f'{name}.{i}.0.weight'), nb), ch)
-    oc, nbo, _, oshape = osp.rulebook_sparse(c, shape, (3, 1, 1), (2, 1, 1), 0)
-    x = bn_relu(Conv.apply(x, W('conv_out.0.weight'), nbo), 128)
-    dense = torch.zeros(n_scenes, *oshape, 128)
-    dense[torch.from_numpy(oc[:, 0]).long(), torch.from_numpy(oc[:, 1]).long(), torch.from_numpy(oc[:, 2]).long(),
-          torch.from_numpy(oc[:, 3]).long()] = x
-    dense.square().mean().backward()
-    t_scene = (time.perf_counter() - t1) / n_scenes
+    def one_pass():
+        t0 = time.perf_counter()
+        coarse = ovcn.vcn_vc_forward(vsd, torch.from_numpy(objs_np[:n_objects]))['coarse'].numpy()
+        surface = opp.get_partial_mesh_batch(objs_np[:n_objects], coarse, k=30)
+        coarse = opp.get_largest_cluster_batch(surface, eps=0.4, min_points=2).astype(np.float32)      # 'clustered'
+        t_vcn = (time.perf_counter() - t0) / n_objects            # s / object
+        t1 = time.perf_counter()
+        sel = pts_np[pts_np[:, 0] < n_scenes]
+        paste = np.concatenate([np.repeat(scene_np[:n_objects, None, None], 1024, 1), coarse], axis=2).reshape(-1, 4)
+        paste = paste[paste[:, 0] < n_scenes]
+        if len(paste):
+            inst = np.unique(paste.astype(np.float32), axis=0)
+            near = np.zeros(len(sel), bool)
+            for b in np.unique(inst[:, 0]):
+                qm = sel[:, 0] == b
+                near[qm] = opp.replace_with_completed_pts(sel[qm, 1:4], inst[inst[:, 0] == b, 1:4], 0.1)[1]
+            allp = np.concatenate([inst, sel[~near]], 0)
+        else:
+            allp = sel
+        feats, coords, _ = ovox.dynamic_mean_vfe(allp, g['point_cloud_range'], g['voxel_size'], g['grid_size'])
+        shape = tuple(m.sparse_shape)
+        x = torch.from_numpy(feats)
+        nb = osp.rulebook_subm(coords, shape, 3)
+        x = bn_relu(Conv.apply(x, W('conv_input.0.weight'), nb), 16)
+        x = bn_relu(Conv.apply(x, W('conv1.0.0.weight'), nb), 16)
+        c = coords
+        for name, pad, ch in (('conv2', 1, 32), ('conv3', 1, 64), ('conv4', (0, 1, 1), 64)):
+            oc, nbo, _, oshape = osp.rulebook_sparse(c, shape, 3, 2, pad)
+            x = bn_relu(Conv.apply(x, W(f'{name}.0.0.weight'), nbo), ch)
+            c, shape = oc, oshape
+            nb = osp.rulebook_subm(c, shape, 3)
+            for i in (1, 2):
+                x = bn_relu(Conv.apply(x, W(f'{name}.{i}.0.weight'), nb), ch)
+        oc, nbo, _, oshape = osp.rulebook_sparse(c, shape, (3, 1, 1), (2, 1, 1), 0)
+        x = bn_relu(Conv.apply(x, W('conv_out.0.weight'), nbo), 128)
+        dense = torch.zeros(n_scenes, *oshape, 128)
+        dense[torch.from_numpy(oc[:, 0]).long(), torch.from_numpy(oc[:, 1]).long(), torch.from_numpy(oc[:, 2]).long(),
+              torch.from_numpy(oc[:, 3]).long()] = x
+        dense.square().mean().backward()
+        t_scene = (time.perf_counter() - t1) / n_scenes
+        return t_vcn, t_scene
+
+    for _ in range(warmup):
+        one_pass()
+    runs = [one_pass() for _ in range(timed)]
+    t_vcn = float(np.median([r[0] for r in runs]))
+    t_scene = float(np.median([r[1] for r in runs]))
     sec_per_scene = t_scene + per_scene_objs * t_vcn
     return {"value": round(1.0 / sec_per_scene, 4), "unit": "scenes/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (numpy/torch-CPU, {threads} threads): VCN_VC fwd + surface select + DBSCAN on {n_objects} objects ({t_vcn:.3f} s/object) + "
-                      f"{n_scenes} scene voxelise+VoxelBackBone8x fwd+bwd ({t_scene:.2f} s/scene); scaled to {per_scene_objs} objects/scene"}
+            "sample": f"oracle (numpy/torch-CPU, {threads} threads), {warmup} warm-up + {timed} timed passes, medians: VCN_VC fwd + surface select + "
+                      f"DBSCAN on {n_objects} objects ({t_vcn:.3f} s/object) + {n_scenes} scene merge+voxelise+VoxelBackBone8x fwd+bwd "
+                      f"({t_scene:.2f} s/scene); scaled to {per_scene_objs} objects/scene"}
+
+
+def _free_port():
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (rank env set, one GPU each) and relay their
+    exit status; rank 0 prints the JSON line on the inherited stdout.  The parent never calls into HIP (a process that has initialised
+    the GPU must not be replaced or forked), it only waits."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dry_run_rank(args, rank, world):
+    """The N > 1 control flow of a rank without a GPU (CPU tests): process group over gloo, the flat-bucket exchange on fake gradients,
+    the barrier / MAX-over-ranks timing protocol, rank 0's JSON line, barrier, teardown."""
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))]
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        for i, p in enumerate(params):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        allreduce_grads(params, world)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    want = sum(range(1, world + 1)) / world
+    ok = all(torch.allclose(p.grad, torch.full_like(p, want * (i + 1))) for i, p in enumerate(params))
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "exchange_ok": bool(ok),
+                          "elapsed_s": round(elapsed, 4)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def main():
@@ -250,18 +328,40 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scenes-per-gpu", type=int, default=None, help="override the 16 scenes per GPU (tests)")
+    ap.add_argument("--objects-per-gpu", type=int, default=None, help="override the 64 objects per GPU (tests)")
+    ap.add_argument("--no-kernel-rooflines", action="store_true", help="skip the per-kernel event timing after the timed region (tests)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU-only control flow of the multi-rank path (gloo), no kernels")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    global SCENES_PER_GPU, OBJECTS_PER_GPU
+    if args.scenes_per_gpu:
+        SCENES_PER_GPU = args.scenes_per_gpu
+    if args.objects_per_gpu:
+        OBJECTS_PER_GPU = args.objects_per_gpu
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.dry_run:
+        sys.exit(dry_run_rank(args, rank, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    # SEEVCN_BENCH_SHARE_GPU=1 + SEEVCN_BENCH_BACKEND=gloo: every rank on cuda:0 (RCCL refuses two ranks per device) -- lets a 1-GPU box
+    # run the whole N > 1 control flow of this file end to end (tests/test_dist.py)
+    if os.environ.get("SEEVCN_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("SEEVCN_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     points, objects, scene, pts_np, objs_np, scene_np = make_inputs(rank, device)
     model = build_model(device).train()
@@ -290,55 +390,64 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         scenes = SCENES_PER_GPU * world * args.steps
+        in_range = int(((pts_np[:, 1] >= 0) & (pts_np[:, 1] < 70.4) & (np.abs(pts_np[:, 2]) < 40) & (pts_np[:, 3] >= -3) & (pts_np[:, 3] < 1)).sum())
         out = {
             "metric": "scenes/sec (VCN+voxel+spconv fwd+bwd)", "value": round(scenes / elapsed, 3), "unit": "scenes/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "VCN_VC fwd on 64 objects x 1024 pts -> kNN surface select (k=30) -> largest DBSCAN cluster (eps 0.4) -> unique + "
-                                   "replace (<0.1 m) into 16 KITTI-shaped 64-beam scenes (~17k pts) -> "
+                                   f"replace (<0.1 m) into 16 KITTI-shaped 64-beam scenes ({in_range / SCENES_PER_GPU / 1e3:.1f}k pts in range each) -> "
                                    "DynMeanVFE -> VoxelBackBone8x + HeightCompression fwd+bwd + SGD (BASELINE configs[1]+[2])",
                        "scenes_per_gpu": SCENES_PER_GPU, "objects_per_gpu": OBJECTS_PER_GPU, "points_per_object": 1024,
+                       "points_in_range_per_scene": round(in_range / SCENES_PER_GPU),
                        "geometry": "KITTI [0,-40,-3,70.4,40,1] @ [0.05,0.05,0.1] -> sparse [41,1600,1408]", "parallelism": f"dp{world}"},
             "completed_objects_per_sec": round(OBJECTS_PER_GPU * world * args.steps / elapsed, 1),
         }
-        avg_ms, executed_flop, launches, vcn_gemm_ms = measure_dominant_kernel(model, inputs)
-        algo_flop_per_launch = VCN_FLOP_PER_OBJECT * OBJECTS_PER_GPU / launches
-        achieved = algo_flop_per_launch / (avg_ms * 1e-3) / 1e12
-        exec_tf = executed_flop / (vcn_gemm_ms * 1e-3) / 1e12
-        vcn_roof = {"bound": "mfma", "kernel": "k_gemm_f32 (sv_gemm_bias_act[_ragged], v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(exec_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(exec_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4), "ms_per_step": round(vcn_gemm_ms, 3),
-                    "note": "achieved = EXECUTED flops (matrix-core utilisation). Each object's 1024 rows are ResamplePoints copies of "
-                            "30-400 points: the per-point layers run on the distinct rows only (bit-identical output), so the time per "
-                            "object is far below what SURVEY 8(d)'s 1.976 GFLOP/object implies",
-                    "algorithmic_flop_per_launch": algo_flop_per_launch, "algorithmic_tflops": round(achieved, 2)}
-        # dominant kernel by time in the step: the register-stationary sparse-conv gather-GEMM (forward + data gradient)
-        name, c_ms, c_flop, c_bytes, c_launches, c_step_ms = measure_spconv_kernel(model, opt, params, inputs, world)
-        c_ach = c_flop / (c_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": f"{name}G> (sv_sparse_conv_gather_gemm_strided, v_mfma_f32_16x16x4_f32; G = tiles per wave, 2-4 by layer size)",
-                           "achieved": round(c_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(c_ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                           "launches_per_step": c_launches, "avg_launch_ms": round(c_ms, 4), "ms_per_step": round(c_step_ms, 3),
-                           "algorithmic_flop_per_launch": round(c_flop), "algorithmic_bytes_per_launch": round(c_bytes),
-                           "algorithmic_GBps": round(c_bytes / (c_ms * 1e-3) / 1e9, 1)}
-        # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the newest committed PMC pass over this
-        # same command (tools/traffic.sh -> profiles/*_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, x2 on reads for gfx950)
-        import glob
-        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1:]:
-            with open(tf) as fh:
-                kernels = json.load(fh).get("kernels", {})
-            hit = [v for k, v in kernels.items() if name in k]          # the G = 2 / 3 / 4 instances of this channel shape
-            if hit:
-                n_disp = sum(v["dispatches"] for v in hit)
-                out["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in hit) / n_disp)
-                out["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
-        out["roofline_vcn_gemm"] = vcn_roof
-        if not args.no_cpu_baseline:
+        if not args.no_kernel_rooflines:
+            # rank 0 only, so NO collective inside: the measured steps run with world = 1 (the exchange step is skipped)
+            kernel_rooflines(out, model, opt, params, inputs)
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pts_np, objs_np, scene_np)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()             # the other ranks wait here while rank 0 measures and prints
         dist.destroy_process_group()
+
+
+def kernel_rooflines(out, model, opt, params, inputs):
+    avg_ms, executed_flop, launches, vcn_gemm_ms = measure_dominant_kernel(model, inputs)
+    algo_flop_per_launch = VCN_FLOP_PER_OBJECT * OBJECTS_PER_GPU / launches
+    achieved = algo_flop_per_launch / (avg_ms * 1e-3) / 1e12
+    exec_tf = executed_flop / (vcn_gemm_ms * 1e-3) / 1e12
+    vcn_roof = {"bound": "mfma", "kernel": "k_gemm_f32 (sv_gemm_bias_act[_ragged], v_mfma_f32_32x32x2_f32)",
+                "achieved": round(exec_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(exec_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4), "ms_per_step": round(vcn_gemm_ms, 3),
+                "note": "achieved = EXECUTED flops (matrix-core utilisation). Each object's 1024 rows are ResamplePoints copies of "
+                        "30-400 points: the per-point layers run on the distinct rows only (bit-identical output), so the time per "
+                        "object is far below what SURVEY 8(d)'s 1.976 GFLOP/object implies; the algorithmic figure below is NOT a rate",
+                "algorithmic_flop_per_launch": algo_flop_per_launch, "algorithmic_tflops": round(achieved, 2)}
+    # dominant kernel by time in the step: the register-stationary sparse-conv gather-GEMM (forward + data gradient)
+    name, c_ms, c_flop, c_bytes, c_launches, c_step_ms = measure_spconv_kernel(model, opt, params, inputs, 1)
+    c_ach = c_flop / (c_ms * 1e-3) / 1e12
+    out["roofline"] = {"bound": "mfma", "kernel": f"{name}G> (sv_sparse_conv_gather_gemm_strided, v_mfma_f32_16x16x4_f32; G = tiles per wave, 2-4 by layer size)",
+                       "achieved": round(c_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(c_ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                       "launches_per_step": c_launches, "avg_launch_ms": round(c_ms, 4), "ms_per_step": round(c_step_ms, 3),
+                       "algorithmic_flop_per_launch": round(c_flop), "algorithmic_bytes_per_launch": round(c_bytes),
+                       "algorithmic_GBps": round(c_bytes / (c_ms * 1e-3) / 1e9, 1)}
+    # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the newest committed PMC pass over this
+    # same command (tools/traffic.sh -> profiles/*_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, x2 on reads for gfx950)
+    import glob
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))[-1:]:
+        with open(tf) as fh:
+            kernels = json.load(fh).get("kernels", {})
+        hit = [v for k, v in kernels.items() if name in k]          # the G = 2 / 3 / 4 instances of this channel shape
+        if hit:
+            n_disp = sum(v["dispatches"] for v in hit)
+            out["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in hit) / n_disp)
+            out["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
+    out["roofline_vcn_gemm"] = vcn_roof
 
 
 if __name__ == "__main__":

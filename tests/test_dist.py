@@ -81,3 +81,47 @@ def test_two_rank_step_keeps_replicas_in_sync_on_one_gpu():
     mp.spawn(_gpu_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     # averaged gradients and updated weights identical on both ranks, finite, while the ranks saw different scenes (different loss)
     assert dict(out) == {0: (True, True, True, True), 1: (True, True, True, True)}
+
+
+def _run_bench(argv, env_extra=None, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line expected, got {len(lines)}: {r.stdout[-500:]}"
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_its_ranks_world2_gloo():
+    """`python bench.py --gpus 2` with no launcher: the parent starts the two ranks itself (dry run = the N > 1 control flow on gloo)."""
+    out = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"])
+    assert out["n_gpus"] == 2 and out["exchange_ok"] is True
+
+
+def test_bench_rank_under_an_external_launcher_world2_gloo():
+    """The torchrun path: WORLD_SIZE already set -> the process is a rank, not a launcher."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+    assert '"exchange_ok": true' in outs[0][0] and "{" not in outs[1][0]
+
+
+@pytest.mark.gpu
+def test_bench_main_two_ranks_end_to_end_on_one_gpu():
+    """bench.py's whole N = 2 path (launcher, per-rank inputs, steps with the exchange, timing protocol, rank-0-only kernel timing,
+    barrier, teardown) with both ranks on cuda:0 over gloo.  Round 1's main() hung here: rank 0 entered a collective alone."""
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--scenes-per-gpu", "2", "--objects-per-gpu", "8", "--no-cpu-baseline"],
+                     {"SEEVCN_BENCH_SHARE_GPU": "1", "SEEVCN_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["achieved"] > 0
+    assert out["config"]["scenes_per_gpu"] == 2
