@@ -409,48 +409,11 @@ int sv_isolate_largest_cluster(const float* points, int row_stride, const int32_
                                double min_eps, double max_eps, double fixed_eps, int min_points, int min_cluster, void* scratch,
                                int32_t* out_local, int32_t* out_count, double* out_eps, void* stream);
 
-/* ---- roiaware_pool3d_cuda.forward / backward (detector3d/pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:60-170,
- * roiaware_pool3d_kernel.cu:39-312; Python: roiaware_pool3d_utils.py:44-107).  rois (N,7) centre boxes, pts (M,3), pts_feature (M,C).
- * pts_idx_of_voxels (N,ox,oy,oz,max_pts) int32, caller zero-filled: slot 0 = number of points kept (first-come in point order, at
- * most max_pts-1), then their indices.  pool_method 0 max (argmax (N,ox,oy,oz,C), -1 = empty voxel), 1 avg.  pooled (N,ox,oy,oz,C).
- * scratch: sv_roiaware_pool3d_scratch_bytes(N, M).  At most 4096 voxels per RoI.  backward accumulates into the zero-filled
- * grad_in (M,C) with atomics, like the reference. */
-int64_t sv_roiaware_pool3d_scratch_bytes(int num_rois, int num_pts);
-/* roiaware_pool3d_cuda.points_in_boxes_cpu (roiaware_pool3d.cpp:121-165; a host loop in the reference): out (N,M) int32 0/1,
- * box test with MARGIN 1e-2 (points_in_boxes_gpu uses 1e-5 and returns one box per point). */
+/* ---- roiaware_pool3d_cuda.points_in_boxes_cpu (detector3d/pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-165; a host loop in the
+ * reference): out (N,M) int32 0/1, box test with MARGIN 1e-2 (points_in_boxes_gpu uses 1e-5 and returns one box per point).
+ * The RoI-aware pooling entries of that module (forward / backward: PartA2 only) and the PV-RCNN++ entries of pointnet2_stack_cuda
+ * (voxel_query, vector_pool, local 3-NN) are not on the path of any BASELINE config and are not part of this library. */
 int sv_points_in_boxes_matrix(const float* boxes, const float* pts, int num_boxes, int num_points, int32_t* out, void* stream);
-int sv_roiaware_pool3d_forward(const float* rois, const float* pts, const float* pts_feature, int num_rois, int num_pts, int channels,
-                               int out_x, int out_y, int out_z, int max_pts_each_voxel, int pool_method, void* scratch, int32_t* argmax,
-                               int32_t* pts_idx_of_voxels, float* pooled_features, void* stream);
-int sv_roiaware_pool3d_backward(const int32_t* pts_idx_of_voxels, const int32_t* argmax, const float* grad_out, int num_rois, int out_x,
-                                int out_y, int out_z, int channels, int max_pts_each_voxel, int pool_method, float* grad_in, void* stream);
-
-/* ---- the rest of pointnet2_stack_cuda (PV-RCNN++; detector3d/pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp:12-31) ----
- * voxel_query_wrapper (voxel_query.cpp:19-40, voxel_query_gpu.cu:11-87): idx (M,nsample); idx[q,0] = -1 for an empty ball. */
-int sv_voxel_query(int M, int R1, int R2, int R3, int nsample, float radius, int z_range, int y_range, int x_range, const float* new_xyz,
-                   const float* xyz, const int32_t* new_coords, const int32_t* point_indices, int32_t* idx, void* stream);
-/* vector_pool_wrapper (vector_pool.cpp:121-170, vector_pool_gpu.cu:217-385).  new_features (M,num_c_out), new_local_xyz (M,3G),
- * point_cnt_of_grid (M,G) zero-filled by the caller; grouped_idxs (num_max_sum_points,3) rows [support row, query, grid] in
- * arbitrary order (a global atomic counter hands out the rows, as in the reference).  *cum_sum (device int32, reset here) = rows needed; the caller reads it back and retries with a larger buffer when it
- * exceeds num_max_sum_points, as the reference's Python loop does (pointnet2_utils.py:402-419). */
-int sv_vector_pool(const float* support_xyz, const int32_t* xyz_batch_cnt, const float* support_features, const float* new_xyz,
-                   const int32_t* new_xyz_batch_cnt, float* new_features, float* new_local_xyz, int32_t* point_cnt_of_grid,
-                   int32_t* grouped_idxs, int32_t* cum_sum, int batch, int M, int num_c_in, int num_c_out, int num_grid_x, int num_grid_y,
-                   int num_grid_z, float max_neighbour_distance, int use_xyz, int num_max_sum_points, int nsample, int neighbor_type,
-                   int pooling_type, void* stream);
-/* vector_pool_grad_wrapper (vector_pool.cpp:173-200, vector_pool_gpu.cu:388-455): accumulates into zero-filled grad_support_features. */
-int sv_vector_pool_grad(const float* grad_new_features, const int32_t* point_cnt_of_grid, const int32_t* grouped_idxs,
-                        float* grad_support_features, int num_grouped, int num_c_in, int num_c_out, int num_total_grids, void* stream);
-/* query_stacked_local_neighbor_idxs_wrapper_stack (vector_pool.cpp:58-90, vector_pool_gpu.cu:113-190): cumsum (device int32,
- * caller zero-filled) += neighbours; start_len (M,2) = [first slot, count <= min(1000, nsample)]. */
-int sv_query_stacked_local_neighbor_idxs(const float* support_xyz, const int32_t* xyz_batch_cnt, const float* new_xyz,
-                                         const int32_t* new_xyz_batch_cnt, int32_t* stack_neighbor_idxs, int32_t* start_len, int32_t* cumsum,
-                                         int avg_length_of_neighbor_idxs, float max_neighbour_distance, int batch, int M, int nsample,
-                                         int neighbor_type, void* stream);
-/* query_three_nn_by_stacked_local_idxs_wrapper_stack (vector_pool.cpp:24-55, vector_pool_gpu.cu:18-83). */
-int sv_query_three_nn_by_stacked_local_idxs(const float* support_xyz, const float* new_xyz_grid_centers, int32_t* new_xyz_grid_idxs,
-                                            float* new_xyz_grid_dist2, const int32_t* stack_neighbor_idxs, const int32_t* start_len, int M,
-                                            int num_total_grids, void* stream);
 
 #ifdef __cplusplus
 }

@@ -81,14 +81,6 @@ SIGNATURES = {
     "sv_vcn_largest_cluster": (c_i, [c_p, c_i, c_i, c_d, c_i, c_i, c_p, c_p, c_p]),
     "sv_points_near_set": (c_i, [c_p, c_i64, c_p, c_i64, c_i, c_d, c_p, c_p]),
     "sv_points_in_boxes_matrix": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
-    "sv_roiaware_pool3d_scratch_bytes": (c_i64, [c_i, c_i]),
-    "sv_roiaware_pool3d_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
-    "sv_roiaware_pool3d_backward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
-    "sv_voxel_query": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "sv_vector_pool": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_p]),
-    "sv_vector_pool_grad": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
-    "sv_query_stacked_local_neighbor_idxs": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_i, c_p]),
-    "sv_query_three_nn_by_stacked_local_idxs": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "sv_crop_points_in_boxes": (c_i, [c_p, c_i64, c_i, c_p, c_i, c_i64, c_p, c_p, c_p]),
     "sv_project_lidar_to_image_kitti": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p]),
     "sv_project_lidar_to_image_camera": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),

@@ -272,3 +272,30 @@ extern "C" int sv_points_in_boxes(const float* boxes, const float* pts, int batc
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
+
+// points_in_boxes_cpu (roiaware_pool3d.cpp:121-165): (N boxes x M points) 0/1 matrix, MARGIN 1e-2 (the GPU variant uses 1e-5)
+__global__ __launch_bounds__(256) void k_points_in_boxes_matrix(int N, int M, const float* __restrict__ boxes, const float* __restrict__ pts,
+                                                                int32_t* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= M) return;
+  const float* b = boxes + (size_t)i * 7;
+  const float x = pts[(size_t)j * 3], y = pts[(size_t)j * 3 + 1], z = pts[(size_t)j * 3 + 2];
+  int in = 0;
+  if (!(fabsf(z - b[2]) > b[5] / 2.0)) {
+    const float cosa = cosf(-b[6]), sina = sinf(-b[6]);
+    const float sx = x - b[0], sy = y - b[1];
+    const float lx = sx * cosa + sy * (-sina), ly = sx * sina + sy * cosa;
+    in = (fabs(lx) < b[3] / 2.0 + (double)1e-2f && fabs(ly) < b[4] / 2.0 + (double)1e-2f) ? 1 : 0;
+  }
+  out[(size_t)i * M + j] = in;
+}
+
+extern "C" int sv_points_in_boxes_matrix(const float* boxes, const float* pts, int num_boxes, int num_points, int32_t* out, void* stream) {
+  SV_CHECK_ARG(num_boxes >= 0 && num_points >= 0, "sv_points_in_boxes_matrix: negative size");
+  if (num_boxes == 0 || num_points == 0) return SV_OK;
+  SV_CHECK_ARG(boxes && pts && out, "sv_points_in_boxes_matrix: null pointer");
+  hipLaunchKernelGGL(k_points_in_boxes_matrix, dim3(sv_div_up(num_points, 256), num_boxes), dim3(256), 0, sv_stream(stream), num_boxes,
+                     num_points, boxes, pts, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -2,17 +2,15 @@
 import torch
 
 from .... import _lib
+from . import iou3d_nms_cuda
 
 
 def _pairs(boxes_a, boxes_b, iou):
-    lib = _lib.load()
     _lib.require_cuda(boxes_a, boxes_b)
     a = boxes_a[:, :7].contiguous().float()
     b = boxes_b[:, :7].contiguous().float()
     out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
-    rc = lib.sv_boxes_overlap_bev(_lib.ptr(a) if a.numel() else None, a.shape[0], _lib.ptr(b) if b.numel() else None, b.shape[0],
-                                  _lib.ptr(out) if out.numel() else None, int(iou), _lib.stream())
-    _lib.check(rc, "sv_boxes_overlap_bev")
+    (iou3d_nms_cuda.boxes_iou_bev_gpu if iou else iou3d_nms_cuda.boxes_overlap_bev_gpu)(a, b, out)
     return out
 
 

@@ -99,68 +99,3 @@ def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
                                              _lib.ptr(weight), _lib.ptr(grad_features), _lib.stream())
     _lib.check(rc, "sv_three_interpolate_grad_stack")
     return 1
-
-
-def voxel_query_wrapper(M, R1, R2, R3, nsample, radius, z_range, y_range, x_range, new_xyz, xyz, new_coords, point_indices, idx):
-    """src/voxel_query.cpp:19-40"""
-    lib = _lib.load()
-    _lib.require_cuda(new_xyz, xyz, new_coords, point_indices, idx)
-    rc = lib.sv_voxel_query(int(M), int(R1), int(R2), int(R3), int(nsample), float(radius), int(z_range), int(y_range), int(x_range),
-                            _lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(new_coords), _lib.ptr(point_indices), _lib.ptr(idx), _lib.stream())
-    _lib.check(rc, "sv_voxel_query")
-    return 1
-
-
-def vector_pool_wrapper(support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt, new_features, new_local_xyz,
-                        point_cnt_of_grid, grouped_idxs, num_grid_x, num_grid_y, num_grid_z, max_neighbour_distance, use_xyz,
-                        num_max_sum_points, nsample, neighbor_type, pooling_type):
-    """src/vector_pool.cpp:121-170; returns num_cum_sum like the reference (one device->host read of the counter)."""
-    lib = _lib.load()
-    _lib.require_cuda(support_xyz, support_features, new_xyz, new_features)
-    cum = torch.zeros(1, dtype=torch.int32, device=support_xyz.device)
-    rc = lib.sv_vector_pool(_lib.ptr(support_xyz), _lib.ptr(xyz_batch_cnt.int().contiguous()), _lib.ptr(support_features), _lib.ptr(new_xyz),
-                            _lib.ptr(new_xyz_batch_cnt.int().contiguous()), _lib.ptr(new_features), _lib.ptr(new_local_xyz),
-                            _lib.ptr(point_cnt_of_grid), _lib.ptr(grouped_idxs) if grouped_idxs.numel() else None, _lib.ptr(cum),
-                            int(xyz_batch_cnt.shape[0]), int(new_xyz.shape[0]), int(support_features.shape[1]), int(new_features.shape[1]),
-                            int(num_grid_x), int(num_grid_y), int(num_grid_z), float(max_neighbour_distance), int(use_xyz),
-                            int(num_max_sum_points), int(nsample), int(neighbor_type), int(pooling_type), _lib.stream())
-    _lib.check(rc, "sv_vector_pool")
-    return int(cum.item())
-
-
-def vector_pool_grad_wrapper(grad_new_features, point_cnt_of_grid, grouped_idxs, grad_support_features):
-    """src/vector_pool.cpp:173-200"""
-    lib = _lib.load()
-    _lib.require_cuda(grad_new_features, grouped_idxs, grad_support_features)
-    rc = lib.sv_vector_pool_grad(_lib.ptr(grad_new_features), _lib.ptr(point_cnt_of_grid), _lib.ptr(grouped_idxs), _lib.ptr(grad_support_features),
-                                 int(grouped_idxs.shape[0]), int(grad_support_features.shape[1]), int(grad_new_features.shape[1]),
-                                 int(point_cnt_of_grid.shape[1]), _lib.stream())
-    _lib.check(rc, "sv_vector_pool_grad")
-    return 1
-
-
-def query_stacked_local_neighbor_idxs_wrapper_stack(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, stack_neighbor_idxs, start_len,
-                                                    cumsum, avg_length_of_neighbor_idxs, max_neighbour_distance, nsample, neighbor_type):
-    """src/vector_pool.cpp:58-90"""
-    lib = _lib.load()
-    _lib.require_cuda(support_xyz, new_xyz, start_len, cumsum)
-    rc = lib.sv_query_stacked_local_neighbor_idxs(_lib.ptr(support_xyz), _lib.ptr(xyz_batch_cnt.int().contiguous()), _lib.ptr(new_xyz),
-                                                  _lib.ptr(new_xyz_batch_cnt.int().contiguous()),
-                                                  _lib.ptr(stack_neighbor_idxs) if stack_neighbor_idxs.numel() else None, _lib.ptr(start_len),
-                                                  _lib.ptr(cumsum), int(avg_length_of_neighbor_idxs), float(max_neighbour_distance),
-                                                  int(xyz_batch_cnt.shape[0]), int(new_xyz.shape[0]), int(nsample), int(neighbor_type),
-                                                  _lib.stream())
-    _lib.check(rc, "sv_query_stacked_local_neighbor_idxs")
-    return 1
-
-
-def query_three_nn_by_stacked_local_idxs_wrapper_stack(support_xyz, new_xyz, new_xyz_grid_centers, new_xyz_grid_idxs, new_xyz_grid_dist2,
-                                                       stack_neighbor_idxs, start_len, M, num_total_grids):
-    """src/vector_pool.cpp:24-55"""
-    lib = _lib.load()
-    _lib.require_cuda(support_xyz, new_xyz_grid_centers, new_xyz_grid_idxs, new_xyz_grid_dist2, start_len)
-    rc = lib.sv_query_three_nn_by_stacked_local_idxs(_lib.ptr(support_xyz), _lib.ptr(new_xyz_grid_centers), _lib.ptr(new_xyz_grid_idxs),
-                                                     _lib.ptr(new_xyz_grid_dist2), _lib.ptr(stack_neighbor_idxs) if stack_neighbor_idxs.numel() else None,
-                                                     _lib.ptr(start_len), int(M), int(num_total_grids), _lib.stream())
-    _lib.check(rc, "sv_query_three_nn_by_stacked_local_idxs")
-    return 1

@@ -1,36 +1,24 @@
 """Chamfer distance modules with the reference's names (see/surface_completion/models/vcn/extensions/chamfer_dist/__init__.py:13-102)
-over sv_chamfer_forward / sv_chamfer_backward."""
+over chamfer.forward / chamfer.backward (chamfer.py -> sv_chamfer_forward / sv_chamfer_backward)."""
 import torch
 
-from .... import _lib
+from . import chamfer
 
 
 class ChamferFunction(torch.autograd.Function):
+    """Same body as the reference's (chamfer_dist/__init__.py:13-25) over the pybind-level module `chamfer`."""
+
     @staticmethod
     def forward(ctx, xyz1, xyz2):
-        lib = _lib.load()
-        _lib.require_cuda(xyz1, xyz2)
-        xyz1, xyz2 = xyz1.contiguous().float(), xyz2.contiguous().float()
-        B, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
-        dev = xyz1.device
-        dist1, dist2 = torch.empty((B, n), dtype=torch.float32, device=dev), torch.empty((B, m), dtype=torch.float32, device=dev)
-        idx1, idx2 = torch.empty((B, n), dtype=torch.int32, device=dev), torch.empty((B, m), dtype=torch.int32, device=dev)
-        _lib.check(lib.sv_chamfer_forward(_lib.ptr(xyz1), _lib.ptr(xyz2), B, n, m, _lib.ptr(dist1), _lib.ptr(dist2), _lib.ptr(idx1), _lib.ptr(idx2),
-                                          _lib.stream()), "sv_chamfer_forward")
+        dist1, dist2, idx1, idx2 = chamfer.forward(xyz1, xyz2)
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
-        ctx.mark_non_differentiable(idx1, idx2)
         return dist1, dist2
 
     @staticmethod
     def backward(ctx, grad_dist1, grad_dist2):
-        lib = _lib.load()
         xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
-        B, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
-        g1, g2 = torch.empty_like(xyz1), torch.empty_like(xyz2)
-        _lib.check(lib.sv_chamfer_backward(_lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(idx1), _lib.ptr(idx2), _lib.ptr(grad_dist1.contiguous().float()),
-                                           _lib.ptr(grad_dist2.contiguous().float()), B, n, m, _lib.ptr(g1), _lib.ptr(g2), _lib.stream()),
-                   "sv_chamfer_backward")
-        return g1, g2
+        grad_xyz1, grad_xyz2 = chamfer.backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2)
+        return grad_xyz1, grad_xyz2
 
 
 def _strip_zeros(xyz1, xyz2, ignore_zeros):
