@@ -175,7 +175,7 @@ def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1, warmup=3, t
     """Oracle (CPU port) on a bounded sample of the same workload: VCN + post-processing on n_objects objects and one scene's
     merge -> voxelise -> VoxelBackBone8x forward/backward (numpy sparse conv inside torch-CPU autograd for BN/ReLU).
     SURVEY 8(d): warm-up passes, then the median of the timed passes (each pass = the whole sample)."""
-    from oracle import vcn as ovcn, voxelize as ovox, spconv as osp, postprocess as opp
+    from oracle import vcn as ovcn, voxelize as ovox, postprocess as opp, spconv_train as ost
     from seevcn_amd.pipeline import KITTI
     from seevcn_amd.pcdet.models import backbones_3d
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -187,25 +187,6 @@ def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1, warmup=3, t
     m = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size'])
     sd = {k: v.numpy() for k, v in seeded_state_dict(m, seed=0).items()}
     per_scene_objs = OBJECTS_PER_GPU // SCENES_PER_GPU
-
-    class Conv(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x, w, nbr):
-            ctx.nbr = nbr
-            ctx.save_for_backward(x, w)
-            return torch.from_numpy(osp.conv_forward(x.numpy(), nbr, w.numpy()).astype(np.float32))
-
-        @staticmethod
-        def backward(ctx, go):
-            x, w = ctx.saved_tensors
-            gf, gw = osp.conv_backward(x.numpy(), ctx.nbr, w.numpy(), go.numpy())
-            return torch.from_numpy(gf.astype(np.float32)), torch.from_numpy(gw.astype(np.float32)), None
-
-    def bn_relu(x, c):
-        return torch.relu(torch.nn.functional.batch_norm(x, None, None, torch.ones(c), torch.zeros(c), True, 0.01, 1e-3))
-
-    def W(key):
-        return torch.from_numpy(osp.weight_to_kio(sd[key])).requires_grad_(True)
 
     def one_pass():
         t0 = time.perf_counter()
@@ -227,24 +208,7 @@ def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1, warmup=3, t
         else:
             allp = sel
         feats, coords, _ = ovox.dynamic_mean_vfe(allp, g['point_cloud_range'], g['voxel_size'], g['grid_size'])
-        shape = tuple(m.sparse_shape)
-        x = torch.from_numpy(feats)
-        nb = osp.rulebook_subm(coords, shape, 3)
-        x = bn_relu(Conv.apply(x, W('conv_input.0.weight'), nb), 16)
-        x = bn_relu(Conv.apply(x, W('conv1.0.0.weight'), nb), 16)
-        c = coords
-        for name, pad, ch in (('conv2', 1, 32), ('conv3', 1, 64), ('conv4', (0, 1, 1), 64)):
-            oc, nbo, _, oshape = osp.rulebook_sparse(c, shape, 3, 2, pad)
-            x = bn_relu(Conv.apply(x, W(f'{name}.0.0.weight'), nbo), ch)
-            c, shape = oc, oshape
-            nb = osp.rulebook_subm(c, shape, 3)
-            for i in (1, 2):
-                x = bn_relu(Conv.apply(x, W(f'{name}.{i}.0.weight'), nb), ch)
-        oc, nbo, _, oshape = osp.rulebook_sparse(c, shape, (3, 1, 1), (2, 1, 1), 0)
-        x = bn_relu(Conv.apply(x, W('conv_out.0.weight'), nbo), 128)
-        dense = torch.zeros(n_scenes, *oshape, 128)
-        dense[torch.from_numpy(oc[:, 0]).long(), torch.from_numpy(oc[:, 1]).long(), torch.from_numpy(oc[:, 2]).long(),
-              torch.from_numpy(oc[:, 3]).long()] = x
+        dense, _, _ = ost.backbone8x_train_chain(sd, feats, coords, n_scenes, m.sparse_shape, dtype=torch.float32)
         dense.square().mean().backward()
         t_scene = (time.perf_counter() - t1) / n_scenes
         return t_vcn, t_scene

@@ -172,3 +172,40 @@ def voxel_backbone8x_forward(sd, features, coords, batch_size, sparse_shape):
     x = _bn_relu(conv_forward(x, nbr_out, weight_to_kio(np.asarray(sd["conv_out.0.weight"]))), sd, "conv_out.1")
     res["out"] = (x, oc, oshape)
     return res
+
+
+def voxel_res_backbone8x_forward(sd, features, coords, batch_size, sparse_shape):
+    """VoxelResBackBone8x.forward (spconv_backbone.py:241-293, layers :191-232; SparseBasicBlock :30-66) in eval mode: conv_input,
+    two residual blocks per level (conv(bias) - bn - relu - conv(bias) - bn, + identity, relu; both convs of a block and both blocks of a
+    level share one submanifold rulebook), strided conv-bn-relu between levels, conv_out (3,1,1)/(2,1,1).  Returns {name: (features, coords,
+    shape)} for x_conv1..4 and out; sd holds 2.x-layout weights under the reference's key names."""
+    def w(key):
+        return weight_to_kio(np.asarray(sd[key]))
+
+    def basic_block(x, nbr, prefix):
+        y = conv_forward(x, nbr, w(prefix + ".conv1.weight"), np.asarray(sd[prefix + ".conv1.bias"], np.float64))
+        y = _bn_relu(y, sd, prefix + ".bn1")
+        y = conv_forward(y, nbr, w(prefix + ".conv2.weight"), np.asarray(sd[prefix + ".conv2.bias"], np.float64))
+        g, b, m, v = (np.asarray(sd[f"{prefix}.bn2.{k}"], np.float64) for k in ("weight", "bias", "running_mean", "running_var"))
+        y = (y - m) / np.sqrt(v + 1e-3) * g + b
+        return np.maximum(y + x, 0.0)
+
+    shape = tuple(int(s) for s in sparse_shape)
+    nbr = rulebook_subm(coords, shape, 3)
+    x = _bn_relu(conv_forward(features, nbr, w("conv_input.0.weight")), sd, "conv_input.1")
+    for i in (0, 1):
+        x = basic_block(x, nbr, f"conv1.{i}")
+    res = {"x_conv1": (x, coords, shape)}
+    c = coords
+    for name, pad in (("conv2", 1), ("conv3", 1), ("conv4", (0, 1, 1))):
+        oc, nbr_out, _, oshape = rulebook_sparse(c, shape, 3, 2, pad)
+        x = _bn_relu(conv_forward(x, nbr_out, w(f"{name}.0.0.weight")), sd, f"{name}.0.1")
+        c, shape = oc, oshape
+        nbr = rulebook_subm(c, shape, 3)
+        for i in (1, 2):
+            x = basic_block(x, nbr, f"{name}.{i}")
+        res["x_" + name] = (x, c, shape)
+    oc, nbr_out, _, oshape = rulebook_sparse(c, shape, (3, 1, 1), (2, 1, 1), 0)
+    x = _bn_relu(conv_forward(x, nbr_out, w("conv_out.0.weight")), sd, "conv_out.1")
+    res["out"] = (x, oc, oshape)
+    return res

@@ -126,3 +126,27 @@ def second_iou_roi_head(in_channel=512, shared_fc=(256, 256), iou_fc=(256, 256),
 SECOND_IOU_POST = dict(RECALL_THRESH_LIST=[0.3, 0.5, 0.7], SCORE_THRESH=0.1, OUTPUT_RAW_SCORE=False, EVAL_METRIC='kitti',
                        NMS_CONFIG=dict(MULTI_CLASSES_NMS=False, NMS_TYPE='nms_gpu', NMS_THRESH=0.01, NMS_PRE_MAXSIZE=4096, NMS_POST_MAXSIZE=500,
                                        SCORE_TYPE='iou'))
+
+
+def centerpoint_model_cfg():
+    """MODEL section of nuscenes_models/cbgs_voxel0075_res3d_centerpoint.yaml:64-140 (values as data)."""
+    return dict(NAME='CenterPoint', VFE=dict(NAME='MeanVFE'), BACKBONE_3D=dict(NAME='VoxelResBackBone8x'),
+                MAP_TO_BEV=dict(NAME='HeightCompression', NUM_BEV_FEATURES=256), BACKBONE_2D=SECOND_BACKBONE_2D, DENSE_HEAD=CENTER_HEAD,
+                POST_PROCESSING=dict(RECALL_THRESH_LIST=[0.3, 0.5, 0.7], EVAL_METRIC='kitti'))
+
+
+# detector3d/tools/cfgs/source-nuscenes/pvrcnn.yaml:60-215 (values as data): the SEE-VCN PV-RCNN -- one class, 4096 keypoints, no x_conv1/x_conv2 sources
+DA_RANGE = [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
+DA_VOXEL = [0.1, 0.1, 0.15]
+
+
+def see_pvrcnn_model_cfg(dynamic_vfe=True, **kw):
+    kw.setdefault('num_keypoints', 4096)
+    kw.setdefault('features_source', ('bev', 'x_conv3', 'x_conv4', 'raw_points'))
+    pfe, point_head, roi_head = pvrcnn_cfg(**kw)
+    roi_head['NMS_CONFIG']['TEST'] = dict(NMS_TYPE='nms_gpu', MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=4096, NMS_POST_MAXSIZE=300, NMS_THRESH=0.85)
+    head = dict(SECOND_DENSE_HEAD, ANCHOR_GENERATOR_CONFIG=[dict(_anchor('car', [4.2, 2.0, 1.6], 0, 0.55, 0.4))])
+    pp = dict(SECOND_POST_PROCESSING, NMS_CONFIG=dict(SECOND_POST_PROCESSING['NMS_CONFIG'], NMS_THRESH=0.7, NMS_POST_MAXSIZE=500))
+    return dict(NAME='PVRCNN', VFE=dict(NAME='DynMeanVFE' if dynamic_vfe else 'MeanVFE'), BACKBONE_3D=dict(NAME='VoxelBackBone8x'),
+                MAP_TO_BEV=dict(NAME='HeightCompression', NUM_BEV_FEATURES=256), BACKBONE_2D=SECOND_BACKBONE_2D, DENSE_HEAD=head,
+                PFE=pfe, POINT_HEAD=point_head, ROI_HEAD=roi_head, POST_PROCESSING=pp)
