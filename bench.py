@@ -131,38 +131,36 @@ def measure_dominant_kernel(model, inputs, reps=5):
 
 
 def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
-    """Live HIP-event timing of every sv_sparse_conv_gather_gemm launch (forward and data-gradient) of `reps` full steps, grouped
-    by kernel instance k_spconv_rs<Cout/16, Cin/16, 4>.  Returns the instance with the largest total time: (name, avg launch ms,
-    algorithmic flop per launch = 2*pairs*Cin*Cout averaged over its launches, algorithmic bytes per launch, launches per step,
-    ms per step).  Pairs are counted from the rulebook actually used (outside the timed events)."""
+    """Live HIP-event timing of every sv_sparse_conv_gather_gemm_planned launch (forward and data-gradient) of `reps` full steps, grouped
+    by kernel instance k_spconv_rs3<NT, KQ, G> (NT = min(C_out, 64) / 16 column tiles per wave, KQ = C_in / 16).  Returns the instance group
+    with the largest total time: (name, avg launch ms, algorithmic flop per launch = 2*pairs*Cin*Cout averaged over its launches, algorithmic
+    bytes per launch, launches per step, ms per step).  Pairs are counted from the rulebook table actually used (outside the timed events)."""
     from seevcn_amd.spconv import functional as F
     records = []
-    orig = F.gather_gemm
+    orig = F.gather_gemm_planned
 
-    def timed(x, nbr, wt, n_rows, *args, **kw):
+    def timed(x, plan, wfrag, n_rows, K, kd, nc, *args, **kw):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        out = orig(x, nbr, wt, n_rows, *args, **kw)
+        out = orig(x, plan, wfrag, n_rows, K, kd, nc, *args, **kw)
         e.record()
-        records.append((int(wt.shape[2]), int(wt.shape[1]), int(wt.shape[0]), int(x.shape[0]), int(n_rows), nbr, s, e))
+        records.append((int(kd), int(nc), int(K), int(x.shape[0]), int(n_rows), plan[0].source, s, e))
         return out
 
-    F.gather_gemm = timed
+    F.gather_gemm_planned = timed
     try:
         for _ in range(reps):
             run_step(model, opt, params, inputs, world)
         torch.cuda.synchronize()
     finally:
-        F.gather_gemm = orig
+        F.gather_gemm_planned = orig
     groups, pair_cache = {}, {}
     for kd, nc, K, n_src, n_rows, nbr, s, e in records:
-        if kd % 16 or nc % 16:
-            continue                                   # the 3->16 input conv runs on the VALU kernel
         key = nbr.data_ptr()
         if key not in pair_cache:
             pair_cache[key] = int((nbr >= 0).sum().item())
         pairs = pair_cache[key]
-        g = groups.setdefault((nc // 16, kd // 16), [0.0, 0.0, 0.0, 0])
+        g = groups.setdefault((min(nc, 64) // 16, kd // 16), [0.0, 0.0, 0.0, 0])
         g[0] += s.elapsed_time(e)
         g[1] += 2.0 * pairs * kd * nc
         g[2] += 4.0 * (n_src * kd + n_rows * nc) + 4.0 * K * kd * nc + 8.0 * pairs    # SURVEY 8(d): features in+out, weights, rulebook pairs
@@ -394,7 +392,7 @@ def kernel_rooflines(out, model, opt, params, inputs):
     # dominant kernel by time in the step: the register-stationary sparse-conv gather-GEMM (forward + data gradient)
     name, c_ms, c_flop, c_bytes, c_launches, c_step_ms = measure_spconv_kernel(model, opt, params, inputs, 1)
     c_ach = c_flop / (c_ms * 1e-3) / 1e12
-    out["roofline"] = {"bound": "mfma", "kernel": f"{name}G> (sv_sparse_conv_gather_gemm_strided, v_mfma_f32_16x16x4_f32; G = tiles per wave, 2-4 by layer size)",
+    out["roofline"] = {"bound": "mfma", "kernel": f"{name}G> (sv_sparse_conv_gather_gemm_planned, v_mfma_f32_16x16x4_f32; G = tiles per wave, 2-4 by layer size)",
                        "achieved": round(c_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(c_ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                        "launches_per_step": c_launches, "avg_launch_ms": round(c_ms, 4), "ms_per_step": round(c_step_ms, 3),

@@ -122,8 +122,10 @@ int sv_rulebook_subm(const int32_t* coords, int64_t n, int batch, const int32_t*
  * ALL ZERO on entry and on return): 3 launches instead of 8, no atomics.  For grids whose map fits comfortably in the 288 GB of HBM (16 KITTI scenes at
  * 5 cm: 5.9 GB); callers fall back to sv_rulebook_subm for larger grids. */
 size_t sv_cellmap_persistent_bytes(int batch, const int32_t* spatial_shape);
+/* table_rows (n, 32) int32 and masks (n) int32, both optional (K <= 27): the same table ROW-MAJOR ([0..26] source rows, rest -1: one 128-byte
+ * line per row) and every row's neighbour mask (bit k = has neighbour k) -- what the convolution plan consumes (sv_conv_plan_build). */
 int sv_rulebook_subm_cellmap(const int32_t* coords, int64_t n, int batch, const int32_t* spatial_shape, const int32_t* ksize,
-                             const int32_t* dilation, void* cellmap, int32_t* nbr, void* stream);
+                             const int32_t* dilation, void* cellmap, int32_t* nbr, int32_t* table_rows, int32_t* masks, void* stream);
 /* SparseConv3d rulebook, phase 1: output coordinates in canonical (ascending ((b*Z+z)*Y+y)*X+x) order and the
  * input-major table nbr_in (K, n_in) = output row fed by (k, input) or -1; *num_out on the device.
  * index_ws: sv_index_persistent_bytes(batch * prod(out_shape)). */
@@ -133,52 +135,56 @@ int sv_rulebook_sparse(const int32_t* coords, int64_t n_in, int batch, const int
                        int32_t* nbr_in, int64_t capacity, int32_t* num_out, void* stream);
 /* phase 2 (after the caller knows n_out): nbr_out (K, n_out) output-major table from nbr_in */
 int sv_rulebook_invert(const int32_t* nbr_in, int64_t n_in, int K, int32_t* nbr_out, int64_t n_out, void* stream);
+/* The same inversion (K <= 27) that also writes the row-major twins and neighbour masks of both tables:
+ *   out_block ((32 + K + 1) * n_out int32, filled here) = [table_rows_out (n_out, 32) | nbr_out (K, n_out) | masks_out (n_out)]
+ *   in_block  ((32 + 1) * n_in int32)                   = [table_rows_in (n_in, 32) | masks_in (n_in)] */
+int sv_rulebook_invert_rows(const int32_t* nbr_in, int64_t n_in, int K, int32_t* out_block, int64_t n_out, int32_t* in_block, void* stream);
 /* counts[k] = number of (in,out) pairs of offset k (spconv's indice_pair_num) */
 int sv_rulebook_pair_counts(const int32_t* nbr, int64_t n_out, int K, int32_t* counts, void* stream);
 
 /* Y[o][n] = epi( sum_k sum_c X[nbr[k][o]][c] * Wt[k][n][c] ),  epi: +bias, *scale+shift (folded BN), +residual, relu.
  *   forward:       X = features (N_in,C_in),  nbr = output-major table, Wt = weight as (K, C_out, C_in)
  *   backward-data: X = grad_out (N_out,C_out), nbr = input-major table, Wt = weight as (K, C_in, C_out)
- * X has n_src rows, nbr/Y have n_rows rows.  fp32 MFMA (v_mfma_f32_16x16x4_f32) when Kd and Nc are multiples of 16
- * (pairs compacted per workgroup by wavefront ballot, accumulators in LDS), VALU otherwise. */
+ * X has n_src rows, nbr/Y have n_rows rows.  Plain entry: packed (K, Nc, Kd) weights and the k-major table; fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32, accumulators in registers) when Kd and Nc are multiples of 16, VALU otherwise (the 3-channel input layer).
+ * This replaces spconv's per-offset gather / GEMM / scatter-add launches (spconv is un-vendored: spconv_backbone.py:8-27 are the call sites). */
 int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
                                int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
                                const float* residual, int relu, void* stream);
-/* Work-balanced tile order of a rulebook table (spconv has no counterpart: its gather/scatter GEMMs are per-offset launches).
- * tile_order (sv_conv_tile_order_bytes(n_rows)) maps [wave*G + slot] to a 16-row tile or -1 (G = tiles_per_wave = sv_conv_tiles_per_wave(n_rows, Kd, Nc) of the conv that will use it): tiles counting-sorted by their number
- * of active kernel offsets and dealt to the waves in snake order.  Compute once per table, pass to every gather-GEMM that uses it
- * (results are identical with or without it). */
-int sv_conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc);   /* the G the gather-GEMM uses for this shape (2, 3 or 4) */
-size_t sv_conv_tile_order_scratch_bytes(int64_t n_rows);
-size_t sv_conv_tile_order_bytes(int64_t n_rows);
-int sv_conv_tile_order(const int32_t* nbr, int64_t n_rows, int K, int tiles_per_wave, void* scratch, int32_t* tile_order, void* stream);
-int sv_sparse_conv_gather_gemm_ordered(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y, int64_t n_rows, int K,
-                                       int Kd, int Nc, const float* bias, const float* scale, const float* shift, const float* residual,
-                                       int relu, const int32_t* tile_order, void* stream);
-/* Same, with the weights given as ANY (K, Nc, Kd) view of a tensor: element strides (w_stride_k, w_stride_n, w_stride_c).  The
- * parameter of spconv-2.x layout (C_out, kz, ky, kx, C_in) serves the forward (Nc = C_out: strides K*C_in... see
- * seevcn_amd/spconv/functional.py) and the data gradient (Nc = C_in) without a transposing copy per call.
- * row_perm (n_rows int32, may be null): tile position p stands for row row_perm[p] of the table and of the output -- 16
- * consecutive positions share their neighbour mask (sv_conv_group_rows); table_k_reversed: offset k reads table
- * row K-1-k (a submanifold table serving its own data gradient, no flipped copy).  Only the rs3 kernel (C_in, C_out multiples of 16
- * up to 64, K <= 27) takes these two. */
-int sv_sparse_conv_gather_gemm_strided(const float* X, int64_t n_src, const int32_t* nbr, const float* W, int64_t w_stride_k,
-                                       int64_t w_stride_n, int64_t w_stride_c, float* Y, int64_t n_rows, int K, int Kd, int Nc,
-                                       const float* bias, const float* scale, const float* shift, const float* residual, int relu,
-                                       const int32_t* tile_order, const int32_t* row_perm, int table_k_reversed, void* stream);
-/* 1 iff the MFMA kernel that takes tile_order / row_perm / table_k_reversed is built for this layer shape (K offsets, Kd input and
- * Nc output channels: multiples of 16 in {16, 32, 64}, K <= 27); other shapes run on the earlier kernels and accept neither. */
-int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc);
-/* masks[row] = bit k set iff nbr[k][row] >= 0 (K <= 31): the sort key of the grouping above. */
-int sv_conv_row_masks(const int32_t* nbr, int64_t n_rows, int K, int32_t* masks, void* stream);
-/* Groups a table's columns by neighbour-mask class (counting sort, 3 launches): masks (n_rows) and row_perm (n_rows), position p
- * of the grouped order is row row_perm[p].  The table is not rewritten: the conv kernel reads it through row_perm.  persistent:
- * sv_conv_group_persistent_bytes() bytes, all zero before the first call and left consistent by every call.
- * sv_conv_tile_order_grouped: the work-balanced tile order of the grouped tiles from the masks alone (no pass over the table). */
-size_t sv_conv_group_persistent_bytes(void);
-int sv_conv_group_rows(const int32_t* nbr, int64_t n_rows, int K, void* persistent, int32_t* masks, int32_t* row_perm, void* stream);
-int sv_conv_tile_order_grouped(const int32_t* masks, const int32_t* row_perm, int64_t n_rows, int tiles_per_wave, void* scratch,
-                               int32_t* tile_order, void* stream);
+
+/* ---- the MFMA kernel on a PLAN of the table (what SubMConv3d / SparseConv3d of seevcn_amd.spconv run; csrc/sparse_conv.hip) ----
+ * Inputs of a plan: the table row-major (n_rows, 32) and the rows' neighbour masks (n_rows) -- written by the rulebook builders
+ * (sv_rulebook_subm_cellmap, sv_rulebook_invert_rows) or, for any k-major table with K <= 27, by sv_conv_table_rows.
+ * sv_conv_plan_build, once per table: rows are split into 8 contiguous regions (one per XCD: workgroup b of the conv launch works on
+ * region b % 8, so a scene's rows are gathered through one L2) and regrouped inside a region into 16-row tiles of equal neighbour-mask
+ * class (counting sort): perm (16*ceil(n_rows/16)) int32 = row at each position (-1 = padding of the last tile), masks_p = its mask.
+ * persistent: sv_conv_plan_persistent_bytes() bytes, all zero before the first call and left zero-consistent by every call.
+ * sv_conv_plan_tiles, once per (table, tiles_per_wave): tile_of (sv_conv_plan_tiles_bytes(n_rows)) maps [wave][slot] to a tile of the
+ * wave's region or -1; tiles are counting-sorted by their number of active offsets and dealt in snake order (equal work per wave).
+ * tiles_per_wave = sv_conv_tiles_per_wave(n_rows, Kd, Nc) of the conv that will use it (2, 3 or 4).
+ * Results are bit-identical to sv_sparse_conv_gather_gemm (same summation order per output element). */
+int sv_conv_table_rows(const int32_t* nbr, int64_t n_rows, int K, int32_t* table_rows, int32_t* masks, void* stream);
+size_t sv_conv_plan_persistent_bytes(void);
+size_t sv_conv_plan_perm_bytes(int64_t n_rows);
+int sv_conv_plan_build(const int32_t* masks, int64_t n_rows, void* persistent, int32_t* perm, int32_t* masks_p, void* stream);
+int sv_conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc);
+size_t sv_conv_plan_tiles_bytes(int64_t n_rows);
+int sv_conv_plan_tiles(const int32_t* masks_p, int64_t n_rows, int tiles_per_wave, int32_t* tile_of, void* stream);
+/* 1 iff the plan kernel is built for this layer shape (K <= 27 offsets, C_in in {16,32,64,128}, C_out in {16,32} or a multiple of 64 up to
+ * 512) and X (n_src rows) is addressable through a 32-bit buffer descriptor; other shapes take sv_sparse_conv_gather_gemm. */
+int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc, int64_t n_src);
+/* Weights of one layer in MFMA fragment order for both directions, from ANY (K, C_in, C_out) view given by its element strides (the
+ * parameter of spconv-2.x layout (C_out, kz, ky, kx, C_in) is such a view: no transposing copy).  frag_fwd serves the forward
+ * (Kd = C_in, Nc = C_out), frag_bwd the data gradient (Kd = C_out, Nc = C_in); K*C_in*C_out floats each, caller-owned (cache them per
+ * weight version; either may be null). */
+int sv_conv_weight_fragments(const float* W, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, int K, int Cin, int Cout, float* frag_fwd,
+                             float* frag_bwd, void* stream);
+/* table_k_reversed: offset k reads table entry K-1-k (a submanifold table serving its own data gradient, no flipped copy). */
+int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src, const int32_t* table_rows, const int32_t* perm, const int32_t* masks_p,
+                                       const int32_t* tile_of, int tiles_per_wave,
+                                       const float* wfrag, float* Y, int64_t n_rows, int K, int Kd, int Nc, const float* bias,
+                                       const float* scale, const float* shift, const float* residual, int relu, int table_k_reversed,
+                                       void* stream);
 /* dW (K, C_in, C_out) = sum_o X[nbr[k][o]]^T dY[o]; deterministic two-stage reduction */
 size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout);
 int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,

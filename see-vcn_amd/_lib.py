@@ -39,22 +39,22 @@ SIGNATURES = {
     "sv_rulebook_scratch_bytes": (c_sz, [c_i64, c_i64]),
     "sv_rulebook_subm": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_cellmap_persistent_bytes": (c_sz, [c_i, c_p]),
-    "sv_rulebook_subm_cellmap": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sv_rulebook_subm_cellmap": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_rulebook_sparse": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "sv_rulebook_invert": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p]),
+    "sv_rulebook_invert_rows": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p, c_p]),
     "sv_rulebook_pair_counts": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
     "sv_sparse_conv_gather_gemm": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p]),
-    "sv_sparse_conv_gather_gemm_ordered": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
-    "sv_sparse_conv_gather_gemm_strided": (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p]),
-    "sv_conv_group_persistent_bytes": (c_sz, []),
-    "sv_conv_group_rows": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p]),
-    "sv_conv_tile_order_grouped": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),
-    "sv_conv_mfma_kernel_applies": (c_i, [c_i, c_i, c_i]),
-    "sv_conv_row_masks": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
+    "sv_conv_plan_persistent_bytes": (c_sz, []),
+    "sv_conv_table_rows": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p]),
+    "sv_conv_plan_perm_bytes": (c_sz, [c_i64]),
+    "sv_conv_plan_build": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "sv_sparse_conv_gather_gemm_planned": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "sv_conv_tiles_per_wave": (c_i, [c_i64, c_i, c_i]),
-    "sv_conv_tile_order_scratch_bytes": (c_sz, [c_i64]),
-    "sv_conv_tile_order_bytes": (c_sz, [c_i64]),
-    "sv_conv_tile_order": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p]),
+    "sv_conv_plan_tiles_bytes": (c_sz, [c_i64]),
+    "sv_conv_plan_tiles": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
+    "sv_conv_mfma_kernel_applies": (c_i, [c_i, c_i, c_i, c_i64]),
+    "sv_conv_weight_fragments": (c_i, [c_p, c_i64, c_i64, c_i64, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_sparse_conv_wgrad_scratch_bytes": (c_sz, [c_i64, c_i, c_i, c_i]),
     "sv_sparse_conv_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
     "sv_sparse_to_dense_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i]),

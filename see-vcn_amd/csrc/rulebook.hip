@@ -234,6 +234,50 @@ __global__ __launch_bounds__(RB_THREADS) void k_subm_query_map(const int4* __res
   }
 }
 
+// One thread per ROW (K <= 27): the 27 neighbour cells are read as independent loads, the k-major table is written with stores that are
+// coalesced across the rows of a wave, and the same values go out once more ROW-MAJOR (128 bytes per row: [0..26] source rows, the rest -1) with
+// the row's neighbour mask -- what the convolution's plan (sparse_conv.hip) consumes: a 16-row tile reads 16 lines instead of 27 x 16 words.
+constexpr int RB_ROW = 32;     // int32 per row of a row-major table (== PL_ROW in sparse_conv.hip)
+constexpr int RB_KMAX = 27;
+typedef int rb_i32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(RB_THREADS) void k_subm_query_rows(const int4* __restrict__ coords, int64_t n, ConvGeom g, CellTiling t,
+                                                                const int32_t* __restrict__ map, int32_t* __restrict__ nbr,
+                                                                int32_t* __restrict__ tab, int32_t* __restrict__ masks) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = coords[i];
+  const bool ok = coord_ok(c, g.batch, g.in_shape);
+  const int hz = g.ksize[0] / 2, hy = g.ksize[1] / 2, hx = g.ksize[2] / 2, kyx = g.ksize[1] * g.ksize[2];
+  int32_t e[RB_ROW];
+#pragma unroll
+  for (int k = 0; k < RB_ROW; ++k) e[k] = -1;
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < RB_KMAX; ++k) {
+    if (k < g.K) {
+      const int kz = k / kyx, ky = (k - kz * kyx) / g.ksize[2], kx = k - kz * kyx - ky * g.ksize[2];
+      const int z = c.y + (kz - hz) * g.dil[0], y = c.z + (ky - hy) * g.dil[1], x = c.w + (kx - hx) * g.dil[2];
+      int32_t r = -1;
+      if (ok && z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2]) r = map[tiled_cell(c.x, z, y, x, t)] - 1;
+      e[k] = r;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RB_KMAX; ++k) {
+    if (k < g.K) {
+      nbr[(int64_t)k * n + i] = e[k];
+      m |= e[k] >= 0 ? (1u << k) : 0u;
+    }
+  }
+  if (masks) masks[i] = (int32_t)m;
+  if (tab) {
+    rb_i32x4* dst = reinterpret_cast<rb_i32x4*>(tab + i * RB_ROW);
+#pragma unroll
+    for (int q = 0; q < RB_ROW / 4; ++q) dst[q] = (rb_i32x4){e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]};
+  }
+}
+
 extern "C" size_t sv_cellmap_persistent_bytes(int batch, const int32_t* spatial_shape) {
   if (batch <= 0 || !spatial_shape) return 0;
   const CellTiling t = cell_tiling(spatial_shape);
@@ -241,7 +285,7 @@ extern "C" size_t sv_cellmap_persistent_bytes(int batch, const int32_t* spatial_
 }
 
 extern "C" int sv_rulebook_subm_cellmap(const int32_t* coords, int64_t n, int batch, const int32_t* shape_host, const int32_t* ksize_host,
-                                        const int32_t* dilation_host, void* cellmap, int32_t* nbr, void* stream) {
+                                        const int32_t* dilation_host, void* cellmap, int32_t* nbr, int32_t* table_rows, int32_t* masks, void* stream) {
   SV_CHECK_ARG(n >= 0 && batch > 0 && shape_host && ksize_host, "rulebook_subm_cellmap: bad arguments");
   SV_CHECK_ARG(n < 0x7fffffff, "rulebook_subm_cellmap: row + 1 must fit an int32");
   if (n == 0) return SV_OK;
@@ -250,13 +294,17 @@ extern "C" int sv_rulebook_subm_cellmap(const int32_t* coords, int64_t n, int ba
   int rc = fill_geom(g, batch, shape_host, ksize_host, nullptr, nullptr, dilation_host, true);
   if (rc) return rc;
   SV_CHECK_ARG((g.ksize[0] & 1) && (g.ksize[1] & 1) && (g.ksize[2] & 1), "rulebook_subm_cellmap: kernel sizes must be odd");
+  SV_CHECK_ARG(g.K <= RB_KMAX || (!table_rows && !masks), "rulebook_subm_cellmap: row-major table / masks need K <= %d", RB_KMAX);
   hipStream_t st = sv_stream(stream);
   const int4* c4 = reinterpret_cast<const int4*>(coords);
   int32_t* map = reinterpret_cast<int32_t*>(cellmap);
   const int grid = sv_grid_1d(n, RB_THREADS);
   const CellTiling t = cell_tiling(g.in_shape);
   hipLaunchKernelGGL(k_cellmap_set, dim3(grid), dim3(RB_THREADS), 0, st, c4, n, g, t, map, 0);
-  hipLaunchKernelGGL(k_subm_query_map, dim3(sv_grid_1d(n * g.K, RB_THREADS, 256 * 16)), dim3(RB_THREADS), 0, st, c4, n, g, t, map, nbr);
+  if (g.K <= RB_KMAX)
+    hipLaunchKernelGGL(k_subm_query_rows, dim3(sv_div_up(n, RB_THREADS)), dim3(RB_THREADS), 0, st, c4, n, g, t, map, nbr, table_rows, masks);
+  else
+    hipLaunchKernelGGL(k_subm_query_map, dim3(sv_grid_1d(n * g.K, RB_THREADS, 256 * 16)), dim3(RB_THREADS), 0, st, c4, n, g, t, map, nbr);
   hipLaunchKernelGGL(k_cellmap_set, dim3(grid), dim3(RB_THREADS), 0, st, c4, n, g, t, map, 1);
   SV_LAUNCH_CHECK();
   return SV_OK;
@@ -357,6 +405,38 @@ __global__ __launch_bounds__(RB_THREADS) void k_invert(const int32_t* __restrict
   }
 }
 
+// The same inversion with one thread per INPUT row (K <= 27), which additionally writes the row-major twins of both tables and the
+// neighbour masks of both sides (what the convolution plans consume): tab_in / masks_in of its own row in one go, tab_out / masks_out
+// of the rows it feeds by scattered stores / atomicOr (tab_out pre-filled with -1, masks_out with 0).
+__global__ __launch_bounds__(RB_THREADS) void k_invert_rows(const int32_t* __restrict__ nbr_in, int64_t n_in, int K, int32_t* __restrict__ nbr_out,
+                                                            int64_t n_out, int32_t* __restrict__ tab_in, int32_t* __restrict__ masks_in,
+                                                            int32_t* __restrict__ tab_out, int32_t* __restrict__ masks_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_in) return;
+  int32_t e[RB_ROW];
+#pragma unroll
+  for (int k = 0; k < RB_ROW; ++k) e[k] = -1;
+#pragma unroll
+  for (int k = 0; k < RB_KMAX; ++k)
+    if (k < K) {
+      const int32_t o = nbr_in[(int64_t)k * n_in + i];
+      e[k] = (o >= 0 && o < n_out) ? o : -1;
+    }
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < RB_KMAX; ++k)
+    if (k < K && e[k] >= 0) {
+      m |= 1u << k;
+      nbr_out[(int64_t)k * n_out + e[k]] = (int32_t)i;
+      tab_out[(int64_t)e[k] * RB_ROW + k] = (int32_t)i;
+      atomicOr(reinterpret_cast<unsigned*>(masks_out) + e[k], 1u << k);
+    }
+  masks_in[i] = (int32_t)m;
+  rb_i32x4* dst = reinterpret_cast<rb_i32x4*>(tab_in + i * RB_ROW);
+#pragma unroll
+  for (int q = 0; q < RB_ROW / 4; ++q) dst[q] = (rb_i32x4){e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]};
+}
+
 extern "C" int sv_rulebook_invert(const int32_t* nbr_in, int64_t n_in, int K, int32_t* nbr_out, int64_t n_out, void* stream) {
   SV_CHECK_ARG(n_in >= 0 && n_out >= 0 && K > 0, "rulebook_invert: bad arguments");
   if (n_out == 0) return SV_OK;
@@ -366,6 +446,28 @@ extern "C" int sv_rulebook_invert(const int32_t* nbr_in, int64_t n_in, int K, in
   if (n_in == 0) return SV_OK;
   SV_CHECK_ARG(nbr_in, "rulebook_invert: null pointer");
   hipLaunchKernelGGL(k_invert, dim3(sv_grid_1d(n_in * K, RB_THREADS, 256 * 16)), dim3(RB_THREADS), 0, st, nbr_in, n_in, K, nbr_out, n_out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// out_block: ONE allocation of (32 * n_out + K * n_out + n_out) int32 = [tab_out (n_out, 32) | nbr_out (K, n_out) | masks_out (n_out)]
+// (filled here with two memsets); in_block: (32 * n_in + n_in) int32 = [tab_in (n_in, 32) | masks_in (n_in)].
+extern "C" int sv_rulebook_invert_rows(const int32_t* nbr_in, int64_t n_in, int K, int32_t* out_block, int64_t n_out, int32_t* in_block, void* stream) {
+  SV_CHECK_ARG(n_in >= 0 && n_out >= 0 && K > 0 && K <= RB_KMAX, "rulebook_invert_rows: 1 <= K <= %d", RB_KMAX);
+  hipStream_t st = sv_stream(stream);
+  if (n_out > 0) {
+    SV_CHECK_ARG(out_block, "rulebook_invert_rows: null pointer");
+    SV_HIP(hipMemsetAsync(out_block, 0xFF, (size_t)(K + RB_ROW) * n_out * 4, st));
+    SV_HIP(hipMemsetAsync(out_block + (size_t)(K + RB_ROW) * n_out, 0, (size_t)n_out * 4, st));
+  }
+  if (n_in == 0) return SV_OK;
+  SV_CHECK_ARG(nbr_in && in_block, "rulebook_invert_rows: null pointer");
+  SV_CHECK_ARG(n_out > 0 || out_block, "rulebook_invert_rows: null pointer");
+  int32_t* tab_out = out_block;                                   // first: 16-byte aligned rows
+  int32_t* nbr_out = out_block + (size_t)RB_ROW * n_out;
+  int32_t* masks_out = nbr_out + (size_t)K * n_out;
+  hipLaunchKernelGGL(k_invert_rows, dim3(sv_div_up(n_in, RB_THREADS)), dim3(RB_THREADS), 0, st, nbr_in, n_in, K, nbr_out, n_out, in_block,
+                     in_block + (size_t)RB_ROW * n_in, tab_out, masks_out);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

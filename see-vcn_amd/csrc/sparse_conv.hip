@@ -9,8 +9,17 @@
 //
 // Every output row is produced exactly once, in registers, with a fixed summation order (k ascending):
 // no atomics, bitwise reproducible.  The dense per-voxel products run on the fp32 MFMA
-// (v_mfma_f32_16x16x4_f32, exact fp32) — 16-row tiles so that a (tile, offset) pair with no neighbour is skipped.
+// (v_mfma_f32_16x16x4_f32, exact fp32) -- 16-row tiles so that a (tile, offset) pair with no neighbour is skipped.
 // Algorithmic traffic per layer: 4*(N_in*C_in + N_out*C_out) + 4*K*C_in*C_out + 4*K*N_out (table) bytes.
+//
+// The MFMA kernel runs on a PLAN of the table (sv_conv_plan_build, once per rulebook table):
+//   * rows are split into 8 contiguous REGIONS (ascending key order = scene / z-slab order), one per XCD: the workgroups of region r are
+//     the ones the dispatcher places on XCD r (blockIdx % 8), so a scene's feature rows are gathered through ONE 4 MiB L2 instead of eight;
+//   * inside a region rows are regrouped into 16-row tiles of equal NEIGHBOUR-MASK CLASS (counting sort, no comparison sort): a tile executes
+//     an offset when any of its rows has that neighbour, so equal-mask tiles waste few MFMA steps;
+//   * the regrouped table is rewritten row-major (128 B per row: 27 neighbours, mask, output row): a tile's prologue reads 2 KiB of
+//     consecutive bytes instead of 27 x 16 scattered words;
+//   * sv_conv_plan_tiles deals a region's tiles to its waves by descending cost in snake order (equal work per wave).
 //
 // Replaces the third-party spconv kernels behind SubMConv3d / SparseConv3d
 // (call sites: detector3d/pcdet/models/backbones_3d/spconv_backbone.py:8-27,77-117).
@@ -21,11 +30,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int SC_THREADS = 256;
-constexpr int SC_ROWS_PER_WAVE = 32;  // two 16-row MFMA tiles
-constexpr int SC_ROWS_PER_BLOCK = SC_ROWS_PER_WAVE * (SC_THREADS / 64);
-constexpr int SC_KSLICE = 64;         // contraction channels staged in LDS at a time
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
   const float* X;         // (n_src, Kd)
@@ -39,9 +44,6 @@ struct ConvArgs {
   int relu;
   int64_t n_rows;
   int K, Kd, Nc;
-  const int32_t* tile_order;  // [wave * 4 + slot] -> 16-row tile (sv_conv_tile_order) or null: tiles by position
-  const int32_t* row_perm;    // table column p produces output row row_perm[p] (sv_conv_group_rows), or null: p itself
-  int k_flip;                 // read table row K-1-k for offset k (a submanifold table serving its own data gradient)
 };
 
 __device__ __forceinline__ float conv_epilogue(float v, int col, int64_t row, const ConvArgs& a) {
@@ -50,82 +52,6 @@ __device__ __forceinline__ float conv_epilogue(float v, int col, int64_t row, co
   if (a.residual) v += a.residual[row * a.Nc + col];
   if (a.relu) v = fmaxf(v, 0.f);
   return v;
-}
-
-// NT = Nc/16 column tiles held in registers. LDS holds a slice of Wt[k] as [Nc][min(Kd,64)+4].
-template <int NT>
-__global__ __launch_bounds__(SC_THREADS) void k_spconv_mfma(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float Ws[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int li = lane & 15, kk = lane >> 4;
-  const int pitch = min(a.Kd, SC_KSLICE) + 4;
-  const int64_t row0 = (int64_t)blockIdx.x * SC_ROWS_PER_BLOCK + wid * SC_ROWS_PER_WAVE;
-
-  f32x4 acc[2][NT];
-#pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  for (int k = 0; k < a.K; ++k) {
-    // gather indices of this wave's 2x16 rows for offset k (coalesced 64 B reads)
-    int32_t j[2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int64_t r = row0 + g * 16 + li;
-      j[g] = r < a.n_rows ? a.nbr[(int64_t)k * a.n_rows + r] : -1;
-    }
-    const bool any0 = __ballot(j[0] >= 0) != 0ull, any1 = __ballot(j[1] >= 0) != 0ull;
-    const unsigned long long blk_any = __syncthreads_or(any0 || any1);
-    if (!blk_any) continue;                // nobody in the workgroup needs W[k] (uniform across the block)
-    // stage Wt[k] -> LDS in contraction slices of <= SC_KSLICE channels (bounds LDS at Nc*(SC_KSLICE+4)*4 bytes)
-    for (int ks = 0; ks < a.Kd; ks += SC_KSLICE) {
-      const int kw = min(SC_KSLICE, a.Kd - ks);      // slice width (multiple of 16)
-      const int wq = kw / 4;                          // float4 per weight row in the slice
-      const float* src = a.Wt + (int64_t)k * a.Nc * a.Kd + ks;
-      for (int e = tid; e < a.Nc * wq; e += SC_THREADS) {
-        const int n = e / wq, c4 = e - n * wq;
-        *reinterpret_cast<float4*>(&Ws[n * pitch + c4 * 4]) = *reinterpret_cast<const float4*>(src + (int64_t)n * a.Kd + c4 * 4);
-      }
-      __syncthreads();
-      if (any0 || any1) {
-        for (int q = 0; q < kw / 16; ++q) {
-          float4 av[2];
-#pragma unroll
-          for (int g = 0; g < 2; ++g)
-            av[g] = j[g] >= 0 ? *reinterpret_cast<const float4*>(a.X + (int64_t)j[g] * a.Kd + ks + q * 16 + kk * 4) : make_float4(0, 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const float4 b = *reinterpret_cast<const float4*>(&Ws[(t * 16 + li) * pitch + q * 16 + kk * 4]);
-            if (any0) {
-              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].x, b.x, acc[0][t], 0, 0, 0);
-              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].y, b.y, acc[0][t], 0, 0, 0);
-              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].z, b.z, acc[0][t], 0, 0, 0);
-              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].w, b.w, acc[0][t], 0, 0, 0);
-            }
-            if (any1) {
-              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].x, b.x, acc[1][t], 0, 0, 0);
-              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].y, b.y, acc[1][t], 0, 0, 0);
-              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].z, b.z, acc[1][t], 0, 0, 0);
-              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].w, b.w, acc[1][t], 0, 0, 0);
-            }
-          }
-        }
-      }
-      __syncthreads();                     // Ws is overwritten by the next slice / offset
-    }
-  }
-  // D layout (16x16): col = lane&15, row = 4*(lane>>4) + reg
-#pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = row0 + g * 16 + kk * 4 + r;
-        const int col = t * 16 + li;
-        if (row < a.n_rows) a.Y[row * a.Nc + col] = conv_epilogue(acc[g][t][r], col, row, a);
-      }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -246,112 +172,60 @@ __global__ __launch_bounds__(256) void k_spconv_rs(ConvArgs a) {
       }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Three-stage variant of k_spconv_rs.  PMC on k_spconv_rs: matrix core busy 38 %, waves waiting for operands that were requested
-// only one 64-MFMA step (~2000 cycles) earlier, less than the gather latency under load; hipcc additionally sinks its own
-// prefetch loads towards their first use.  Here every operand load of the loop is an inline-asm buffer_load_dwordx4 (hipcc can
-// neither move it nor wait for it), issued TWO steps ahead into a 3-deep register ring, and retired with a counted
-// s_waitcnt vmcnt(2 x loads-per-step) that names the stage's registers ("+v", form (ii) of cdna_hip_programming.md 5.7).
-// Every step issues exactly RS_G + NT loads: rows without a neighbour use an out-of-range buffer offset (the range check
-// returns zeros without a memory access), steps past the end issue out-of-range dummies.  The wave's neighbour indices are parked
-// in LDS once, so the loop contains no compiler-visible VMEM load.  Same ownership, skipping and summation order as k_spconv_rs.
-// ------------------------------------------------------------------------------------------------
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ i32x4 make_srd(const void* p, uint32_t bytes) {
-  const uint64_t a = (uint64_t)p;
-  i32x4 r;
-  r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-  r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffffu));      // stride 0
-  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-  r.w = 0x00020000;
-  return r;
-}
-__device__ __forceinline__ f32x4 buf_load_b128(i32x4 srd, uint32_t voff) {
-  f32x4 v;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(srd) : "memory");
-  return v;
+template <int NT, int G>
+static int launch_rs_kq(const ConvArgs& a, int kq, hipStream_t st) {
+  const int64_t n_tiles = (a.n_rows + 15) / 16;
+  const int64_t n_waves = (n_tiles + G - 1) / G;
+  const dim3 grid((unsigned)((n_waves + 3) / 4));
+  switch (kq) {
+    case 1: hipLaunchKernelGGL((k_spconv_rs<NT, 1, G>), grid, dim3(256), 0, st, a); return 0;
+    case 2: hipLaunchKernelGGL((k_spconv_rs<NT, 2, G>), grid, dim3(256), 0, st, a); return 0;
+    case 4: hipLaunchKernelGGL((k_spconv_rs<NT, 4, G>), grid, dim3(256), 0, st, a); return 0;
+    case 8: hipLaunchKernelGGL((k_spconv_rs<NT, 8, G>), grid, dim3(256), 0, st, a); return 0;
+  }
+  return -1;
 }
 
+static int try_launch_rs(const ConvArgs& a, hipStream_t st) {
+  if (a.Kd % 16 || a.Nc % 16 || a.K > 64) return -1;
+  switch (a.Nc / 16) {
+    case 1: return launch_rs_kq<1, 4>(a, a.Kd / 16, st);
+    case 2: return launch_rs_kq<2, 4>(a, a.Kd / 16, st);
+    case 4: return launch_rs_kq<4, 4>(a, a.Kd / 16, st);
+    case 8: return launch_rs_kq<8, 4>(a, a.Kd / 16, st);
+  }
+  return -1;
+}
+
+
+// ================================================================================================
+// Plan of a rulebook table for the MFMA kernel
+// ================================================================================================
+constexpr int PL_REGIONS = 8;          // one region per XCD (MI355X: 8 XCDs, workgroup b runs on XCD b % 8)
+constexpr int PL_CLASSES = 4096;       // neighbour-mask classes (class_key)
+constexpr int PL_WG = 1024;            // rows per workgroup of the plan kernels; region boundaries are multiples of it (and so of 16)
+constexpr int PL_ROW = 32;             // int32 per row of the regrouped table: [0..26] source rows, [27] mask, [28] output row, [29..31] unused
 constexpr int RS3_KMAX = 27;
 
-// weights re-laid in MFMA fragment order, one contiguous KiB per (offset, 16-channel step, column tile): the B-operand load of
-// a wave then touches 8 whole cache lines instead of 16 half lines at 16 different rows.  Rewritten by every call (<= 442 KB);
-// calls on one device are serialised on one stream ("Error behaviour and streams").
-__device__ __attribute__((aligned(256))) float g_wfrag[RS3_KMAX * 64 * 64];
-
-struct WStride {
-  int64_t k, n, c;     // element strides of the (K, Nc, Kd) weight view
-};
-__global__ __launch_bounds__(256) void k_weight_fragments(const float* __restrict__ wt, WStride ws, int K, int Nc, int Kd, float* __restrict__ wf) {
-  const int total = K * Nc * Kd / 4;                      // float4 units
-  const int KQ = Kd / 16, NT = Nc / 16;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int lane = i & 63, t = (i >> 6) % NT, q = ((i >> 6) / NT) % KQ, k = (i >> 6) / (NT * KQ);
-    const int li = lane & 15, kk = lane >> 4;
-    const float* src = wt + k * ws.k + (t * 16 + li) * ws.n + (q * 16 + kk * 4) * ws.c;
-    float4 v;
-    if (ws.c == 1 && (((uintptr_t)src) & 15) == 0) v = *reinterpret_cast<const float4*>(src);
-    else v = make_float4(src[0], src[ws.c], src[2 * ws.c], src[3 * ws.c]);
-    reinterpret_cast<float4*>(wf)[i] = v;
-  }
-}
-// any weight view -> contiguous (K, Nc, Kd) for the kernels that read the weights in place
-constexpr int64_t WPACK_FLOATS = 27 * 128 * 128;
-__device__ __attribute__((aligned(256))) float g_wpack[WPACK_FLOATS];
-__global__ __launch_bounds__(256) void k_weight_pack(const float* __restrict__ wt, WStride ws, int K, int Nc, int Kd, float* __restrict__ out) {
-  const int64_t total = (int64_t)K * Nc * Kd;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % Kd), n = (int)((i / Kd) % Nc), k = (int)(i / ((int64_t)Kd * Nc));
-    out[i] = wt[k * ws.k + n * ws.n + c * ws.c];
-  }
+// first row of region r: regions are runs of whole PL_WG-row blocks, as equal as possible
+__host__ __device__ inline int64_t plan_region_start(int64_t n_rows, int r) {
+  const int64_t nblk = (n_rows + PL_WG - 1) / PL_WG;
+  const int64_t s = (nblk * r / PL_REGIONS) * PL_WG;
+  return s < n_rows ? s : n_rows;
 }
 
-// Neighbour mask of every row of a table: bit k set iff nbr[k][row] >= 0 (K <= 32).  Rows with equal masks make 16-row tiles whose
-// every executed (tile, offset) step is useful; tiles of consecutive rows waste 40-80 % of them.
-__global__ __launch_bounds__(256) void k_row_masks(const int32_t* __restrict__ nbr, int64_t n_rows, int K, int32_t* __restrict__ masks) {
-  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n_rows; row += (int64_t)gridDim.x * 256) {
-    unsigned m = 0;
-    for (int k0 = 0; k0 < K; k0 += 9) {
-      int32_t j[9];
-#pragma unroll
-      for (int u = 0; u < 9; ++u) j[u] = k0 + u < K ? nbr[(int64_t)(k0 + u) * n_rows + row] : -1;
-#pragma unroll
-      for (int u = 0; u < 9; ++u) m |= j[u] >= 0 ? (1u << (k0 + u)) : 0u;
-    }
-    masks[row] = (int32_t)m;
-  }
+// Mask class.  A 16-row tile executes offset k when ANY of its rows has neighbour k, so rows should share tiles with rows of (nearly) the
+// same mask.  Measured on the rulebooks of the bench scenes (useful / executed MFMA steps, 8 regions): tiles of consecutive rows 0.21-0.58,
+// a hash of the mask (round 1) 0.48-0.74, this key 0.72-0.87, an exact sort by mask 0.70-0.85.  The key is the MIDDLE z-plane of the mask
+// (bits 9..17: the 9 in-plane neighbours, the bulk of a LiDAR surface's neighbourhood) + which of the other two planes are occupied; rows
+// with an empty middle plane (the input-major table of a stride-2 conv: the mask is a function of coordinate parity) are keyed by their
+// first occupied plane instead.  Equal keys -> equal in-plane pattern; the other planes only add the offsets some row actually has.
+__host__ __device__ inline int class_key(unsigned m) {
+  const unsigned bot = m & 0x1ffu, mid = (m >> 9) & 0x1ffu, top = (m >> 18) & 0x1ffu;
+  const unsigned zs = (bot != 0u ? 1u : 0u) | (top != 0u ? 2u : 0u);
+  return mid ? (int)((zs << 9) | mid) : (int)(2048u | (zs << 9) | (bot ? bot : top));
 }
-
-extern "C" int sv_conv_row_masks(const int32_t* nbr, int64_t n_rows, int K, int32_t* masks, void* stream) {
-  SV_CHECK_ARG(n_rows >= 0 && K > 0 && K <= 31, "sv_conv_row_masks: 1 <= K <= 31 (got %d)", K);
-  if (n_rows == 0) return SV_OK;
-  SV_CHECK_ARG(nbr && masks, "sv_conv_row_masks: null pointer");
-  hipLaunchKernelGGL(k_row_masks, dim3(sv_grid_1d(n_rows, 256)), dim3(256), 0, sv_stream(stream), nbr, n_rows, K, masks);
-  SV_LAUNCH_CHECK();
-  return SV_OK;
-}
-
-// Regrouping of a table's columns by neighbour mask without a sort: a counting sort over GR_BUCKETS classes of the mask
-// (group_key).  Three launches: masks + class histogram, an exclusive scan over the classes, and the placement row_perm[p] = row.
-// The table itself is NOT rewritten: the conv kernel reads its 16 x 27 entries per tile through row_perm (a 2 us start-up per
-// wave instead of a 50 MB pass per table).  Histogram and cursors are bumped once per (wave, class) -- lanes with equal keys are
-// found with ballots -- so the hot classes (one mask covers ~20 % of the rows) do not serialise on one address.
-// `hist` is persistent and all-zero between calls.
-constexpr int GR_BUCKETS = 4096;
-__device__ __forceinline__ int group_key(unsigned mask) {
-  // equal masks -> equal class; classes ordered by the number of active offsets first (neighbouring tiles then cost the same and
-  // mixed tiles at class borders waste little), a 7-bit hash of the mask inside one count
-  return (__popc(mask) << 7) | (int)((mask * 2654435761u) >> 25);
-}
-struct GroupArgs {
-  const int32_t* nbr;
-  int64_t n_rows;
-  int K;
-  int32_t* masks;     // out (n_rows)
-  int32_t* hist;      // [0..B): class counts (zero on entry, zeroed again by the scan); [B..2B): class starts; [2B..3B): cursors
-  int32_t* perm;      // out (n_rows)
-};
 
 // "for every distinct key among the live lanes": this lane's rank inside its key group, the group's size and its first lane
 __device__ __forceinline__ void wave_key_groups(int key, bool live, int& rank, int& size, int& first_lane) {
@@ -371,41 +245,50 @@ __device__ __forceinline__ void wave_key_groups(int key, bool live, int& rank, i
   }
 }
 
-// 1024 rows per workgroup, one per thread.  Class counts go wave -> LDS (one atomic per (wave, class)) -> global (one atomic per
-// (workgroup, class) that occurs): the hottest class sees ~n_rows / 1024 global atomics instead of one per wave.
-constexpr int GR_WG = 1024;
-__global__ __launch_bounds__(GR_WG) void k_group_masks(GroupArgs a) {
-  __shared__ int s_hist[GR_BUCKETS];
-  for (int i = threadIdx.x; i < GR_BUCKETS; i += GR_WG) s_hist[i] = 0;
+struct PlanArgs {
+  const int32_t* masks;   // (n_rows) neighbour mask of every row (written by the rulebook builders)
+  int64_t n_rows;
+  int32_t* hist;          // persistent: [0 .. R*C) class counts (zero between calls), [R*C .. 2R*C) class starts, [2R*C .. 3R*C) cursors
+  int32_t* perm;          // out: (n_pad) row at each position, -1 in the padding of the last tile; n_pad = 16 * ceil(n_rows / 16)
+  int32_t* masks_p;       // out: (n_pad) mask of the row at each position
+};
+
+__device__ __forceinline__ int plan_region_of_row(int64_t n_rows, int64_t row) {
+  int r = 0;
+#pragma unroll
+  for (int q = 1; q < PL_REGIONS; ++q) r += row >= plan_region_start(n_rows, q) ? 1 : 0;   // starts are non-decreasing
+  return r;
+}
+
+// pass 1: per-(region, class) histogram.  One row per thread; counts go wave -> LDS -> global, so the hottest class (one mask covers
+// ~20 % of the rows) sees one global atomic per 1024 rows.  A workgroup lies inside one region.
+__global__ __launch_bounds__(PL_WG) void k_plan_hist(PlanArgs a) {
+  __shared__ int s_hist[PL_CLASSES];
+  for (int i = threadIdx.x; i < PL_CLASSES; i += PL_WG) s_hist[i] = 0;
   __syncthreads();
-  const int64_t row = (int64_t)blockIdx.x * GR_WG + threadIdx.x;
+  const int64_t row = (int64_t)blockIdx.x * PL_WG + threadIdx.x;
   const bool live = row < a.n_rows;
-  unsigned m = 0;
-  if (live) {
-    for (int k0 = 0; k0 < a.K; k0 += 9) {
-      int32_t j[9];
-#pragma unroll
-      for (int u = 0; u < 9; ++u) j[u] = k0 + u < a.K ? a.nbr[(int64_t)(k0 + u) * a.n_rows + row] : -1;
-#pragma unroll
-      for (int u = 0; u < 9; ++u) m |= j[u] >= 0 ? (1u << (k0 + u)) : 0u;
-    }
-    a.masks[row] = (int32_t)m;
-  }
+  const unsigned m = live ? (unsigned)a.masks[row] : 0u;
   int rank, size, first_lane;
-  const int key = group_key(m);
+  const int key = class_key(m);
   wave_key_groups(key, live, rank, size, first_lane);
   if (live && rank == 0) atomicAdd(&s_hist[key], size);
   __syncthreads();
-  for (int i = threadIdx.x; i < GR_BUCKETS; i += GR_WG)
-    if (s_hist[i]) atomicAdd(&a.hist[i], s_hist[i]);
+  const int region = plan_region_of_row(a.n_rows, (int64_t)blockIdx.x * PL_WG);
+  int32_t* gh = a.hist + (size_t)region * PL_CLASSES;
+  for (int i = threadIdx.x; i < PL_CLASSES; i += PL_WG)
+    if (s_hist[i]) atomicAdd(&gh[i], s_hist[i]);
 }
 
-__global__ __launch_bounds__(1024) void k_group_scan(GroupArgs a) {
+// pass 2: one workgroup per region: exclusive scan of its class counts -> first position of every class; counts and cursors back to zero
+__global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
   __shared__ int s_part[1024];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, region = blockIdx.x;
+  constexpr int RC = PL_REGIONS * PL_CLASSES;
+  int32_t* cnt = a.hist + (size_t)region * PL_CLASSES;
   int v[4], sum = 0;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) v[u] = a.hist[tid * 4 + u], sum += v[u];
+  for (int u = 0; u < 4; ++u) v[u] = cnt[tid * 4 + u], sum += v[u];
   s_part[tid] = sum;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan of the 1024 partial sums
@@ -414,157 +297,163 @@ __global__ __launch_bounds__(1024) void k_group_scan(GroupArgs a) {
     s_part[tid] += t;
     __syncthreads();
   }
-  int run = s_part[tid] - sum;
+  int run = (int)plan_region_start(a.n_rows, region) + s_part[tid] - sum;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    a.hist[GR_BUCKETS + tid * 4 + u] = run;
-    a.hist[2 * GR_BUCKETS + tid * 4 + u] = 0;
-    a.hist[tid * 4 + u] = 0;
+    a.hist[RC + region * PL_CLASSES + tid * 4 + u] = run;
+    a.hist[2 * RC + region * PL_CLASSES + tid * 4 + u] = 0;
+    cnt[tid * 4 + u] = 0;
     run += v[u];
   }
 }
 
-__global__ __launch_bounds__(GR_WG) void k_group_place(GroupArgs a) {
-  __shared__ int s_cnt[GR_BUCKETS];          // rows of this workgroup per class, then the workgroup's first position in the class
-  for (int i = threadIdx.x; i < GR_BUCKETS; i += GR_WG) s_cnt[i] = 0;
+// pass 3: placement.  position = class start + (rows of the class placed by earlier workgroups: one global atomic per (workgroup, class))
+// + (rows of the class in earlier waves of this workgroup: LDS) + rank inside the wave.  Threads past n_rows fill the padding of the last tile.
+__global__ __launch_bounds__(PL_WG) void k_plan_place(PlanArgs a) {
+  __shared__ int s_cnt[PL_CLASSES];
+  constexpr int RC = PL_REGIONS * PL_CLASSES;
+  for (int i = threadIdx.x; i < PL_CLASSES; i += PL_WG) s_cnt[i] = 0;
   __syncthreads();
-  const int64_t row = (int64_t)blockIdx.x * GR_WG + threadIdx.x;
+  const int64_t row = (int64_t)blockIdx.x * PL_WG + threadIdx.x;
+  const int64_t n_pad = (a.n_rows + 15) / 16 * 16;
   const bool live = row < a.n_rows;
-  const int key = live ? group_key((unsigned)a.masks[row]) : 0;
+  const unsigned m = live ? (unsigned)a.masks[row] : 0u;
+  const int key = live ? class_key(m) : 0;
   int rank, size, first_lane;
   wave_key_groups(key, live, rank, size, first_lane);
   int wave_off = 0;
-  if (live && rank == 0) wave_off = atomicAdd(&s_cnt[key], size);      // this wave's offset inside the workgroup's share of the class
+  if (live && rank == 0) wave_off = atomicAdd(&s_cnt[key], size);
   wave_off = __shfl(wave_off, first_lane);
   __syncthreads();
-  for (int i = threadIdx.x; i < GR_BUCKETS; i += GR_WG) {
+  const int region = plan_region_of_row(a.n_rows, (int64_t)blockIdx.x * PL_WG);
+  for (int i = threadIdx.x; i < PL_CLASSES; i += PL_WG) {
     const int c = s_cnt[i];
-    if (c) s_cnt[i] = a.hist[GR_BUCKETS + i] + atomicAdd(&a.hist[2 * GR_BUCKETS + i], c);
+    if (c) s_cnt[i] = a.hist[RC + region * PL_CLASSES + i] + atomicAdd(&a.hist[2 * RC + region * PL_CLASSES + i], c);
   }
   __syncthreads();
-  const int64_t pos = (int64_t)s_cnt[key] + wave_off + rank;
-  if (live && pos >= 0 && pos < a.n_rows) a.perm[pos] = (int32_t)row;      // the range check only matters if the persistent counters were clobbered
+  int64_t pos = -1;
+  if (live) pos = (int64_t)s_cnt[key] + wave_off + rank;
+  else if (row < n_pad) pos = row;
+  if (pos < 0 || pos >= n_pad) return;            // the range check only matters if the persistent counters were clobbered
+  a.perm[pos] = live ? (int32_t)row : -1;
+  a.masks_p[pos] = (int32_t)m;
 }
 
-// cost of the regrouped tiles from the masks alone: active offsets of tile t = popcount(OR of its 16 rows' masks)
-__global__ __launch_bounds__(256) void k_tile_cost_masks(const int32_t* __restrict__ masks, const int32_t* __restrict__ perm, int64_t n_rows,
-                                                         int64_t n_tiles, uint8_t* __restrict__ cost) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  unsigned m = p < n_rows ? (unsigned)masks[perm[p]] : 0u;
-#pragma unroll
-  for (int off = 8; off > 0; off >>= 1) m |= __shfl_xor(m, off);
-  const int64_t t = p >> 4;
-  if ((threadIdx.x & 15) == 0 && t < n_tiles) {
-    const int c = __popc(m);
-    cost[t] = (uint8_t)(c > 31 ? 31 : c);
-  }
+extern "C" size_t sv_conv_plan_persistent_bytes(void) { return (size_t)3 * PL_REGIONS * PL_CLASSES * sizeof(int32_t); }
+extern "C" size_t sv_conv_plan_perm_bytes(int64_t n_rows) {
+  const int64_t n_pad = ((n_rows > 0 ? n_rows : 0) + 15) / 16 * 16;
+  return (size_t)(n_pad > 0 ? n_pad : 16) * sizeof(int32_t);
 }
 
-extern "C" size_t sv_conv_group_persistent_bytes(void) { return (size_t)3 * GR_BUCKETS * sizeof(int32_t); }
-
-extern "C" int sv_conv_group_rows(const int32_t* nbr, int64_t n_rows, int K, void* persistent, int32_t* masks, int32_t* row_perm,
-                                  void* stream) {
-  SV_CHECK_ARG(n_rows >= 0 && K > 0 && K <= 27, "sv_conv_group_rows: 1 <= K <= 27 (got %d)", K);
+extern "C" int sv_conv_plan_build(const int32_t* masks, int64_t n_rows, void* persistent, int32_t* perm, int32_t* masks_p, void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && n_rows < (int64_t)1 << 30, "sv_conv_plan_build: 0 <= n_rows < 2^30");
   if (n_rows == 0) return SV_OK;
-  SV_CHECK_ARG(nbr && persistent && masks && row_perm, "sv_conv_group_rows: null pointer");
-  GroupArgs a;
-  a.nbr = nbr, a.n_rows = n_rows, a.K = K, a.masks = masks, a.hist = static_cast<int32_t*>(persistent), a.perm = row_perm;
-  const int wgs = sv_div_up(n_rows, GR_WG);
+  SV_CHECK_ARG(masks && persistent && perm && masks_p, "sv_conv_plan_build: null pointer");
+  PlanArgs a;
+  a.masks = masks, a.n_rows = n_rows, a.hist = static_cast<int32_t*>(persistent), a.perm = perm, a.masks_p = masks_p;
+  const int wgs = sv_div_up(n_rows, PL_WG);      // covers the <= 15 padding positions too: n_pad <= wgs * PL_WG
   hipStream_t st = sv_stream(stream);
-  hipLaunchKernelGGL(k_group_masks, dim3(wgs), dim3(GR_WG), 0, st, a);
-  hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(k_group_place, dim3(wgs), dim3(GR_WG), 0, st, a);
+  hipLaunchKernelGGL(k_plan_hist, dim3(wgs), dim3(PL_WG), 0, st, a);
+  hipLaunchKernelGGL(k_plan_scan, dim3(PL_REGIONS), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(k_plan_place, dim3(wgs), dim3(PL_WG), 0, st, a);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
 
-// Work-balanced tile assignment.  A 16-row tile costs as many MFMA steps as it has kernel offsets with at least one neighbour
-// (9 / 18 / 27 for the bench layers, depending on how many z-slices it spans); with tiles dealt to waves by position the
-// busiest wave had 1.8x the mean work and set the kernel time.  Tiles are counting-sorted by cost and dealt to the waves in
-// snake order (max / mean 1.05).  Order inside a cost bucket is arbitrary: every output row is still produced by one wave with
-// the same summation order, so results do not depend on it.
-// The order is a property of the rulebook table: sv_conv_tile_order computes it once (two small launches), the conv launches
-// that use the table pass it in.
-struct TileOrderArgs {
-  const int32_t* nbr;
-  int64_t n_rows, n_tiles, n_waves;
-  int K, G;             // G = tiles per wave of the conv kernel that will use the order
-  uint8_t* cost;        // scratch: (n_tiles)
-  int32_t* hist;        // scratch: [0][32] tiles per cost, [1][32] running fill per cost
-  int32_t* tile_of;     // out: [wave * G + slot] -> tile or -1
-};
-
-constexpr int TO_WGS = 512;
-
-__global__ __launch_bounds__(256) void k_tile_cost(TileOrderArgs a) {
-  __shared__ int s_hist[32];
-  const int lane = threadIdx.x & 63;
-  if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
-  __syncthreads();
-  const int64_t n_groups = (a.n_tiles + 3) / 4;                      // one wave per 4 tiles (64 rows)
-  for (int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; w < n_groups; w += (int64_t)gridDim.x * 4) {
-    const int64_t row = w * 64 + lane;
-    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    for (int k0 = 0; k0 < a.K; k0 += 9) {               // 9 independent loads in flight per lane (27 = 3 x 9)
+// neighbour masks of a k-major table (for tables that did not come with masks from their builder)
+__global__ __launch_bounds__(256) void k_row_masks(const int32_t* __restrict__ nbr, int64_t n_rows, int K, int32_t* __restrict__ masks) {
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n_rows; row += (int64_t)gridDim.x * 256) {
+    unsigned m = 0;
+    for (int k0 = 0; k0 < K; k0 += 9) {
       int32_t j[9];
 #pragma unroll
-      for (int u = 0; u < 9; ++u) j[u] = (row < a.n_rows && k0 + u < a.K) ? a.nbr[(int64_t)(k0 + u) * a.n_rows + row] : -1;
+      for (int u = 0; u < 9; ++u) j[u] = k0 + u < K ? nbr[(int64_t)(k0 + u) * n_rows + row] : -1;
 #pragma unroll
-      for (int u = 0; u < 9; ++u) {
-        const unsigned long long v = __ballot(j[u] >= 0);
-        c0 += (v & 0xffffull) != 0, c1 += ((v >> 16) & 0xffffull) != 0, c2 += ((v >> 32) & 0xffffull) != 0, c3 += (v >> 48) != 0;
-      }
+      for (int u = 0; u < 9; ++u) m |= j[u] >= 0 ? (1u << (k0 + u)) : 0u;
     }
-    if (lane < 4) {
-      const int64_t t = w * 4 + lane;
-      int c = lane == 0 ? c0 : (lane == 1 ? c1 : (lane == 2 ? c2 : c3));
-      c = c > 31 ? 31 : c;
-      if (t < a.n_tiles) {
-        a.cost[t] = (uint8_t)c;
-        atomicAdd(&s_hist[c], 1);
-      }
-    }
-  }
-  __syncthreads();
-  if (a.hist && threadIdx.x < 32 && s_hist[threadIdx.x]) atomicAdd(&a.hist[threadIdx.x], s_hist[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void k_tile_deal(TileOrderArgs a) {
-  __shared__ int s_start[32], s_cnt[32], s_base[32];
-  if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0;
-  if (threadIdx.x == 0) {                 // descending cost: the most expensive bucket first
-    int acc = 0;
-    for (int c = 31; c >= 0; --c) s_start[c] = acc, acc += a.hist[c];
-  }
-  __syncthreads();
-  // this workgroup's contiguous slice of tiles: count per bucket, reserve one range per bucket, then place
-  const int64_t per = (a.n_tiles + gridDim.x - 1) / gridDim.x, t0 = blockIdx.x * per, t1 = min(a.n_tiles, t0 + per);
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.tile_of[0] = a.G;
-  for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) atomicAdd(&s_cnt[a.cost[t]], 1);
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    s_base[threadIdx.x] = s_cnt[threadIdx.x] ? s_start[threadIdx.x] + atomicAdd(&a.hist[32 + threadIdx.x], s_cnt[threadIdx.x]) : 0;
-    s_cnt[threadIdx.x] = 0;
-  }
-  __syncthreads();
-  for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) {
-    const int c = a.cost[t];
-    const int64_t p = s_base[c] + atomicAdd(&s_cnt[c], 1);
-    const int64_t r = p / a.n_waves, i = p - r * a.n_waves;
-    const int64_t wv = (r & 1) ? a.n_waves - 1 - i : i;          // snake: dense and sparse tiles alternate per wave
-    a.tile_of[4 + wv * a.G + r] = (int32_t)t;      // 4-int header: [0] = G
+    masks[row] = (int32_t)m;
   }
 }
+// k-major (K, n_rows) -> row-major (n_rows, 32) + masks, for tables that did not come with them from their builder
+__global__ __launch_bounds__(256) void k_table_rows(const int32_t* __restrict__ nbr, int64_t n_rows, int K, int32_t* __restrict__ tab, int32_t* __restrict__ masks) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n_rows) return;
+  int32_t e[PL_ROW];
+#pragma unroll
+  for (int k = 0; k < PL_ROW; ++k) e[k] = -1;
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < RS3_KMAX; ++k)
+    if (k < K) {
+      e[k] = nbr[(int64_t)k * n_rows + row];
+      m |= e[k] >= 0 ? (1u << k) : 0u;
+    }
+  masks[row] = (int32_t)m;
+  i32x4* dst = reinterpret_cast<i32x4*>(tab + row * PL_ROW);
+#pragma unroll
+  for (int q = 0; q < PL_ROW / 4; ++q) dst[q] = (i32x4){e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]};
+}
+extern "C" int sv_conv_table_rows(const int32_t* nbr, int64_t n_rows, int K, int32_t* table_rows, int32_t* masks, void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && K > 0 && K <= RS3_KMAX, "sv_conv_table_rows: 1 <= K <= %d (got %d)", RS3_KMAX, K);
+  if (n_rows == 0) return SV_OK;
+  SV_CHECK_ARG(nbr && table_rows && masks, "sv_conv_table_rows: null pointer");
+  hipLaunchKernelGGL(k_table_rows, dim3(sv_div_up(n_rows, 256)), dim3(256), 0, sv_stream(stream), nbr, n_rows, K, table_rows, masks);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
 
-// Same result class as k_tile_deal for up to TO_ONE_WG_TILES tiles, in ONE workgroup and without the two fills: the histogram lives
-// in LDS, every slot of the order (header, tiles, -1 padding) is written here.
-constexpr int TO_ONE_WG_TILES = 65536;
-__global__ __launch_bounds__(1024) void k_tile_deal_one(TileOrderArgs a) {
+// ------------------------------------------------------------------------------------------------ tiles -> waves
+// Work-balanced tile assignment inside every region.  A 16-row tile costs as many MFMA steps as it has kernel offsets with at least one
+// neighbour (3 .. 27); a launch lasts as long as its busiest SIMD, and all waves of a launch are resident at once (one round), so the waves
+// must carry equal work: the region's tiles are counting-sorted by cost and dealt to its waves in snake order (max / mean 1.05; by
+// position 1.6-1.8).  Order inside a cost bucket is arbitrary: every output row is still produced by one wave with the same summation
+// order, results do not depend on it.  One workgroup per region, costs in LDS.
+struct PlanDims {
+  int32_t tile0[PL_REGIONS];    // first tile of the region
+  int32_t tiles[PL_REGIONS];    // tiles of the region
+  int32_t waves[PL_REGIONS];    // ceil(tiles / G)
+  int32_t woff[PL_REGIONS];     // waves of the regions before
+  int32_t max_blocks;           // max over regions of ceil(waves / 4)
+  int32_t G;
+};
+static PlanDims plan_dims(int64_t n_rows, int G) {
+  PlanDims d{};
+  const int64_t n_tiles = (n_rows + 15) / 16;
+  int off = 0;
+  d.G = G;
+  for (int r = 0; r < PL_REGIONS; ++r) {
+    const int64_t s = plan_region_start(n_rows, r), e = r + 1 < PL_REGIONS ? plan_region_start(n_rows, r + 1) : n_rows;
+    d.tile0[r] = (int32_t)(s / 16);
+    d.tiles[r] = (int32_t)((r + 1 < PL_REGIONS ? e / 16 : n_tiles) - s / 16);
+    d.waves[r] = (d.tiles[r] + G - 1) / G;
+    d.woff[r] = off;
+    off += d.waves[r];
+    const int b = (d.waves[r] + 3) / 4;
+    if (b > d.max_blocks) d.max_blocks = b;
+  }
+  return d;
+}
+
+constexpr int PL_MAX_REGION_TILES = 65536;
+__global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ masks_p, PlanDims d, int32_t* __restrict__ tile_of) {
+  __shared__ uint8_t s_cost[PL_MAX_REGION_TILES];
   __shared__ int s_cnt[32], s_start[32];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, r = blockIdx.x;
+  const int nt = d.tiles[r], nw = d.waves[r], G = d.G;
   if (tid < 32) s_cnt[tid] = 0;
   __syncthreads();
-  for (int64_t t = tid; t < a.n_tiles; t += 1024) atomicAdd(&s_cnt[a.cost[t]], 1);
+  for (int t = tid; t < nt; t += 1024) {
+    const i32x4* mp = reinterpret_cast<const i32x4*>(masks_p + ((int64_t)d.tile0[r] + t) * 16);
+    unsigned m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const i32x4 v = mp[q];
+      m |= (unsigned)v.x | (unsigned)v.y | (unsigned)v.z | (unsigned)v.w;
+    }
+    const int c = __popc(m) > 31 ? 31 : __popc(m);
+    s_cost[t] = (uint8_t)c;
+    atomicAdd(&s_cnt[c], 1);
+  }
   __syncthreads();
   if (tid == 0) {                          // descending cost: the most expensive bucket first
     int acc = 0;
@@ -572,20 +461,20 @@ __global__ __launch_bounds__(1024) void k_tile_deal_one(TileOrderArgs a) {
   }
   __syncthreads();
   if (tid < 32) s_cnt[tid] = 0;
-  if (tid < 4) a.tile_of[tid] = tid == 0 ? a.G : -1;
   __syncthreads();
-  const int64_t slots = a.n_waves * a.G;
-  for (int64_t t = tid; t < slots; t += 1024) {
-    if (t < a.n_tiles) {
-      const int c = a.cost[t];
-      const int64_t p = s_start[c] + atomicAdd(&s_cnt[c], 1);
-      const int64_t r = p / a.n_waves, i = p - r * a.n_waves;
-      const int64_t wv = (r & 1) ? a.n_waves - 1 - i : i;          // snake: dense and sparse tiles alternate per wave
-      a.tile_of[4 + wv * a.G + r] = (int32_t)t;
-    } else {                                                        // positions n_tiles .. slots-1 of the snake stay empty
-      const int64_t r = t / a.n_waves, i = t - r * a.n_waves;
-      const int64_t wv = (r & 1) ? a.n_waves - 1 - i : i;
-      a.tile_of[4 + wv * a.G + r] = -1;
+  int32_t* out = tile_of + (int64_t)d.woff[r] * G;
+  const int slots = nw * G;
+  for (int t = tid; t < slots; t += 1024) {
+    if (t < nt) {
+      const int c = s_cost[t];
+      const int p = s_start[c] + atomicAdd(&s_cnt[c], 1);
+      const int rnd = p / nw, i = p - rnd * nw;
+      const int wv = (rnd & 1) ? nw - 1 - i : i;          // snake: dense and sparse tiles alternate per wave
+      out[wv * G + rnd] = d.tile0[r] + t;
+    } else {                                              // positions nt .. slots-1 of the snake stay empty
+      const int rnd = t / nw, i = t - rnd * nw;
+      const int wv = (rnd & 1) ? nw - 1 - i : i;
+      out[wv * G + rnd] = -1;
     }
   }
 }
@@ -595,14 +484,17 @@ __global__ __launch_bounds__(1024) void k_tile_deal_one(TileOrderArgs a) {
 // operand latency behind.  Model: time ~ ceil(WGs / 256) * G / eff(waves per SIMD), eff = 0.45 / 0.75 / 0.9 for 1 / 2 / >= 3
 // resident workgroups per CU (measured shape of the curve on the bench layers), + 4 % per step of G below 4 for the extra
 // weight-slab loads.  Measured on the 64->64 layers: 8412 tiles G = 4 230 us, G = 3 183 us; 4012 tiles G = 4 130 us, G = 2 105 us.
-// (The same whole-rounds idea applied to the weight-gradient grid made it slower: its workgroups are unequal, dispatch order
-// already balances them.)
-static int conv_tiles_per_wave(int64_t n_rows) {
-  const int64_t n_tiles = (n_rows + 15) / 16;
+static int conv_col_blocks(int Nc) { return Nc > 64 ? Nc / 64 : 1; }
+static int conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc) {
+  const int nc_blk = Nc > 64 ? 64 : Nc;
+  if ((Kd / 16) * (nc_blk / 16) < 4) return 4;      // layers with < 32x32 channel products per tile are bound by their operand loads: keep G = 4
   int best = 4;
   double best_score = 1e30;
   for (int g = 4; g >= 2; --g) {
-    const int64_t wgs = ((n_tiles + g - 1) / g + 3) / 4;
+    const PlanDims d = plan_dims(n_rows, g);
+    int64_t wgs = 0;
+    for (int r = 0; r < PL_REGIONS; ++r) wgs += (d.waves[r] + 3) / 4;
+    wgs *= conv_col_blocks(Nc);
     if (wgs <= 0) continue;
     const int64_t per_cu = (wgs + 255) / 256;
     const double eff = per_cu >= 3 ? 0.9 : (per_cu == 2 ? 0.75 : 0.45);
@@ -611,110 +503,145 @@ static int conv_tiles_per_wave(int64_t n_rows) {
   }
   return best;
 }
-// layers with fewer than 32x32 channel products per tile are bound by their operand loads, not by matrix-core time: keep G = 4
-static int conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc) { return (Kd / 16) * (Nc / 16) < 4 ? 4 : conv_tiles_per_wave(n_rows); }
 extern "C" int sv_conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc) { return conv_tiles_per_wave(n_rows < 0 ? 0 : n_rows, Kd, Nc); }
-
-static size_t tile_order_scratch_bytes(int64_t n_rows) { return (size_t)((n_rows + 15) / 16) + 256 + 64 * sizeof(int32_t); }
-
-extern "C" size_t sv_conv_tile_order_scratch_bytes(int64_t n_rows) { return tile_order_scratch_bytes(n_rows < 0 ? 0 : n_rows); }
-extern "C" size_t sv_conv_tile_order_bytes(int64_t n_rows) {
+extern "C" size_t sv_conv_plan_tiles_bytes(int64_t n_rows) {
   const int64_t n_tiles = ((n_rows < 0 ? 0 : n_rows) + 15) / 16;
-  return (size_t)(((n_tiles + 1) / 2) * 2 + 16) * sizeof(int32_t);     // 4-int header + enough slots for any G in {2, 3, 4}
+  return (size_t)(n_tiles + 4 * PL_REGIONS + 16) * sizeof(int32_t);     // sum over regions of ceil(tiles_r / G) * G <= n_tiles + 8 * (G - 1)
 }
 
-extern "C" int sv_conv_tile_order(const int32_t* nbr, int64_t n_rows, int K, int tiles_per_wave, void* scratch, int32_t* tile_order,
-                                  void* stream) {
-  SV_CHECK_ARG(n_rows >= 0 && K > 0 && tiles_per_wave >= 2 && tiles_per_wave <= 4, "sv_conv_tile_order: bad sizes (tiles_per_wave %d)", tiles_per_wave);
+extern "C" int sv_conv_plan_tiles(const int32_t* masks_p, int64_t n_rows, int tiles_per_wave, int32_t* tile_of, void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && tiles_per_wave >= 1 && tiles_per_wave <= 4, "sv_conv_plan_tiles: bad sizes (tiles_per_wave %d)", tiles_per_wave);
   if (n_rows == 0) return SV_OK;
-  SV_CHECK_ARG(nbr && scratch && tile_order, "sv_conv_tile_order: null pointer");
-  TileOrderArgs a{};
-  a.nbr = nbr, a.n_rows = n_rows, a.K = K;
-  a.n_tiles = (n_rows + 15) / 16;
-  a.G = tiles_per_wave;
-  a.n_waves = (a.n_tiles + a.G - 1) / a.G;
-  a.hist = reinterpret_cast<int32_t*>(scratch);
-  a.cost = reinterpret_cast<uint8_t*>(scratch) + 64 * sizeof(int32_t);
-  a.tile_of = tile_order;
-  hipStream_t st = sv_stream(stream);
-  const int wgs = (int)((a.n_tiles + 15) / 16 < TO_WGS ? (a.n_tiles + 15) / 16 : TO_WGS);
-  if (a.n_tiles <= TO_ONE_WG_TILES) {
-    a.hist = nullptr;
-    hipLaunchKernelGGL(k_tile_cost, dim3(wgs), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_tile_deal_one, dim3(1), dim3(1024), 0, st, a);
-  } else {
-    SV_HIP(hipMemsetAsync(a.hist, 0, 64 * sizeof(int32_t), st));
-    SV_HIP(hipMemsetAsync(tile_order, 0xFF, (size_t)(4 + a.n_waves * a.G) * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_tile_cost, dim3(wgs), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_tile_deal, dim3(wgs), dim3(256), 0, st, a);
+  SV_CHECK_ARG(masks_p && tile_of, "sv_conv_plan_tiles: null pointer");
+  const PlanDims d = plan_dims(n_rows, tiles_per_wave);
+  for (int r = 0; r < PL_REGIONS; ++r) SV_CHECK_ARG(d.tiles[r] <= PL_MAX_REGION_TILES, "sv_conv_plan_tiles: at most %d tiles per region", PL_MAX_REGION_TILES);
+  hipLaunchKernelGGL(k_plan_deal, dim3(PL_REGIONS), dim3(1024), 0, sv_stream(stream), masks_p, d, tile_of);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weights in MFMA fragment order
+// One contiguous KiB per (offset, 16-channel step, column tile): the B-operand load of a wave touches 8 whole cache lines instead of 16
+// half lines at 16 different rows.  Both directions of a layer in one launch, into caller-owned buffers (cached by the host per weight
+// version; round 1 kept ONE device-global buffer, which two streams would have raced on):
+//   fwd:  Wt[k][n = c_out][c = c_in]      bwd:  Wt[k][n = c_in][c = c_out]         from W (K, C_in, C_out) given by its element strides
+struct WStride {
+  int64_t k, i, o;     // element strides of the (K, C_in, C_out) weight view
+};
+__global__ __launch_bounds__(256) void k_weight_fragments(const float* __restrict__ w, WStride ws, int K, int Cin, int Cout, float* __restrict__ wf_fwd,
+                                                          float* __restrict__ wf_bwd) {
+  const int total = K * Cin * Cout / 4;                      // float4 units per direction
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * total; i += gridDim.x * 256) {
+    const bool bwd = i >= total;
+    const int e = bwd ? i - total : i;
+    const int Nc = bwd ? Cin : Cout, Kd = bwd ? Cout : Cin;
+    const int64_t sn = bwd ? ws.i : ws.o, sc = bwd ? ws.o : ws.i;
+    const int KQ = Kd / 16, NT = Nc / 16;
+    const int lane = e & 63, t = (e >> 6) % NT, q = ((e >> 6) / NT) % KQ, k = (e >> 6) / (NT * KQ);
+    const int li = lane & 15, kk = lane >> 4;
+    const float* src = w + k * ws.k + (t * 16 + li) * sn + (q * 16 + kk * 4) * sc;
+    float4 v;
+    if (sc == 1 && (((uintptr_t)src) & 15) == 0) v = *reinterpret_cast<const float4*>(src);
+    else v = make_float4(src[0], src[sc], src[2 * sc], src[3 * sc]);
+    float* dst = bwd ? wf_bwd : wf_fwd;
+    if (dst) reinterpret_cast<float4*>(dst)[e] = v;
   }
+}
+
+extern "C" int sv_conv_weight_fragments(const float* W, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, int K, int Cin, int Cout, float* frag_fwd,
+                                        float* frag_bwd, void* stream) {
+  SV_CHECK_ARG(W && K > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, "sv_conv_weight_fragments: channels must be multiples of 16");
+  SV_CHECK_ARG(frag_fwd || frag_bwd, "sv_conv_weight_fragments: no output");
+  SV_CHECK_ARG(((uintptr_t)frag_fwd % 16 == 0) && ((uintptr_t)frag_bwd % 16 == 0), "sv_conv_weight_fragments: outputs must be 16-byte aligned");
+  const WStride ws{stride_k, stride_cin, stride_cout};
+  hipLaunchKernelGGL(k_weight_fragments, dim3(sv_grid_1d((int64_t)K * Cin * Cout / 2, 256)), dim3(256), 0, sv_stream(stream), W, ws, K, Cin, Cout, frag_fwd,
+                     frag_bwd);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
 
-extern "C" int sv_conv_tile_order_grouped(const int32_t* masks, const int32_t* row_perm, int64_t n_rows, int tiles_per_wave, void* scratch,
-                                          int32_t* tile_order, void* stream) {
-  SV_CHECK_ARG(n_rows >= 0 && tiles_per_wave >= 2 && tiles_per_wave <= 4, "sv_conv_tile_order_grouped: bad sizes");
-  if (n_rows == 0) return SV_OK;
-  SV_CHECK_ARG(masks && row_perm && scratch && tile_order, "sv_conv_tile_order_grouped: null pointer");
-  TileOrderArgs a{};
-  a.n_rows = n_rows, a.n_tiles = (n_rows + 15) / 16, a.G = tiles_per_wave;
-  SV_CHECK_ARG(a.n_tiles <= TO_ONE_WG_TILES, "sv_conv_tile_order_grouped: at most %d tiles", TO_ONE_WG_TILES);
-  a.n_waves = (a.n_tiles + a.G - 1) / a.G;
-  a.cost = reinterpret_cast<uint8_t*>(scratch) + 64 * sizeof(int32_t);
-  a.tile_of = tile_order;
-  hipStream_t st = sv_stream(stream);
-  hipLaunchKernelGGL(k_tile_cost_masks, dim3(sv_div_up(a.n_tiles * 16, 256)), dim3(256), 0, st, masks, row_perm, n_rows, a.n_tiles, a.cost);
-  hipLaunchKernelGGL(k_tile_deal_one, dim3(1), dim3(1024), 0, st, a);
-  SV_LAUNCH_CHECK();
-  return SV_OK;
+// ------------------------------------------------------------------------------------------------
+// The MFMA kernel on a plan.  Register-stationary like k_spconv_rs above, plus:
+//   * PMC on k_spconv_rs: matrix core busy 38 %, waves waiting for operands that were requested only one 64-MFMA step (~2000 cycles)
+//     earlier, less than the gather latency under load; hipcc additionally sinks its own prefetch loads towards their first use.  Here
+//     every operand load of the loop is an inline-asm buffer_load_dwordx4 (hipcc can neither move it nor wait for it), issued TWO steps
+//     ahead into a 3-deep register ring, and retired with a counted s_waitcnt vmcnt(2 x loads-per-step) that names the stage's registers
+//     ("+v", form (ii) of cdna_hip_programming.md 5.7).  Every step issues exactly RS_G + NT loads: rows without a neighbour use an
+//     out-of-range buffer offset (the range check returns zeros without a memory access), steps past the end issue out-of-range dummies;
+//   * a wave's tiles come from the plan: tile_of[wave][slot] inside the region of its XCD (blockIdx.x % 8), rows + masks + output rows
+//     from the regrouped row-major table (one 128-byte line per row);
+//   * blockIdx.y selects a block of 64 output columns (C_out = 128 runs as two column blocks that gather the same rows);
+//   * the wave's neighbour indices are parked in LDS once, so the loop contains no compiler-visible VMEM load.
+// Same ownership, skipping and summation order (k ascending, channels ascending) as k_spconv_rs -> bitwise reproducible, and bit-identical to
+// the ungrouped kernels.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ i32x4 make_srd(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffffu));      // stride 0
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
 }
+__device__ __forceinline__ f32x4 buf_load_b128(i32x4 srd, uint32_t voff) {
+  f32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(srd) : "memory");
+  return v;
+}
+
+struct PlanView {
+  const int32_t* tab;       // (n_rows, PL_ROW) row-major table, natural row order
+  const int32_t* perm;      // (n_pad) row at each position (-1 padding)
+  const int32_t* masks_p;   // (n_pad) its mask
+  const int32_t* tile_of;   // [wave][G]
+  PlanDims d;
+  int k_flip;               // read table entry K-1-k for offset k (a submanifold table serving its own data gradient)
+  int nc_total;             // columns of Y and of the weight fragments (a.Nc is the block's share)
+};
 
 template <int NT, int KQ, int RS_G>
-__global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_bytes, uint32_t w_bytes) {
-  constexpr int Kd = KQ * 16, Nc = NT * 16;
-  __shared__ int32_t s_idx_all[4][RS3_KMAX][64];
+__global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, PlanView pv, const float* __restrict__ wfrag, uint32_t x_bytes, uint32_t w_bytes) {
+  constexpr int Kd = KQ * 16;
+  __shared__ int32_t s_idx_all[4][RS3_KMAX + 1][64];       // [k][lane]: source row of (tile lane>>4, row lane&15); [27][lane]: its output row
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int li = lane & 15, kk = lane >> 4;
-  const int64_t n_tiles = (a.n_rows + 15) / 16;
-  const int64_t n_waves = (n_tiles + RS_G - 1) / RS_G;
-  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid;
-  if (wave_id >= n_waves) return;
+  const int region = blockIdx.x % PL_REGIONS, lw = (blockIdx.x / PL_REGIONS) * 4 + wid;
+  if (lw >= pv.d.waves[region]) return;
   int32_t(*s_idx)[64] = s_idx_all[wid];
-  // rows past the end for an empty slot
-  auto tile_row0 = [&](int g) {
-    if (!a.tile_order || a.tile_order[0] != RS_G) return (wave_id + (int64_t)g * n_waves) * 16;   // by position (strided)
-    const int32_t t = a.tile_order[4 + wave_id * RS_G + g];
-    return (t >= 0 && t < n_tiles) ? (int64_t)t * 16 : a.n_rows;
-  };
+  const int nt_total = pv.nc_total / 16, col_tile0 = blockIdx.y * NT;
 
-  // neighbour indices of the wave's rows -> LDS (lane = (tile lane>>4, row lane&15)); per-offset tile masks in lane k of maskreg
+  // the wave's rows of the regrouped table -> LDS; per-offset tile masks in lane k of maskreg
   unsigned maskreg = 0;
   {
-    const int g = (lane >> 4) % RS_G;
-    const int64_t p = tile_row0(g) + li;
-    const bool valid = (lane >> 4) < RS_G && p < a.n_rows;
-    const int64_t r = (valid && a.row_perm) ? (int64_t)a.row_perm[p] : p;     // regrouped tiles: 16 arbitrary rows
-    for (int k0 = 0; k0 < a.K; k0 += 9) {                  // 9 table reads in flight: 3 load latencies before the first MFMA, not 27
-      int32_t jv[9];
+    const int g = lane >> 4;
+    const int32_t t = g < RS_G ? pv.tile_of[((int64_t)pv.d.woff[region] + lw) * RS_G + g] : -1;
+    i32x4 e[PL_ROW / 4];
+    const int64_t p = (int64_t)t * 16 + li;
+    const int32_t row = t >= 0 ? pv.perm[p] : -1;
+    unsigned m = row >= 0 ? (unsigned)pv.masks_p[p] : 0u;
+    if (row >= 0) {
+      const i32x4* rowp = reinterpret_cast<const i32x4*>(pv.tab + (int64_t)row * PL_ROW);
 #pragma unroll
-      for (int u = 0; u < 9; ++u) {
-        const int k = k0 + u;
-        jv[u] = (valid && k < a.K) ? a.nbr[(int64_t)(a.k_flip ? a.K - 1 - k : k) * a.n_rows + r] : -1;
-      }
+      for (int q = 0; q < (RS3_KMAX + 3) / 4; ++q) e[q] = rowp[q];
+    } else {
 #pragma unroll
-      for (int u = 0; u < 9; ++u) {
-        const int k = k0 + u;
-        if (k < a.K) {
-          s_idx[k][lane] = jv[u];
-          const unsigned long long vote = __ballot(jv[u] >= 0);
-          unsigned m = 0;
-#pragma unroll
-          for (int t = 0; t < RS_G; ++t) m |= ((vote >> (16 * t)) & 0xffffull) ? (1u << t) : 0u;
-          if (lane == k) maskreg = m;
-        }
-      }
+      for (int q = 0; q < (RS3_KMAX + 3) / 4; ++q) e[q] = (i32x4){-1, -1, -1, -1};
     }
+#pragma unroll
+    for (int k = 0; k < RS3_KMAX; ++k)
+      if (k < a.K) s_idx[pv.k_flip ? a.K - 1 - k : k][lane] = e[k >> 2][k & 3];
+    s_idx[RS3_KMAX][lane] = row;                           // output row (-1: padding)
+    if (pv.k_flip) m = __brev(m) >> (32 - a.K);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) m |= __shfl_xor(m, off, 16);      // OR over the tile's 16 rows
+    unsigned mk = 0;
+#pragma unroll
+    for (int t2 = 0; t2 < RS_G; ++t2) {
+      const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)m, 16 * t2);
+      mk |= ((tm >> (lane & 31)) & 1u) << t2;
+    }
+    maskreg = lane < a.K ? mk : 0u;
   }
   const unsigned long long active = __ballot(maskreg != 0);
 
@@ -725,7 +652,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_by
     for (int t = 0; t < NT; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (active) {
-    const i32x4 srd_x = make_srd(a.X, x_bytes), srd_w = make_srd(g_wfrag, w_bytes);
+    const i32x4 srd_x = make_srd(a.X, x_bytes), srd_w = make_srd(wfrag, w_bytes);
     f32x4 A[3][RS_G], B[3][NT];
     // load iterator (two steps ahead of the compute iterator)
     unsigned long long la = active;
@@ -745,7 +672,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_by
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const uint32_t off = live ? (uint32_t)(((((kl * KQ + ql) * NT + t) * 64 + lane) * 4) * 4) : 0xfffffff0u;
+        const uint32_t off = live ? (uint32_t)(((((kl * KQ + ql) * nt_total + col_tile0 + t) * 64 + lane) * 4) * 4) : 0xfffffff0u;
         Bs[t] = buf_load_b128(srd_w, off);
       }
       if (live && ++ql == KQ) {
@@ -814,73 +741,74 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, uint32_t x_by
 #pragma unroll
   for (int g = 0; g < RS_G; ++g)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = s_idx[RS3_KMAX][g * 16 + kk * 4 + r];
+      if (row < 0) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t p = tile_row0(g) + kk * 4 + r;
-        const int col = t * 16 + li;
-        if (p < a.n_rows) {
-          const int64_t row = a.row_perm ? (int64_t)a.row_perm[p] : p;
-          a.Y[row * Nc + col] = conv_epilogue(acc[g][t][r], col, row, a);
-        }
+      for (int t = 0; t < NT; ++t) {
+        const int col = (col_tile0 + t) * 16 + li;
+        a.Y[row * pv.nc_total + col] = conv_epilogue(acc[g][t][r], col, row, a);
       }
+    }
 }
 
-// shapes the rs3 kernel is instantiated for (the only kernel that takes row_perm / table_k_reversed)
+// shapes the plan kernel is instantiated for: C_in in {16, 32, 64, 128}, C_out in {16, 32, 64} or a multiple of 64, K <= 27
 static bool rs3_applies(int K, int Kd, int Nc) {
-  if (K > RS3_KMAX || Kd % 16 || Nc % 16 || Kd > 64 || Nc > 64 || Kd < 16 || Nc < 16) return false;
-  const int nt = Nc / 16, kq = Kd / 16;
-  return nt != 3 && kq != 3 && !(nt == 4 && kq == 3) && !(nt == 3 && kq == 4);
+  if (K > RS3_KMAX || K < 1) return false;
+  const bool kd_ok = Kd == 16 || Kd == 32 || Kd == 64 || Kd == 128;
+  const bool nc_ok = Nc == 16 || Nc == 32 || (Nc >= 64 && Nc % 64 == 0 && Nc <= 512);
+  return kd_ok && nc_ok;
 }
-extern "C" int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc) { return rs3_applies(K, Kd, Nc) ? 1 : 0; }
-
-static int try_launch_rs3(const ConvArgs& a, const WStride& ws, int64_t n_src, hipStream_t st) {
-  if (!rs3_applies(a.K, a.Kd, a.Nc)) return -1;
-  const uint64_t xb = (uint64_t)n_src * a.Kd * 4, wb = (uint64_t)a.K * a.Nc * a.Kd * 4;
-  if (xb >= 0xfffffff0ull || wb >= 0xfffffff0ull) return -1;
-  const int64_t n_tiles = (a.n_rows + 15) / 16;
-  const int G = conv_tiles_per_wave(a.n_rows, a.Kd, a.Nc);   // the value the caller passed to sv_conv_tile_order for a.tile_order
-  const int64_t n_waves = (n_tiles + G - 1) / G;
-  const dim3 grid((unsigned)((n_waves + 3) / 4));
-  const int nt = a.Nc / 16, kq = a.Kd / 16;
-  float* wf = nullptr;
-  if (hipGetSymbolAddress(reinterpret_cast<void**>(&wf), HIP_SYMBOL(g_wfrag)) != hipSuccess) return -1;
-  hipLaunchKernelGGL(k_weight_fragments, dim3(sv_grid_1d((int64_t)a.K * a.Nc * a.Kd / 4, 256)), dim3(256), 0, st, a.Wt, ws, a.K, a.Nc, a.Kd, wf);
-#define RS3_CASE(NTV, KQV)                                                                                                       \
-  if (nt == NTV && kq == KQV) {                                                                                                  \
-    if (G == 4) hipLaunchKernelGGL((k_spconv_rs3<NTV, KQV, 4>), grid, dim3(256), 0, st, a, (uint32_t)xb, (uint32_t)wb);          \
-    else if (G == 3) hipLaunchKernelGGL((k_spconv_rs3<NTV, KQV, 3>), grid, dim3(256), 0, st, a, (uint32_t)xb, (uint32_t)wb);     \
-    else hipLaunchKernelGGL((k_spconv_rs3<NTV, KQV, 2>), grid, dim3(256), 0, st, a, (uint32_t)xb, (uint32_t)wb);                 \
-    return 0;                                                                                                                    \
-  }
-  RS3_CASE(4, 4) RS3_CASE(4, 2) RS3_CASE(2, 4) RS3_CASE(2, 2) RS3_CASE(2, 1) RS3_CASE(1, 2) RS3_CASE(1, 1) RS3_CASE(4, 1) RS3_CASE(1, 4)
-#undef RS3_CASE
-  return -1;
+extern "C" int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc, int64_t n_src) {
+  // the gathers address X through a 32-bit buffer descriptor
+  return (rs3_applies(K, Kd, Nc) && (uint64_t)(n_src < 0 ? 0 : n_src) * Kd * 4 < 0xfffffff0ull) ? 1 : 0;
 }
 
-template <int NT, int G>
-static int launch_rs_kq(const ConvArgs& a, int kq, hipStream_t st) {
-  const int64_t n_tiles = (a.n_rows + 15) / 16;
-  const int64_t n_waves = (n_tiles + G - 1) / G;
-  const dim3 grid((unsigned)((n_waves + 3) / 4));
-  switch (kq) {
-    case 1: hipLaunchKernelGGL((k_spconv_rs<NT, 1, G>), grid, dim3(256), 0, st, a); return 0;
-    case 2: hipLaunchKernelGGL((k_spconv_rs<NT, 2, G>), grid, dim3(256), 0, st, a); return 0;
-    case 4: hipLaunchKernelGGL((k_spconv_rs<NT, 4, G>), grid, dim3(256), 0, st, a); return 0;
-    case 8: hipLaunchKernelGGL((k_spconv_rs<NT, 8, G>), grid, dim3(256), 0, st, a); return 0;
+template <int NT, int KQ>
+static void launch_rs3_g(const ConvArgs& a, const PlanView& pv, const float* wfrag, uint32_t xb, uint32_t wb, dim3 grid, hipStream_t st) {
+  switch (pv.d.G) {
+    case 4: hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 4>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb); break;
+    case 3: hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 3>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb); break;
+    default: hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb); break;
   }
-  return -1;
+}
+template <int NT>
+static void launch_rs3_kq(const ConvArgs& a, const PlanView& pv, const float* wfrag, uint32_t xb, uint32_t wb, dim3 grid, hipStream_t st) {
+  switch (a.Kd / 16) {
+    case 1: launch_rs3_g<NT, 1>(a, pv, wfrag, xb, wb, grid, st); break;
+    case 2: launch_rs3_g<NT, 2>(a, pv, wfrag, xb, wb, grid, st); break;
+    case 4: launch_rs3_g<NT, 4>(a, pv, wfrag, xb, wb, grid, st); break;
+    default: launch_rs3_g<NT, 8>(a, pv, wfrag, xb, wb, grid, st); break;
+  }
 }
 
-static int try_launch_rs(const ConvArgs& a, hipStream_t st) {
-  if (a.Kd % 16 || a.Nc % 16 || a.K > 64) return -1;
-  switch (a.Nc / 16) {
-    case 1: return launch_rs_kq<1, 4>(a, a.Kd / 16, st);
-    case 2: return launch_rs_kq<2, 4>(a, a.Kd / 16, st);
-    case 4: return launch_rs_kq<4, 4>(a, a.Kd / 16, st);
-    case 8: return launch_rs_kq<8, 4>(a, a.Kd / 16, st);
+extern "C" int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src, const int32_t* table_rows, const int32_t* perm, const int32_t* masks_p,
+                                                  const int32_t* tile_of, int tiles_per_wave,
+                                                  const float* wfrag, float* Y, int64_t n_rows, int K, int Kd, int Nc, const float* bias,
+                                                  const float* scale, const float* shift, const float* residual, int relu, int table_k_reversed,
+                                                  void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && K > 0 && Kd > 0 && Nc > 0, "sparse_conv (planned): bad sizes");
+  if (n_rows == 0) return SV_OK;
+  SV_CHECK_ARG(X && table_rows && perm && masks_p && tile_of && wfrag && Y, "sparse_conv (planned): null pointer");
+  SV_CHECK_ARG((scale == nullptr) == (shift == nullptr), "sparse_conv: scale and shift go together");
+  SV_CHECK_ARG(sv_conv_mfma_kernel_applies(K, Kd, Nc, n_src), "sparse_conv (planned): no MFMA kernel for K %d, C_in %d, C_out %d, %lld source rows "
+               "(ask sv_conv_mfma_kernel_applies first)", K, Kd, Nc, (long long)n_src);
+  SV_CHECK_ARG(tiles_per_wave >= 2 && tiles_per_wave <= 4, "sparse_conv (planned): tiles_per_wave must be 2..4");
+  SV_CHECK_ARG((uintptr_t)X % 16 == 0 && (uintptr_t)wfrag % 16 == 0 && (uintptr_t)table_rows % 16 == 0, "sparse_conv (planned): 16-byte alignment");
+  ConvArgs a{X, nullptr, nullptr, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc};
+  PlanView pv;
+  pv.tab = table_rows, pv.perm = perm, pv.masks_p = masks_p, pv.tile_of = tile_of, pv.d = plan_dims(n_rows, tiles_per_wave), pv.k_flip = table_k_reversed ? 1 : 0, pv.nc_total = Nc;
+  const int nc_blk = Nc > 64 ? 64 : Nc;
+  const dim3 grid((unsigned)(PL_REGIONS * pv.d.max_blocks), (unsigned)(Nc / nc_blk));
+  const uint32_t xb = (uint32_t)((uint64_t)n_src * Kd * 4), wb = (uint32_t)((uint64_t)K * Nc * Kd * 4);
+  hipStream_t st = sv_stream(stream);
+  switch (nc_blk / 16) {
+    case 1: launch_rs3_kq<1>(a, pv, wfrag, xb, wb, grid, st); break;
+    case 2: launch_rs3_kq<2>(a, pv, wfrag, xb, wb, grid, st); break;
+    default: launch_rs3_kq<4>(a, pv, wfrag, xb, wb, grid, st); break;
   }
-  return -1;
+  SV_LAUNCH_CHECK();
+  return SV_OK;
 }
 
 // Generic VALU path for channel counts the MFMA tiling does not cover (e.g. the C_in = 3 input layer):
@@ -906,32 +834,6 @@ __global__ __launch_bounds__(256) void k_spconv_valu(ConvArgs a) {
     }
     for (int u = 0; u < 4 && n0 + u < a.Nc; ++u) a.Y[row * a.Nc + n0 + u] = conv_epilogue(acc[u], n0 + u, row, a);
   }
-}
-
-static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, const int64_t* w_strides, float* Y, int64_t n_rows,
-                            int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift, const float* residual, int relu,
-                            const int32_t* tile_order, const int32_t* row_perm, int table_k_reversed, void* stream);
-
-extern "C" int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
-                                          int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
-                                          const float* residual, int relu, void* stream) {
-  return gather_gemm_impl(X, n_src, nbr, Wt, nullptr, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, nullptr, nullptr, 0, stream);
-}
-
-extern "C" int sv_sparse_conv_gather_gemm_ordered(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
-                                                  int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale,
-                                                  const float* shift, const float* residual, int relu, const int32_t* tile_order,
-                                                  void* stream) {
-  return gather_gemm_impl(X, n_src, nbr, Wt, nullptr, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, tile_order, nullptr, 0, stream);
-}
-
-extern "C" int sv_sparse_conv_gather_gemm_strided(const float* X, int64_t n_src, const int32_t* nbr, const float* W, int64_t w_stride_k,
-                                                  int64_t w_stride_n, int64_t w_stride_c, float* Y, int64_t n_rows, int K, int Kd, int Nc,
-                                                  const float* bias, const float* scale, const float* shift, const float* residual, int relu,
-                                                  const int32_t* tile_order, const int32_t* row_perm, int table_k_reversed, void* stream) {
-  const int64_t ws[3] = {w_stride_k, w_stride_n, w_stride_c};
-  return gather_gemm_impl(X, n_src, nbr, W, ws, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu, tile_order, row_perm,
-                          table_k_reversed, stream);
 }
 
 // Input layer (C_in = 3 or 4 point features -> 16 channels, spconv_backbone.py:77-81): HBM-bound -- 4*K bytes of neighbour table and
@@ -976,51 +878,26 @@ __global__ __launch_bounds__(256) void k_spconv_small_cin(ConvArgs a) {
   }
 }
 
-static int gather_gemm_impl(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, const int64_t* w_strides, float* Y, int64_t n_rows,
-                            int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift, const float* residual, int relu,
-                            const int32_t* tile_order, const int32_t* row_perm, int table_k_reversed, void* stream) {
+// Plain entry: packed (K, Nc, Kd) weights, k-major table, no plan -- the register-stationary MFMA kernel for channel multiples of 16, the
+// small-C_in kernel for the 3 / 4-channel input layer, the VALU kernel for everything else.
+extern "C" int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
+                                          int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
+                                          const float* residual, int relu, void* stream) {
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Kd > 0 && Nc > 0, "sparse_conv: bad sizes");
   if (n_rows == 0) return SV_OK;
   SV_CHECK_ARG(X && nbr && Wt && Y, "sparse_conv: null pointer");
   SV_CHECK_ARG((scale == nullptr) == (shift == nullptr), "sparse_conv: scale and shift go together");
-  ConvArgs a{X, nbr, Wt, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc, tile_order, row_perm, table_k_reversed};
+  (void)n_src;
+  ConvArgs a{X, nbr, Wt, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc};
   hipStream_t st = sv_stream(stream);
   const int nt = Nc / 16;
-  WStride ws{(int64_t)Nc * Kd, (int64_t)Kd, 1};
-  if (w_strides) ws = WStride{w_strides[0], w_strides[1], w_strides[2]};
-  const bool w_packed = ws.k == (int64_t)Nc * Kd && ws.n == Kd && ws.c == 1;
-  static const bool force_v1 = getenv("SEEVCN_SPCONV_V1") != nullptr;
-  static const bool use_rs3 = getenv("SEEVCN_SPCONV_NORS3") == nullptr;
-  // the rs3 path re-lays the weights into fragment order anyway: it reads any (K, Nc, Kd) view through its strides
-  if ((Kd % 16 == 0) && (Nc % 16 == 0) && ((uintptr_t)X % 16 == 0) && !force_v1 && use_rs3 && try_launch_rs3(a, ws, n_src, st) == 0) {
-    SV_LAUNCH_CHECK();
-    return SV_OK;
-  }
-  SV_CHECK_ARG(!row_perm && !table_k_reversed, "sparse_conv: row_perm / table_k_reversed (grouped table) need the rs3 kernel: C_in, C_out multiples of 16 up to 64, K <= %d", RS3_KMAX);
-  if (!w_packed) {                          // the other kernels read a contiguous (K, Nc, Kd) array
-    const int64_t total = (int64_t)K * Nc * Kd;
-    SV_CHECK_ARG(total <= WPACK_FLOATS, "sparse_conv: a strided weight view of %lld floats does not fit the pack buffer; pass it contiguous", (long long)total);
-    float* wp = nullptr;
-    SV_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&wp), HIP_SYMBOL(g_wpack)));
-    hipLaunchKernelGGL(k_weight_pack, dim3(sv_grid_1d(total, 256)), dim3(256), 0, st, Wt, ws, K, Nc, Kd, wp);
-    a.Wt = Wt = wp;
-  }
   const bool mfma_ok = (Kd % 16 == 0) && (Nc % 16 == 0) && (nt == 1 || nt == 2 || nt == 4 || nt == 8) &&
                        ((uintptr_t)X % 16 == 0) && ((uintptr_t)Wt % 16 == 0);
-  if (mfma_ok && !force_v1 && try_launch_rs(a, st) == 0) {
+  if (mfma_ok && try_launch_rs(a, st) == 0) {
     SV_LAUNCH_CHECK();
     return SV_OK;
   }
-  if (mfma_ok) {
-    const int grid = sv_div_up(n_rows, SC_ROWS_PER_BLOCK);
-    const size_t lds = (size_t)Nc * ((Kd < SC_KSLICE ? Kd : SC_KSLICE) + 4) * sizeof(float);
-    switch (nt) {
-      case 1: hipLaunchKernelGGL(k_spconv_mfma<1>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
-      case 2: hipLaunchKernelGGL(k_spconv_mfma<2>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
-      case 4: hipLaunchKernelGGL(k_spconv_mfma<4>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
-      default: hipLaunchKernelGGL(k_spconv_mfma<8>, dim3(grid), dim3(SC_THREADS), lds, st, a); break;
-    }
-  } else if ((Kd == 3 || Kd == 4) && K * Nc * Kd <= SC_SMALL_LDS) {
+  if ((Kd == 3 || Kd == 4) && K * Nc * Kd <= SC_SMALL_LDS) {
     const dim3 grid(sv_grid_1d(n_rows * ((Nc + 3) / 4), 256, 256 * 8));
     if (Kd == 3) hipLaunchKernelGGL(k_spconv_small_cin<3>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_spconv_small_cin<4>, grid, dim3(256), 0, st, a);

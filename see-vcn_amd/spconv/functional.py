@@ -1,6 +1,7 @@
 """Host wrappers + autograd Functions over the rulebook / sparse-conv entry points of libseevcn_hip.so."""
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -20,6 +21,38 @@ def conv_out_shape(in_shape, ksize, stride, padding, dilation):
     return [int(x) for x in out]
 
 
+class TablePlan:
+    """Plan of one rulebook table for the MFMA kernel: the row-major table + masks (from the rulebook builder, or made here from a
+    k-major table), the regrouping of the rows (sv_conv_plan_build) and the tile -> wave assignment per tiles-per-wave value
+    (sv_conv_plan_tiles).  Built once per table, reused by every launch on it."""
+
+    def __init__(self, table, n_rows, K, rows=None, masks=None):
+        lib = _lib.load()
+        dev = table.device
+        self.n_rows, self.K = int(n_rows), int(K)
+        self.source = table                      # keep the k-major table alive with its plan
+        if rows is None or masks is None:
+            rows = torch.empty((max(self.n_rows, 1), 32), dtype=torch.int32, device=dev)
+            masks = torch.empty((max(self.n_rows, 1),), dtype=torch.int32, device=dev)
+            _lib.check(lib.sv_conv_table_rows(_lib.ptr(table), self.n_rows, self.K, _lib.ptr(rows), _lib.ptr(masks), _lib.stream()), "sv_conv_table_rows")
+        self.rows, self.masks = rows, masks
+        n_perm = lib.sv_conv_plan_perm_bytes(self.n_rows) // 4
+        self.perm = torch.empty((n_perm,), dtype=torch.int32, device=dev)
+        self.masks_p = torch.empty((n_perm,), dtype=torch.int32, device=dev)
+        hist = _lib.workspace.persistent("conv_plan_hist", lib.sv_conv_plan_persistent_bytes(), dev)
+        _lib.check(lib.sv_conv_plan_build(_lib.ptr(masks), self.n_rows, _lib.ptr(hist), _lib.ptr(self.perm), _lib.ptr(self.masks_p), _lib.stream()),
+                   "sv_conv_plan_build")
+        self._tiles = {}
+
+    def tiles(self, g):
+        if g not in self._tiles:
+            lib = _lib.load()
+            t = torch.empty((lib.sv_conv_plan_tiles_bytes(self.n_rows) // 4,), dtype=torch.int32, device=self.perm.device)
+            _lib.check(lib.sv_conv_plan_tiles(_lib.ptr(self.masks_p), self.n_rows, int(g), _lib.ptr(t), _lib.stream()), "sv_conv_plan_tiles")
+            self._tiles[g] = t
+        return self._tiles[g]
+
+
 class Rulebook:
     """Output-major table nbr_out (K, N_out) plus, for strided convs, the input-major nbr_in (K, N_in)."""
 
@@ -28,8 +61,8 @@ class Rulebook:
         self.out_indices, self.out_shape = out_indices, out_shape
         self.n_in, self.n_out, self.subm, self.ksize = n_in, n_out, subm, ksize
         self._nbr_in_subm = None
-        self._orders = {}
-        self._groups = {}
+        self.rows_out = self.masks_out = self.rows_in = self.masks_in = None     # row-major twins + neighbour masks from the builders
+        self._plans = {}
         self._inverse = None
         self.in_indices = self.in_shape = None      # set by the conv that built the rulebook
 
@@ -42,10 +75,14 @@ class Rulebook:
         assert not self.subm and self.nbr_in is not None
         if self._inverse is None:
             self._inverse = Rulebook(self.nbr_in, self.nbr_out, self.in_indices, self.in_shape, self.n_out, self.n_in, False, self.ksize)
+            inv = self._inverse
+            inv.rows_out, inv.masks_out, inv.rows_in, inv.masks_in = self.rows_in, self.masks_in, self.rows_out, self.masks_out
+            self._inverse._plans = {"fwd": self._plans.get("bwd"), "bwd": self._plans.get("fwd")}
+            self._inverse._plans = {k: v for k, v in self._inverse._plans.items() if v is not None}
         return self._inverse
 
     def table_for_backward_data(self):
-        """Input-major table. For SubM it is the output-major table with the offsets reversed
+        """Input-major k-major table (the plain kernels). For SubM it is the output-major table with the offsets reversed
         (coord[j] = coord[i] + d  <=>  coord[i] = coord[j] - d)."""
         if not self.subm:
             return self.nbr_in
@@ -53,65 +90,27 @@ class Rulebook:
             self._nbr_in_subm = torch.flip(self.nbr_out, dims=[0]).contiguous()
         return self._nbr_in_subm
 
-    def tile_order(self, table, kd, nc):
-        """Work-balanced tile order of one of this rulebook's tables (sv_conv_tile_order) for a (kd -> nc)-channel gather-GEMM,
-        computed once and reused by every launch with the same tiles-per-wave on that table."""
-        lib = _lib.load()
-        n_rows, K = table.shape[1], table.shape[0]
-        if not TILE_ORDER or n_rows == 0 or (int(kd) // 16) * (int(nc) // 16) < 4 or kd % 16 or nc % 16:
-            return None              # load-bound small-channel layers: the order does not pay for its own launch
-        g = lib.sv_conv_tiles_per_wave(n_rows, int(kd), int(nc))
-        if self.subm and self._nbr_in_subm is not None and table.data_ptr() == self._nbr_in_subm.data_ptr():
-            table = self.nbr_out     # the flipped table has the same number of active offsets per tile: one order serves both directions
-        key = (table.data_ptr(), g)
-        if key not in self._orders:
-            order = torch.empty((lib.sv_conv_tile_order_bytes(n_rows) // 4,), dtype=torch.int32, device=table.device)
-            scratch = _lib.workspace.scratch("tile_order", lib.sv_conv_tile_order_scratch_bytes(n_rows), table.device)
-            _lib.check(lib.sv_conv_tile_order(_lib.ptr(table), n_rows, K, g, _lib.ptr(scratch), _lib.ptr(order), _lib.stream()), "sv_conv_tile_order")
-            self._orders[key] = (order, table)       # keep the table alive with its order
-        return self._orders[key][0]
-
     def plan(self, direction, kd, nc):
-        """(table, tile_order, row_perm, table_k_reversed) for a (kd -> nc)-channel gather-GEMM over this rulebook; direction 'fwd' (output-major
-        table) or 'bwd' (input-major table).  When the MFMA kernel applies (channels multiples of 16 up to 64, K <= 27) the
-        table's columns are regrouped by neighbour mask: row_perm[p] is the row that column p of the returned table produces.
-        A 16-row tile executes an offset when ANY of its rows has that neighbour; tiles of consecutive rows waste 40-80 % of
-        those steps (70 % on a strided conv's input-major table, whose masks are a function of coordinate parity), tiles of
-        equal-mask rows almost none.  Computed once per table and reused by every launch on it."""
+        """(TablePlan, tile_of, tiles_per_wave, table_k_reversed) for a (kd -> nc)-channel gather-GEMM over this rulebook, or None when the plan
+        kernel does not take the layer (sv_conv_mfma_kernel_applies is the single source of truth; SEEVCN_SPCONV_PLAN=0 forces the plain
+        kernels for A/B runs).  direction 'fwd' = output-major table, 'bwd' = input-major table; a submanifold table serves its own data
+        gradient with the offsets read in reverse, so it has one plan."""
         assert direction in ("fwd", "bwd")
         kd, nc = int(kd), int(nc)
         n_rows = self.n_out if direction == "fwd" else self.n_in
-        mfma_kernel = bool(_lib.load().sv_conv_mfma_kernel_applies(int(self.K), kd, nc))              # k_spconv_rs3 takes the layer
-        # narrow layers are bound by their loads, and reading the table through the permutation costs them more than equal-mask tiles save
-        groupable = GROUP_ROWS and mfma_kernel and max(kd, nc) >= 64 and 64 <= n_rows <= 16 * 65536
-        if not groupable:
-            if direction == "bwd" and self.subm and mfma_kernel:
-                # the submanifold table read with its offsets reversed IS its input-major table: no flipped copy, same tile order
-                return self.nbr_out, self.tile_order(self.nbr_out, kd, nc), None, True
-            table = self.nbr_out if direction == "fwd" else self.table_for_backward_data()
-            return table, self.tile_order(table, kd, nc), None, False
-        key = "fwd" if (direction == "fwd" or self.subm) else "bwd"    # a submanifold table serves its own data gradient reversed
+        n_src = self.n_in if direction == "fwd" else self.n_out
         lib = _lib.load()
-        base = self.nbr_out if key == "fwd" else self.nbr_in
-        if key not in self._groups:
-            perm = torch.empty((n_rows,), dtype=torch.int32, device=base.device)
-            masks = torch.empty((n_rows,), dtype=torch.int32, device=base.device)
-            hist = _lib.workspace.persistent("conv_group_hist", lib.sv_conv_group_persistent_bytes(), base.device)
-            _lib.check(lib.sv_conv_group_rows(_lib.ptr(base), n_rows, self.K, _lib.ptr(hist), _lib.ptr(masks), _lib.ptr(perm), _lib.stream()),
-                       "sv_conv_group_rows")
-            self._groups[key] = (perm, masks)
-        perm, masks = self._groups[key]
-        if (kd // 16) * (nc // 16) < 4:
-            return base, None, perm, (direction == "bwd" and self.subm)       # load-bound layers: equal-mask tiles already cost the same
+        if not USE_PLAN or n_rows == 0 or not lib.sv_conv_mfma_kernel_applies(int(self.K), kd, nc, int(n_src)):
+            return None
+        key = "fwd" if (direction == "fwd" or self.subm) else "bwd"
+        if key not in self._plans:
+            if key == "fwd":
+                self._plans[key] = TablePlan(self.nbr_out, n_rows, self.K, self.rows_out, self.masks_out)
+            else:
+                self._plans[key] = TablePlan(self.nbr_in, n_rows, self.K, self.rows_in, self.masks_in)
+        tp = self._plans[key]
         g = lib.sv_conv_tiles_per_wave(n_rows, kd, nc)
-        okey = ("grouped", key, g)
-        if okey not in self._orders:
-            order = torch.empty((lib.sv_conv_tile_order_bytes(n_rows) // 4,), dtype=torch.int32, device=base.device)
-            scratch = _lib.workspace.scratch("tile_order", lib.sv_conv_tile_order_scratch_bytes(n_rows), base.device)
-            _lib.check(lib.sv_conv_tile_order_grouped(_lib.ptr(masks), _lib.ptr(perm), n_rows, g, _lib.ptr(scratch), _lib.ptr(order), _lib.stream()),
-                       "sv_conv_tile_order_grouped")
-            self._orders[okey] = (order, base)
-        return base, self._orders[okey][0], perm, (direction == "bwd" and self.subm)
+        return tp, tp.tiles(g), g, (direction == "bwd" and self.subm)
 
     def pair_counts(self):
         lib = _lib.load()
@@ -123,11 +122,7 @@ class Rulebook:
 
 # dense cell -> row maps (4 B per cell) up to this size replace the rank dictionary in submanifold rulebooks (MI355X: 288 GB of HBM)
 CELLMAP_MAX_BYTES = int(os.environ.get("SEEVCN_CELLMAP_MAX_BYTES", 24 << 30))
-TILE_ORDER = os.environ.get("SEEVCN_TILE_ORDER", "1") != "0"      # work-balanced tile order (sv_conv_tile_order); 0: tiles by position
-# Group table rows by neighbour mask before the MFMA gather-GEMM (Rulebook.plan): 16-row tiles of equal mask waste almost none of
-# their MFMA steps.  Applied to the layers with >= 64 channels on one side (the narrow ones are load-bound and lose more to the
-# permuted table reads than they gain); same-box A/B on the bench: GPU time 7.81 -> 7.63 ms per step, the 64->64 kernel 177 -> 145 us.
-GROUP_ROWS = os.environ.get("SEEVCN_GROUP_ROWS", "1") != "0"
+USE_PLAN = os.environ.get("SEEVCN_SPCONV_PLAN", "1") != "0"      # 0: every layer on the plain kernels (A/B runs, tests)
 
 
 def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1)):
@@ -142,11 +137,17 @@ def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 
     nbr = torch.empty((K, n), dtype=torch.int32, device=dev)
     map_bytes = lib.sv_cellmap_persistent_bytes(int(batch_size), _i3(spatial_shape))
     if map_bytes <= CELLMAP_MAX_BYTES:
-        cellmap = _lib.workspace.persistent(f"rb_cellmap_{tuple(spatial_shape)}_{batch_size}", map_bytes, dev)
+        # keyed by the grid only: the map is b-major, so one sized for the largest batch seen serves every smaller batch (Workspace grows it)
+        cellmap = _lib.workspace.persistent(f"rb_cellmap_{tuple(spatial_shape)}", map_bytes, dev)
+        with_rows = K <= 27 and n > 0
+        rows = torch.empty((n, 32), dtype=torch.int32, device=dev) if with_rows else None
+        masks = torch.empty((n,), dtype=torch.int32, device=dev) if with_rows else None
         rc = lib.sv_rulebook_subm_cellmap(_lib.ptr(indices), n, int(batch_size), _i3(spatial_shape), _i3(ksize), _i3(dilation),
-                                          _lib.ptr(cellmap), _lib.ptr(nbr), _lib.stream())
+                                          _lib.ptr(cellmap), _lib.ptr(nbr), _lib.ptr(rows), _lib.ptr(masks), _lib.stream())
         _lib.check(rc, "sv_rulebook_subm_cellmap")
-        return Rulebook(nbr, None, indices, list(spatial_shape), n, n, True, list(ksize))
+        rb = Rulebook(nbr, None, indices, list(spatial_shape), n, n, True, list(ksize))
+        rb.rows_out, rb.masks_out = rows, masks
+        return rb
     ws = _lib.workspace.persistent(f"rb_index_{tuple(spatial_shape)}_{batch_size}", lib.sv_index_persistent_bytes(ncells), dev)
     scratch = _lib.workspace.scratch("rb_scratch", lib.sv_rulebook_scratch_bytes(n, ncells), dev)
     rc = lib.sv_rulebook_subm(_lib.ptr(indices), n, int(batch_size), _i3(spatial_shape), _i3(ksize), _i3(dilation),
@@ -181,25 +182,91 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
     _lib.check(rc, "sv_rulebook_sparse")
     n_out = int(num_out.item())  # host needs the size to allocate the output rows (spconv syncs here too)
     out_coords = out_coords[:n_out]
-    nbr_out = torch.empty((K, n_out), dtype=torch.int32, device=dev)
-    rc = lib.sv_rulebook_invert(_lib.ptr(nbr_in) if n_in else None, n_in, K, _lib.ptr(nbr_out) if n_out else None, n_out, _lib.stream())
-    _lib.check(rc, "sv_rulebook_invert")
-    return Rulebook(nbr_out, nbr_in, out_coords, oshape, n_in, n_out, False, list(ksize))
+    if K > 27 or n_in == 0 or n_out == 0:
+        nbr_out = torch.empty((K, n_out), dtype=torch.int32, device=dev)
+        rc = lib.sv_rulebook_invert(_lib.ptr(nbr_in) if n_in else None, n_in, K, _lib.ptr(nbr_out) if n_out else None, n_out, _lib.stream())
+        _lib.check(rc, "sv_rulebook_invert")
+        return Rulebook(nbr_out, nbr_in, out_coords, oshape, n_in, n_out, False, list(ksize))
+    # one block per side: [rows (n, 32) | k-major table (K, n) | masks (n)] -- the row-major twins and masks feed the convolution plans
+    out_block = torch.empty(((32 + K + 1) * n_out,), dtype=torch.int32, device=dev)
+    in_block = torch.empty((33 * n_in,), dtype=torch.int32, device=dev)
+    rc = lib.sv_rulebook_invert_rows(_lib.ptr(nbr_in), n_in, K, _lib.ptr(out_block), n_out, _lib.ptr(in_block), _lib.stream())
+    _lib.check(rc, "sv_rulebook_invert_rows")
+    nbr_out = out_block[32 * n_out:(32 + K) * n_out].view(K, n_out)
+    rb = Rulebook(nbr_out, nbr_in, out_coords, oshape, n_in, n_out, False, list(ksize))
+    rb.rows_out, rb.masks_out = out_block[:32 * n_out].view(n_out, 32), out_block[(32 + K) * n_out:]
+    rb.rows_in, rb.masks_in = in_block[:32 * n_in].view(n_in, 32), in_block[32 * n_in:]
+    return rb
 
 
-def gather_gemm(x, nbr, wt, n_rows, bias=None, scale=None, shift=None, residual=None, relu=False, tile_order=None, row_perm=None,
-                table_k_reversed=False):
-    """Y (n_rows, Nc) = epi(sum_k X[nbr[k]] @ wt[k].T); wt is ANY (K, Nc, Kd) float32 view (its strides go to the kernel: no
-    transposing copy of the parameter per call).  tile_order: Rulebook.tile_order(nbr)."""
+class _FragmentCache:
+    """Weights in MFMA fragment order (sv_conv_weight_fragments), both directions, cached per weight TENSOR and version: an optimiser step
+    bumps the version and the next forward re-lays the 2 x 442 KB once; eval re-uses them for every call.  An entry is tied to the base
+    tensor by a weak reference (a data pointer alone can be handed to a new tensor after the old one is freed).  The buffers belong to
+    the cache entry, not to the library: convs on different streams never share a staging buffer."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, weight_kio):
+        base = weight_kio._base if weight_kio._base is not None else weight_kio
+        K, cin, cout = weight_kio.shape
+        key = id(base)
+        sig = (weight_kio.data_ptr(), tuple(weight_kio.stride()), (K, cin, cout), weight_kio._version)
+        hit = self._d.get(key)
+        if hit is not None and hit[0]() is base:
+            if hit[1] == sig:
+                return hit[2], hit[3]
+            fwd, bwd = hit[2], hit[3]
+            if fwd.numel() != K * cin * cout:
+                fwd = bwd = None
+        else:
+            fwd = bwd = None
+        if fwd is None:
+            fwd = torch.empty((K * cin * cout,), dtype=torch.float32, device=weight_kio.device)
+            bwd = torch.empty_like(fwd)
+        lib = _lib.load()
+        sk, si, so = weight_kio.stride()
+        _lib.check(lib.sv_conv_weight_fragments(ctypes.c_void_p(weight_kio.data_ptr()), sk, si, so, K, cin, cout, _lib.ptr(fwd), _lib.ptr(bwd), _lib.stream()),
+                   "sv_conv_weight_fragments")
+        d = self._d
+        self._d[key] = (weakref.ref(base, lambda _r, k=key: d.pop(k, None)), sig, fwd, bwd)
+        return fwd, bwd
+
+    def clear(self):
+        self._d.clear()
+
+
+fragment_cache = _FragmentCache()
+
+
+def gather_gemm_planned(x, plan, wfrag, n_rows, K, kd, nc, bias=None, scale=None, shift=None, residual=None, relu=False):
+    """Y (n_rows, nc) = epi(sum_k X[nbr[k]] @ W[k]) on a table plan (Rulebook.plan) with the weights in fragment order."""
+    lib = _lib.load()
+    tp, tile_of, g, rev = plan
+    assert x.shape[1] == kd and x.dtype == torch.float32
+    x = x.contiguous()
+    y = torch.empty((n_rows, nc), dtype=torch.float32, device=x.device)
+    rc = lib.sv_sparse_conv_gather_gemm_planned(_lib.ptr(x) if x.numel() else None, x.shape[0], _lib.ptr(tp.rows), _lib.ptr(tp.perm), _lib.ptr(tp.masks_p),
+                                                _lib.ptr(tile_of), int(g), _lib.ptr(wfrag),
+                                                _lib.ptr(y) if n_rows else None, n_rows, int(K), int(kd), int(nc), _lib.ptr(bias), _lib.ptr(scale),
+                                                _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), int(bool(rev)), _lib.stream())
+    _lib.check(rc, "sv_sparse_conv_gather_gemm_planned")
+    return y
+
+
+def gather_gemm(x, nbr, wt, n_rows, bias=None, scale=None, shift=None, residual=None, relu=False):
+    """Plain kernels: Y (n_rows, Nc) = epi(sum_k X[nbr[k]] @ wt[k].T) with the k-major table and a (K, Nc, Kd) weight (made contiguous here:
+    only the 3-channel input layer and odd channel counts come this way)."""
     lib = _lib.load()
     K, Nc, Kd = wt.shape
     assert x.shape[1] == Kd and nbr.shape[0] == K and wt.dtype == torch.float32
     x = x.contiguous()
+    wt = wt.contiguous()
     y = torch.empty((n_rows, Nc), dtype=torch.float32, device=x.device)
-    sk, sn, sc = wt.stride()
-    rc = lib.sv_sparse_conv_gather_gemm_strided(_lib.ptr(x) if x.numel() else None, x.shape[0], _lib.ptr(nbr) if nbr.numel() else None, ctypes.c_void_p(wt.data_ptr()),
-                                                sk, sn, sc, _lib.ptr(y) if n_rows else None, n_rows, K, Kd, Nc, _lib.ptr(bias), _lib.ptr(scale),
-                                                _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), _lib.ptr(tile_order), _lib.ptr(row_perm), int(bool(table_k_reversed)), _lib.stream())
+    rc = lib.sv_sparse_conv_gather_gemm(_lib.ptr(x) if x.numel() else None, x.shape[0], _lib.ptr(nbr) if nbr.numel() else None, _lib.ptr(wt),
+                                        _lib.ptr(y) if n_rows else None, n_rows, K, Kd, Nc, _lib.ptr(bias), _lib.ptr(scale),
+                                        _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), _lib.stream())
     _lib.check(rc, "sv_sparse_conv_gather_gemm")
     return y
 
@@ -223,9 +290,13 @@ class SparseConvFunction(torch.autograd.Function):
     def forward(ctx, features, weight_kio, rulebook):
         _lib.require_cuda(features, weight_kio)
         features = features.contiguous().float()
-        wt = weight_kio.detach().permute(0, 2, 1)               # (K, C_out, C_in) view
-        table, order, perm, rev = rulebook.plan("fwd", wt.shape[2], wt.shape[1])
-        out = gather_gemm(features, table, wt, rulebook.n_out, tile_order=order, row_perm=perm, table_k_reversed=rev)
+        w = weight_kio.detach()
+        K, cin, cout = w.shape
+        plan = rulebook.plan("fwd", cin, cout)
+        if plan is not None:
+            out = gather_gemm_planned(features, plan, fragment_cache.get(weight_kio)[0], rulebook.n_out, K, cin, cout)     # not the detached copy: the cache keys on ._base
+        else:
+            out = gather_gemm(features, rulebook.nbr_out, w.permute(0, 2, 1), rulebook.n_out)      # (K, C_out, C_in)
         ctx.rulebook = rulebook
         ctx.save_for_backward(features, weight_kio)
         return out
@@ -239,8 +310,11 @@ class SparseConvFunction(torch.autograd.Function):
         gf = gw = None
         if ctx.needs_input_grad[0]:
             # dX[i] = sum_k dY[nbr_in[k][i]] @ W[k]^T  -> Wt[k][n=c_in][c=c_out] = W[k][c_in][c_out]: weight_kio itself
-            table, order, perm, rev = rb.plan("bwd", cout, cin)
-            gf = gather_gemm(grad_out, table, weight_kio.detach(), rb.n_in, tile_order=order, row_perm=perm, table_k_reversed=rev)
+            plan = rb.plan("bwd", cout, cin)
+            if plan is not None:
+                gf = gather_gemm_planned(grad_out, plan, fragment_cache.get(weight_kio)[1], rb.n_in, K, cout, cin)
+            else:
+                gf = gather_gemm(grad_out, rb.table_for_backward_data(), weight_kio.detach(), rb.n_in)
         if ctx.needs_input_grad[1]:
             gw = wgrad(features, rb.nbr_out, grad_out, K, cin, cout)
         return gf, gw, None

@@ -82,7 +82,7 @@ def test_hip_centerpoint_res_backbone_at_config5_size(cuda, hip_lib):
     with torch.no_grad():
         mk = lambda ft: spconv.SparseConvTensor(ft, x4.indices, x4.spatial_shape, 1)
         ya, yb, yc = conv(mk(xa)).features, conv(mk(xb)).features, conv(mk(2.0 * xa - 3.0 * xb)).features
-        bias = conv.bias
+        bias = conv.bias.detach()
     np.testing.assert_allclose((yc - bias).cpu().numpy(), (2.0 * (ya - bias) - 3.0 * (yb - bias)).cpu().numpy(), rtol=1e-3, atol=2e-3)
 
 
@@ -160,8 +160,8 @@ def test_hip_pvrcnn_train_step_at_config4_size(cuda, hip_lib):
         want = op2.ball_query(radius, ns, xyz3[s1:s1 + int(c3n[1])].cpu().numpy(), [int(c3n[1])], new_xyz[sl].cpu().numpy(), [300])
         assert np.array_equal(idx[sl].cpu().numpy(), want), radius
     # D19 at size: the 9000 -> 512 proposal NMS of scene 0 against the oracle sweep
-    scores = bd["batch_cls_preds"][0].max(dim=1)[0]
-    boxes = bd["batch_box_preds"][0]
+    scores = bd["batch_cls_preds"][0].detach().max(dim=1)[0]
+    boxes = bd["batch_box_preds"][0].detach()
     top = torch.topk(scores, k=9000)[1]
     keep, _ = iou3d_nms_utils.nms_gpu(boxes[top], scores[top], 0.8)
     sb, ss = boxes[top].cpu().numpy(), scores[top].cpu().numpy()

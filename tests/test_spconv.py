@@ -190,10 +190,11 @@ def test_hip_subm_rulebook_bit_exact(cuda, hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64)])
-def test_hip_conv_with_mask_grouped_tiles_is_bit_identical(cuda, hip_lib, cin, cout):
-    """Rulebook.plan with GROUP_ROWS: 16-row tiles of equal neighbour mask, table read through row_perm, submanifold data gradient on the
-    reversed table -- same summation order per output row, so outputs and gradients must equal the ungrouped run bit for bit."""
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (64, 64), (64, 128), (128, 128), (128, 64)])
+def test_hip_conv_on_a_table_plan_is_bit_identical_to_the_plain_kernels(cuda, hip_lib, cin, cout):
+    """Rulebook.plan: regions per XCD, 16-row tiles of equal neighbour-mask class, regrouped row-major table, cost-sorted tile deal, column
+    blocks for C_out = 128, submanifold data gradient on the reversed table -- same summation order per output element, so outputs and
+    gradients must equal the plain (ungrouped, k-major table) kernels bit for bit."""
     import seevcn_amd.spconv as spconv
     from seevcn_amd.spconv import functional as Fsp
     rng = np.random.default_rng(9)
@@ -202,20 +203,109 @@ def test_hip_conv_with_mask_grouped_tiles_is_bit_identical(cuda, hip_lib, cin, c
     feats = rng.normal(size=(len(coords), cin)).astype(np.float32)
     for subm in (True, False):
         res = []
-        for grouped in (False, True):
-            saved, Fsp.GROUP_ROWS = Fsp.GROUP_ROWS, grouped
+        for planned in (False, True):
+            saved, Fsp.USE_PLAN = Fsp.USE_PLAN, planned
             try:
                 torch.manual_seed(0)
                 conv = (spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="k") if subm
                         else spconv.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False)).to(cuda)
-                f = torch.from_numpy(feats).to(cuda).requires_grad_(True)
-                out = conv(spconv.SparseConvTensor(f, torch.from_numpy(coords).to(cuda), list(shape), batch)).features
+                x = spconv.SparseConvTensor(torch.from_numpy(feats).to(cuda).requires_grad_(True), torch.from_numpy(coords).to(cuda), list(shape), batch)
+                out = conv(x).features
+                if planned:
+                    rb = x.indice_dict["k"] if subm else None
+                    assert rb is None or ("fwd" in rb._plans and rb.plan("bwd", cout, cin)[3] is True)     # the plan kernel really took the layer
                 out.square().sum().backward()
-                res.append((out.detach().cpu().numpy(), f.grad.cpu().numpy(), conv.weight.grad.cpu().numpy()))
+                res.append((out.detach().cpu().numpy(), x.features.grad.cpu().numpy(), conv.weight.grad.cpu().numpy()))
             finally:
-                Fsp.GROUP_ROWS = saved
+                Fsp.USE_PLAN = saved
         for a, b in zip(*res):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_hip_weight_fragment_cache_follows_the_weight_tensor(cuda, hip_lib):
+    """Fragments are cached per weight tensor + version: reused while the parameter is unchanged, re-laid after an in-place update, and never
+    handed to a different tensor that happens to get the same device address."""
+    import seevcn_amd.spconv as spconv
+    from seevcn_amd.spconv import functional as Fsp
+    conv = spconv.SubMConv3d(16, 32, 3, padding=1, bias=False).to(cuda)
+    f0 = Fsp.fragment_cache.get(conv.weight_kio())
+    f1 = Fsp.fragment_cache.get(conv.weight_kio())
+    assert f1[0] is f0[0] and f1[1] is f0[1]                       # same buffers, no re-layout
+    before = f0[0].clone()
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    f2 = Fsp.fragment_cache.get(conv.weight_kio())
+    assert torch.equal(f2[0], 2.0 * before)                        # version bump -> re-laid from the new values
+    w = torch.randn(27, 16, 16, device=cuda)
+    a = Fsp.fragment_cache.get(w)[0].clone()
+    ptr = w.data_ptr()
+    del w
+    w2 = torch.randn(27, 16, 16, device=cuda)                       # usually re-uses the freed block
+    b = Fsp.fragment_cache.get(w2)[0]
+    want = torch.empty_like(b)
+    # fragment order of the forward view Wt[k][n = c_out][c = c_in]: float4 unit ((k*KQ + q)*NT + t)*64 + lane holds 4 consecutive c_in
+    wt = w2.permute(0, 2, 1).contiguous().view(27, 1, 16, 1, 4, 4)   # (k, t, li, q, kk, 4) with NT = KQ = 1
+    want = wt.permute(0, 3, 1, 4, 2, 5).reshape(-1)                 # (k, q, t, kk, li, 4): lane = kk*16 + li
+    assert torch.equal(b, want), "stale fragments served for a new tensor" if w2.data_ptr() == ptr else "fragment layout"
+
+
+@pytest.mark.gpu
+def test_hip_table_plan_is_a_permutation_into_regions_with_balanced_waves(cuda, hip_lib):
+    """Structure of a plan at bench size: every row appears exactly once, inside its own region; tile_of covers every tile exactly once per
+    region; rows of a tile share their mask class in >= 85 % of the tiles; the busiest wave has <= 1.15x the mean work."""
+    import seevcn_amd.synth as synth
+    from seevcn_amd.pcdet.ops import voxel_ops
+    from seevcn_amd.spconv import functional as Fsp
+    bs = 8
+    pts, _ = synth.make_scene_batch(bs, seed=2000)
+    feats, coords, _ = voxel_ops.voxelize_dynamic(torch.from_numpy(pts).to(cuda), [0, -40, -3, 70.4, 40, 1], [0.05, 0.05, 0.1], [1408, 1600, 40], bs)
+    rs = Fsp.build_sparse_rulebook(coords, bs, [41, 1600, 1408], [3, 3, 3], [4, 4, 4], [1, 1, 1])          # a coarser level: ~40 k rows
+    rb = Fsp.build_subm_rulebook(rs.out_indices, bs, rs.out_shape, [3, 3, 3])
+    n = rb.n_out
+    tp, tile_of, g, rev = rb.plan("fwd", 64, 64)
+    assert rev is False and g in (2, 3, 4)
+    n_pad = (n + 15) // 16 * 16
+    rows = tp.perm.cpu().numpy()
+    assert len(rows) == n_pad
+    assert np.array_equal(np.sort(rows[rows >= 0]), np.arange(n)) and (rows[n:] == -1).all()
+    nbr = rb.nbr_out.cpu().numpy()
+    tab_rm = tp.rows.cpu().numpy()
+    assert np.array_equal(tab_rm[:, :27], nbr.T) and (tab_rm[:, 27:] == -1).all()       # the row-major twin of the k-major table
+    masks = ((nbr.T >= 0) * (1 << np.arange(27))).sum(1).astype(np.int64)
+    assert np.array_equal(masks, tp.masks.cpu().numpy().astype(np.int64))
+    mp = tp.masks_p.cpu().numpy().astype(np.int64)
+    live = rows >= 0
+    assert np.array_equal(mp[live], masks[rows[live]]) and (mp[~live] == 0).all()
+    tab = np.zeros((n_pad, 29), np.int64)                                                 # position-ordered view used below: [27] = mask
+    tab[:, 27] = mp
+    nblk = (n + 1023) // 1024
+    starts = [min((nblk * r // 8) * 1024, n) for r in range(9)]
+    starts[8] = n
+    for r in range(8):                                                                    # a row stays inside its region (= on its XCD)
+        seg = rows[starts[r]:starts[r + 1] if r < 7 else n_pad]
+        seg = seg[seg >= 0]
+        assert ((seg >= starts[r]) & (seg < starts[r + 1])).all(), r
+    tiles = tile_of.cpu().numpy()
+    n_tiles = n_pad // 16
+    cost = np.array([bin(int(np.bitwise_or.reduce(tab[16 * t:16 * t + 16, 27]))).count("1") for t in range(n_tiles)])
+    off, work = 0, []
+    seen = np.zeros(n_tiles, int)
+    for r in range(8):
+        t0, t1 = starts[r] // 16, (starts[r + 1] // 16 if r < 7 else n_tiles)
+        nw = -(-(t1 - t0) // g)
+        w = tiles[off * g:(off + nw) * g].reshape(nw, g)
+        off += nw
+        assert ((w == -1) | ((w >= t0) & (w < t1))).all(), r
+        np.add.at(seen, w[w >= 0], 1)
+        work += [cost[x[x >= 0]].sum() for x in w]
+    assert (seen == 1).all()
+    work = np.array(work, float)
+    # equal work per wave as far as whole tiles allow: the busiest wave is within 15 % of the mean, or holds the single most expensive tile
+    # plus the cheapest ones (a 27-offset tile cannot be split)
+    assert work.max() <= max(1.15 * work.mean(), cost.max() + (g - 1) * np.sort(cost)[len(cost) // 10]), (work.max(), work.mean(), cost.max())
+    useful = sum(bin(int(m)).count("1") for m in tab[:, 27])
+    assert useful / (16.0 * cost.sum()) >= 0.75                                           # useful / executed MFMA steps (consecutive rows: ~0.55)
 
 
 @pytest.mark.gpu
@@ -456,15 +546,13 @@ def test_hip_sparse_conv_full_size_properties(cuda, hip_lib, config):
         cin = cout = 64
         x1, x2 = (torch.randn((n_in, cin), device=cuda, generator=gen) for _ in range(2))
         w = torch.randn((book.K, cin, cout), device=cuda, generator=gen) * 0.1
-        wt = w.permute(0, 2, 1)
         dy = torch.randn((n_out, cout), device=cuda, generator=gen)
-        table, order, perm, rev = book.plan("fwd", cin, cout)
-        conv = lambda x: Fsp.gather_gemm(x, table, wt, n_out, tile_order=order, row_perm=perm, table_k_reversed=rev)
+        pf = book.plan("fwd", cin, cout)
+        conv = lambda x: Fsp.gather_gemm_planned(x, pf, Fsp.fragment_cache.get(w)[0], n_out, book.K, cin, cout)
         y1, y2, y12 = conv(x1), conv(x2), conv(2.0 * x1 - 3.0 * x2)
         scale = float(y12.abs().max())
         assert float((y12 - (2.0 * y1 - 3.0 * y2)).abs().max()) <= 1e-4 * scale
-        tb, ob, pb, rvb = book.plan("bwd", cout, cin)
-        dx = Fsp.gather_gemm(dy, tb, w, n_in, tile_order=ob, row_perm=pb, table_k_reversed=rvb)
+        dx = Fsp.gather_gemm_planned(dy, book.plan("bwd", cout, cin), Fsp.fragment_cache.get(w)[1], n_in, book.K, cout, cin)
         dw = Fsp.wgrad(x1, book.nbr_out, dy, book.K, cin, cout)
         lhs = float((y1.double() * dy.double()).sum())
         assert abs(lhs - float((x1.double() * dx.double()).sum())) <= 1e-4 * abs(lhs) + 1e-3

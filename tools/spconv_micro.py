@@ -48,7 +48,7 @@ def timeit(fn, reps=10):
 def main():
     dev = torch.device("cuda:0")
     bs = int(os.environ.get("BS", "16"))
-    pts, _ = synth.make_scene_batch(bs, seed=2000)
+    pts, _ = synth.make_scene_batch(bs, seed=2000, n_az=int(os.environ.get("N_AZ", "384")))
     g = dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.05, 0.05, 0.1], grid_size=[1408, 1600, 40])
     p = torch.from_numpy(pts).to(dev)
     feats, coords, _ = voxel_ops.voxelize_dynamic(p, g["point_cloud_range"], g["voxel_size"], g["grid_size"], bs)
@@ -78,17 +78,27 @@ def main():
             c, shape = rb.out_indices, rb.out_shape
             continue
         tf = td = tw = float("nan")
-        plain = os.environ.get("ORDER", "1") != "1"
+        pf = rb.plan("fwd", cin, cout)
+        pb = rb.plan("bwd", cout, cin)
+        tplan = float("nan")
+        if pf is not None and not name.startswith("_"):
+            tplan = timeit(lambda: Fsp.TablePlan(rb.nbr_out, rb.n_out, rb.K).tiles(pf[2]), 5)
         if mode in ("all", "fwd"):
-            table, order, perm, rev = (rb.nbr_out, None, None, False) if plain else rb.plan("fwd", cin, cout)
-            tf = timeit(lambda: Fsp.gather_gemm(x, table, wt, rb.n_out, tile_order=order, row_perm=perm, table_k_reversed=rev))
+            if pf is None:
+                tf = timeit(lambda: Fsp.gather_gemm(x, rb.nbr_out, wt, rb.n_out))
+            else:
+                ff = Fsp.fragment_cache.get(w)[0]
+                tf = timeit(lambda: Fsp.gather_gemm_planned(x, pf, ff, rb.n_out, K, cin, cout))
         if mode in ("all", "bwd"):
-            table_b, order_b, perm_b, rev_b = (rb.table_for_backward_data(), None, None, False) if plain else rb.plan("bwd", cout, cin)
-            td = timeit(lambda: Fsp.gather_gemm(dy, table_b, w, rb.n_in, tile_order=order_b, row_perm=perm_b, table_k_reversed=rev_b))
+            if pb is None:
+                td = timeit(lambda: Fsp.gather_gemm(dy, rb.table_for_backward_data(), w, rb.n_in))
+            else:
+                fb = Fsp.fragment_cache.get(w)[1]
+                td = timeit(lambda: Fsp.gather_gemm_planned(dy, pb, fb, rb.n_in, K, cout, cin))
         if mode in ("all", "wgrad"):
             tw = timeit(lambda: Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout))
         fl = 2.0 * pairs * cin * cout
-        print(f"{name:8s} {cin:3d}->{cout:3d} N_in={rb.n_in:7d} N_out={rb.n_out:7d} pairs={pairs:8d} rulebook {tb:7.1f} us | "
+        print(f"{name:8s} {cin:3d}->{cout:3d} N_in={rb.n_in:7d} N_out={rb.n_out:7d} pairs={pairs:8d} rulebook {tb:7.1f} us plan {tplan:6.1f} us | "
               f"fwd {tf:7.1f} us ({fl / tf / 1e6:6.2f} TF) | bwd-data {td:7.1f} us ({fl / td / 1e6:6.2f} TF) | wgrad {tw:7.1f} us ({fl / tw / 1e6:6.2f} TF)")
         tot += tf + td + tw
         c, shape = rb.out_indices, rb.out_shape
