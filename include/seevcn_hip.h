@@ -159,16 +159,18 @@ int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr
  * region b % 8, so a scene's rows are gathered through one L2) and regrouped inside a region into 16-row tiles of equal neighbour-mask
  * class (counting sort): perm (16*ceil(n_rows/16)) int32 = row at each position (-1 = padding of the last tile), masks_p = its mask.
  * persistent: sv_conv_plan_persistent_bytes() bytes, all zero before the first call and left zero-consistent by every call.
- * sv_conv_plan_tiles, once per (table, tiles_per_wave): tile_of (sv_conv_plan_tiles_bytes(n_rows)) maps [wave][slot] to a tile of the
- * wave's region or -1; tiles are counting-sorted by their number of active offsets and dealt in snake order (equal work per wave).
- * tiles_per_wave = sv_conv_tiles_per_wave(n_rows, Kd, Nc) of the conv that will use it (2, 3 or 4).
+ * sv_conv_plan_tiles, once per (table, tiles_per_wave): tile_of (sv_conv_plan_tiles_bytes(n_rows, tiles_per_wave)) maps [region][wave][slot] to a
+ * tile of the region or -1.  A launch is one resident round of 4 waves per SIMD (8 regions x 128 workgroups); a region's tiles are
+ * counting-sorted by their number of active offsets and dealt, round after round, to the 128 SIMDs of the region's XCD in ascending order of
+ * their load so far (equal work per SIMD); a wave works through its slots tiles_per_wave tiles at a time.
+ * tiles_per_wave = sv_conv_tiles_per_wave(n_rows, Kd, Nc) of the conv that will use it (2 or 4).
  * Results are bit-identical to sv_sparse_conv_gather_gemm (same summation order per output element). */
 int sv_conv_table_rows(const int32_t* nbr, int64_t n_rows, int K, int32_t* table_rows, int32_t* masks, void* stream);
 size_t sv_conv_plan_persistent_bytes(void);
 size_t sv_conv_plan_perm_bytes(int64_t n_rows);
 int sv_conv_plan_build(const int32_t* masks, int64_t n_rows, void* persistent, int32_t* perm, int32_t* masks_p, void* stream);
 int sv_conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc);
-size_t sv_conv_plan_tiles_bytes(int64_t n_rows);
+size_t sv_conv_plan_tiles_bytes(int64_t n_rows, int tiles_per_wave);
 int sv_conv_plan_tiles(const int32_t* masks_p, int64_t n_rows, int tiles_per_wave, int32_t* tile_of, void* stream);
 /* 1 iff the plan kernel is built for this layer shape (K <= 27 offsets, C_in in {16,32,64,128}, C_out in {16,32} or a multiple of 64 up to
  * 512) and X (n_src rows) is addressable through a 32-bit buffer descriptor; other shapes take sv_sparse_conv_gather_gemm. */
@@ -185,6 +187,10 @@ int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src, const int3
                                        const float* wfrag, float* Y, int64_t n_rows, int K, int Kd, int Nc, const float* bias,
                                        const float* scale, const float* shift, const float* residual, int relu, int table_k_reversed,
                                        void* stream);
+/* Measurement aid (tools/conv_trace.py): while buf is non-null every wave of sv_sparse_conv_gather_gemm_planned writes 8 uint64 to it
+ * (s_memtime at start / after the prologue / after the main loop / at the end, HW_ID, XCC_ID, tile-offset steps, block << 8 | wave);
+ * buf holds grid.x * grid.y * 4 slots of 64 bytes (size it as 8 * (n_tiles + 64) * columns / 64 slots).  Not for production use. */
+int sv_debug_conv_trace(void* buf);
 /* dW (K, C_in, C_out) = sum_o X[nbr[k][o]]^T dY[o]; deterministic two-stage reduction */
 size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout);
 int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,

@@ -403,44 +403,60 @@ extern "C" int sv_conv_table_rows(const int32_t* nbr, int64_t n_rows, int K, int
 }
 
 // ------------------------------------------------------------------------------------------------ tiles -> waves
-// Work-balanced tile assignment inside every region.  A 16-row tile costs as many MFMA steps as it has kernel offsets with at least one
-// neighbour (3 .. 27); a launch lasts as long as its busiest SIMD, and all waves of a launch are resident at once (one round), so the waves
-// must carry equal work: the region's tiles are counting-sorted by cost and dealt to its waves in snake order (max / mean 1.05; by
-// position 1.6-1.8).  Order inside a cost bucket is arbitrary: every output row is still produced by one wave with the same summation
-// order, results do not depend on it.  One workgroup per region, costs in LDS.
+// A conv launch is ONE resident round of PL_WAVES_PER_SIMD waves on every SIMD: 8 regions x 128 workgroups of 4 waves.  Observed placement
+// (tools/conv_trace.py, MAP=1; speed only, never correctness): workgroup b runs on XCD b % 8; inside an XCD the dispatcher walks the 4 shader
+// engines and their CUs in turn, so workgroups j, j + 32, j + 64, j + 96 of a region stack up on one CU; the 4 waves of a workgroup go to the
+// CU's 4 SIMDs in a rotation whose start varies.  A launch lasts as long as its busiest SIMD; a 16-row tile costs as many MFMA steps as it
+// has kernel offsets with at least one neighbour (3 .. 27) and cannot be split.  So the deal balances CUs, and gives the 4 waves of a
+// workgroup equal work (whichever SIMD each lands on): the region's tiles are counting-sorted by cost and taken in QUADS of 4 consecutive
+// (near-equal) tiles; round after round the next 32 quads go to the 32 CU bins in ascending order of their load so far (the largest quad of
+// the round to the least loaded CU: a sorted-rounds form of longest-processing-time-first); inside a bin round j goes to workgroup j % 4
+// (one tile of the quad per wave), tile slot j / 4.  A wave works through its slots G tiles at a time (n_pass passes).
+// Measured on the 64->64 layers with per-wave stamps: the round-1 snake deal of whole waves left the busiest SIMD at 1.19x (139 k rows) to
+// 1.65x (66 k rows) the mean and 16 % of the SIMDs with a wave less than the others.
+// Order inside a cost bucket is arbitrary: every output row is still produced by one wave with the same summation order, results do not
+// depend on the deal.  One workgroup per region, everything in LDS.
+constexpr int PL_WAVES_PER_SIMD = 4;
+constexpr int PL_BINS = 32;                                         // CUs per XCD
+constexpr int PL_QUAD = 4;                                          // tiles dealt together: one per wave of a workgroup
+constexpr int PL_REGION_WAVES = PL_BINS * PL_QUAD * PL_WAVES_PER_SIMD;   // 512 waves = 128 workgroups per region
+constexpr int PL_MAX_REGION_TILES = 16384;                          // LDS bound of the deal (2 M rows per launch)
 struct PlanDims {
   int32_t tile0[PL_REGIONS];    // first tile of the region
   int32_t tiles[PL_REGIONS];    // tiles of the region
-  int32_t waves[PL_REGIONS];    // ceil(tiles / G)
-  int32_t woff[PL_REGIONS];     // waves of the regions before
-  int32_t max_blocks;           // max over regions of ceil(waves / 4)
-  int32_t G;
+  int32_t G;                    // tiles a wave works on at a time
+  int32_t n_pass;               // passes: a wave has n_pass * G tile slots
 };
 static PlanDims plan_dims(int64_t n_rows, int G) {
   PlanDims d{};
   const int64_t n_tiles = (n_rows + 15) / 16;
-  int off = 0;
+  int max_tiles = 0;
   d.G = G;
   for (int r = 0; r < PL_REGIONS; ++r) {
     const int64_t s = plan_region_start(n_rows, r), e = r + 1 < PL_REGIONS ? plan_region_start(n_rows, r + 1) : n_rows;
     d.tile0[r] = (int32_t)(s / 16);
     d.tiles[r] = (int32_t)((r + 1 < PL_REGIONS ? e / 16 : n_tiles) - s / 16);
-    d.waves[r] = (d.tiles[r] + G - 1) / G;
-    d.woff[r] = off;
-    off += d.waves[r];
-    const int b = (d.waves[r] + 3) / 4;
-    if (b > d.max_blocks) d.max_blocks = b;
+    if (d.tiles[r] > max_tiles) max_tiles = d.tiles[r];
   }
+  const int quads = (max_tiles + PL_QUAD - 1) / PL_QUAD;
+  const int rounds = (quads + PL_BINS - 1) / PL_BINS;                            // quads per CU bin
+  const int slots = (rounds + PL_WAVES_PER_SIMD - 1) / PL_WAVES_PER_SIMD;        // tiles per wave
+  d.n_pass = slots > 0 ? (slots + G - 1) / G : 1;
   return d;
 }
 
-constexpr int PL_MAX_REGION_TILES = 65536;
 __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ masks_p, PlanDims d, int32_t* __restrict__ tile_of) {
   __shared__ uint8_t s_cost[PL_MAX_REGION_TILES];
+  __shared__ uint16_t s_sorted[PL_MAX_REGION_TILES];     // tiles of the region in descending cost order
   __shared__ int s_cnt[32], s_start[32];
+  __shared__ int s_load[PL_BINS], s_rank[PL_BINS];
+  static_assert(PL_BINS == 32, "the deal ranks the bins with 32 threads per bin");
   const int tid = threadIdx.x, r = blockIdx.x;
-  const int nt = d.tiles[r], nw = d.waves[r], G = d.G;
+  const int nt = d.tiles[r], slots = d.n_pass * d.G;
+  int32_t* out = tile_of + (int64_t)r * PL_REGION_WAVES * slots;
+  for (int i = tid; i < PL_REGION_WAVES * slots; i += 1024) out[i] = -1;
   if (tid < 32) s_cnt[tid] = 0;
+  if (tid < PL_BINS) s_load[tid] = 0;
   __syncthreads();
   for (int t = tid; t < nt; t += 1024) {
     const i32x4* mp = reinterpret_cast<const i32x4*>(masks_p + ((int64_t)d.tile0[r] + t) * 16);
@@ -462,51 +478,53 @@ __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ 
   __syncthreads();
   if (tid < 32) s_cnt[tid] = 0;
   __syncthreads();
-  int32_t* out = tile_of + (int64_t)d.woff[r] * G;
-  const int slots = nw * G;
-  for (int t = tid; t < slots; t += 1024) {
-    if (t < nt) {
-      const int c = s_cost[t];
-      const int p = s_start[c] + atomicAdd(&s_cnt[c], 1);
-      const int rnd = p / nw, i = p - rnd * nw;
-      const int wv = (rnd & 1) ? nw - 1 - i : i;          // snake: dense and sparse tiles alternate per wave
-      out[wv * G + rnd] = d.tile0[r] + t;
-    } else {                                              // positions nt .. slots-1 of the snake stay empty
-      const int rnd = t / nw, i = t - rnd * nw;
-      const int wv = (rnd & 1) ? nw - 1 - i : i;
-      out[wv * G + rnd] = -1;
+  for (int t = tid; t < nt; t += 1024) {
+    const int c = s_cost[t];
+    s_sorted[s_start[c] + atomicAdd(&s_cnt[c], 1)] = (uint16_t)t;
+  }
+  __syncthreads();
+  // sorted rounds over quads of 4 consecutive tiles: 32 threads per bin count the bins that come before it (lighter, or equally loaded with
+  // a lower id)
+  const int bin = tid >> 5, part = tid & 31;
+  const int nq = (nt + PL_QUAD - 1) / PL_QUAD;
+  for (int j = 0; j * PL_BINS < nq; ++j) {
+    if (part == 0) s_rank[bin] = 0;
+    __syncthreads();
+    const int mine = s_load[bin];
+    {
+      const int l = s_load[part];
+      if (l < mine || (l == mine && part < bin)) atomicAdd(&s_rank[bin], 1);
     }
+    __syncthreads();
+    const int qd = j * PL_BINS + s_rank[bin];            // the rank-th largest quad of this round
+    if (part < PL_QUAD && qd < nq) {
+      const int p = qd * PL_QUAD + part;
+      if (p < nt) {
+        const int t = s_sorted[p];
+        // bin = CU; its workgroup of this round in snake order (0 1 2 3 3 2 1 0 ...): the four workgroups of a CU end up with equal work
+        // too -- a wave left alone on its SIMD at the end of the launch cannot keep the matrix pipe busy; wave = position inside the quad
+        const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;
+        const int lw = (bin + PL_BINS * wg) * 4 + part;
+        out[(int64_t)lw * slots + j / PL_WAVES_PER_SIMD] = d.tile0[r] + t;
+        atomicAdd(&s_load[bin], (int)s_cost[t]);
+      }
+    }
+    __syncthreads();
   }
 }
 
-// Tiles per wave.  A launch lasts as long as its fullest CU: 526 workgroups (4 waves each) on 256 CUs put 3 on 14 CUs and 2 on
-// the rest (1.46x the mean), and a launch with fewer workgroups than CUs leaves one wave per SIMD with nothing to hide its
-// operand latency behind.  Model: time ~ ceil(WGs / 256) * G / eff(waves per SIMD), eff = 0.45 / 0.75 / 0.9 for 1 / 2 / >= 3
-// resident workgroups per CU (measured shape of the curve on the bench layers), + 4 % per step of G below 4 for the extra
-// weight-slab loads.  Measured on the 64->64 layers: 8412 tiles G = 4 230 us, G = 3 183 us; 4012 tiles G = 4 130 us, G = 2 105 us.
-static int conv_col_blocks(int Nc) { return Nc > 64 ? Nc / 64 : 1; }
+// Tiles a wave holds in registers at a time: 2 for the 64-column kernels (113 VGPRs: four waves per SIMD), 4 for the narrow ones (their
+// MFMA work per weight load is small).  The weight loads are shared by the G tiles of a pass.
 static int conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc) {
-  const int nc_blk = Nc > 64 ? 64 : Nc;
-  if ((Kd / 16) * (nc_blk / 16) < 4) return 4;      // layers with < 32x32 channel products per tile are bound by their operand loads: keep G = 4
-  int best = 4;
-  double best_score = 1e30;
-  for (int g = 4; g >= 2; --g) {
-    const PlanDims d = plan_dims(n_rows, g);
-    int64_t wgs = 0;
-    for (int r = 0; r < PL_REGIONS; ++r) wgs += (d.waves[r] + 3) / 4;
-    wgs *= conv_col_blocks(Nc);
-    if (wgs <= 0) continue;
-    const int64_t per_cu = (wgs + 255) / 256;
-    const double eff = per_cu >= 3 ? 0.9 : (per_cu == 2 ? 0.75 : 0.45);
-    const double score = (double)per_cu * g / eff * (1.0 + 0.04 * (4 - g));
-    if (score < best_score - 1e-9) best_score = score, best = g;
-  }
-  return best;
+  (void)n_rows;
+  (void)Kd;
+  return (Nc > 32) ? 2 : 4;
 }
 extern "C" int sv_conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc) { return conv_tiles_per_wave(n_rows < 0 ? 0 : n_rows, Kd, Nc); }
-extern "C" size_t sv_conv_plan_tiles_bytes(int64_t n_rows) {
-  const int64_t n_tiles = ((n_rows < 0 ? 0 : n_rows) + 15) / 16;
-  return (size_t)(n_tiles + 4 * PL_REGIONS + 16) * sizeof(int32_t);     // sum over regions of ceil(tiles_r / G) * G <= n_tiles + 8 * (G - 1)
+extern "C" size_t sv_conv_plan_tiles_bytes(int64_t n_rows, int tiles_per_wave) {
+  if (tiles_per_wave < 1) tiles_per_wave = 1;
+  const PlanDims d = plan_dims(n_rows < 0 ? 0 : n_rows, tiles_per_wave);
+  return (size_t)PL_REGIONS * PL_REGION_WAVES * d.n_pass * d.G * sizeof(int32_t);
 }
 
 extern "C" int sv_conv_plan_tiles(const int32_t* masks_p, int64_t n_rows, int tiles_per_wave, int32_t* tile_of, void* stream) {
@@ -598,24 +616,34 @@ struct PlanView {
   PlanDims d;
   int k_flip;               // read table entry K-1-k for offset k (a submanifold table serving its own data gradient)
   int nc_total;             // columns of Y and of the weight fragments (a.Nc is the block's share)
+  int debug;                // measurement only (SEEVCN_RS3_DEBUG): bit 0 = no gathered-row loads, bit 1 = no weight loads (results are wrong)
+  unsigned long long* trace;   // measurement only (sv_debug_conv_trace): 8 words per wave, or null
 };
 
 template <int NT, int KQ, int RS_G>
-__global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, PlanView pv, const float* __restrict__ wfrag, uint32_t x_bytes, uint32_t w_bytes) {
+__global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs a, PlanView pv, const float* __restrict__ wfrag, uint32_t x_bytes,
+                                                                        uint32_t w_bytes) {
   constexpr int Kd = KQ * 16;
   __shared__ int32_t s_idx_all[4][RS3_KMAX + 1][64];       // [k][lane]: source row of (tile lane>>4, row lane&15); [27][lane]: its output row
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int li = lane & 15, kk = lane >> 4;
   const int region = blockIdx.x % PL_REGIONS, lw = (blockIdx.x / PL_REGIONS) * 4 + wid;
-  if (lw >= pv.d.waves[region]) return;
+  const unsigned long long t_start = pv.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long t_pro = 0ull, t_loop = 0ull;
+  unsigned trace_work = 0;
   int32_t(*s_idx)[64] = s_idx_all[wid];
   const int nt_total = pv.nc_total / 16, col_tile0 = blockIdx.y * NT;
+  const i32x4 srd_x = make_srd(a.X, x_bytes), srd_w = make_srd(wfrag, w_bytes);
+  const int32_t* my_tiles = pv.tile_of + ((int64_t)region * PL_REGION_WAVES + lw) * (pv.d.n_pass * RS_G);
 
+#pragma nounroll
+  for (int pass = 0; pass < pv.d.n_pass; ++pass) {
+  if (my_tiles[pass * RS_G] < 0) break;                    // slots are filled front to back: an empty first slot ends the wave's list
   // the wave's rows of the regrouped table -> LDS; per-offset tile masks in lane k of maskreg
   unsigned maskreg = 0;
   {
     const int g = lane >> 4;
-    const int32_t t = g < RS_G ? pv.tile_of[((int64_t)pv.d.woff[region] + lw) * RS_G + g] : -1;
+    const int32_t t = g < RS_G ? my_tiles[pass * RS_G + g] : -1;
     i32x4 e[PL_ROW / 4];
     const int64_t p = (int64_t)t * 16 + li;
     const int32_t row = t >= 0 ? pv.perm[p] : -1;
@@ -630,7 +658,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, PlanView pv, 
     }
 #pragma unroll
     for (int k = 0; k < RS3_KMAX; ++k)
-      if (k < a.K) s_idx[pv.k_flip ? a.K - 1 - k : k][lane] = e[k >> 2][k & 3];
+      s_idx[k][lane] = e[k >> 2][k & 3];            // table order (entries >= K are -1 in the table); a reversed table is read at K-1-k in the loop
     s_idx[RS3_KMAX][lane] = row;                           // output row (-1: padding)
     if (pv.k_flip) m = __brev(m) >> (32 - a.K);
 #pragma unroll
@@ -644,6 +672,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, PlanView pv, 
     maskreg = lane < a.K ? mk : 0u;
   }
   const unsigned long long active = __ballot(maskreg != 0);
+  if (pv.trace && pass == 0) t_pro = __builtin_amdgcn_s_memtime();
 
   f32x4 acc[RS_G][NT];
 #pragma unroll
@@ -652,27 +681,35 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, PlanView pv, 
     for (int t = 0; t < NT; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (active) {
-    const i32x4 srd_x = make_srd(a.X, x_bytes), srd_w = make_srd(wfrag, w_bytes);
     f32x4 A[3][RS_G], B[3][NT];
+    // defined here so that their live ranges start inside the pass (the asm waits below read-modify them: left undefined, hipcc keeps all
+    // 18-24 stage registers alive across the whole pass loop, prologue and epilogue included, and spills 55 VGPRs at four waves per SIMD)
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+#pragma unroll
+      for (int g = 0; g < RS_G; ++g) A[st][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < NT; ++t) B[st][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     // load iterator (two steps ahead of the compute iterator)
     unsigned long long la = active;
     int kl = __ffsll((long long)la) - 1, ql = 0;
     int32_t jl[RS_G];
     auto read_j = [&]() {
 #pragma unroll
-      for (int g = 0; g < RS_G; ++g) jl[g] = s_idx[kl][g * 16 + li];
+      for (int g = 0; g < RS_G; ++g) jl[g] = s_idx[pv.k_flip ? a.K - 1 - kl : kl][g * 16 + li];
     };
     read_j();
     auto issue = [&](f32x4 (&As)[RS_G], f32x4 (&Bs)[NT]) {       // exactly NLOAD loads, always
       const bool live = kl >= 0;
 #pragma unroll
       for (int g = 0; g < RS_G; ++g) {
-        const uint32_t off = (live && jl[g] >= 0) ? (uint32_t)((jl[g] * Kd + ql * 16 + kk * 4) * 4) : 0xfffffff0u;
+        const uint32_t off = (live && jl[g] >= 0 && !(pv.debug & 1)) ? (uint32_t)((jl[g] * Kd + ql * 16 + kk * 4) * 4) : 0xfffffff0u;
         As[g] = buf_load_b128(srd_x, off);
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const uint32_t off = live ? (uint32_t)(((((kl * KQ + ql) * nt_total + col_tile0 + t) * 64 + lane) * 4) * 4) : 0xfffffff0u;
+        const uint32_t off = (live && !(pv.debug & 2)) ? (uint32_t)(((((kl * KQ + ql) * nt_total + col_tile0 + t) * 64 + lane) * 4) * 4) : 0xfffffff0u;
         Bs[t] = buf_load_b128(srd_w, off);
       }
       if (live && ++ql == KQ) {
@@ -705,7 +742,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, PlanView pv, 
       // v_mfma_f32_16x16x4_f32 issues 47 cycles after its producer, an independent one after 32)
 #pragma unroll
       for (int g = 0; g < RS_G; ++g)
-        if ((mc >> g) & 1u) {
+        if (((mc >> g) & 1u) && !(pv.debug & 4)) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g].x, Bs[t].x, acc[g][t], 0, 0, 0);
 #pragma unroll
@@ -737,6 +774,10 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, PlanView pv, 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // retire the dummy loads before the registers are reused
   }
+  if (pv.trace) {
+    t_loop = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < a.K; ++k) trace_work += __popc((unsigned)__builtin_amdgcn_readlane((int)maskreg, k));
+  }
   // D layout (16x16): col = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll
   for (int g = 0; g < RS_G; ++g)
@@ -750,6 +791,17 @@ __global__ __launch_bounds__(256, 3) void k_spconv_rs3(ConvArgs a, PlanView pv, 
         a.Y[row * pv.nc_total + col] = conv_epilogue(acc[g][t][r], col, row, a);
       }
     }
+  }   // pass
+  if (pv.trace && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    unsigned hw = 0, xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned work = trace_work;
+    unsigned long long* o = pv.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+    o[0] = t_start, o[1] = t_pro, o[2] = t_loop, o[3] = t_end, o[4] = hw, o[5] = xcc, o[6] = work, o[7] = ((unsigned long long)blockIdx.x << 8) | wid;
+  }
 }
 
 // shapes the plan kernel is instantiated for: C_in in {16, 32, 64, 128}, C_out in {16, 32, 64} or a multiple of 64, K <= 27
@@ -766,11 +818,9 @@ extern "C" int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc, int64_t n_src)
 
 template <int NT, int KQ>
 static void launch_rs3_g(const ConvArgs& a, const PlanView& pv, const float* wfrag, uint32_t xb, uint32_t wb, dim3 grid, hipStream_t st) {
-  switch (pv.d.G) {
-    case 4: hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 4>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb); break;
-    case 3: hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 3>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb); break;
-    default: hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb); break;
-  }
+  // tiles per pass: conv_tiles_per_wave (2 for the 64-column kernels, 4 for the narrow ones)
+  if constexpr (NT == 4) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+  else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 4>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
 }
 template <int NT>
 static void launch_rs3_kq(const ConvArgs& a, const PlanView& pv, const float* wfrag, uint32_t xb, uint32_t wb, dim3 grid, hipStream_t st) {
@@ -780,6 +830,13 @@ static void launch_rs3_kq(const ConvArgs& a, const PlanView& pv, const float* wf
     case 4: launch_rs3_g<NT, 4>(a, pv, wfrag, xb, wb, grid, st); break;
     default: launch_rs3_g<NT, 8>(a, pv, wfrag, xb, wb, grid, st); break;
   }
+}
+
+// measurement only: per-wave time stamps of the next planned launches go to `buf` (8 x uint64 per wave slot: grid.x * grid.y * 4 slots); null = off
+static unsigned long long* g_conv_trace = nullptr;
+extern "C" int sv_debug_conv_trace(void* buf) {
+  g_conv_trace = static_cast<unsigned long long*>(buf);
+  return SV_OK;
 }
 
 extern "C" int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src, const int32_t* table_rows, const int32_t* perm, const int32_t* masks_p,
@@ -793,13 +850,16 @@ extern "C" int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src,
   SV_CHECK_ARG((scale == nullptr) == (shift == nullptr), "sparse_conv: scale and shift go together");
   SV_CHECK_ARG(sv_conv_mfma_kernel_applies(K, Kd, Nc, n_src), "sparse_conv (planned): no MFMA kernel for K %d, C_in %d, C_out %d, %lld source rows "
                "(ask sv_conv_mfma_kernel_applies first)", K, Kd, Nc, (long long)n_src);
-  SV_CHECK_ARG(tiles_per_wave >= 2 && tiles_per_wave <= 4, "sparse_conv (planned): tiles_per_wave must be 2..4");
+  SV_CHECK_ARG(tiles_per_wave == conv_tiles_per_wave(n_rows, Kd, Nc), "sparse_conv (planned): tiles_per_wave must be sv_conv_tiles_per_wave(n_rows, Kd, Nc)");
   SV_CHECK_ARG((uintptr_t)X % 16 == 0 && (uintptr_t)wfrag % 16 == 0 && (uintptr_t)table_rows % 16 == 0, "sparse_conv (planned): 16-byte alignment");
   ConvArgs a{X, nullptr, nullptr, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc};
   PlanView pv;
   pv.tab = table_rows, pv.perm = perm, pv.masks_p = masks_p, pv.tile_of = tile_of, pv.d = plan_dims(n_rows, tiles_per_wave), pv.k_flip = table_k_reversed ? 1 : 0, pv.nc_total = Nc;
+  static const int debug = getenv("SEEVCN_RS3_DEBUG") ? atoi(getenv("SEEVCN_RS3_DEBUG")) : 0;
+  pv.debug = debug;
+  pv.trace = g_conv_trace;
   const int nc_blk = Nc > 64 ? 64 : Nc;
-  const dim3 grid((unsigned)(PL_REGIONS * pv.d.max_blocks), (unsigned)(Nc / nc_blk));
+  const dim3 grid((unsigned)(PL_REGIONS * PL_REGION_WAVES / 4), (unsigned)(Nc / nc_blk));
   const uint32_t xb = (uint32_t)((uint64_t)n_src * Kd * 4), wb = (uint32_t)((uint64_t)K * Nc * Kd * 4);
   hipStream_t st = sv_stream(stream);
   switch (nc_blk / 16) {

@@ -47,7 +47,7 @@ class TablePlan:
     def tiles(self, g):
         if g not in self._tiles:
             lib = _lib.load()
-            t = torch.empty((lib.sv_conv_plan_tiles_bytes(self.n_rows) // 4,), dtype=torch.int32, device=self.perm.device)
+            t = torch.empty((lib.sv_conv_plan_tiles_bytes(self.n_rows, int(g)) // 4,), dtype=torch.int32, device=self.perm.device)
             _lib.check(lib.sv_conv_plan_tiles(_lib.ptr(self.masks_p), self.n_rows, int(g), _lib.ptr(t), _lib.stream()), "sv_conv_plan_tiles")
             self._tiles[g] = t
         return self._tiles[g]

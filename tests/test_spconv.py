@@ -286,24 +286,27 @@ def test_hip_table_plan_is_a_permutation_into_regions_with_balanced_waves(cuda, 
         seg = rows[starts[r]:starts[r + 1] if r < 7 else n_pad]
         seg = seg[seg >= 0]
         assert ((seg >= starts[r]) & (seg < starts[r + 1])).all(), r
-    tiles = tile_of.cpu().numpy()
+    tiles = tile_of.cpu().numpy().reshape(8, 512, -1)                                     # [region][wave of the region][slot]
+    assert tiles.shape[2] % g == 0
     n_tiles = n_pad // 16
     cost = np.array([bin(int(np.bitwise_or.reduce(tab[16 * t:16 * t + 16, 27]))).count("1") for t in range(n_tiles)])
-    off, work = 0, []
     seen = np.zeros(n_tiles, int)
+    cu_work = []
     for r in range(8):
         t0, t1 = starts[r] // 16, (starts[r + 1] // 16 if r < 7 else n_tiles)
-        nw = -(-(t1 - t0) // g)
-        w = tiles[off * g:(off + nw) * g].reshape(nw, g)
-        off += nw
+        w = tiles[r]
         assert ((w == -1) | ((w >= t0) & (w < t1))).all(), r
-        np.add.at(seen, w[w >= 0], 1)
-        work += [cost[x[x >= 0]].sum() for x in w]
-    assert (seen == 1).all()
-    work = np.array(work, float)
-    # equal work per wave as far as whole tiles allow: the busiest wave is within 15 % of the mean, or holds the single most expensive tile
-    # plus the cheapest ones (a 27-offset tile cannot be split)
-    assert work.max() <= max(1.15 * work.mean(), cost.max() + (g - 1) * np.sort(cost)[len(cost) // 10]), (work.max(), work.mean(), cost.max())
+        filled = w >= 0
+        assert (filled[:, :-1] >= filled[:, 1:]).all()                                      # slots are filled front to back
+        np.add.at(seen, w[filled], 1)
+        wave_work = np.where(filled, cost[np.maximum(w, 0)], 0).sum(1).reshape(128, 4)      # [workgroup][wave]
+        if t1 - t0 >= 512:
+            assert (wave_work.max(1) - wave_work.min(1)).max() <= 4                        # the 4 waves of a workgroup carry near-equal work
+        cu_work += list(wave_work.sum(1).reshape(4, 32).sum(0))                            # workgroups j, j+32, j+64, j+96 share a CU
+    assert (seen == 1).all()                                                                # every tile exactly once
+    cu_work = np.array(cu_work, float).reshape(8, 32)
+    per_region = cu_work.mean(1, keepdims=True)
+    assert (cu_work <= 1.08 * per_region + 27).all(), (cu_work.max(1) / per_region[:, 0])   # CU bins within 8 % (+ one tile) of their XCD's mean
     useful = sum(bin(int(m)).count("1") for m in tab[:, 27])
     assert useful / (16.0 * cost.sum()) >= 0.75                                           # useful / executed MFMA steps (consecutive rows: ~0.55)
 
