@@ -128,17 +128,19 @@ int sv_rulebook_subm_cellmap(const int32_t* coords, int64_t n, int batch, const 
                              const int32_t* dilation, void* cellmap, int32_t* nbr, int32_t* table_rows, int32_t* masks, void* stream);
 /* SparseConv3d rulebook, phase 1: output coordinates in canonical (ascending ((b*Z+z)*Y+y)*X+x) order and the
  * input-major table nbr_in (K, n_in) = output row fed by (k, input) or -1; *num_out on the device.
+ * in_block (optional, K <= 27): (32 + 1) * n_in int32 = [table_rows_in (n_in, 32) | masks_in (n_in)], the same table row-major plus every
+ * input row's mask (bit k = feeds an output through offset k) -- what the data-gradient plan consumes.
  * index_ws: sv_index_persistent_bytes(batch * prod(out_shape)). */
 int sv_rulebook_sparse(const int32_t* coords, int64_t n_in, int batch, const int32_t* in_shape_host,
                        const int32_t* ksize_host, const int32_t* stride_host, const int32_t* padding_host,
                        const int32_t* dilation_host, void* index_ws, void* scratch, int32_t* out_coords,
-                       int32_t* nbr_in, int64_t capacity, int32_t* num_out, void* stream);
+                       int32_t* nbr_in, int32_t* in_block, int64_t capacity, int32_t* num_out, void* stream);
 /* phase 2 (after the caller knows n_out): nbr_out (K, n_out) output-major table from nbr_in */
 int sv_rulebook_invert(const int32_t* nbr_in, int64_t n_in, int K, int32_t* nbr_out, int64_t n_out, void* stream);
-/* The same inversion (K <= 27) that also writes the row-major twins and neighbour masks of both tables:
- *   out_block ((32 + K + 1) * n_out int32, filled here) = [table_rows_out (n_out, 32) | nbr_out (K, n_out) | masks_out (n_out)]
- *   in_block  ((32 + 1) * n_in int32)                   = [table_rows_in (n_in, 32) | masks_in (n_in)] */
-int sv_rulebook_invert_rows(const int32_t* nbr_in, int64_t n_in, int K, int32_t* out_block, int64_t n_out, int32_t* in_block, void* stream);
+/* The same inversion (K <= 27) from the row-major input table (sv_rulebook_sparse's in_block) that also writes the row-major twin and the
+ * neighbour masks of the output side:
+ *   out_block ((32 + K + 1) * n_out int32, filled here) = [table_rows_out (n_out, 32) | nbr_out (K, n_out) | masks_out (n_out)] */
+int sv_rulebook_invert_rows(const int32_t* table_rows_in, int64_t n_in, int K, int32_t* out_block, int64_t n_out, void* stream);
 /* counts[k] = number of (in,out) pairs of offset k (spconv's indice_pair_num) */
 int sv_rulebook_pair_counts(const int32_t* nbr, int64_t n_out, int K, int32_t* counts, void* stream);
 

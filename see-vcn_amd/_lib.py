@@ -40,9 +40,9 @@ SIGNATURES = {
     "sv_rulebook_subm": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_cellmap_persistent_bytes": (c_sz, [c_i, c_p]),
     "sv_rulebook_subm_cellmap": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "sv_rulebook_sparse": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
+    "sv_rulebook_sparse": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "sv_rulebook_invert": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p]),
-    "sv_rulebook_invert_rows": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p, c_p]),
+    "sv_rulebook_invert_rows": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p]),
     "sv_rulebook_pair_counts": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
     "sv_sparse_conv_gather_gemm": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p]),
     "sv_conv_plan_persistent_bytes": (c_sz, []),

@@ -262,6 +262,9 @@ __device__ __forceinline__ int plan_region_of_row(int64_t n_rows, int64_t row) {
 
 // pass 1: per-(region, class) histogram.  One row per thread; counts go wave -> LDS -> global, so the hottest class (one mask covers
 // ~20 % of the rows) sees one global atomic per 1024 rows.  A workgroup lies inside one region.
+// (Tried: letting the last workgroup to arrive -- release fence + ticket -- do the scan below, and the same for the BatchNorm statistics:
+// one launch less each, but 24 us instead of 7 + 6.5: every workgroup's agent-scope release writes back its XCD's L2.  A kernel boundary
+// costs 1.5 us on this GPU; separate launches it is.)
 __global__ __launch_bounds__(PL_WG) void k_plan_hist(PlanArgs a) {
   __shared__ int s_hist[PL_CLASSES];
   for (int i = threadIdx.x; i < PL_CLASSES; i += PL_WG) s_hist[i] = 0;
@@ -280,30 +283,47 @@ __global__ __launch_bounds__(PL_WG) void k_plan_hist(PlanArgs a) {
     if (s_hist[i]) atomicAdd(&gh[i], s_hist[i]);
 }
 
-// pass 2: one workgroup per region: exclusive scan of its class counts -> first position of every class; counts and cursors back to zero
-__global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
-  __shared__ int s_part[1024];
-  const int tid = threadIdx.x, region = blockIdx.x;
+// pass 2: counts -> class starts: exclusive scan per region, counts and cursors back to zero.  One workgroup: 1024 threads x 32 consecutive
+// classes = 8 regions x 4096 classes, 128 threads (2 waves) per region.
+__global__ __launch_bounds__(PL_WG) void k_plan_scan(PlanArgs a) {
   constexpr int RC = PL_REGIONS * PL_CLASSES;
-  int32_t* cnt = a.hist + (size_t)region * PL_CLASSES;
-  int v[4], sum = 0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  int32_t* cnt = a.hist + (size_t)tid * 32;
+  int v[32], sum = 0;
+  {
+    const i32x4* c4 = reinterpret_cast<const i32x4*>(cnt);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) v[u] = cnt[tid * 4 + u], sum += v[u];
-  s_part[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan of the 1024 partial sums
-    const int t = tid >= d ? s_part[tid - d] : 0;
-    __syncthreads();
-    s_part[tid] += t;
-    __syncthreads();
+    for (int q = 0; q < 8; ++q) {
+      const i32x4 t = c4[q];
+      v[4 * q] = t.x, v[4 * q + 1] = t.y, v[4 * q + 2] = t.z, v[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) sum += v[u];
   }
-  int run = (int)plan_region_start(a.n_rows, region) + s_part[tid] - sum;
+  int incl = sum;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    a.hist[RC + region * PL_CLASSES + tid * 4 + u] = run;
-    a.hist[2 * RC + region * PL_CLASSES + tid * 4 + u] = 0;
-    cnt[tid * 4 + u] = 0;
-    run += v[u];
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  __shared__ int s_wave[PL_WG / 64];
+  if (lane == 63) s_wave[tid >> 6] = incl;
+  __syncthreads();
+  const int r = tid >> 7;                                                      // region of this thread's classes
+  int run = (int)plan_region_start(a.n_rows, r) + incl - sum + (((tid >> 6) & 1) ? s_wave[(tid >> 6) - 1] : 0);
+  i32x4* st4 = reinterpret_cast<i32x4*>(a.hist + RC + tid * 32);
+  i32x4* cu4 = reinterpret_cast<i32x4*>(a.hist + 2 * RC + tid * 32);
+  i32x4* cn4 = reinterpret_cast<i32x4*>(cnt);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    i32x4 t;
+    t.x = run, run += v[4 * q];
+    t.y = run, run += v[4 * q + 1];
+    t.z = run, run += v[4 * q + 2];
+    t.w = run, run += v[4 * q + 3];
+    st4[q] = t;
+    cu4[q] = (i32x4){0, 0, 0, 0};
+    cn4[q] = (i32x4){0, 0, 0, 0};
   }
 }
 
@@ -354,7 +374,7 @@ extern "C" int sv_conv_plan_build(const int32_t* masks, int64_t n_rows, void* pe
   const int wgs = sv_div_up(n_rows, PL_WG);      // covers the <= 15 padding positions too: n_pad <= wgs * PL_WG
   hipStream_t st = sv_stream(stream);
   hipLaunchKernelGGL(k_plan_hist, dim3(wgs), dim3(PL_WG), 0, st, a);
-  hipLaunchKernelGGL(k_plan_scan, dim3(PL_REGIONS), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PL_WG), 0, st, a);
   hipLaunchKernelGGL(k_plan_place, dim3(wgs), dim3(PL_WG), 0, st, a);
   SV_LAUNCH_CHECK();
   return SV_OK;
@@ -409,9 +429,12 @@ extern "C" int sv_conv_table_rows(const int32_t* nbr, int64_t n_rows, int K, int
 // CU's 4 SIMDs in a rotation whose start varies.  A launch lasts as long as its busiest SIMD; a 16-row tile costs as many MFMA steps as it
 // has kernel offsets with at least one neighbour (3 .. 27) and cannot be split.  So the deal balances CUs, and gives the 4 waves of a
 // workgroup equal work (whichever SIMD each lands on): the region's tiles are counting-sorted by cost and taken in QUADS of 4 consecutive
-// (near-equal) tiles; round after round the next 32 quads go to the 32 CU bins in ascending order of their load so far (the largest quad of
-// the round to the least loaded CU: a sorted-rounds form of longest-processing-time-first); inside a bin round j goes to workgroup j % 4
-// (one tile of the quad per wave), tile slot j / 4.  A wave works through its slots G tiles at a time (n_pass passes).
+// (near-equal) tiles; round after round the next 32 quads go to the 32 CU bins in snake order; inside a bin the rounds walk the four
+// workgroups in snake order as well (one tile of the quad per wave), tile slot round / 4.  A wave works through its slots G tiles at a time
+// (n_pass passes).  With >= 16 rounds (the bench's 64-channel layers have 16-34) the busiest CU carries 1.04-1.09x its XCD's mean; a
+// region with a few 27-offset tiles and only ~7 rounds of 5-9-offset ones ends at up to 1.45x, because every CU gets one quad per round
+// whatever it already holds.  Ranking the bins by load every round (sorted rounds) measured the same there and cost 14 us per deal
+// instead of 4; a true longest-processing-time deal needs unequal tile counts per wave -- not built.
 // Measured on the 64->64 layers with per-wave stamps: the round-1 snake deal of whole waves left the busiest SIMD at 1.19x (139 k rows) to
 // 1.65x (66 k rows) the mean and 16 % of the SIMDs with a wave less than the others.
 // Order inside a cost bucket is arbitrary: every output row is still produced by one wave with the same summation order, results do not
@@ -449,14 +472,11 @@ __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ 
   __shared__ uint8_t s_cost[PL_MAX_REGION_TILES];
   __shared__ uint16_t s_sorted[PL_MAX_REGION_TILES];     // tiles of the region in descending cost order
   __shared__ int s_cnt[32], s_start[32];
-  __shared__ int s_load[PL_BINS], s_rank[PL_BINS];
-  static_assert(PL_BINS == 32, "the deal ranks the bins with 32 threads per bin");
   const int tid = threadIdx.x, r = blockIdx.x;
   const int nt = d.tiles[r], slots = d.n_pass * d.G;
   int32_t* out = tile_of + (int64_t)r * PL_REGION_WAVES * slots;
   for (int i = tid; i < PL_REGION_WAVES * slots; i += 1024) out[i] = -1;
   if (tid < 32) s_cnt[tid] = 0;
-  if (tid < PL_BINS) s_load[tid] = 0;
   __syncthreads();
   for (int t = tid; t < nt; t += 1024) {
     const i32x4* mp = reinterpret_cast<const i32x4*>(masks_p + ((int64_t)d.tile0[r] + t) * 16);
@@ -483,33 +503,18 @@ __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ 
     s_sorted[s_start[c] + atomicAdd(&s_cnt[c], 1)] = (uint16_t)t;
   }
   __syncthreads();
-  // sorted rounds over quads of 4 consecutive tiles: 32 threads per bin count the bins that come before it (lighter, or equally loaded with
-  // a lower id)
-  const int bin = tid >> 5, part = tid & 31;
+  // quads of 4 consecutive tiles of the sorted list, dealt to the 32 CU bins in snake order (0 .. 31, 31 .. 0, ...); inside a bin the rounds
+  // walk the four workgroups in snake order too.  One thread per quad.
   const int nq = (nt + PL_QUAD - 1) / PL_QUAD;
-  for (int j = 0; j * PL_BINS < nq; ++j) {
-    if (part == 0) s_rank[bin] = 0;
-    __syncthreads();
-    const int mine = s_load[bin];
-    {
-      const int l = s_load[part];
-      if (l < mine || (l == mine && part < bin)) atomicAdd(&s_rank[bin], 1);
-    }
-    __syncthreads();
-    const int qd = j * PL_BINS + s_rank[bin];            // the rank-th largest quad of this round
-    if (part < PL_QUAD && qd < nq) {
+  for (int qd = tid; qd < nq; qd += 1024) {
+    const int j = qd / PL_BINS, pos = qd % PL_BINS;                 // round of the bin, position in the round
+    const int bin = (j & 1) ? PL_BINS - 1 - pos : pos;
+    const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;
+#pragma unroll
+    for (int part = 0; part < PL_QUAD; ++part) {
       const int p = qd * PL_QUAD + part;
-      if (p < nt) {
-        const int t = s_sorted[p];
-        // bin = CU; its workgroup of this round in snake order (0 1 2 3 3 2 1 0 ...): the four workgroups of a CU end up with equal work
-        // too -- a wave left alone on its SIMD at the end of the launch cannot keep the matrix pipe busy; wave = position inside the quad
-        const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;
-        const int lw = (bin + PL_BINS * wg) * 4 + part;
-        out[(int64_t)lw * slots + j / PL_WAVES_PER_SIMD] = d.tile0[r] + t;
-        atomicAdd(&s_load[bin], (int)s_cost[t]);
-      }
+      if (p < nt) out[(int64_t)((bin + PL_BINS * wg) * 4 + part) * slots + j / PL_WAVES_PER_SIMD] = d.tile0[r] + s_sorted[p];
     }
-    __syncthreads();
   }
 }
 

@@ -176,21 +176,22 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
     out_coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     nbr_in = torch.empty((K, n_in), dtype=torch.int32, device=dev)
     num_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+    with_rows = K <= 27 and n_in > 0
+    in_block = torch.empty((33 * n_in,), dtype=torch.int32, device=dev) if with_rows else None     # [rows (n_in, 32) | masks (n_in)]
     rc = lib.sv_rulebook_sparse(_lib.ptr(indices), n_in, int(batch_size), _i3(spatial_shape), _i3(ksize), _i3(stride),
                                 _i3(padding), _i3(dilation), _lib.ptr(ws), _lib.ptr(scratch), _lib.ptr(out_coords),
-                                _lib.ptr(nbr_in) if n_in else None, cap, _lib.ptr(num_out), _lib.stream())
+                                _lib.ptr(nbr_in) if n_in else None, _lib.ptr(in_block), cap, _lib.ptr(num_out), _lib.stream())
     _lib.check(rc, "sv_rulebook_sparse")
     n_out = int(num_out.item())  # host needs the size to allocate the output rows (spconv syncs here too)
     out_coords = out_coords[:n_out]
-    if K > 27 or n_in == 0 or n_out == 0:
+    if not with_rows or n_out == 0:
         nbr_out = torch.empty((K, n_out), dtype=torch.int32, device=dev)
         rc = lib.sv_rulebook_invert(_lib.ptr(nbr_in) if n_in else None, n_in, K, _lib.ptr(nbr_out) if n_out else None, n_out, _lib.stream())
         _lib.check(rc, "sv_rulebook_invert")
         return Rulebook(nbr_out, nbr_in, out_coords, oshape, n_in, n_out, False, list(ksize))
-    # one block per side: [rows (n, 32) | k-major table (K, n) | masks (n)] -- the row-major twins and masks feed the convolution plans
+    # one block for the output side: [rows (n_out, 32) | k-major table (K, n_out) | masks (n_out)] -- the row-major twins and masks feed the plans
     out_block = torch.empty(((32 + K + 1) * n_out,), dtype=torch.int32, device=dev)
-    in_block = torch.empty((33 * n_in,), dtype=torch.int32, device=dev)
-    rc = lib.sv_rulebook_invert_rows(_lib.ptr(nbr_in), n_in, K, _lib.ptr(out_block), n_out, _lib.ptr(in_block), _lib.stream())
+    rc = lib.sv_rulebook_invert_rows(_lib.ptr(in_block), n_in, K, _lib.ptr(out_block), n_out, _lib.stream())
     _lib.check(rc, "sv_rulebook_invert_rows")
     nbr_out = out_block[32 * n_out:(32 + K) * n_out].view(K, n_out)
     rb = Rulebook(nbr_out, nbr_in, out_coords, oshape, n_in, n_out, False, list(ksize))
@@ -200,28 +201,26 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
 
 
 class _FragmentCache:
-    """Weights in MFMA fragment order (sv_conv_weight_fragments), both directions, cached per weight TENSOR and version: an optimiser step
-    bumps the version and the next forward re-lays the 2 x 442 KB once; eval re-uses them for every call.  An entry is tied to the base
-    tensor by a weak reference (a data pointer alone can be handed to a new tensor after the old one is freed).  The buffers belong to
-    the cache entry, not to the library: convs on different streams never share a staging buffer."""
+    """Weights in MFMA fragment order (sv_conv_weight_fragments), both directions in one launch, into buffers owned by the weight tensor's
+    cache entry (tied to the base tensor by a weak reference: a data pointer alone can be handed to a new tensor after the old one is
+    freed).  The buffers belong to the entry, not to the library: convs on different streams never share a staging buffer (round 1 kept one
+    device-global buffer).  The fragments are RE-LAID ON EVERY FORWARD (one 4 us launch per layer): a tensor's version counter cannot be
+    trusted to detect an update -- torch's fused optimisers (SGD(fused=True), the bench's) change the weights without bumping it --
+    and the backward of the same iteration takes the pair the forward made (SparseConvFunction keeps it in ctx)."""
 
     def __init__(self):
         self._d = {}
 
-    def get(self, weight_kio):
+    def get(self, weight_kio, refresh=True):
         base = weight_kio._base if weight_kio._base is not None else weight_kio
         K, cin, cout = weight_kio.shape
         key = id(base)
-        sig = (weight_kio.data_ptr(), tuple(weight_kio.stride()), (K, cin, cout), weight_kio._version)
         hit = self._d.get(key)
-        if hit is not None and hit[0]() is base:
-            if hit[1] == sig:
-                return hit[2], hit[3]
-            fwd, bwd = hit[2], hit[3]
-            if fwd.numel() != K * cin * cout:
-                fwd = bwd = None
-        else:
-            fwd = bwd = None
+        fwd = bwd = None
+        if hit is not None and hit[0]() is base and hit[1].numel() == K * cin * cout and hit[1].device == weight_kio.device:
+            fwd, bwd = hit[1], hit[2]
+            if not refresh:
+                return fwd, bwd
         if fwd is None:
             fwd = torch.empty((K * cin * cout,), dtype=torch.float32, device=weight_kio.device)
             bwd = torch.empty_like(fwd)
@@ -230,7 +229,7 @@ class _FragmentCache:
         _lib.check(lib.sv_conv_weight_fragments(ctypes.c_void_p(weight_kio.data_ptr()), sk, si, so, K, cin, cout, _lib.ptr(fwd), _lib.ptr(bwd), _lib.stream()),
                    "sv_conv_weight_fragments")
         d = self._d
-        self._d[key] = (weakref.ref(base, lambda _r, k=key: d.pop(k, None)), sig, fwd, bwd)
+        self._d[key] = (weakref.ref(base, lambda _r, k=key: d.pop(k, None)), fwd, bwd)
         return fwd, bwd
 
     def clear(self):
@@ -293,8 +292,10 @@ class SparseConvFunction(torch.autograd.Function):
         w = weight_kio.detach()
         K, cin, cout = w.shape
         plan = rulebook.plan("fwd", cin, cout)
+        ctx.frag_bwd = None
         if plan is not None:
-            out = gather_gemm_planned(features, plan, fragment_cache.get(weight_kio)[0], rulebook.n_out, K, cin, cout)     # not the detached copy: the cache keys on ._base
+            frag_fwd, ctx.frag_bwd = fragment_cache.get(weight_kio)     # not the detached copy: the cache keys on ._base
+            out = gather_gemm_planned(features, plan, frag_fwd, rulebook.n_out, K, cin, cout)
         else:
             out = gather_gemm(features, rulebook.nbr_out, w.permute(0, 2, 1), rulebook.n_out)      # (K, C_out, C_in)
         ctx.rulebook = rulebook
@@ -312,7 +313,8 @@ class SparseConvFunction(torch.autograd.Function):
             # dX[i] = sum_k dY[nbr_in[k][i]] @ W[k]^T  -> Wt[k][n=c_in][c=c_out] = W[k][c_in][c_out]: weight_kio itself
             plan = rb.plan("bwd", cout, cin)
             if plan is not None:
-                gf = gather_gemm_planned(grad_out, plan, fragment_cache.get(weight_kio)[1], rb.n_in, K, cout, cin)
+                frag_bwd = ctx.frag_bwd if ctx.frag_bwd is not None else fragment_cache.get(weight_kio)[1]
+                gf = gather_gemm_planned(grad_out, plan, frag_bwd, rb.n_in, K, cout, cin)
             else:
                 gf = gather_gemm(grad_out, rb.table_for_backward_data(), weight_kio.detach(), rb.n_in)
         if ctx.needs_input_grad[1]:

@@ -57,6 +57,10 @@ class VCN_CN(nn.Module):
         coarse = self.shape_fc(feature_global).reshape(-1, self.number_coarse, 3)
         return {'coarse': cn_to_vc(restore_scale(coarse.contiguous(), boxes), boxes)}
 
+    def train(self, mode=True):
+        self._prepared.invalidate()          # see PreparedCache.invalidate
+        return super().train(mode)
+
     def forward(self, in_dict):
         if self.training:
             return self._forward_train(in_dict)

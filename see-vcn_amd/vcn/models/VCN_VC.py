@@ -111,6 +111,10 @@ class VCN_VC(nn.Module):
                 'reg_rot': torch.matmul(rot_mat, rot_from_heading(frustum_angle)),
                 'reg_centre': rotate_points_along_z(centre, frustum_angle).squeeze(1)}
 
+    def train(self, mode=True):
+        self._prepared.invalidate()          # see PreparedCache.invalidate
+        return super().train(mode)
+
     def forward(self, in_dict):
         if self.training:
             return self._forward_train(in_dict)

@@ -55,6 +55,11 @@ class PreparedCache:
     def __init__(self, module, builder):
         self.module, self.builder, self.key, self.value = module, builder, None, None
 
+    def invalidate(self):
+        """Version counters miss updates made by torch's fused optimisers (SGD / Adam with fused=True do not bump them): the owning modules call
+        this on every train() / eval() switch, so weights trained with such an optimiser are re-folded before inference."""
+        self.key = None
+
     def get(self):
         tensors = list(self.module.parameters()) + list(self.module.buffers())
         key = tuple((t.data_ptr(), t._version, t.device) for t in tensors)
