@@ -406,6 +406,14 @@ int sv_project_lidar_to_image_kitti(const float* points, int64_t n_points, int r
 int sv_project_lidar_to_image_camera(const float* points, int64_t n_points, int row_stride, const double* extrinsic, const double* intrinsic,
                                      const double* distcoeff, int camera_model, int img_w, int img_h, int32_t* uvd_int, double* uvd,
                                      uint8_t* fov, void* stream);
+/* NuScenesObjects.map_pointcloud_to_image (datasets/nuscenes/nuscenes_objects.py:237-295; the nuscenes-devkit chain it restates, devkit not
+ * vendored): lidar -> ego(sweep) -> global -> ego(image) -> camera with float32 storage after each of the 8 rotate / translate steps, then
+ * view_points(K, normalize) in float64.  rotations (4,3,3) HOST row-major: [R_lidar2ego, R_ego2global, R_ego_cam2global^T, R_cam2ego^T];
+ * translations (4,3) HOST: [t_lidar, t_ego, -t_ego_cam, -t_cam]; intrinsic (3,3) HOST.  fov[i] = depth > min_dist and 0 < u < W and 0 < v < H;
+ * pts_img (n,2) = floor(u,v) (-1 outside the FOV); pc_cam (n,3) float32 camera-frame points. */
+int sv_project_lidar_to_image_nuscenes(const float* points, int64_t n_points, int row_stride, const double* rotations, const double* translations,
+                                       const double* intrinsic, int img_w, int img_h, double min_dist, float* pc_cam, int32_t* pts_img,
+                                       uint8_t* fov, void* stream);
 /* get_pts_in_mask (datasets/shared_utils.py:36-106): per instance the FOV points with mask[v,u] set.  Give either masks
  * (I,img_h,img_w) uint8 or rects (I,4) int32 [x0,y0,x1,y1] (use_bbox, :56-60).  Lists as in sv_crop_points_in_boxes. */
 int sv_points_in_masks(const int32_t* uv, const uint8_t* fov, int64_t n_points, const uint8_t* masks, const int32_t* rects,

@@ -131,6 +131,55 @@ def project_custom_camera(points, intrinsic, extrinsic, distcoeff, img_h, img_w,
     return fov, np.round(uv, 0).astype(int), uv
 
 
+def quaternion_rotation_matrix(q):
+    """pyquaternion's Quaternion(q).rotation_matrix for a (w, x, y, z) quaternion (normalised first, as pyquaternion does): the nuScenes
+    records store rotations this way (calibrated_sensor / ego_pose 'rotation')."""
+    w, x, y, z = (np.asarray(q, np.float64) / np.linalg.norm(np.asarray(q, np.float64)))
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], np.float64)
+
+
+def map_pointcloud_to_image_nuscenes(points, cs_lidar, pose_lidar, pose_cam, cs_cam, img_shape, min_dist=1.0):
+    """NuScenesObjects.map_pointcloud_to_image (see/surface_completion/datasets/nuscenes/nuscenes_objects.py:237-295) without the devkit:
+    the records are dicts with 'rotation' (w,x,y,z) and 'translation' (3,) (+ 'camera_intrinsic' for the camera), points (N, >=3).
+    LidarPointCloud keeps float32 points and rotate() / translate() store back into that array (nuscenes-devkit data_classes.py), so every
+    step rounds to float32; view_points(normalize=True) runs in float64.  PARITY UNPINNED w.r.t. the devkit (un-vendored pip dependency,
+    not installed): restated from the reference's own lines + the devkit's published PointCloud.rotate / translate / view_points."""
+    pc = np.ascontiguousarray(np.asarray(points, np.float32)[:, :3].T)          # (3, N) float32
+    pc_lidar = pc.copy()
+
+    def rotate(R):
+        pc[:3, :] = np.dot(R, pc[:3, :])
+
+    def translate(t):
+        for i in range(3):
+            pc[i, :] = pc[i, :] + t[i]
+
+    rotate(quaternion_rotation_matrix(cs_lidar['rotation']))
+    translate(np.array(cs_lidar['translation'], np.float64))
+    rotate(quaternion_rotation_matrix(pose_lidar['rotation']))
+    translate(np.array(pose_lidar['translation'], np.float64))
+    translate(-np.array(pose_cam['translation'], np.float64))
+    rotate(quaternion_rotation_matrix(pose_cam['rotation']).T)
+    translate(-np.array(cs_cam['translation'], np.float64))
+    rotate(quaternion_rotation_matrix(cs_cam['rotation']).T)
+    depths = pc[2, :]
+    K = np.asarray(cs_cam['camera_intrinsic'], np.float64)
+    viewpad = np.eye(4)
+    viewpad[:3, :3] = K
+    pts = np.dot(viewpad, np.concatenate((pc, np.ones((1, pc.shape[1]))))).astype(np.float64)[:3, :]
+    pts = pts / pts[2:3, :].repeat(3, 0).reshape(3, pc.shape[1])
+    fov = np.ones(depths.shape[0], dtype=bool)
+    fov = np.logical_and(fov, depths > min_dist)
+    fov = np.logical_and(fov, pts[0, :] > 0)
+    fov = np.logical_and(fov, pts[0, :] < img_shape[1])
+    fov = np.logical_and(fov, pts[1, :] > 0)
+    fov = np.logical_and(fov, pts[1, :] < img_shape[0])
+    return {"pc_lidar": pc_lidar[:3, fov].T, "pc_cam": pc[:3, fov].T, "pts_img": np.floor(pts[:2, fov]).astype(int).T, "fov_inds": fov,
+            "img_shape": tuple(img_shape[:2])}
+
+
 def pts_in_masks(pts_img, masks=None, rects=None):
     """get_pts_in_mask (shared_utils.py:36-106): per instance, positions (into the FOV-filtered arrays) of the points whose
     pixel is set; instances without points are dropped by the caller."""

@@ -151,6 +151,59 @@ __global__ __launch_bounds__(256) void k_project_camera(CameraArgs a) {
   if (a.uvd) a.uvd[i * 3] = u, a.uvd[i * 3 + 1] = v, a.uvd[i * 3 + 2] = cam[2];
 }
 
+// NuScenesObjects.map_pointcloud_to_image (datasets/nuscenes/nuscenes_objects.py:237-295, the nuscenes-devkit transform chain it restates):
+// lidar frame -> ego (sweep time) -> global -> ego (image time) -> camera, then the pinhole projection.  The devkit's LidarPointCloud keeps
+// its points in FLOAT32 and every rotate() / translate() stores back into that array, so each of the 8 steps rounds to float32: the chain
+// is kept step by step (a pre-multiplied 4x4 would differ in the last bits and flip pixels / FOV tests at the borders).
+// step s: p = float32(R_s . p) (rotate: float64 dot, stored float32)  or  p = float32(p + t_s) (translate).
+struct NuscArgs {
+  const float* points;
+  int64_t n;
+  int row_stride;
+  double rot[4][9];       // lidar->ego, ego->global, global->ego_cam (already transposed), ego_cam->camera (already transposed)
+  double trans[4][3];     // +t for steps 0, 1; -t for steps 2, 3 (already negated)
+  double kmat[9];         // camera intrinsic
+  int img_w, img_h;
+  double min_dist;
+  float* pc_cam;          // (n, 3) float32 camera-frame points
+  int32_t* pts_img;       // (n, 2) floor(u, v), -1 outside the FOV
+  uint8_t* fov;
+};
+__device__ __forceinline__ void nusc_rotate(float (&p)[3], const double* R) {
+  const double x = p[0], y = p[1], z = p[2];
+  p[0] = (float)(R[0] * x + R[1] * y + R[2] * z);
+  p[1] = (float)(R[3] * x + R[4] * y + R[5] * z);
+  p[2] = (float)(R[6] * x + R[7] * y + R[8] * z);
+}
+__global__ __launch_bounds__(256) void k_project_nuscenes(NuscArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const float* q = a.points + i * a.row_stride;
+  float p[3] = {q[0], q[1], q[2]};
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {                  // sensor -> ego -> global: rotate, then translate
+    nusc_rotate(p, a.rot[s]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = (float)((double)p[c] + a.trans[s][c]);
+  }
+#pragma unroll
+  for (int s = 2; s < 4; ++s) {                  // global -> ego (image time) -> camera: translate by -t, then rotate by R^T
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = (float)((double)p[c] + a.trans[s][c]);
+    nusc_rotate(p, a.rot[s]);
+  }
+  // view_points(pc_cam, K, normalize=True): float64 K . p, divided by the third row
+  const double x = p[0], y = p[1], z = p[2];
+  const double u3 = a.kmat[0] * x + a.kmat[1] * y + a.kmat[2] * z, v3 = a.kmat[3] * x + a.kmat[4] * y + a.kmat[5] * z,
+               w3 = a.kmat[6] * x + a.kmat[7] * y + a.kmat[8] * z;
+  const double u = u3 / w3, v = v3 / w3;
+  const bool in = (double)p[2] > a.min_dist && u > 0.0 && u < (double)a.img_w && v > 0.0 && v < (double)a.img_h;
+  a.fov[i] = in ? 1 : 0;
+  a.pc_cam[i * 3] = p[0], a.pc_cam[i * 3 + 1] = p[1], a.pc_cam[i * 3 + 2] = p[2];
+  a.pts_img[i * 2] = in ? (int32_t)floor(u) : -1;
+  a.pts_img[i * 2 + 1] = in ? (int32_t)floor(v) : -1;
+}
+
 // get_pts_in_mask (shared_utils.py:36-106): for instance g, the FOV points whose pixel is set in mask g (masks (I,H,W) uint8)
 // or, with rects (I,4) = [x0,y0,x1,y1] already truncated to int, inside the box (use_bbox, :56-60).
 __global__ __launch_bounds__(ISO_THREADS) void k_mask_select(const int32_t* __restrict__ uv, const uint8_t* __restrict__ fov, int64_t n,
@@ -365,6 +418,25 @@ extern "C" int sv_project_lidar_to_image_camera(const float* points, int64_t n_p
   for (int i = 0; i < 5; ++i) a.dist[i] = distcoeff[i];
   a.model = camera_model, a.img_w = img_w, a.img_h = img_h, a.uvd_int = uvd_int, a.uvd = uvd, a.fov = fov;
   hipLaunchKernelGGL(k_project_camera, dim3(sv_div_up(n_points, 256)), dim3(256), 0, sv_stream(stream), a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_project_lidar_to_image_nuscenes(const float* points, int64_t n_points, int row_stride, const double* rotations, const double* translations,
+                                                  const double* intrinsic, int img_w, int img_h, double min_dist, float* pc_cam, int32_t* pts_img,
+                                                  uint8_t* fov, void* stream) {
+  SV_CHECK_ARG(n_points >= 0 && row_stride >= 3 && img_w > 0 && img_h > 0, "sv_project_lidar_to_image_nuscenes: bad sizes");
+  if (n_points == 0) return SV_OK;
+  SV_CHECK_ARG(points && rotations && translations && intrinsic && pc_cam && pts_img && fov, "sv_project_lidar_to_image_nuscenes: null pointer");
+  NuscArgs a;
+  a.points = points, a.n = n_points, a.row_stride = row_stride;
+  for (int s = 0; s < 4; ++s) {
+    for (int e = 0; e < 9; ++e) a.rot[s][e] = rotations[s * 9 + e];
+    for (int e = 0; e < 3; ++e) a.trans[s][e] = translations[s * 3 + e];
+  }
+  for (int e = 0; e < 9; ++e) a.kmat[e] = intrinsic[e];
+  a.img_w = img_w, a.img_h = img_h, a.min_dist = min_dist, a.pc_cam = pc_cam, a.pts_img = pts_img, a.fov = fov;
+  hipLaunchKernelGGL(k_project_nuscenes, dim3(sv_div_up(n_points, 256)), dim3(256), 0, sv_stream(stream), a);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -241,6 +241,7 @@ constexpr int RB_ROW = 32;     // int32 per row of a row-major table (== PL_ROW 
 constexpr int RB_KMAX = 27;
 typedef int rb_i32x4 __attribute__((ext_vector_type(4)));
 
+template <bool FULL3>   // FULL3: 3x3x3 kernel, offsets decomposed at compile time
 __global__ __launch_bounds__(RB_THREADS) void k_subm_query_rows(const int4* __restrict__ coords, int64_t n, ConvGeom g, CellTiling t,
                                                                 const int32_t* __restrict__ map, int32_t* __restrict__ nbr,
                                                                 int32_t* __restrict__ tab, int32_t* __restrict__ masks) {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_subm_query_rows(const int4* __re
 #pragma unroll
   for (int k = 0; k < RB_KMAX; ++k) {
     if (k < g.K) {
-      const int kz = k / kyx, ky = (k - kz * kyx) / g.ksize[2], kx = k - kz * kyx - ky * g.ksize[2];
+      const int kz = FULL3 ? k / 9 : k / kyx, ky = FULL3 ? (k / 3) % 3 : (k - kz * kyx) / g.ksize[2], kx = FULL3 ? k % 3 : k - kz * kyx - ky * g.ksize[2];
       const int z = c.y + (kz - hz) * g.dil[0], y = c.z + (ky - hy) * g.dil[1], x = c.w + (kx - hx) * g.dil[2];
       int32_t r = -1;
       if (ok && z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2]) r = map[tiled_cell(c.x, z, y, x, t)] - 1;
@@ -301,8 +302,10 @@ extern "C" int sv_rulebook_subm_cellmap(const int32_t* coords, int64_t n, int ba
   const int grid = sv_grid_1d(n, RB_THREADS);
   const CellTiling t = cell_tiling(g.in_shape);
   hipLaunchKernelGGL(k_cellmap_set, dim3(grid), dim3(RB_THREADS), 0, st, c4, n, g, t, map, 0);
-  if (g.K <= RB_KMAX)
-    hipLaunchKernelGGL(k_subm_query_rows, dim3(sv_div_up(n, RB_THREADS)), dim3(RB_THREADS), 0, st, c4, n, g, t, map, nbr, table_rows, masks);
+  if (g.ksize[0] == 3 && g.ksize[1] == 3 && g.ksize[2] == 3)
+    hipLaunchKernelGGL(k_subm_query_rows<true>, dim3(sv_div_up(n, RB_THREADS)), dim3(RB_THREADS), 0, st, c4, n, g, t, map, nbr, table_rows, masks);
+  else if (g.K <= RB_KMAX)
+    hipLaunchKernelGGL(k_subm_query_rows<false>, dim3(sv_div_up(n, RB_THREADS)), dim3(RB_THREADS), 0, st, c4, n, g, t, map, nbr, table_rows, masks);
   else
     hipLaunchKernelGGL(k_subm_query_map, dim3(sv_grid_1d(n * g.K, RB_THREADS, 256 * 16)), dim3(RB_THREADS), 0, st, c4, n, g, t, map, nbr);
   hipLaunchKernelGGL(k_cellmap_set, dim3(grid), dim3(RB_THREADS), 0, st, c4, n, g, t, map, 1);
@@ -355,18 +358,58 @@ __global__ __launch_bounds__(RB_THREADS) void k_sparse_phase(const int4* __restr
 // of occupied cells per chunk and the prefix inside a chunk then come from ONE streaming pass over the bitmap (k_index_count: 8 bytes per
 // 32 cells; 47 MB for 16 KITTI scenes at stride 2) instead of a returning atomic per candidate plus a separate prefix pass over the occupied
 // chunks.  Measured before (bench scenes, four strided layers per step): mark 62 us (returning atomics), prefix 26 us.
+// Per-axis candidates of one input coordinate: for kernel index ka along the axis, the output coordinate it feeds (or -1).  3 divisions per
+// axis (none for stride 1 or 2) instead of 3 per kernel offset: the 27 offsets of a 3x3x3 kernel are the products of these.
+struct AxisCand {
+  int o[3][3];       // [axis][ka] output coordinate or -1  (kernel sizes up to 3 per axis)
+};
+__device__ __forceinline__ AxisCand axis_candidates(const int4 c, const ConvGeom& g) {
+  AxisCand a;
+  const int cc[3] = {c.y, c.z, c.w};
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const int s = g.stride[ax];
+#pragma unroll
+    for (int ka = 0; ka < 3; ++ka) {
+      int o = -1;
+      if (ka < g.ksize[ax]) {
+        const int t = cc[ax] + g.pad[ax] - ka * g.dil[ax];
+        if (t >= 0) {
+          if (s == 1) o = t;
+          else if (s == 2) o = (t & 1) ? -1 : (t >> 1);
+          else o = (t % s) ? -1 : t / s;
+          if (o >= g.out_shape[ax]) o = -1;
+        }
+      }
+      a.o[ax][ka] = o;
+    }
+  }
+  return a;
+}
+__device__ __forceinline__ bool small_kernel(const ConvGeom& g) { return g.ksize[0] <= 3 && g.ksize[1] <= 3 && g.ksize[2] <= 3; }
+
+template <bool FULL3>   // FULL3: 3x3x3 kernel, offsets decomposed at compile time
 __global__ __launch_bounds__(RB_THREADS) void k_sparse_mark_rows(const int4* __restrict__ coords, int64_t n, ConvGeom g, SvIndexView ix, int clear) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = coords[i];
   if (!coord_ok(c, g.batch, g.in_shape)) return;
   const int kyx = g.ksize[1] * g.ksize[2];
+  const bool small = FULL3 || small_kernel(g);            // wave-uniform
+  const AxisCand ac = small ? axis_candidates(c, g) : AxisCand{};
 #pragma unroll
   for (int k = 0; k < RB_KMAX; ++k) {
     if (k < g.K) {
-      const int kz = k / kyx, ky = (k - kz * kyx) / g.ksize[2], kx = k - kz * kyx - ky * g.ksize[2];
+      const int kz = FULL3 ? k / 9 : k / kyx, ky = FULL3 ? (k / 3) % 3 : (k - kz * kyx) / g.ksize[2], kx = FULL3 ? k % 3 : k - kz * kyx - ky * g.ksize[2];
       int oz, oy, ox;
-      if (out_coord(c, kz, ky, kx, g, oz, oy, ox)) {
+      bool hit;
+      if (small) {
+        oz = ac.o[0][kz % 3], oy = ac.o[1][ky % 3], ox = ac.o[2][kx % 3];
+        hit = (oz | oy | ox) >= 0;
+      } else {
+        hit = out_coord(c, kz, ky, kx, g, oz, oy, ox);
+      }
+      if (hit) {
         const int64_t key = lin_key(c.x, oz, oy, ox, g.out_shape);
         if (clear) {
           ix.words[key >> 5] = make_uint2(0u, 0u);
@@ -407,6 +450,7 @@ __device__ __forceinline__ int32_t index_lookup_chunked(const SvIndexView& ix, i
   return ix.chunk_base[key >> SV_CHUNK_SHIFT] + (int32_t)wd.y + __popc(wd.x & (bit - 1u));
 }
 
+template <bool FULL3>
 __global__ __launch_bounds__(RB_THREADS) void k_sparse_lookup_rows(const int4* __restrict__ coords, int64_t n, ConvGeom g, SvIndexView ix,
                                                                    int32_t* __restrict__ nbr_in, int4* __restrict__ out_coords, int64_t capacity,
                                                                    int32_t* __restrict__ tab_in, int32_t* __restrict__ masks_in) {
@@ -415,6 +459,8 @@ __global__ __launch_bounds__(RB_THREADS) void k_sparse_lookup_rows(const int4* _
   const int4 c = coords[i];
   const bool ok = coord_ok(c, g.batch, g.in_shape);
   const int kyx = g.ksize[1] * g.ksize[2];
+  const bool small = FULL3 || small_kernel(g);            // wave-uniform
+  const AxisCand ac = small ? axis_candidates(c, g) : AxisCand{};
   int32_t e[RB_ROW];
 #pragma unroll
   for (int k = 0; k < RB_ROW; ++k) e[k] = -1;
@@ -422,9 +468,16 @@ __global__ __launch_bounds__(RB_THREADS) void k_sparse_lookup_rows(const int4* _
 #pragma unroll
   for (int k = 0; k < RB_KMAX; ++k) {
     if (k < g.K) {
-      const int kz = k / kyx, ky = (k - kz * kyx) / g.ksize[2], kx = k - kz * kyx - ky * g.ksize[2];
+      const int kz = FULL3 ? k / 9 : k / kyx, ky = FULL3 ? (k / 3) % 3 : (k - kz * kyx) / g.ksize[2], kx = FULL3 ? k % 3 : k - kz * kyx - ky * g.ksize[2];
       int oz, oy, ox;
-      if (ok && out_coord(c, kz, ky, kx, g, oz, oy, ox)) {
+      bool hit;
+      if (small) {
+        oz = ac.o[0][kz % 3], oy = ac.o[1][ky % 3], ox = ac.o[2][kx % 3];
+        hit = (oz | oy | ox) >= 0;
+      } else {
+        hit = out_coord(c, kz, ky, kx, g, oz, oy, ox);
+      }
+      if (ok && hit) {
         int32_t r = index_lookup_chunked(ix, lin_key(c.x, oz, oy, ox, g.out_shape));
         if (r >= capacity) r = -1;
         if (r >= 0) {
@@ -480,13 +533,17 @@ extern "C" int sv_rulebook_sparse(const int32_t* coords, int64_t n_in, int batch
     // rows: mark (no-return atomics) -> count the whole bitmap -> scan the chunk counts -> look up, write both input-major tables -> clear
     const int rows_grid = sv_div_up(n_in, RB_THREADS);
     const int64_t nchunks = sv_index_nchunks(ncells);
-    hipLaunchKernelGGL(k_sparse_mark_rows, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 0);
+    const bool full3 = g.ksize[0] == 3 && g.ksize[1] == 3 && g.ksize[2] == 3;
+    if (full3) hipLaunchKernelGGL(k_sparse_mark_rows<true>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 0);
+    else hipLaunchKernelGGL(k_sparse_mark_rows<false>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 0);
     hipLaunchKernelGGL(k_index_count, dim3(sv_grid_1d(nchunks * 32, RB_THREADS, 256 * 16)), dim3(RB_THREADS), 0, st, ix, nchunks);
     rc = sv_index_scan_launch(ix, num_out, scan_tmp, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_sparse_lookup_rows, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, nbr_in, oc4, capacity, in_block,
-                       in_block ? in_block + (size_t)RB_ROW * n_in : nullptr);
-    hipLaunchKernelGGL(k_sparse_mark_rows, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 1);
+    int32_t* masks_in = in_block ? in_block + (size_t)RB_ROW * n_in : nullptr;
+    if (full3) hipLaunchKernelGGL(k_sparse_lookup_rows<true>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, nbr_in, oc4, capacity, in_block, masks_in);
+    else hipLaunchKernelGGL(k_sparse_lookup_rows<false>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, nbr_in, oc4, capacity, in_block, masks_in);
+    if (full3) hipLaunchKernelGGL(k_sparse_mark_rows<true>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 1);
+    else hipLaunchKernelGGL(k_sparse_mark_rows<false>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 1);
     SV_LAUNCH_CHECK();
     return SV_OK;
   }

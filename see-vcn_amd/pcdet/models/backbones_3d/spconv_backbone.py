@@ -1,5 +1,6 @@
 from functools import partial
 
+import torch
 import torch.nn as nn
 
 from ....spconv import norm
@@ -67,6 +68,8 @@ class _BackBone8xBase(nn.Module):
         voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         input_sp_tensor = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(),
                                                   spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+        # all rulebooks + conv plans first: their host syncs then wait for index kernels only, and the layer loop below is enqueued without one
+        spconv.prebuild_rulebooks(self, input_sp_tensor, with_backward=self.training and torch.is_grad_enabled())
         x = self.conv_input(input_sp_tensor)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)

@@ -53,6 +53,8 @@ class SparseConvolution(SparseModule):
         if rb is not None and self.subm:
             assert rb.subm and rb.ksize == self.kernel_size, f"indice_key {self.indice_key} reused with a different kernel"
             return rb
+        if rb is not None and not rb.subm and rb.in_indices is x.indices and rb.ksize == self.kernel_size:
+            return rb                                   # built ahead of the layer loop by prebuild_rulebooks on these very indices
         if self.subm:
             rb = Fsp.build_subm_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation)
         else:
@@ -105,3 +107,33 @@ class SparseInverseConv3d(SparseConvolution):
         if self.bias is not None:
             feats = feats + self.bias
         return SparseConvTensor(feats, rb.in_indices, rb.in_shape, x.batch_size, x.grid, x.indice_dict)
+
+
+def prebuild_rulebooks(root, x, with_backward=True):
+    """Build every rulebook (and conv plan) a network will need on `x` BEFORE its layers run.  A strided rulebook needs the number of output
+    sites on the host (to allocate the next level), i.e. a device -> host sync; done lazily inside the layer loop, each of those syncs waits
+    for all the convolution work queued so far and then leaves the GPU idle until the host has enqueued the next layers.  Done here, the
+    syncs wait for small index kernels only and the whole layer loop is enqueued without one (spconv builds its indice pairs lazily, layer
+    by layer: spconv_backbone.py:141-157 is the caller).  `root` is walked in definition order, which is the execution order of the
+    reference's backbones; convolutions without an indice_key or inverse convolutions end the walk (they are then handled lazily)."""
+    idx, shape = x.indices, list(x.spatial_shape)
+    for m in root.modules():
+        if not isinstance(m, SparseConvolution):
+            continue
+        if m.inverse or m.indice_key is None:
+            return
+        rb = x.indice_dict.get(m.indice_key)
+        if rb is None:
+            if m.subm:
+                rb = Fsp.build_subm_rulebook(idx, x.batch_size, shape, m.kernel_size, m.dilation)
+            else:
+                rb = Fsp.build_sparse_rulebook(idx, x.batch_size, shape, m.kernel_size, m.stride, m.padding, m.dilation)
+            rb.in_indices, rb.in_shape = idx, list(shape)
+            x.indice_dict[m.indice_key] = rb
+        elif rb.in_indices is not idx:
+            return                                        # the key is bound to other indices: not the simple chain this walk assumes
+        rb.plan("fwd", m.in_channels, m.out_channels)
+        if with_backward:
+            rb.plan("bwd", m.out_channels, m.in_channels)
+        if not m.subm:
+            idx, shape = rb.out_indices, list(rb.out_shape)

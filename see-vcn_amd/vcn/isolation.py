@@ -112,6 +112,42 @@ def map_pointcloud_to_image_custom(points, calib, img_shape, camera_model="pinho
             "fov_inds": fov_np, "img_shape": (img_h, img_w), "_device": (pts, uvd_int[:, :2].contiguous(), fovb)}
 
 
+def _quat_to_matrix(q):
+    """Rotation matrix of a (w, x, y, z) quaternion, normalised first (what pyquaternion's Quaternion(q).rotation_matrix returns)."""
+    w, x, y, z = (np.asarray(q, np.float64) / np.linalg.norm(np.asarray(q, np.float64)))
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], np.float64)
+
+
+def map_pointcloud_to_image_nuscenes(points, cs_lidar, pose_lidar, pose_cam, cs_cam, img_shape, min_dist=1.0, device='cuda'):
+    """NuScenesObjects.map_pointcloud_to_image (datasets/nuscenes/nuscenes_objects.py:237-295) on arrays: the four nuScenes records the
+    reference fetches through the devkit -- calibrated_sensor and ego_pose of the LIDAR_TOP sample_data, ego_pose and calibrated_sensor
+    of the camera sample_data, each a dict with 'rotation' (w,x,y,z) and 'translation' (3,), the last one also 'camera_intrinsic' -- are
+    passed in directly (no devkit needed).  Same return dict as the reference: pc_lidar, pc_cam (float32 camera frame), pts_img
+    (floor(u,v) int), fov_inds, img_shape."""
+    lib = _lib.load()
+    img_h, img_w = int(img_shape[0]), int(img_shape[1])
+    pts = _dev_points(points, device)
+    n = pts.shape[0]
+    rot = np.ascontiguousarray(np.stack([_quat_to_matrix(cs_lidar['rotation']), _quat_to_matrix(pose_lidar['rotation']),
+                                         _quat_to_matrix(pose_cam['rotation']).T, _quat_to_matrix(cs_cam['rotation']).T]), dtype=np.float64)
+    tr = np.ascontiguousarray(np.stack([np.asarray(cs_lidar['translation'], np.float64), np.asarray(pose_lidar['translation'], np.float64),
+                                        -np.asarray(pose_cam['translation'], np.float64), -np.asarray(cs_cam['translation'], np.float64)]), dtype=np.float64)
+    k = np.ascontiguousarray(cs_cam['camera_intrinsic'], dtype=np.float64)
+    pc_cam = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+    uv = torch.empty((n, 2), dtype=torch.int32, device=pts.device)
+    fov = torch.empty((n,), dtype=torch.uint8, device=pts.device)
+    _lib.check(lib.sv_project_lidar_to_image_nuscenes(_lib.ptr(pts), n, pts.stride(0), rot.ctypes.data, tr.ctypes.data, k.ctypes.data, img_w, img_h,
+                                                      float(min_dist), _lib.ptr(pc_cam), _lib.ptr(uv), _lib.ptr(fov), _lib.stream()),
+               "sv_project_lidar_to_image_nuscenes")
+    fovb = fov.bool()
+    fov_np = fovb.cpu().numpy()
+    src = points if isinstance(points, np.ndarray) else points.cpu().numpy()
+    return {"pc_lidar": src[fov_np, :3], "pc_cam": pc_cam[fovb].cpu().numpy(), "pts_img": uv[fovb].cpu().numpy().astype(int),
+            "fov_inds": fov_np, "img_shape": (img_h, img_w), "_device": (pts, uv, fovb)}
+
+
 def points_in_masks_device(uv, fov, masks=None, rects=None, cap=None):
     """uv (N,2) int32, fov (N) bool/uint8, masks (I,H,W) uint8 or rects (I,4) int32 -> index (I,cap) int32 ascending point
     indices, count (I) int32 (CUDA tensors)."""
