@@ -283,12 +283,12 @@ __global__ __launch_bounds__(PL_WG) void k_plan_hist(PlanArgs a) {
     if (s_hist[i]) atomicAdd(&gh[i], s_hist[i]);
 }
 
-// pass 2: counts -> class starts: exclusive scan per region, counts and cursors back to zero.  One workgroup: 1024 threads x 32 consecutive
-// classes = 8 regions x 4096 classes, 128 threads (2 waves) per region.
-__global__ __launch_bounds__(PL_WG) void k_plan_scan(PlanArgs a) {
+// pass 2: counts -> class starts: exclusive scan per region, counts and cursors back to zero.  One 128-thread workgroup per region, 32
+// consecutive classes per thread (a single 1024-thread workgroup for all regions took 17 us: one CU moving 0.5 MB).
+__global__ __launch_bounds__(128) void k_plan_scan(PlanArgs a) {
   constexpr int RC = PL_REGIONS * PL_CLASSES;
-  const int tid = threadIdx.x, lane = tid & 63;
-  int32_t* cnt = a.hist + (size_t)tid * 32;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, g = r * 128 + tid;      // g: global 32-class group
+  int32_t* cnt = a.hist + (size_t)g * 32;
   int v[32], sum = 0;
   {
     const i32x4* c4 = reinterpret_cast<const i32x4*>(cnt);
@@ -306,13 +306,12 @@ __global__ __launch_bounds__(PL_WG) void k_plan_scan(PlanArgs a) {
     const int t = __shfl_up(incl, d, 64);
     if (lane >= d) incl += t;
   }
-  __shared__ int s_wave[PL_WG / 64];
-  if (lane == 63) s_wave[tid >> 6] = incl;
+  __shared__ int s_wave0;
+  if (tid == 63) s_wave0 = incl;
   __syncthreads();
-  const int r = tid >> 7;                                                      // region of this thread's classes
-  int run = (int)plan_region_start(a.n_rows, r) + incl - sum + (((tid >> 6) & 1) ? s_wave[(tid >> 6) - 1] : 0);
-  i32x4* st4 = reinterpret_cast<i32x4*>(a.hist + RC + tid * 32);
-  i32x4* cu4 = reinterpret_cast<i32x4*>(a.hist + 2 * RC + tid * 32);
+  int run = (int)plan_region_start(a.n_rows, r) + incl - sum + (tid >= 64 ? s_wave0 : 0);
+  i32x4* st4 = reinterpret_cast<i32x4*>(a.hist + RC + g * 32);
+  i32x4* cu4 = reinterpret_cast<i32x4*>(a.hist + 2 * RC + g * 32);
   i32x4* cn4 = reinterpret_cast<i32x4*>(cnt);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -374,7 +373,7 @@ extern "C" int sv_conv_plan_build(const int32_t* masks, int64_t n_rows, void* pe
   const int wgs = sv_div_up(n_rows, PL_WG);      // covers the <= 15 padding positions too: n_pad <= wgs * PL_WG
   hipStream_t st = sv_stream(stream);
   hipLaunchKernelGGL(k_plan_hist, dim3(wgs), dim3(PL_WG), 0, st, a);
-  hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PL_WG), 0, st, a);
+  hipLaunchKernelGGL(k_plan_scan, dim3(PL_REGIONS), dim3(128), 0, st, a);
   hipLaunchKernelGGL(k_plan_place, dim3(wgs), dim3(PL_WG), 0, st, a);
   SV_LAUNCH_CHECK();
   return SV_OK;
@@ -1001,6 +1000,7 @@ struct WgradArgs {
   float* partial;        // (nchunks, K, Cin, Cout)
   int64_t n_rows;
   int K, Cin, Cout, nchunks, chunk_rows;
+  int xcd_order;         // workgroup -> (chunk, offset, tile group) decoded per XCD (k_spconv_wgrad)
 };
 
 template <int N> struct WgVec;
@@ -1022,9 +1022,29 @@ template <int CT, int NTL>  // register tile grid: CT x NTL tiles of 16x16 (rows
 __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {
   __shared__ int32_t pj[4][64 * WG_SUB], pr[4][64 * WG_SUB];
   __shared__ float red[CT * NTL * 256];
-  const int k = blockIdx.y, chunk = blockIdx.x;
+  // 1-D grid = (chunk fastest, offset, tile group).  SEEVCN_WGRAD_XCD=1 decodes it instead so that the chunks of one eighth of the rows run on
+  // ONE XCD (workgroup b runs on XCD b % 8; a scene's rows then go through one L2 for all 27 offsets, offset-major inside the XCD).  Measured
+  // (round 2, 64 -> 64 layers): 170 / 98 us against 155 / 86 us in the plain order -- this kernel is bound by its busiest workgroups (the
+  // centre offset has a pair for every row, a corner offset for one row in twenty), not by its 4x over-fetch; the plain order spreads the
+  // heavy offsets over all XCDs.  Off by default.
+  int k, chunk, zgroup;
+  {
+    const int cpr = (a.nchunks + 7) / 8;                       // chunks per region
+    const int b = blockIdx.x;
+    if (a.xcd_order) {
+      const int xcd = b % 8, j = b / 8;
+      chunk = xcd * cpr + j % cpr;
+      k = (j / cpr) % a.K;
+      zgroup = j / (cpr * a.K);
+    } else {
+      chunk = b % a.nchunks;
+      k = (b / a.nchunks) % a.K;
+      zgroup = b / (a.nchunks * a.K);
+    }
+    if (chunk >= a.nchunks) return;
+  }
   const int ngroups_n = (a.Cout / 16) / NTL;
-  const int c_base = (blockIdx.z / ngroups_n) * CT * 16, n_base = (blockIdx.z % ngroups_n) * NTL * 16;
+  const int c_base = (zgroup / ngroups_n) * CT * 16, n_base = (zgroup % ngroups_n) * NTL * 16;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, kk = lane >> 4;
   f32x4 acc[CT][NTL];
@@ -1188,7 +1208,9 @@ extern "C" size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int 
 template <int CT, int NTL>
 static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
   const int groups = (((a.Cin + 15) / 16) / CT) * ((a.Cout / 16) / NTL);
-  hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL>), dim3(a.nchunks, a.K, groups), dim3(256), 0, st, a);
+  const int cpr = (a.nchunks + 7) / 8;
+  const unsigned blocks = a.xcd_order ? (unsigned)(8 * cpr * a.K * groups) : (unsigned)(a.nchunks * a.K * groups);
+  hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL>), dim3(blocks), dim3(256), 0, st, a);
 }
 
 extern "C" int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
@@ -1213,7 +1235,8 @@ extern "C" int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const fl
   }
   const int groups = mfma ? (ct / tiles_c) * (nt / tiles_n) : 1;
   const int chunk_rows = wgrad_chunk_rows(n_rows, K, groups);
-  WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, (int)((n_rows + chunk_rows - 1) / chunk_rows), chunk_rows};
+  static const int xcd_order = (getenv("SEEVCN_WGRAD_XCD") && atoi(getenv("SEEVCN_WGRAD_XCD")) == 1) ? 1 : 0;
+  WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, (int)((n_rows + chunk_rows - 1) / chunk_rows), chunk_rows, xcd_order};
   int nslabs = a.nchunks;
   if (mfma) {
     if (tiles_c == 4) launch_wgrad<4, 4>(a, st);
