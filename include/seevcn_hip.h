@@ -225,6 +225,17 @@ int sv_stack_farthest_point_sampling(const float* xyz, const int32_t* xyz_batch_
 int sv_ball_query_stack(int batch, int M, int max_queries_per_scene, float radius, int nsample, const float* new_xyz,
                         const int32_t* new_xyz_batch_start, const int32_t* new_xyz_batch_cnt, const float* xyz,
                         const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int32_t* idx, void* stream);
+/* ---- fused set-abstraction reduction, eval mode (csrc/set_abstraction.hip): the tail of StackSAModuleMSG.forward
+ * (ops/pointnet2/pointnet2_stack/pointnet2_modules.py:78-112) for one radius scale -- QueryAndGroup's gather (xyz relative to the query in
+ * front of the features, an empty ball = zeros; pointnet2_utils.py:112-159) -> two Conv2d 1x1 + BatchNorm2d(eval) + ReLU -> max over nsample --
+ * without the (M, C+3, nsample) tensor.  idx / row_start as for sv_group_points_stack (raw ball-query output).
+ * sv_sa_prepare_weights folds an eval-mode BatchNorm into a conv weight (c_out, c_in): xyz_first = 1 for the first layer (c_in = 3 + C, C a
+ * multiple of 16: output (c_out, 16*(C/16+1)) = [features | xyz | zeros]), 0 for the second (same shape); b_out (c_out).
+ * sv_sa_mlp_max: C <= 128 features (multiple of 16, 0 = xyz only), nsample 16 or 32, C1 / C2 in {16, 32, 48, 64}; out (M, C2). */
+int sv_sa_prepare_weights(const float* weight, const float* bn_weight, const float* bn_bias, const float* running_mean,
+                          const float* running_var, float eps, int c_out, int c_in, int xyz_first, float* w_out, float* b_out, void* stream);
+int sv_sa_mlp_max(const float* xyz, const float* features, const float* new_xyz, const int32_t* idx, const int32_t* row_start, int64_t M, int C,
+                  int nsample, const float* w1, const float* b1, int C1, const float* w2, const float* b2, int C2, float* out, void* stream);
 /* group_points_wrapper / group_points_grad_wrapper (src/group_points.cpp:31-69, kernels group_points_gpu.cu:15-102):
  * out (M,C,nsample)[m][c][s] = features[row_start[m] + idx[m][s]][c]; row_start[m] = first feature row of query m's scene.
  * The gradient zero-fills grad_features (N,C) and scatter-adds with fp32 atomics like the reference. */

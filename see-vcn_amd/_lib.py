@@ -64,6 +64,8 @@ SIGNATURES = {
     "sv_farthest_point_sampling": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_stack_farthest_point_sampling": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_ball_query_stack": (c_i, [c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sv_sa_prepare_weights": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "sv_sa_mlp_max": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p]),
     "sv_group_points_stack": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_group_points_grad_stack": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_boxes_overlap_bev": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p]),

@@ -197,3 +197,51 @@ def test_hip_three_nn_interpolate_stack_vs_oracle(cuda, hip_lib):
     for j in range(3):
         ref.index_add_(0, idx[:, j].long(), gw * weight[:, j:j + 1])
     torch.testing.assert_close(g1, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_in,mlps,nsamples", [(0, [[16, 16], [16, 16]], [16, 16]), (16, [[16, 16], [16, 32]], [16, 32]), (64, [[64, 64], [64, 64]], [16, 32]),
+                                                 (128, [[64, 64], [64, 64]], [16, 16])])
+def test_hip_fused_set_abstraction_matches_the_unfused_path(cuda, hip_lib, c_in, mlps, nsamples):
+    """Eval-mode StackSAModuleMSG: the fused kernel (ball query -> gather + 2-layer MLP on the matrix core + max, no (M, C+3, ns) tensor) against
+    the reference-shaped path (QueryAndGroup -> Conv2d / BatchNorm2d / ReLU -> max_pool2d), incl. empty balls and balls with fewer than nsample
+    neighbours; element-wise per channel.  (The unfused path is pinned to the reference's own modules by tests/golden/pvrcnn_heads.npz.)"""
+    import seevcn_amd.synth as synth
+    from tolerances import assert_close_per_channel
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as pm
+    pts, _ = synth.make_scene_batch(3, seed=2000, n_az=60)
+    counts = np.bincount(pts[:, 0].astype(int), minlength=3)
+    xyz = np.ascontiguousarray(pts[:, 1:4])
+    rng = np.random.default_rng(c_in + 1)
+    qcnt = [700, 513, 64]
+    starts = np.cumsum(counts) - counts
+    new = np.concatenate([xyz[starts[b]:starts[b] + counts[b]][rng.integers(0, counts[b], q)] + rng.normal(0, 0.3, (q, 3)) for b, q in enumerate(qcnt)]).astype(np.float32)
+    new[7] = [500, 500, 500]                                                # an empty ball
+    feats = rng.normal(size=(len(xyz), c_in)).astype(np.float32) if c_in else None
+    torch.manual_seed(c_in)
+    m = pm.StackSAModuleMSG(radii=[0.4, 1.2], nsamples=nsamples, mlps=[[c_in] + list(x) for x in mlps], use_xyz=True, pool_method='max_pool').to(cuda)
+    for mod in m.modules():                                                # non-trivial eval-mode statistics
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.uniform_(-0.5, 0.5)
+            mod.running_var.uniform_(0.5, 2.0)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.uniform_(-0.3, 0.3)
+    m.eval()
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(cuda) if dt is None else torch.tensor(a, dtype=dt, device=cuda)
+    args = (t(xyz), t(counts.tolist(), torch.int32), t(new), t(qcnt, torch.int32))
+    f = t(feats) if c_in else None
+    with torch.no_grad():
+        assert m._fused_ok(0, args[0], args[2], f) and m._fused_ok(1, args[0], args[2], f)
+        _, fused = m(*args, features=f)
+        saved, pm.FUSED_SA_OFF = pm.FUSED_SA_OFF, True
+        try:
+            _, plain = m(*args, features=f)
+        finally:
+            pm.FUSED_SA_OFF = saved
+    assert fused.shape == plain.shape == (sum(qcnt), mlps[0][-1] + mlps[1][-1])
+    assert_close_per_channel(fused.cpu().numpy(), plain.cpu().numpy(), rtol=1e-3, atol_frac=1e-4, name="fused SA output")
+    # the empty ball: relu(BN shift) through both layers, identical rows for every empty query
+    assert torch.isfinite(fused).all()
+    # gradients needed -> the fused (forward-only) kernel steps aside
+    m.train()
+    assert not m._fused_ok(0, args[0], args[2], f)
