@@ -219,6 +219,14 @@ int sv_farthest_point_sampling(const float* xyz, int b, int n, int m, float* tem
  * GLOBAL row indices (scene start + local index). max_n = largest scene. */
 int sv_stack_farthest_point_sampling(const float* xyz, const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int batch,
                                      int max_n, int m, float* temp, int32_t* idx, void* stream);
+/* The same with SEVERAL workgroups per scene (16; batch * 16 <= 256 workgroups, 4096 <= max_n <= 65536, m < 65536 -- otherwise it falls back
+ * to one workgroup per scene): every round the workgroups exchange their best candidate through self-tagged 16-byte granules in
+ * multi_scratch (sv_fps_multi_scratch_bytes(batch) bytes, any content).  Index-exact with the single-workgroup kernel.  This path reads an
+ * error word back and therefore returns with the stream synchronised; if a partner workgroup never arrives (bounded poll) it retries with
+ * write-through granules and then fails with SV_ERR_HIP.  SEEVCN_FPS_MULTI=0: always one workgroup per scene; =1: write-through only. */
+size_t sv_fps_multi_scratch_bytes(int batch);
+int sv_stack_farthest_point_sampling_multi(const float* xyz, const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int batch,
+                                           int max_n, int m, float* temp, void* multi_scratch, int32_t* idx, void* stream);
 /* ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx) (src/ball_query.cpp:31-47,
  * kernel ball_query_gpu.cu:16-66): idx (M,nsample) scene-local indices of the first nsample points with d^2 < r^2 in index
  * order, padded with the first hit; idx[m][0] = -1 for an empty ball. */

@@ -9,6 +9,8 @@
 // traffic inside the M sequential rounds) and needs one barrier per round; ball query is wave-cooperative — a
 // wave scans the candidate points 64 at a time with coalesced loads from an LDS tile shared by the workgroup's
 // queries and appends hits in index order with ballot + prefix popcount.
+#include <stdlib.h>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -161,9 +163,178 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_stream(const float* __restr
   }
 }
 
+// ---- several workgroups per scene.  One workgroup per scene leaves 252 of 256 CUs idle at batch 4 and pays ~4 us per round for its
+// 34-40 points per thread (16 ms for the 4096 keypoints of the SEE-VCN PV-RCNN, source-nuscenes/pvrcnn.yaml:111).  Here FPS_W workgroups
+// share a scene (2-3 points per thread); every round each publishes its best candidate as two self-tagged 16-byte granules
+// {key, x, tag} {y, z, tag} -- one `sc1` store each, no drain, no flag, no fence (MI355X_MICROARCH.md, "data-tagged granules") -- and every wave
+// polls the 2 x FPS_W granules of its scene (one per lane, `sc1` loads) until all carry the round's tag.  The records alternate between two
+// banks by round parity so that a fast workgroup cannot overwrite a granule a slow one still has to read; the per-wave candidates in LDS
+// alternate the same way, which leaves ONE workgroup barrier per round.  Same keys, same tie rule, same winners as the single-workgroup
+// kernel.  The FPS_W workgroups of a scene must be resident together (batch * FPS_W <= 256 workgroups, checked by the host); the poll is
+// bounded and raises *err instead of hanging.  one_xcd: the scene's workgroups are dealt to ONE XCD (workgroup i runs on XCD i % 8) and
+// the granules are plain stores that stay in that XCD's L2, where the `sc1` polls of the same XCD find them: 1.9 us per round instead of
+// 2.8 with write-through (`sc1`) granules that any XCD may read (measured, 4 x 17k points -> 4096: 7.9 / 11.3 ms; one workgroup per
+// scene 16.4 ms).
+constexpr int FPS_W = 16;
+struct FpsRecord {
+  unsigned int h0[4];          // key lo, key hi, x, tag
+  unsigned int h1[4];          // y, z, tag, 0
+};
+typedef unsigned int fps_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void fps_store16(void* p, fps_u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void fps_store16_l2(void* p, fps_u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ fps_u32x4 fps_load16(const void* p) {
+  fps_u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+template <int P>
+__global__ __launch_bounds__(FPS_THREADS) void k_fps_multi(const float* __restrict__ xyz_all, const int32_t* __restrict__ starts,
+                                                           const int32_t* __restrict__ counts, int fixed_n, int m, int32_t* __restrict__ idx_all,
+                                                           int add_offset, FpsRecord* __restrict__ records, unsigned nonce, int32_t* __restrict__ err,
+                                                           int batch, int one_xcd, int spin_limit) {
+  constexpr int NW = FPS_THREADS / 64;
+  static_assert(2 * FPS_W <= 64 && (NW & (NW - 1)) == 0, "one granule per lane");
+  __shared__ unsigned long long skey[2][NW];
+  __shared__ float sxyz[2][NW][3];
+  int b = blockIdx.x / FPS_W, w = blockIdx.x % FPS_W;
+  if (one_xcd) {                                                // workgroup i runs on XCD i % 8: a scene's workgroups all on one
+    const int slot = blockIdx.x >> 3;
+    b = (slot / FPS_W) * 8 + (blockIdx.x & 7);
+    w = slot % FPS_W;
+    if (b >= batch) return;
+  }
+  const int start = starts ? starts[b] : b * fixed_n;
+  const int n = counts ? counts[b] : fixed_n;
+  const float* xyz = xyz_all + (int64_t)start * 3;
+  int32_t* idx = idx_all + (int64_t)b * m;
+  if (n <= 0 || m <= 0) return;
+  int log2t = 0;
+  while ((2 << log2t) <= n && log2t < 10) ++log2t;             // T = 2^floor(log2 n), capped at 1024
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  FpsRecord* rec = records + (size_t)b * 2 * FPS_W;            // [parity][workgroup]
+  float px[P], py[P], pz[P], pt[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int k = (i * FPS_W + w) * FPS_THREADS + tid;
+    const bool ok = k < n;
+    px[i] = ok ? xyz[k * 3] : 0.f;
+    py[i] = ok ? xyz[k * 3 + 1] : 0.f;
+    pz[i] = ok ? xyz[k * 3 + 2] : 0.f;
+    pt[i] = 1e10f;
+  }
+  if (w == 0 && tid == 0) idx[0] = add_offset ? start : 0;
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];                  // first pick is index 0 (sampling_gpu.cu:44-46)
+  for (int j = 1; j < m; ++j) {
+    const int par = j & 1;
+    float bd = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
+    int bk = -1;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const int k = (i * FPS_W + w) * FPS_THREADS + tid;
+      const float d = (px[i] - x1) * (px[i] - x1) + (py[i] - y1) * (py[i] - y1) + (pz[i] - z1) * (pz[i] - z1);
+      const float d2 = fminf(d, pt[i]);
+      pt[i] = d2;
+      bool up = k < n && d2 > bd;
+      if (k < n && d2 == bd) up = fps_key(d2, k, log2t) > fps_key(bd, bk, log2t);
+      bd = up ? d2 : bd;
+      bk = up ? k : bk;
+      bx = up ? px[i] : bx; by = up ? py[i] : by; bz = up ? pz[i] : bz;
+    }
+    const unsigned long long best = bk >= 0 ? fps_key(bd, bk, log2t) : 0ull;
+    const unsigned long long wbest = wave_max_u64(best);
+    if (best == wbest && best != 0ull) {
+      skey[par][wid] = wbest;
+      sxyz[par][wid][0] = bx; sxyz[par][wid][1] = by; sxyz[par][wid][2] = bz;
+    } else if (wbest == 0ull && lane == 0) {
+      skey[par][wid] = 0ull;
+    }
+    __syncthreads();
+    const unsigned tag = (nonce << 16) | (unsigned)j;
+    FpsRecord* bank = rec + (size_t)par * FPS_W;
+    if (wid == 0) {                                             // this workgroup's candidate -> its record
+      const int sl = lane & (NW - 1);
+      const unsigned long long mine = skey[par][sl];
+      const unsigned long long wg_best = wave_max_u64(mine);
+      const int src = __ffsll((long long)__ballot(mine == wg_best)) - 1;
+      if (lane == src || lane == src + NW) {                    // two lanes hold the winner (NW < 64): one stores each granule
+        fps_u32x4 v;
+        if (lane == src) v = fps_u32x4{(unsigned)(wg_best & 0xffffffffull), (unsigned)(wg_best >> 32), __float_as_uint(sxyz[par][sl][0]), tag};
+        else v = fps_u32x4{__float_as_uint(sxyz[par][sl][1]), __float_as_uint(sxyz[par][sl][2]), tag, 0u};
+        if (one_xcd) fps_store16_l2(lane == src ? (void*)bank[w].h0 : (void*)bank[w].h1, v);
+        else fps_store16(lane == src ? (void*)bank[w].h0 : (void*)bank[w].h1, v);
+      }
+    }
+    // every wave: poll the 2 x FPS_W granules of the scene, one per lane
+    const bool poller = lane < 2 * FPS_W;
+    const int half = lane / FPS_W;
+    const void* gp = half == 0 ? (const void*)bank[lane & (FPS_W - 1)].h0 : (const void*)bank[lane & (FPS_W - 1)].h1;
+    fps_u32x4 g = fps_u32x4{0u, 0u, 0u, 0u};
+    bool ready = !poller;
+    int spins = 0;
+    while (true) {
+      if (!ready) {
+        g = fps_load16(gp);
+        ready = (half == 0 ? g.w : g.z) == tag;
+      }
+      if (__ballot(!ready) == 0ull) break;
+      if (++spins > spin_limit) {                                // ~ seconds: a missing partner (not co-resident) must not hang the GPU
+        if (lane == 0) *err = 1;
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const unsigned long long key = lane < FPS_W ? ((unsigned long long)g.y << 32) | g.x : 0ull;
+    const unsigned long long win = wave_max_u64(key);
+    const int wl = __ffsll((long long)__ballot(lane < FPS_W && key == win)) - 1;
+    x1 = __uint_as_float(__shfl(g.z, wl, 64));
+    y1 = __uint_as_float(__shfl(g.x, wl + FPS_W, 64));
+    z1 = __uint_as_float(__shfl(g.y, wl + FPS_W, 64));
+    if (w == 0 && tid == 0) {
+      const unsigned int tie = 0x7FFFFFFFu - (unsigned int)(win & 0xFFFFFFFFull);
+      const unsigned int rev = log2t ? (tie >> (31 - log2t)) : 0u;
+      const unsigned int lo = log2t ? (__brev(rev) >> (32 - log2t)) : 0u;
+      const int old = (int)(((tie & ((1u << (31 - log2t)) - 1u)) << log2t) | lo);
+      idx[j] = add_offset ? start + old : old;
+    }
+  }
+}
+
 static int fps_launch(const float* xyz, const int32_t* starts, const int32_t* counts, int batch, int fixed_n, int max_n, int m,
-                      float* temp, int32_t* idx, int add_offset, hipStream_t st) {
+                      float* temp, int32_t* idx, int add_offset, hipStream_t st, void* multi_scratch = nullptr) {
   if (batch <= 0 || m <= 0) return SV_OK;
+  static unsigned nonce = 0;
+  static const bool multi_off = getenv("SEEVCN_FPS_MULTI") && atoi(getenv("SEEVCN_FPS_MULTI")) == 0;
+  // several workgroups per scene when the scene is large enough to keep them busy, they all fit the chip at once and m fits the 16-bit tag
+  if (multi_scratch && !multi_off && batch * FPS_W <= 256 && max_n >= 4096 && max_n <= 8 * FPS_W * FPS_THREADS && m < 65536) {
+    FpsRecord* rec = reinterpret_cast<FpsRecord*>(multi_scratch);
+    int32_t* err = reinterpret_cast<int32_t*>(rec + (size_t)batch * 2 * FPS_W);
+    static const int first_mode = getenv("SEEVCN_FPS_MULTI") && atoi(getenv("SEEVCN_FPS_MULTI")) == 1 ? 0 : 1;
+    const int p = (max_n + FPS_W * FPS_THREADS - 1) / (FPS_W * FPS_THREADS);
+    // first with the scene's workgroups on one XCD and its L2 as the meeting point (1.9 us per round); were the dispatch order ever not
+    // "workgroup i -> XCD i % 8" a partner would poll a stale line of its own L2, time out and raise the error word: then once more with
+    // write-through records, which hold for any placement (2.8 us per round).  The error word is read back, so this path ends synchronised.
+    for (int one_xcd = first_mode; one_xcd >= 0; --one_xcd) {
+      SV_HIP(hipMemsetAsync(err, 0, 4, st));
+      nonce = (nonce + 1) & 0xffffu;
+      if (nonce == 0) nonce = 1;
+      const int spin_limit = one_xcd ? 1 << 17 : 1 << 21;
+      dim3 grid(one_xcd ? (batch + 7) / 8 * 8 * FPS_W : batch * FPS_W), block(FPS_THREADS);
+      if (p <= 1) hipLaunchKernelGGL(k_fps_multi<1>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset, rec, nonce, err, batch, one_xcd, spin_limit);
+      else if (p <= 2) hipLaunchKernelGGL(k_fps_multi<2>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset, rec, nonce, err, batch, one_xcd, spin_limit);
+      else if (p <= 4) hipLaunchKernelGGL(k_fps_multi<4>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset, rec, nonce, err, batch, one_xcd, spin_limit);
+      else hipLaunchKernelGGL(k_fps_multi<8>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset, rec, nonce, err, batch, one_xcd, spin_limit);
+      SV_LAUNCH_CHECK();
+      int32_t host_err = 0;
+      SV_HIP(hipMemcpyAsync(&host_err, err, 4, hipMemcpyDeviceToHost, st));
+      SV_HIP(hipStreamSynchronize(st));
+      if (host_err == 0) return SV_OK;
+    }
+    sv_set_error("farthest_point_sampling: a partner workgroup never arrived (GPU shared with another process?); SEEVCN_FPS_MULTI=0 selects one workgroup per scene");
+    return SV_ERR_HIP;
+  }
   const int p = (max_n + FPS_THREADS - 1) / FPS_THREADS;
   dim3 grid(batch), block(FPS_THREADS);
   if (p <= 4) hipLaunchKernelGGL(k_fps_reg<4>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
@@ -180,6 +351,9 @@ static int fps_launch(const float* xyz, const int32_t* starts, const int32_t* co
   return SV_OK;
 }
 
+// scratch of the multi-workgroup path: 2 x FPS_W records per scene + an error word (read it back to detect a missing partner; 0 = fine)
+extern "C" size_t sv_fps_multi_scratch_bytes(int batch) { return (size_t)(batch > 0 ? batch : 0) * 2 * FPS_W * sizeof(FpsRecord) + 64; }
+
 extern "C" int sv_farthest_point_sampling(const float* xyz, int b, int n, int m, float* temp, int32_t* idx, void* stream) {
   SV_CHECK_ARG(b >= 0 && n > 0 && m >= 0 && (b == 0 || (xyz && idx)), "farthest_point_sampling: bad arguments");
   SV_CHECK_ARG((int64_t)n < (1ll << 30), "farthest_point_sampling: n too large");
@@ -192,6 +366,14 @@ extern "C" int sv_stack_farthest_point_sampling(const float* xyz, const int32_t*
   if (batch == 0 || m == 0) return SV_OK;
   SV_CHECK_ARG(xyz && xyz_batch_start && xyz_batch_cnt && idx, "stack_farthest_point_sampling: null pointer");
   return fps_launch(xyz, xyz_batch_start, xyz_batch_cnt, batch, 0, max_n, m, temp, idx, 1, sv_stream(stream));
+}
+
+extern "C" int sv_stack_farthest_point_sampling_multi(const float* xyz, const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int batch,
+                                                      int max_n, int m, float* temp, void* multi_scratch, int32_t* idx, void* stream) {
+  SV_CHECK_ARG(batch >= 0 && m >= 0 && max_n >= 0, "stack_farthest_point_sampling: bad arguments");
+  if (batch == 0 || m == 0) return SV_OK;
+  SV_CHECK_ARG(xyz && xyz_batch_start && xyz_batch_cnt && idx, "stack_farthest_point_sampling: null pointer");
+  return fps_launch(xyz, xyz_batch_start, xyz_batch_cnt, batch, 0, max_n, m, temp, idx, 1, sv_stream(stream), multi_scratch);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -67,9 +67,12 @@ def stack_farthest_point_sampling(points, xyz_batch_cnt, npoint, max_n=None):
         max_n = int(cnt.max().item())
     idx = torch.empty((batch, npoint), dtype=torch.int32, device=points.device)
     temp = torch.empty((points.shape[0],), dtype=torch.float32, device=points.device) if max_n > 24576 else None
-    rc = lib.sv_stack_farthest_point_sampling(_lib.ptr(points), _lib.ptr(starts), _lib.ptr(cnt), batch, int(max_n), int(npoint),
-                                              _lib.ptr(temp), _lib.ptr(idx), _lib.stream())
-    _lib.check(rc, "sv_stack_farthest_point_sampling")
+    # several workgroups per scene where that applies (sv_stack_farthest_point_sampling_multi decides; same indices either way)
+    nbytes = int(lib.sv_fps_multi_scratch_bytes(batch))
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=points.device)
+    rc = lib.sv_stack_farthest_point_sampling_multi(_lib.ptr(points), _lib.ptr(starts), _lib.ptr(cnt), batch, int(max_n), int(npoint),
+                                                    _lib.ptr(temp), _lib.ptr(scratch), _lib.ptr(idx), _lib.stream())
+    _lib.check(rc, "sv_stack_farthest_point_sampling_multi")
     return idx
 
 

@@ -83,6 +83,24 @@ def test_hip_stack_fps_matches_per_scene(cuda, hip_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("counts,m", [([20000, 4097], 1024), ([65536], 300), ([5000, 5000, 5000, 5000], 2048)])
+def test_hip_stack_fps_several_workgroups_per_scene_index_exact(cuda, hip_lib, counts, m):
+    """Scenes of >= 4096 points take the 16-workgroups-per-scene kernel (records exchanged every round): same picks as the oracle,
+    including exact duplicates that tie on distance (tie rule of sampling_gpu.cu:16-21 lives in the key)."""
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as pu
+    rng = np.random.default_rng(len(counts) + m)
+    xyz = rng.normal(size=(sum(counts), 3)).astype(np.float32) * 20
+    xyz[counts[0] // 2:counts[0]] = xyz[:counts[0] - counts[0] // 2]          # duplicates inside scene 0
+    for _ in range(2):                                                         # twice: stale records of the first call must not match
+        idx = pu.stack_farthest_point_sample(torch.from_numpy(xyz).to(cuda), torch.tensor(counts, dtype=torch.int32, device=cuda), m).cpu().numpy()
+        s = 0
+        for b, c in enumerate(counts):
+            ref = op2.farthest_point_sampling(xyz[s:s + c], m) + s
+            assert np.array_equal(idx[b], ref), (b, np.nonzero(idx[b] != ref)[0][:5])
+            s += c
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("radius,nsample", [(0.4, 16), (0.8, 16), (2.4, 32), (0.05, 4)])
 def test_hip_ball_query_group_vs_oracle(cuda, hip_lib, radius, nsample):
     import seevcn_amd.synth as synth
