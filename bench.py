@@ -7,6 +7,7 @@ VoxelBackBone8x (sparse 3-D conv) + HeightCompression forward, loss, backward, S
 HBM before the timed region.  Scenes shard data-parallel (weak scaling); gradients are all-reduced over RCCL.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+  python bench.py --config {stageA,second,pvrcnn,centerpoint} [--gpus N] [--steps K] [--warmup W]     side modes (bench_configs.py)
 
 With --gpus N > 1 and no WORLD_SIZE in the environment the process is only a launcher: it starts N rank processes (one GPU each,
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches the GPU and exits with their status -- the role of
@@ -294,6 +295,8 @@ def main():
     ap.add_argument("--objects-per-gpu", type=int, default=None, help="override the 64 objects per GPU (tests)")
     ap.add_argument("--no-kernel-rooflines", action="store_true", help="skip the per-kernel event timing after the timed region (tests)")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only control flow of the multi-rank path (gloo), no kernels")
+    ap.add_argument("--config", default="main", choices=("main", "stageA", "second", "pvrcnn", "centerpoint"),
+                    help="main (default): the headline step; the others are side modes over the other BASELINE configs (bench_configs.py)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -324,6 +327,13 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.config != "main":
+        side_mode(args, rank, world, device)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     points, objects, scene, pts_np, objs_np, scene_np = make_inputs(rank, device)
     model = build_model(device).train()
@@ -374,6 +384,35 @@ def main():
     if world > 1:
         dist.barrier()             # the other ranks wait here while rank 0 measures and prints
         dist.destroy_process_group()
+
+
+def side_mode(args, rank, world, device):
+    """--config X: the same timing protocol over one of the other BASELINE configs (bench_configs.py); `value` = units of all ranks / max time."""
+    import bench_configs
+    sys.modules.setdefault("bench", sys.modules[__name__])                 # bench_configs reaches allreduce_grads / SCENE_N_AZ through `import bench`
+    step, units, unit, metric, config = bench_configs.build(args.config, rank, device, scenes=args.scenes_per_gpu)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        config["parallelism"] = f"dp{world}"
+        print(json.dumps({"metric": metric, "value": round(units * world * args.steps / elapsed, 3), "unit": unit, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "side_mode": args.config}), flush=True)
 
 
 def kernel_rooflines(out, model, opt, params, inputs):

@@ -252,6 +252,15 @@ int sv_group_points_stack(int M, int C, int nsample, const float* features, cons
 int sv_group_points_grad_stack(int M, int C, int N, int nsample, const float* grad_out, const int32_t* idx,
                                const int32_t* row_start, float* grad_features, void* stream);
 
+/* Neighbourhoods as rows (seevcn extension; the channel-last twin of QueryAndGroup.forward, pointnet2_utils.py:62-83):
+ * out[(m * nsample + s), :] = [xyz[j] - new_xyz[m] | features[j]] (3 + C floats), j = row_start[m] + idx[m][s]; zero rows where idx[m][0] < 0
+ * (empty ball, as ball_query leaves it).  features may be null when C == 0.  _grad: grad_features (N, C) = scatter-add of the feature
+ * columns of grad_rows (zeroed inside). */
+int sv_group_rows_stack(int64_t M, int C, int nsample, const float* xyz, const float* features, const float* new_xyz, const int32_t* idx,
+                        const int32_t* row_start, float* out, void* stream);
+int sv_group_rows_grad_stack(int64_t M, int C, int64_t N, int nsample, const float* grad_rows, const int32_t* idx, const int32_t* row_start,
+                             float* grad_features, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Rotated-box geometry (detector3d/pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:12-17,
  * detector3d/pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:172-177). Boxes are (N,7) fp32 [x,y,z,dx,dy,dz,heading].

@@ -481,16 +481,74 @@ __global__ __launch_bounds__(256) void k_group_points(int64_t total, int C, int 
   }
 }
 
-__global__ __launch_bounds__(256) void k_group_points_grad(int64_t total, int C, int nsample, const float* __restrict__ grad_out,
+// One thread per (query, channel): the nsample gradients of that pair are contiguous (grad_out is (M, C, nsample)), lanes run over the
+// channels so the atomic adds of a wave go to consecutive addresses of one feature row, and the slots that repeat the first neighbour
+// (ball_query pads short balls that way, ball_query_gpu.cu:52-58) are summed in a register first: one add per DISTINCT neighbour instead of
+// one per slot.  (One thread per element with the slot index fastest -- the reference's layout, group_points_gpu.cu:27-45 -- put 32 lanes
+// on the same address for every padded ball: 99 ms at 110 592 queries x 128 channels x 16 slots.)
+__global__ __launch_bounds__(256) void k_group_points_grad(int64_t pairs, int C, int nsample, const float* __restrict__ grad_out,
                                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ row_start,
                                                            float* __restrict__ grad_features) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int s = (int)(e % nsample);
-    const int64_t t = e / nsample;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < pairs; t += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(t % C);
     const int64_t m = t / C;
-    const int32_t j = idx[m * nsample + s];
-    atomicAdd(&grad_features[((int64_t)row_start[m] + j) * C + c], grad_out[e]);   // group_points_gpu.cu:44
+    const int32_t* id = idx + m * nsample;
+    const float* g = grad_out + t * nsample;
+    const int64_t row0 = row_start[m];
+    const int32_t j0 = id[0];
+    float acc = g[0];
+    for (int s = 1; s < nsample; ++s) {
+      const int32_t j = id[s];
+      const float v = g[s];
+      if (j == j0) acc += v;
+      else atomicAdd(&grad_features[(row0 + j) * C + c], v);
+    }
+    atomicAdd(&grad_features[(row0 + j0) * C + c], acc);
+  }
+}
+
+// ---- neighbourhoods as ROWS: out[(m * nsample + s), :] = [xyz[j] - new_xyz[m] (3) | features[j] (C)] with j = row_start[m] + idx[m][s];
+// an empty ball (idx[m][0] < 0) gives zero rows.  The channel-last twin of QueryAndGroup's (M, 3 + C, nsample) tensor
+// (pointnet2_utils.py:62-83): the shared MLP of a set-abstraction scale is then ONE (M * nsample, 3 + C) x (3 + C, C') GEMM.
+__global__ __launch_bounds__(256) void k_group_rows(int64_t total, int C, int nsample, const float* __restrict__ xyz, const float* __restrict__ features,
+                                                    const float* __restrict__ new_xyz, const int32_t* __restrict__ idx,
+                                                    const int32_t* __restrict__ row_start, float* __restrict__ out) {
+  const int cg = C + 3;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % cg);
+    const int64_t r = e / cg;
+    const int64_t m = r / nsample;
+    const int32_t j0 = idx[m * nsample];
+    float v = 0.f;
+    if (j0 >= 0) {
+      const int64_t row = (int64_t)row_start[m] + idx[r];
+      v = c < 3 ? xyz[row * 3 + c] - new_xyz[m * 3 + c] : features[row * C + (c - 3)];
+    }
+    out[e] = v;
+  }
+}
+
+// gradient of the feature part of k_group_rows: one thread per (query, channel), lanes over channels, repeats of the first neighbour summed first
+__global__ __launch_bounds__(256) void k_group_rows_grad(int64_t pairs, int C, int nsample, const float* __restrict__ grad_rows,
+                                                         const int32_t* __restrict__ idx, const int32_t* __restrict__ row_start,
+                                                         float* __restrict__ grad_features) {
+  const int cg = C + 3;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < pairs; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(t % C);
+    const int64_t m = t / C;
+    const int32_t* id = idx + m * nsample;
+    const int32_t j0 = id[0];
+    if (j0 < 0) continue;
+    const float* g = grad_rows + m * nsample * cg + 3 + c;
+    const int64_t row0 = row_start[m];
+    float acc = g[0];
+    for (int s = 1; s < nsample; ++s) {
+      const int32_t j = id[s];
+      const float v = g[(int64_t)s * cg];
+      if (j == j0) acc += v;
+      else atomicAdd(&grad_features[(row0 + j) * C + c], v);
+    }
+    atomicAdd(&grad_features[(row0 + j0) * C + c], acc);
   }
 }
 
@@ -516,9 +574,37 @@ extern "C" int sv_group_points_grad_stack(int M, int C, int N, int nsample, cons
   }
   if (M == 0) return SV_OK;
   SV_CHECK_ARG(grad_out && idx && row_start, "group_points_grad: null pointer");
-  const int64_t total = (int64_t)M * C * nsample;
-  hipLaunchKernelGGL(k_group_points_grad, dim3(sv_grid_1d(total, 256, 256 * 16)), dim3(256), 0, st, total, C, nsample, grad_out, idx, row_start,
+  const int64_t pairs = (int64_t)M * C;
+  hipLaunchKernelGGL(k_group_points_grad, dim3(sv_grid_1d(pairs, 256, 256 * 64)), dim3(256), 0, st, pairs, C, nsample, grad_out, idx, row_start,
                      grad_features);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_group_rows_stack(int64_t M, int C, int nsample, const float* xyz, const float* features, const float* new_xyz, const int32_t* idx,
+                                   const int32_t* row_start, float* out, void* stream) {
+  SV_CHECK_ARG(M >= 0 && C >= 0 && nsample > 0, "group_rows: bad arguments");
+  if (M == 0) return SV_OK;
+  SV_CHECK_ARG(xyz && new_xyz && idx && row_start && out && (C == 0 || features), "group_rows: null pointer");
+  const int64_t total = M * nsample * (C + 3);
+  hipLaunchKernelGGL(k_group_rows, dim3(sv_grid_1d(total, 256, 256 * 64)), dim3(256), 0, sv_stream(stream), total, C, nsample, xyz, features, new_xyz, idx,
+                     row_start, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_group_rows_grad_stack(int64_t M, int C, int64_t N, int nsample, const float* grad_rows, const int32_t* idx, const int32_t* row_start,
+                                        float* grad_features, void* stream) {
+  SV_CHECK_ARG(M >= 0 && C > 0 && nsample > 0 && N >= 0, "group_rows_grad: bad arguments");
+  hipStream_t st = sv_stream(stream);
+  if (N > 0) {
+    SV_CHECK_ARG(grad_features, "group_rows_grad: null pointer");
+    SV_HIP(hipMemsetAsync(grad_features, 0, (size_t)N * C * 4, st));
+  }
+  if (M == 0) return SV_OK;
+  SV_CHECK_ARG(grad_rows && idx && row_start, "group_rows_grad: null pointer");
+  const int64_t pairs = M * C;
+  hipLaunchKernelGGL(k_group_rows_grad, dim3(sv_grid_1d(pairs, 256, 256 * 64)), dim3(256), 0, st, pairs, C, nsample, grad_rows, idx, row_start, grad_features);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -59,6 +59,42 @@ class GroupingOperation(Function):
 grouping_operation = GroupingOperation.apply
 
 
+class GroupRows(Function):
+    """Neighbourhoods as rows (seevcn extension): (M * nsample, 3 + C) = [xyz[j] - new_xyz[m] | features[j]], zero rows for empty balls --
+    the channel-last twin of QueryAndGroup's (M, 3 + C, nsample) tensor, so that a scale's shared MLP is one GEMM over all rows.
+    idx (M, nsample) int32 as ball_query_wrapper leaves it (idx[m][0] == -1 marks an empty ball); row_start (M,) first row of the query's scene."""
+
+    @staticmethod
+    def forward(ctx, xyz, features, new_xyz, idx, row_start):
+        from ..... import _lib
+        lib = _lib.load()
+        M, ns = idx.shape
+        C = 0 if features is None else features.shape[1]
+        out = torch.empty((M * ns, 3 + C), dtype=torch.float32, device=xyz.device)
+        _lib.check(lib.sv_group_rows_stack(M, C, ns, _lib.ptr(xyz), _lib.ptr(features) if C else None, _lib.ptr(new_xyz), _lib.ptr(idx), _lib.ptr(row_start),
+                                           _lib.ptr(out), _lib.stream()), "sv_group_rows_stack")
+        ctx.n = 0 if features is None else features.shape[0]
+        ctx.c = C
+        ctx.save_for_backward(idx, row_start)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        from ..... import _lib
+        if ctx.c == 0 or not ctx.needs_input_grad[1]:
+            return None, None, None, None, None
+        lib = _lib.load()
+        idx, row_start = ctx.saved_tensors
+        M, ns = idx.shape
+        grad = torch.empty((ctx.n, ctx.c), dtype=torch.float32, device=grad_rows.device)
+        _lib.check(lib.sv_group_rows_grad_stack(M, ctx.c, ctx.n, ns, _lib.ptr(grad_rows.contiguous()), _lib.ptr(idx), _lib.ptr(row_start), _lib.ptr(grad),
+                                                _lib.stream()), "sv_group_rows_grad_stack")
+        return None, grad, None, None, None
+
+
+group_rows = GroupRows.apply
+
+
 class QueryAndGroup(nn.Module):
     def __init__(self, radius, nsample, use_xyz=True):
         super().__init__()

@@ -251,11 +251,11 @@ def test_hip_fused_set_abstraction_matches_the_unfused_path(cuda, hip_lib, c_in,
     with torch.no_grad():
         assert m._fused_ok(0, args[0], args[2], f) and m._fused_ok(1, args[0], args[2], f)
         _, fused = m(*args, features=f)
-        saved, pm.FUSED_SA_OFF = pm.FUSED_SA_OFF, True
+        saved, pm.FUSED_SA_OFF, pm.ROWS_SA_OFF = (pm.FUSED_SA_OFF, pm.ROWS_SA_OFF), True, True
         try:
             _, plain = m(*args, features=f)
         finally:
-            pm.FUSED_SA_OFF = saved
+            pm.FUSED_SA_OFF, pm.ROWS_SA_OFF = saved
     assert fused.shape == plain.shape == (sum(qcnt), mlps[0][-1] + mlps[1][-1])
     assert_close_per_channel(fused.cpu().numpy(), plain.cpu().numpy(), rtol=1e-3, atol_frac=1e-4, name="fused SA output")
     # the empty ball: relu(BN shift) through both layers, identical rows for every empty query
@@ -263,3 +263,70 @@ def test_hip_fused_set_abstraction_matches_the_unfused_path(cuda, hip_lib, c_in,
     # gradients needed -> the fused (forward-only) kernel steps aside
     m.train()
     assert not m._fused_ok(0, args[0], args[2], f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_in,mlps,nsamples", [(0, [[16, 16], [16, 16]], [16, 16]), (64, [[64, 64], [64, 128]], [16, 32]), (128, [[64, 64], [64, 64]], [16, 16])])
+def test_hip_rows_set_abstraction_train_step_matches_the_conv2d_path(cuda, hip_lib, c_in, mlps, nsamples):
+    """Train-mode StackSAModuleMSG: neighbourhood rows -> GEMM -> fused BatchNorm/ReLU -> max against the reference-shaped path (QueryAndGroup ->
+    Conv2d / BatchNorm2d / ReLU -> max_pool2d over (1, C, M, nsample)): outputs, running statistics, and the gradients of the point features and of
+    every weight, element-wise per channel.  Includes an empty ball and balls padded with their first neighbour."""
+    import copy
+    import seevcn_amd.synth as synth
+    from tolerances import assert_close_per_channel
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as pm
+    pts, _ = synth.make_scene_batch(3, seed=2000, n_az=60)
+    counts = np.bincount(pts[:, 0].astype(int), minlength=3)
+    xyz = np.ascontiguousarray(pts[:, 1:4])
+    rng = np.random.default_rng(c_in + 5)
+    qcnt = [700, 513, 64]
+    starts = np.cumsum(counts) - counts
+    new = np.concatenate([xyz[starts[b]:starts[b] + counts[b]][rng.integers(0, counts[b], q)] + rng.normal(0, 0.3, (q, 3)) for b, q in enumerate(qcnt)]).astype(np.float32)
+    new[7] = [500, 500, 500]
+    feats = rng.normal(size=(len(xyz), c_in)).astype(np.float32) if c_in else None
+    torch.manual_seed(c_in)
+    m1 = pm.StackSAModuleMSG(radii=[0.4, 1.2], nsamples=nsamples, mlps=[[c_in] + list(x) for x in mlps], use_xyz=True, pool_method='max_pool').to(cuda).train()
+    m2 = copy.deepcopy(m1)
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(cuda) if dt is None else torch.tensor(a, dtype=dt, device=cuda)
+    args = (t(xyz), t(counts.tolist(), torch.int32), t(new), t(qcnt, torch.int32))
+    f1 = t(feats).requires_grad_(True) if c_in else None
+    f2 = t(feats).requires_grad_(True) if c_in else None
+    assert m1._rows_ok(0, args[0], args[2], f1) and m1._rows_ok(1, args[0], args[2], f1)
+    _, rows = m1(*args, features=f1)
+    saved, pm.ROWS_SA_OFF = pm.ROWS_SA_OFF, True
+    try:
+        _, conv = m2(*args, features=f2)
+    finally:
+        pm.ROWS_SA_OFF = saved
+    assert rows.shape == conv.shape == (sum(qcnt), mlps[0][-1] + mlps[1][-1])
+    assert_close_per_channel(rows.detach().cpu().numpy(), conv.detach().cpu().numpy(), rtol=1e-3, atol_frac=1e-4, name="rows SA output")
+    w = torch.from_numpy(rng.normal(size=tuple(rows.shape)).astype(np.float32)).to(cuda)
+    (rows * w).sum().backward()
+    (conv * w).sum().backward()
+    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        a, b = p1.grad.reshape(p1.shape[0], -1).cpu().numpy(), p2.grad.reshape(p2.shape[0], -1).cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3 * float(np.abs(b).max()) + 1e-6, err_msg=n1)
+    for (n1, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+        np.testing.assert_allclose(b1.cpu().numpy(), b2.cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=n1)
+    if c_in:
+        assert_close_per_channel(f1.grad.cpu().numpy(), f2.grad.cpu().numpy(), rtol=2e-3, atol_frac=1e-3, name="feature gradient")
+
+
+@pytest.mark.gpu
+def test_hip_group_points_grad_with_padded_balls_vs_index_add(cuda, hip_lib):
+    """GroupingOperation.backward (one thread per query x channel, first-neighbour repeats summed first) == a plain index_add."""
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as pu
+    rng = np.random.default_rng(9)
+    n, c, ns = [500, 300], 20, 16
+    qc = [64, 40]
+    feats = torch.from_numpy(rng.normal(size=(sum(n), c)).astype(np.float32)).to(cuda).requires_grad_(True)
+    idx = np.concatenate([rng.integers(0, n[b], size=(qc[b], ns)) for b in range(2)]).astype(np.int32)
+    idx[::3, 5:] = idx[::3, :1]                                                # balls padded with their first neighbour
+    idx_t = torch.from_numpy(idx).to(cuda)
+    out = pu.grouping_operation(feats, torch.tensor(n, dtype=torch.int32, device=cuda), idx_t, torch.tensor(qc, dtype=torch.int32, device=cuda))
+    g = torch.from_numpy(rng.normal(size=tuple(out.shape)).astype(np.float32)).to(cuda)
+    out.backward(g)
+    rows = idx.astype(np.int64) + np.repeat([0, n[0]], qc)[:, None]
+    want = torch.zeros_like(feats)
+    want.index_add_(0, torch.from_numpy(rows.reshape(-1)).to(cuda), g.permute(0, 2, 1).reshape(-1, c))
+    torch.testing.assert_close(feats.grad, want, rtol=1e-4, atol=1e-4)

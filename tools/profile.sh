@@ -1,13 +1,15 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/profile.sh <tag> [steps]
+# usage (on the GPU box, from the repo root): tools/profile.sh <tag> [steps] [extra bench.py arguments, e.g. --config pvrcnn]
 # rocprofv3 --kernel-trace --stats over the bench command (no PMC in this pass); leaves gpurun_out/<tag>_kernel_stats.csv
 TAG=$1
 STEPS=${2:-20}
+shift; shift
+EXTRA="$@"
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 rm -rf gpurun_out/prof_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --steps $STEPS --warmup 5 --no-cpu-baseline > gpurun_out/prof_$TAG.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --steps $STEPS --warmup 5 --no-cpu-baseline $EXTRA > gpurun_out/prof_$TAG.log 2>&1
 F=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$F" gpurun_out/${TAG}_kernel_stats.csv
 tail -1 gpurun_out/prof_$TAG.log | cut -c1-200
