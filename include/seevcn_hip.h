@@ -272,6 +272,9 @@ int sv_boxes_overlap_bev(const float* boxes_a, int num_a, const float* boxes_b, 
  * (iou3d_nms.cpp:111-131: D2H copy of the mask + host sweep) the greedy sweep runs on the device. n <= 65536. */
 size_t sv_nms_scratch_bytes(int n);
 int sv_nms(const float* boxes, int n, float thresh, int normal, void* scratch, int64_t* keep, int32_t* num_out, void* stream);
+/* The same, stopping once max_keep boxes are kept: keep[0..*num_out) is the prefix sv_nms would return, *num_out = min(kept, max_keep)
+ * (seevcn extension for callers that truncate to NMS_POST_MAXSIZE, model_nms_utils.py:21). */
+int sv_nms_prefix(const float* boxes, int n, float thresh, int normal, int max_keep, void* scratch, int64_t* keep, int32_t* num_out, void* stream);
 /* points_in_boxes_gpu: boxes (B,T,7), pts (B,M,3) -> out (B,M) int32 index of the first box containing the point or -1 */
 int sv_points_in_boxes(const float* boxes, const float* pts, int batch, int num_boxes, int num_points, int32_t* out, void* stream);
 

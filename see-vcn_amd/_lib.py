@@ -75,6 +75,7 @@ SIGNATURES = {
     "sv_boxes_overlap_bev": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p]),
     "sv_nms_scratch_bytes": (c_sz, [c_i]),
     "sv_nms": (c_i, [c_p, c_i, c_f, c_i, c_p, c_p, c_p, c_p]),
+    "sv_nms_prefix": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_points_in_boxes": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "sv_voxelize_hard_scratch_bytes": (c_sz, [c_i, c_i64, c_i]),
     "sv_voxelize_hard": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),

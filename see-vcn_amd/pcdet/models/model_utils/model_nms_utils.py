@@ -17,7 +17,8 @@ def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
         box_scores_nms, indices = torch.topk(box_scores, k=min(cfg_get(nms_config, 'NMS_PRE_MAXSIZE'), box_scores.shape[0]))
         boxes_for_nms = box_preds[indices]
         keep_idx, _ = getattr(iou3d_nms_utils, cfg_get(nms_config, 'NMS_TYPE'))(boxes_for_nms[:, 0:7], box_scores_nms,
-                                                                                 cfg_get(nms_config, 'NMS_THRESH'))
+                                                                                 cfg_get(nms_config, 'NMS_THRESH'),
+                                                                                 max_keep=cfg_get(nms_config, 'NMS_POST_MAXSIZE'))
         selected = indices[keep_idx[:cfg_get(nms_config, 'NMS_POST_MAXSIZE')]]
     if score_thresh is not None:
         original_idxs = scores_mask.nonzero().view(-1)

@@ -76,10 +76,10 @@ class PVRCNNHead(RoIHeadTemplate):
                 batch_dict['roi_labels'] = targets_dict['roi_labels']
         pooled = self.roi_grid_pool(batch_dict)                                   # (BxN, g^3, C)
         n_rcnn = pooled.shape[0]
-        pooled = pooled.permute(0, 2, 1).contiguous().view(n_rcnn, -1, 1)         # (BxN, C*g^3, 1)
-        shared = self.shared_fc_layer(pooled)
-        rcnn_cls = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
-        rcnn_reg = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        pooled = pooled.permute(0, 2, 1).contiguous().view(n_rcnn, -1)            # (BxN, C*g^3)
+        shared = self.run_fc(self.shared_fc_layer, pooled)
+        rcnn_cls = self.run_fc(self.cls_layers, shared)                           # (BxN, num_class)
+        rcnn_reg = self.run_fc(self.reg_layers, shared)                           # (BxN, code_size * num_class)
         if not self.training:
             batch_dict['batch_cls_preds'], batch_dict['batch_box_preds'] = self.generate_predicted_boxes(
                 batch_size=batch_dict['batch_size'], rois=batch_dict['rois'], cls_preds=rcnn_cls, box_preds=rcnn_reg)

@@ -73,8 +73,8 @@ class SECONDHead(RoIHeadTemplate):
             batch_dict['roi_labels'] = targets_dict['roi_labels']
         pooled_features = self.roi_grid_pool(batch_dict)
         batch_size_rcnn = pooled_features.shape[0]
-        shared_features = self.shared_fc_layer(pooled_features.view(batch_size_rcnn, -1, 1))
-        rcnn_iou = self.iou_layers(shared_features).transpose(1, 2).contiguous().squeeze(dim=1)
+        shared_features = self.run_fc(self.shared_fc_layer, pooled_features.reshape(batch_size_rcnn, -1))
+        rcnn_iou = self.run_fc(self.iou_layers, shared_features)
         if not self.training:
             batch_dict['batch_cls_preds'] = rcnn_iou.view(batch_dict['batch_size'], -1, rcnn_iou.shape[-1])
             batch_dict['batch_box_preds'] = batch_dict['rois']

@@ -55,7 +55,7 @@ def boxes_iou3d_gpu(boxes_a, boxes_b):
     return overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-6)
 
 
-def _nms(boxes, scores, thresh, pre_maxsize, normal):
+def _nms(boxes, scores, thresh, pre_maxsize, normal, max_keep=None):
     lib = _lib.load()
     _lib.require_cuda(boxes, scores)
     assert boxes.shape[1] == 7
@@ -68,16 +68,17 @@ def _nms(boxes, scores, thresh, pre_maxsize, normal):
     keep = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
     num_out = torch.zeros((1,), dtype=torch.int32, device=dev)
     scratch = _lib.workspace.scratch("nms", lib.sv_nms_scratch_bytes(n), dev)
-    rc = lib.sv_nms(_lib.ptr(sorted_boxes) if n else None, n, float(thresh), int(normal), _lib.ptr(scratch), _lib.ptr(keep), _lib.ptr(num_out),
-                    _lib.stream())
-    _lib.check(rc, "sv_nms")
+    rc = lib.sv_nms_prefix(_lib.ptr(sorted_boxes) if n else None, n, float(thresh), int(normal), n if max_keep is None else min(n, int(max_keep)),
+                           _lib.ptr(scratch), _lib.ptr(keep), _lib.ptr(num_out), _lib.stream())
+    _lib.check(rc, "sv_nms_prefix")
     return order[keep[:int(num_out.item())]].contiguous(), None
 
 
-def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
-    """Rotated NMS; returns (kept indices into `boxes` in score order, None) like the reference (:84-99)."""
-    return _nms(boxes, scores, thresh, pre_maxsize, False)
+def nms_gpu(boxes, scores, thresh, pre_maxsize=None, max_keep=None, **kwargs):
+    """Rotated NMS; returns (kept indices into `boxes` in score order, None) like the reference (:84-99).  max_keep (seevcn extension): stop
+    after that many survivors -- the same prefix, for callers that truncate to NMS_POST_MAXSIZE anyway."""
+    return _nms(boxes, scores, thresh, pre_maxsize, False, max_keep)
 
 
-def nms_normal_gpu(boxes, scores, thresh, **kwargs):
-    return _nms(boxes, scores, thresh, None, True)
+def nms_normal_gpu(boxes, scores, thresh, max_keep=None, **kwargs):
+    return _nms(boxes, scores, thresh, None, True, max_keep)

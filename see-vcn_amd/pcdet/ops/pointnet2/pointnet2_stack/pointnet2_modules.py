@@ -154,7 +154,7 @@ class StackSAModuleMSG(nn.Module):
         layers = list(self.mlps[k])
         for i in range(0, len(layers), 3):
             conv, bn = layers[i], layers[i + 1]
-            x = F.linear(x, conv.weight.view(conv.out_channels, conv.in_channels))
+            x = pointnet2_utils.rows_linear(x, conv.weight.view(conv.out_channels, conv.in_channels))
             training = bn.training
             x = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, training, True,
                                      bn.num_batches_tracked if training else None)

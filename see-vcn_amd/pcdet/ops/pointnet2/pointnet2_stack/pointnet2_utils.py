@@ -95,6 +95,37 @@ class GroupRows(Function):
 group_rows = GroupRows.apply
 
 
+class RowsLinear(Function):
+    """y = x @ w.T for a tall x (R rows, R ~ 10^5..10^6, 16..259 columns).  The weight gradient dy.T @ x contracts over R into a tiny
+    (C_out, C_in) result: as ONE library GEMM that is a single output tile walking all R rows (7.6 ms at R = 1.77 M on MI355X); here R is cut
+    into S slices contracted by one batched GEMM and summed (split-K), S chosen so every slice still has >= 1024 rows."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            r = x.shape[0]
+            s = 1
+            while s < 256 and r % (2 * s) == 0 and r // (2 * s) >= 1024:
+                s *= 2
+            if s == 1:
+                dw = dy.t() @ x
+            else:
+                dw = torch.bmm(dy.view(s, r // s, -1).transpose(1, 2), x.view(s, r // s, -1)).sum(dim=0)
+        return dx, dw
+
+
+rows_linear = RowsLinear.apply
+
+
 class QueryAndGroup(nn.Module):
     def __init__(self, radius, nsample, use_xyz=True):
         super().__init__()

@@ -114,6 +114,10 @@ def test_hip_nms_matches_oracle(cuda, hip_lib, n, thr):
     assert np.array_equal(keep_n.cpu().numpy(), order[ob.nms(b[order], thr, normal=True)])
     kp, _ = u.nms_gpu(torch.from_numpy(b).to(cuda), torch.from_numpy(s).to(cuda), thr, pre_maxsize=min(n, 512))
     assert np.array_equal(kp.cpu().numpy(), order[:512][ob.nms(b[order[:512]], thr)])
+    # max_keep: the sweep stops early and returns exactly the prefix (what NMS_POST_MAXSIZE callers slice off anyway)
+    for mk in (1, 37, 64, 65, len(ref), len(ref) + 10):
+        km, _ = u.nms_gpu(torch.from_numpy(b).to(cuda), torch.from_numpy(s).to(cuda), thr, max_keep=mk)
+        assert np.array_equal(km.cpu().numpy(), ref[:mk]), mk
 
 
 @pytest.mark.gpu
