@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/evidence.sh <tag>      e.g. r02_a
+# One call that leaves everything profiles/ holds for a round under gpurun_out/: the default bench line, the rocprofv3 kernel stats of the
+# same command (whole process + steady steps), the PMC traffic passes, the side-mode bench lines with their steady kernel tables, and the
+# micro-benchmarks (per-layer sparse conv, FPS).
+TAG=$1
+cd $GRAFT_REPO_ROOT
+timeout 900 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+tail -c 600 gpurun_out/${TAG}_bench.json
+TOP=8 tools/profile.sh ${TAG}_main 20 2>&1 | head -10
+tools/traffic.sh ${TAG} 2>&1 | tail -6
+: > gpurun_out/${TAG}_side_modes.jsonl
+for c in stageA second pvrcnn centerpoint; do
+  timeout 600 python3 bench.py --config $c --steps 10 --warmup 5 2>/dev/null | grep '^{' >> gpurun_out/${TAG}_side_modes.jsonl
+  TOP=6 tools/profile.sh ${TAG}_$c 5 --config $c 2>&1 | head -8
+done
+cut -c1-220 gpurun_out/${TAG}_side_modes.jsonl
+timeout 300 python3 tools/spconv_micro.py > gpurun_out/${TAG}_spconv_micro.txt 2>&1
+timeout 120 python3 tools/fps_micro.py > gpurun_out/${TAG}_fps_micro.txt 2>&1
+tail -3 gpurun_out/${TAG}_spconv_micro.txt
+rm -rf gpurun_out/${TAG}_pmc_FETCH_SIZE gpurun_out/${TAG}_pmc_WRITE_SIZE gpurun_out/prof_*.log

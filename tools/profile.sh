@@ -13,7 +13,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
 F=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$F" gpurun_out/${TAG}_kernel_stats.csv
 T=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
-python3 tools/steady_stats.py "$T" $((STEPS + 5)) 5 > gpurun_out/${TAG}_steady_kernels.csv
+python3 tools/steady_stats.py "$T" $((STEPS + 5)) 5 "FusedSgd|fused_sgd" gpurun_out/${TAG}_step_sequence.txt > gpurun_out/${TAG}_steady_kernels.csv
 head -1 gpurun_out/${TAG}_steady_kernels.csv
 python3 - <<PY
 import csv

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel statistics of the STEADY steps of a rocprofv3 kernel trace of bench.py.
 
-  tools/steady_stats.py <kernel_trace.csv> <total steps incl. warm-up> <warm-up steps to drop> [marker regex] > table
+  tools/steady_stats.py <kernel_trace.csv> <total steps incl. warm-up> <warm-up steps to drop> [marker regex [sequence file]] > table
 
 rocprofv3's own *_kernel_stats.csv sums the whole process: the first step of a detector carries MIOpen's solver search (its naive reference
 convolutions, 30-100 ms each, dozens of them) and one-off workspace set-up, which swamp the per-step picture.  Here the timeline is cut into
@@ -29,6 +29,13 @@ def main():
         ends = [marks[(k + 1) * per - 1] for k in range(total_steps)]
         first = ends[drop - 1] + 1 if drop > 0 else 0
         kept, steps = rows[first:ends[-1] + 1], total_steps - drop
+    if len(sys.argv) > 5:                                        # launch sequence of the last kept step: name, duration, gap to the previous end
+        last = rows[ends[-2] + 1:ends[-1] + 1] if marks and len(marks) >= total_steps and total_steps > 1 else kept
+        with open(sys.argv[5], "w") as fh:
+            prev = last[0][0]
+            for s0, e0, n in last:
+                fh.write(f"{(e0 - s0) / 1e3:9.1f} us  gap {(s0 - prev) / 1e3:7.1f} us  {n[:140]}\n")
+                prev = e0
     agg = defaultdict(lambda: [0, 0])
     for s, e, n in kept:
         agg[n][0] += 1
