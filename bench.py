@@ -103,6 +103,60 @@ def run_step(model, opt, params, inputs, world):
     return loss
 
 
+def device_spinup(seconds, device):
+    """Untimed: keeps the GPU busy for `seconds` so that the measured steps run at sustained clocks (not a step, not counted as warm-up)."""
+    if seconds <= 0:
+        return
+    a = torch.randn(4096, 4096, device=device)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            a = torch.nn.functional.normalize(a @ a, dim=1)
+        torch.cuda.synchronize()
+
+
+class Prefetch:
+    """The input side of batch N + 1 (SceneStep.front: stage A, voxelisation, rulebooks, plans -- no weights involved) on a side stream while
+    batch N trains on the main stream: the role of the reference's dataloader workers + offline completion, which also run beside the training
+    step (tools/train_utils/train_utils.py:22-29 fetches the next batch while the GPU works).  Every step still does one front and one compute;
+    the front's device -> host reads (voxel / site counts) wait for the side stream only, so the main stream never drains."""
+
+    def __init__(self, model, inputs):
+        self.model, self.inputs = model, inputs
+        self.side = torch.cuda.Stream(priority=-1)
+        self.ready = None
+
+    def issue(self):
+        from seevcn_amd.pipeline import record_stream_tree
+        main = torch.cuda.current_stream()
+        if self.ready is None:
+            self.side.wait_stream(main)                                       # first call: inputs / weights were produced on the main stream
+        with torch.cuda.stream(self.side):
+            bd = self.model.front(*self.inputs, SCENES_PER_GPU)
+            ev = self.side.record_event()
+        record_stream_tree(bd, main)
+        self.ready = (bd, ev)
+
+    def take(self):
+        if self.ready is None:
+            self.issue()
+        bd, ev = self.ready
+        torch.cuda.current_stream().wait_event(ev)
+        return bd
+
+
+def run_step_prefetched(model, opt, params, pre, world):
+    """compute(N) on the main stream, then front(N + 1) on the side stream (issued after, so the main stream's queue is already full)."""
+    bd = pre.take()
+    opt.zero_grad(set_to_none=True)
+    loss = loss_fn(model.compute(bd))
+    loss.backward()
+    allreduce_grads(params, world)
+    opt.step()
+    pre.issue()
+    return loss
+
+
 def measure_dominant_kernel(model, inputs, reps=5):
     """Live HIP-event timing of the dominant kernel (the fp32-MFMA GEMM of the VCN layers): every
     sv_gemm_bias_act launch of one VCN forward is bracketed by events on the launch stream."""
@@ -295,6 +349,9 @@ def main():
     ap.add_argument("--objects-per-gpu", type=int, default=None, help="override the 64 objects per GPU (tests)")
     ap.add_argument("--no-kernel-rooflines", action="store_true", help="skip the per-kernel event timing after the timed region (tests)")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only control flow of the multi-rank path (gloo), no kernels")
+    ap.add_argument("--no-prefetch", action="store_true", help="run the input side (stage A, voxelise, rulebooks) in line on the main stream")
+    ap.add_argument("--spinup", type=float, default=0.0, help="seconds of untimed device spin-up (dense GEMMs) before the warm-up steps (A/B switch: a GPU "
+                    "that idled may start below its sustained clocks; measured here: no effect, default off)")
     ap.add_argument("--config", default="main", choices=("main", "stageA", "second", "pvrcnn", "centerpoint"),
                     help="main (default): the headline step; the others are side modes over the other BASELINE configs (bench_configs.py)")
     args = ap.parse_args()
@@ -341,14 +398,17 @@ def main():
     opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, fused=True)     # one multi-tensor kernel instead of ~70 small launches
     inputs = (points, objects, scene)
 
+    device_spinup(args.spinup, device)
+    pre = None if args.no_prefetch else Prefetch(model, inputs)
+    step = (lambda: run_step(model, opt, params, inputs, world)) if pre is None else (lambda: run_step_prefetched(model, opt, params, pre, world))
     for _ in range(args.warmup):
-        run_step(model, opt, params, inputs, world)
+        step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_step(model, opt, params, inputs, world)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -372,8 +432,9 @@ def main():
                                    "DynMeanVFE -> VoxelBackBone8x + HeightCompression fwd+bwd + SGD (BASELINE configs[1]+[2])",
                        "scenes_per_gpu": SCENES_PER_GPU, "objects_per_gpu": OBJECTS_PER_GPU, "points_per_object": 1024,
                        "points_in_range_per_scene": round(in_range / SCENES_PER_GPU),
-                       "geometry": "KITTI [0,-40,-3,70.4,40,1] @ [0.05,0.05,0.1] -> sparse [41,1600,1408]", "parallelism": f"dp{world}"},
-            "completed_objects_per_sec": round(OBJECTS_PER_GPU * world * args.steps / elapsed, 1),
+                       "geometry": "KITTI [0,-40,-3,70.4,40,1] @ [0.05,0.05,0.1] -> sparse [41,1600,1408]", "parallelism": f"dp{world}",
+                       "input_side": "in line" if pre is None else "side stream, one batch ahead (every step = 1 front + 1 compute)"},
+            "completed_objects_per_sec": round(OBJECTS_PER_GPU * world * args.steps / elapsed, 1), "device_spinup_s": args.spinup,
         }
         if not args.no_kernel_rooflines:
             # rank 0 only, so NO collective inside: the measured steps run with world = 1 (the exchange step is skipped)

@@ -174,6 +174,11 @@ int sv_conv_plan_build(const int32_t* masks, int64_t n_rows, void* persistent, i
 int sv_conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc);
 size_t sv_conv_plan_tiles_bytes(int64_t n_rows, int tiles_per_wave);
 int sv_conv_plan_tiles(const int32_t* masks_p, int64_t n_rows, int tiles_per_wave, int32_t* tile_of, void* stream);
+/* Both of the above for one tiles_per_wave value in ONE launch (one workgroup per region, all passes in LDS): perm, masks_p and tile_of as
+ * sv_conv_plan_build + sv_conv_plan_tiles leave them, up to the order of the rows inside a class (results of the convolution do not depend
+ * on it). */
+int sv_conv_plan_build_dealt(const int32_t* masks, int64_t n_rows, int tiles_per_wave, int32_t* perm, int32_t* masks_p, int32_t* tile_of,
+                             void* stream);
 /* 1 iff the plan kernel is built for this layer shape (K <= 27 offsets, C_in in {16,32,64,128}, C_out in {16,32} or a multiple of 64 up to
  * 512) and X (n_src rows) is addressable through a 32-bit buffer descriptor; other shapes take sv_sparse_conv_gather_gemm. */
 int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc, int64_t n_src);
@@ -411,11 +416,21 @@ int sv_vcn_surface_select(const float* partial, const float* complete, int batch
  * noise (the reference raises there); out rows of that object are left untouched. */
 int sv_vcn_largest_cluster(const float* points, int batch, int n, double eps, int min_points, int total_pts, float* out,
                            int32_t* n_cluster, void* stream);
+/* Exact duplicates among n rows [b,x,y,z] (float32, 16-byte aligned): every copy of a row but the first gets b = -1 in place.  The unsorted form of np.unique(np.vstack(instances), axis=0) (SEE_VCN.py:115) for consumers that need the set only; no host
+ * sync.  scratch: sv_dedup_rows_scratch_bytes(n) bytes, any content. */
+size_t sv_dedup_rows_scratch_bytes(int64_t n);
+int sv_dedup_rows(float* rows, int64_t n, void* scratch, void* stream);
+
 /* replace_with_completed_pts (see/surface_completion/SEE_VCN.py:247-265): near[i] = 1 iff some ref point lies closer than
  * thresh to query i (float64 distance, strict <).  ref is expected row-sorted (np.unique) for the tile culling to pay.
  * row_dim 3: rows [x,y,z]; row_dim 4: rows [b,x,y,z] (a batch of scenes, only rows with equal b are compared). */
 int sv_points_near_set(const float* query, int64_t n_query, const float* ref, int64_t n_ref, int row_dim, double thresh,
                        uint8_t* near, void* stream);
+/* The same result through per-tile boxes made once (scratch: sv_points_near_set_scratch_bytes(n_ref) bytes): waves open a reference tile
+ * only if one of their queries is within thresh of its box; reference rows with scene id < 0 (row_dim 4, sv_dedup_rows) are ignored. */
+size_t sv_points_near_set_scratch_bytes(int64_t n_ref);
+int sv_points_near_set_boxed(const float* query, int64_t n_query, const float* ref, int64_t n_ref, int row_dim, double thresh, void* scratch,
+                             uint8_t* near, void* stream);
 
 /* ---- point isolation: the CPU step in front of VCN --------------------------------------------------
  * isolate_gt_pts (see/surface_completion/SEE_VCN.py:61-82): open3d `pcd.crop(OrientedBoundingBox)` for every box of a scene.

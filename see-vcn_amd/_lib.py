@@ -53,6 +53,7 @@ SIGNATURES = {
     "sv_debug_conv_trace": (c_i, [c_p]),
     "sv_conv_tiles_per_wave": (c_i, [c_i64, c_i, c_i]),
     "sv_conv_plan_tiles_bytes": (c_sz, [c_i64, c_i]),
+    "sv_conv_plan_build_dealt": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p]),
     "sv_conv_plan_tiles": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
     "sv_conv_mfma_kernel_applies": (c_i, [c_i, c_i, c_i, c_i64]),
     "sv_conv_weight_fragments": (c_i, [c_p, c_i64, c_i64, c_i64, c_i, c_i, c_i, c_p, c_p, c_p]),
@@ -87,7 +88,11 @@ SIGNATURES = {
     "sv_vcn_surface_select_scratch_bytes": (c_sz, [c_i]),
     "sv_vcn_surface_select": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_vcn_largest_cluster": (c_i, [c_p, c_i, c_i, c_d, c_i, c_i, c_p, c_p, c_p]),
+    "sv_dedup_rows_scratch_bytes": (c_sz, [c_i64]),
+    "sv_dedup_rows": (c_i, [c_p, c_i64, c_p, c_p]),
     "sv_points_near_set": (c_i, [c_p, c_i64, c_p, c_i64, c_i, c_d, c_p, c_p]),
+    "sv_points_near_set_scratch_bytes": (c_sz, [c_i64]),
+    "sv_points_near_set_boxed": (c_i, [c_p, c_i64, c_p, c_i64, c_i, c_d, c_p, c_p, c_p]),
     "sv_points_in_boxes_matrix": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "sv_crop_points_in_boxes": (c_i, [c_p, c_i64, c_i, c_p, c_i, c_i64, c_p, c_p, c_p]),
     "sv_project_lidar_to_image_kitti": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p]),

@@ -517,6 +517,146 @@ __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ 
   }
 }
 
+// The whole plan of a table in ONE launch: the 8 regions are independent (own classes, own positions, own tiles, own waves), so one
+// 1024-thread workgroup per region runs the four passes above back to back out of LDS -- class histogram, exclusive scan, placement
+// (perm / masks_p and the OR of each tile's masks), cost sort + deal -- with workgroup barriers between them instead of kernel boundaries
+// and no global counters at all.  A step of the bench builds 12 plans: 12 launches instead of 48, and none of the ~5 us kernels whose
+// cost is their launch.  Same placement rule (class start + rows of the class placed before), same deal; the order of the rows inside a
+// class depends on LDS atomic order, as it depended on global atomic order before -- results do not depend on it.
+// LDS: 2 x 16 KB class tables + 6 bytes per tile of the largest region.
+struct PlanFusedArgs {
+  const int32_t* masks;
+  int64_t n_rows;
+  int32_t* perm;
+  int32_t* masks_p;
+  int32_t* tile_of;
+  PlanDims d;
+  int max_tiles;          // tiles of the largest region (LDS layout)
+};
+
+__global__ __launch_bounds__(1024) void k_plan_region(PlanFusedArgs a) {
+  extern __shared__ int32_t s_dyn[];
+  int32_t* s_start = s_dyn;                                   // [PL_CLASSES] counts, then class starts
+  int32_t* s_cur = s_dyn + PL_CLASSES;                        // [PL_CLASSES] rows of the class placed so far
+  uint32_t* s_tmask = reinterpret_cast<uint32_t*>(s_dyn + 2 * PL_CLASSES);            // [max_tiles] OR of the tile's 16 masks
+  uint16_t* s_sorted = reinterpret_cast<uint16_t*>(s_tmask + a.max_tiles);            // [max_tiles] tiles in descending cost order
+  __shared__ int s_wsum[16], s_cnt[32], s_cstart[32];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = blockIdx.x;
+  const int64_t row0 = plan_region_start(a.n_rows, r);
+  const int64_t row1 = r + 1 < PL_REGIONS ? plan_region_start(a.n_rows, r + 1) : a.n_rows;
+  const int64_t n_pad = (a.n_rows + 15) / 16 * 16;
+  const int nt = a.d.tiles[r], slots = a.d.n_pass * a.d.G;
+  int32_t* out = a.tile_of + (int64_t)r * PL_REGION_WAVES * slots;
+  for (int i = tid; i < PL_CLASSES; i += 1024) s_start[i] = 0, s_cur[i] = 0;
+  for (int i = tid; i < nt; i += 1024) s_tmask[i] = 0u;
+  for (int i = tid; i < PL_REGION_WAVES * slots; i += 1024) out[i] = -1;
+  if (tid < 32) s_cnt[tid] = 0;
+  __syncthreads();
+  // pass 1: class histogram of the region.  PLR_B masks per thread are requested before the first is used: one workgroup has ~31 rows per
+  // thread and nothing else to hide the load latency behind (one load at a time: 30 us per plan, most of it waiting)
+  constexpr int PLR_B = 8;
+  for (int64_t base = row0; base < row1; base += 1024 * PLR_B) {
+    unsigned m[PLR_B];
+#pragma unroll
+    for (int u = 0; u < PLR_B; ++u) {
+      const int64_t row = base + u * 1024 + tid;
+      m[u] = row < row1 ? (unsigned)a.masks[row] : 0xFFFFFFFFu;            // bit 31 is never set in a mask: marks "no row"
+    }
+#pragma unroll
+    for (int u = 0; u < PLR_B; ++u)
+      if (m[u] != 0xFFFFFFFFu) atomicAdd(&s_start[class_key(m[u])], 1);    // LDS atomic per row: cheaper here than grouping the wave's keys first
+  }
+  __syncthreads();
+  // pass 2: counts -> starts (4 consecutive classes per thread)
+  {
+    int v[4], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = s_start[tid * 4 + u], sum += v[u];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wsum[wid] = incl;
+    __syncthreads();
+    int run = (int)row0 + incl - sum;
+    for (int w = 0; w < wid; ++w) run += s_wsum[w];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s_start[tid * 4 + u] = run, run += v[u];
+  }
+  __syncthreads();
+  // pass 3: placement + the OR of every tile's masks.  The last region also writes the padding of the last tile.
+  const int64_t end = r + 1 < PL_REGIONS ? row1 : n_pad;
+  for (int64_t base = row0; base < end; base += 1024 * PLR_B) {
+    unsigned m[PLR_B];
+#pragma unroll
+    for (int u = 0; u < PLR_B; ++u) {
+      const int64_t row = base + u * 1024 + tid;
+      m[u] = row < row1 ? (unsigned)a.masks[row] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < PLR_B; ++u) {
+      const int64_t row = base + u * 1024 + tid;
+      const bool live = m[u] != 0xFFFFFFFFu;
+      int64_t pos = -1;
+      if (live) {
+        const int key = class_key(m[u]);
+        pos = (int64_t)s_start[key] + atomicAdd(&s_cur[key], 1);
+      } else if (row < end) {
+        pos = row;                                            // padding positions n_rows .. n_pad - 1
+      }
+      if (pos >= row0 && pos < n_pad) {
+        a.perm[pos] = live ? (int32_t)row : -1;
+        a.masks_p[pos] = live ? (int32_t)m[u] : 0;
+        if (live && m[u]) atomicOr(&s_tmask[(pos - row0) >> 4], m[u]);
+      }
+    }
+  }
+  __syncthreads();
+  // pass 4: tiles by descending cost, quads dealt to the 32 CU bins in snake order (k_plan_deal).  Neighbouring tiles are of neighbouring
+  // classes and cost about the same: a wave's 64 tiles hit 2-4 of the 32 counters, so the wave groups its keys before the LDS atomic
+  for (int base = 0; base < nt; base += 1024) {
+    const int t = base + tid;
+    const bool live = t < nt;
+    const int c = live ? min(__popc(s_tmask[t]), 31) : 0;
+    int rank, size, first_lane;
+    wave_key_groups(c, live, rank, size, first_lane);
+    if (live && rank == 0) atomicAdd(&s_cnt[c], size);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int c = 31; c >= 0; --c) s_cstart[c] = acc, acc += s_cnt[c];
+  }
+  __syncthreads();
+  if (tid < 32) s_cnt[tid] = 0;
+  __syncthreads();
+  for (int base = 0; base < nt; base += 1024) {
+    const int t = base + tid;
+    const bool live = t < nt;
+    const int c = live ? min(__popc(s_tmask[t]), 31) : 0;
+    int rank, size, first_lane;
+    wave_key_groups(c, live, rank, size, first_lane);
+    int off = 0;
+    if (live && rank == 0) off = atomicAdd(&s_cnt[c], size);
+    off = __shfl(off, first_lane);
+    if (live) s_sorted[s_cstart[c] + off + rank] = (uint16_t)t;
+  }
+  __syncthreads();
+  const int nq = (nt + PL_QUAD - 1) / PL_QUAD;
+  for (int qd = tid; qd < nq; qd += 1024) {
+    const int j = qd / PL_BINS, pos = qd % PL_BINS;
+    const int bin = (j & 1) ? PL_BINS - 1 - pos : pos;
+    const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;
+#pragma unroll
+    for (int part = 0; part < PL_QUAD; ++part) {
+      const int p = qd * PL_QUAD + part;
+      if (p < nt) out[(int64_t)((bin + PL_BINS * wg) * 4 + part) * slots + j / PL_WAVES_PER_SIMD] = a.d.tile0[r] + s_sorted[p];
+    }
+  }
+}
+
 // Tiles a wave holds in registers at a time: 2 for the 64-column kernels (113 VGPRs: four waves per SIMD), 4 for the narrow ones (their
 // MFMA work per weight load is small).  The weight loads are shared by the G tiles of a pass.
 static int conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc) {
@@ -538,6 +678,33 @@ extern "C" int sv_conv_plan_tiles(const int32_t* masks_p, int64_t n_rows, int ti
   const PlanDims d = plan_dims(n_rows, tiles_per_wave);
   for (int r = 0; r < PL_REGIONS; ++r) SV_CHECK_ARG(d.tiles[r] <= PL_MAX_REGION_TILES, "sv_conv_plan_tiles: at most %d tiles per region", PL_MAX_REGION_TILES);
   hipLaunchKernelGGL(k_plan_deal, dim3(PL_REGIONS), dim3(1024), 0, sv_stream(stream), masks_p, d, tile_of);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// perm + masks_p + tile_of(tiles_per_wave) of a table in one launch (k_plan_region); same outputs as sv_conv_plan_build followed by
+// sv_conv_plan_tiles up to the order of the rows inside a class
+extern "C" int sv_conv_plan_build_dealt(const int32_t* masks, int64_t n_rows, int tiles_per_wave, int32_t* perm, int32_t* masks_p, int32_t* tile_of,
+                                        void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && n_rows < (int64_t)1 << 30 && tiles_per_wave >= 1 && tiles_per_wave <= 4, "sv_conv_plan_build_dealt: bad sizes");
+  if (n_rows == 0) return SV_OK;
+  SV_CHECK_ARG(masks && perm && masks_p && tile_of, "sv_conv_plan_build_dealt: null pointer");
+  PlanFusedArgs a;
+  a.masks = masks, a.n_rows = n_rows, a.perm = perm, a.masks_p = masks_p, a.tile_of = tile_of;
+  a.d = plan_dims(n_rows, tiles_per_wave);
+  a.max_tiles = 1;
+  for (int r = 0; r < PL_REGIONS; ++r) {
+    SV_CHECK_ARG(a.d.tiles[r] <= PL_MAX_REGION_TILES, "sv_conv_plan_build_dealt: at most %d tiles per region", PL_MAX_REGION_TILES);
+    if (a.d.tiles[r] > a.max_tiles) a.max_tiles = a.d.tiles[r];
+  }
+  a.max_tiles = (a.max_tiles + 1) & ~1;                                  // keeps the uint16 array 4-byte aligned
+  const size_t lds = (size_t)2 * PL_CLASSES * 4 + (size_t)a.max_tiles * 6;
+  static bool raised = false;
+  if (lds > 48 * 1024 && !raised) {
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_region), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    raised = true;
+  }
+  hipLaunchKernelGGL(k_plan_region, dim3(PL_REGIONS), dim3(1024), lds, sv_stream(stream), a);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

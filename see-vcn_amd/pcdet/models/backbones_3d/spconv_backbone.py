@@ -67,7 +67,8 @@ class _BackBone8xBase(nn.Module):
     def forward(self, batch_dict):
         voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         input_sp_tensor = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(),
-                                                  spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+                                                  spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'],
+                                                  indice_dict=batch_dict.get('spconv_indice_dict'))      # seevcn: rulebooks built ahead (pipeline.front)
         # all rulebooks + conv plans first: their host syncs then wait for index kernels only, and the layer loop below is enqueued without one
         spconv.prebuild_rulebooks(self, input_sp_tensor, with_backward=self.training and torch.is_grad_enabled())
         x = self.conv_input(input_sp_tensor)

@@ -50,10 +50,49 @@ class SceneStep(nn.Module):
         clustered, _ = get_largest_cluster_batch_device(surface, eps=self.cluster_eps, min_points=2, total_pts=coarse.shape[1])
         return complete_scene_batch_device(points, clustered, object_scene, 0.1, compact=False)   # replaced points: scene id -1, dropped by the VFE
 
-    def forward(self, points, objects, object_scene, batch_size):
-        pts = self.complete_and_paste(points, objects, object_scene)
-        bd = {'batch_size': batch_size, 'points': pts}
-        bd = self.vfe(bd)
+    def front(self, points, objects, object_scene, batch_size):
+        """The INPUT side of the step -- everything that depends on the scene batch only, not on the trained weights: stage A (frozen VCN,
+        surface selection, cluster, merge), dynamic voxelisation + mean VFE, and every rulebook / convolution plan of the backbone.  No
+        gradients.  This is what the reference does ahead of the training step (SEE-VCN writes completed clouds offline, SEE_VCN.py:85-115;
+        pcdet voxelises in dataloader workers, dataset.py:126-160); here it may run on a side stream for batch N + 1 while batch N trains
+        (bench.py), and its device -> host reads (voxel counts) then wait for index kernels only."""
+        from . import spconv
+        with torch.no_grad():
+            pts = self.complete_and_paste(points, objects, object_scene)
+            bd = self.vfe({'batch_size': batch_size, 'points': pts})
+            sp = spconv.SparseConvTensor(features=bd['voxel_features'], indices=bd['voxel_coords'].int(), spatial_shape=self.backbone_3d.sparse_shape,
+                                         batch_size=batch_size)
+            spconv.prebuild_rulebooks(self.backbone_3d, sp, with_backward=self.training)
+            bd['voxel_coords'] = sp.indices                       # the very tensor the rulebooks are bound to
+            bd['spconv_indice_dict'] = sp.indice_dict
+        return bd
+
+    def compute(self, bd):
+        """The trained side: VoxelBackBone8x over the prebuilt rulebooks -> HeightCompression (autograd graph starts here)."""
         bd = self.backbone_3d(bd)
         bd = self.map_to_bev(bd)
         return bd
+
+    def forward(self, points, objects, object_scene, batch_size):
+        return self.compute(self.front(points, objects, object_scene, batch_size))
+
+
+def record_stream_tree(obj, stream, _seen=None):
+    """tensor.record_stream(stream) on every CUDA tensor reachable from obj (dicts, sequences, SparseConvTensor / Rulebook / TablePlan
+    objects): tensors produced on a side stream and consumed on `stream` must tell the caching allocator so, or a later side-stream allocation
+    may reuse their memory while `stream` still reads it."""
+    seen = set() if _seen is None else _seen
+    if id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            record_stream_tree(v, stream, seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            record_stream_tree(v, stream, seen)
+    elif hasattr(obj, '__dict__') and type(obj).__module__.startswith(__name__.split('.')[0]):
+        record_stream_tree(vars(obj), stream, seen)

@@ -26,7 +26,7 @@ class TablePlan:
     k-major table), the regrouping of the rows (sv_conv_plan_build) and the tile -> wave assignment per tiles-per-wave value
     (sv_conv_plan_tiles).  Built once per table, reused by every launch on it."""
 
-    def __init__(self, table, n_rows, K, rows=None, masks=None):
+    def __init__(self, table, n_rows, K, rows=None, masks=None, g=None):
         lib = _lib.load()
         dev = table.device
         self.n_rows, self.K = int(n_rows), int(K)
@@ -39,16 +39,24 @@ class TablePlan:
         n_perm = lib.sv_conv_plan_perm_bytes(self.n_rows) // 4
         self.perm = torch.empty((n_perm,), dtype=torch.int32, device=dev)
         self.masks_p = torch.empty((n_perm,), dtype=torch.int32, device=dev)
+        self._tiles = {}
+        if g is not None and FUSED_PLAN:
+            # regrouping + the tile deal for this tiles-per-wave value in one launch (one workgroup per region)
+            t = torch.empty((lib.sv_conv_plan_tiles_bytes(self.n_rows, int(g)) // 4,), dtype=torch.int32, device=dev)
+            _lib.check(lib.sv_conv_plan_build_dealt(_lib.ptr(masks), self.n_rows, int(g), _lib.ptr(self.perm), _lib.ptr(self.masks_p), _lib.ptr(t),
+                                                    _lib.stream()), "sv_conv_plan_build_dealt")
+            self._tiles[int(g)] = t
+            return
         hist = _lib.workspace.persistent("conv_plan_hist", lib.sv_conv_plan_persistent_bytes(), dev)
         _lib.check(lib.sv_conv_plan_build(_lib.ptr(masks), self.n_rows, _lib.ptr(hist), _lib.ptr(self.perm), _lib.ptr(self.masks_p), _lib.stream()),
                    "sv_conv_plan_build")
-        self._tiles = {}
 
     def tiles(self, g):
+        g = int(g)
         if g not in self._tiles:
             lib = _lib.load()
-            t = torch.empty((lib.sv_conv_plan_tiles_bytes(self.n_rows, int(g)) // 4,), dtype=torch.int32, device=self.perm.device)
-            _lib.check(lib.sv_conv_plan_tiles(_lib.ptr(self.masks_p), self.n_rows, int(g), _lib.ptr(t), _lib.stream()), "sv_conv_plan_tiles")
+            t = torch.empty((lib.sv_conv_plan_tiles_bytes(self.n_rows, g) // 4,), dtype=torch.int32, device=self.perm.device)
+            _lib.check(lib.sv_conv_plan_tiles(_lib.ptr(self.masks_p), self.n_rows, g, _lib.ptr(t), _lib.stream()), "sv_conv_plan_tiles")
             self._tiles[g] = t
         return self._tiles[g]
 
@@ -103,13 +111,13 @@ class Rulebook:
         if not USE_PLAN or n_rows == 0 or not lib.sv_conv_mfma_kernel_applies(int(self.K), kd, nc, int(n_src)):
             return None
         key = "fwd" if (direction == "fwd" or self.subm) else "bwd"
+        g = lib.sv_conv_tiles_per_wave(n_rows, kd, nc)
         if key not in self._plans:
             if key == "fwd":
-                self._plans[key] = TablePlan(self.nbr_out, n_rows, self.K, self.rows_out, self.masks_out)
+                self._plans[key] = TablePlan(self.nbr_out, n_rows, self.K, self.rows_out, self.masks_out, g=g)
             else:
-                self._plans[key] = TablePlan(self.nbr_in, n_rows, self.K, self.rows_in, self.masks_in)
+                self._plans[key] = TablePlan(self.nbr_in, n_rows, self.K, self.rows_in, self.masks_in, g=g)
         tp = self._plans[key]
-        g = lib.sv_conv_tiles_per_wave(n_rows, kd, nc)
         return tp, tp.tiles(g), g, (direction == "bwd" and self.subm)
 
     def pair_counts(self):
@@ -122,6 +130,7 @@ class Rulebook:
 
 # dense cell -> row maps (4 B per cell) up to this size replace the rank dictionary in submanifold rulebooks (MI355X: 288 GB of HBM)
 CELLMAP_MAX_BYTES = int(os.environ.get("SEEVCN_CELLMAP_MAX_BYTES", 24 << 30))
+FUSED_PLAN = os.environ.get("SEEVCN_FUSED_PLAN", "1") != "0"     # 0: plans built by the four separate kernels (A/B runs, tests)
 USE_PLAN = os.environ.get("SEEVCN_SPCONV_PLAN", "1") != "0"      # 0: every layer on the plain kernels (A/B runs, tests)
 
 

@@ -20,8 +20,9 @@ def points_near_set(query, ref, thresh):
     q, r = query.detach().float().contiguous(), ref.detach().float().contiguous()
     assert q.dim() == 2 and q.shape[1] == r.shape[1] and q.shape[1] in (3, 4)
     near = torch.empty((q.shape[0],), dtype=torch.uint8, device=q.device)
-    _lib.check(lib.sv_points_near_set(_lib.ptr(q) if q.numel() else None, q.shape[0], _lib.ptr(r) if r.numel() else None, r.shape[0], q.shape[1], float(thresh),
-                                      _lib.ptr(near) if q.numel() else None, _lib.stream()), "sv_points_near_set")
+    scratch = _lib.workspace.scratch("near_set_boxes", lib.sv_points_near_set_scratch_bytes(r.shape[0]), q.device)
+    _lib.check(lib.sv_points_near_set_boxed(_lib.ptr(q) if q.numel() else None, q.shape[0], _lib.ptr(r) if r.numel() else None, r.shape[0], q.shape[1],
+                                            float(thresh), _lib.ptr(scratch), _lib.ptr(near) if q.numel() else None, _lib.stream()), "sv_points_near_set_boxed")
     return near.bool()
 
 
@@ -51,10 +52,19 @@ def complete_scene_batch_device(points, clustered, object_scene, point_dist_thre
     compact=False keeps the replaced scene points in place with scene id -1 (every consumer downstream -- the voxelisers -- drops
     rows whose scene id is out of range): no boolean-mask compaction, hence no host sync, when the cloud only feeds voxelisation."""
     bcol = object_scene.to(clustered.dtype).view(-1, 1, 1).expand(-1, clustered.shape[1], 1)
-    inst = torch.unique(torch.cat([bcol, clustered], dim=2).view(-1, 4), dim=0)        # row-sorted: scene id first, like one np.unique per scene
-    near = points_near_set(points, inst, point_dist_thresh)
+    rows = torch.cat([bcol, clustered], dim=2).view(-1, 4)
     if compact:
+        inst = torch.unique(rows, dim=0)                          # row-sorted: scene id first, like one np.unique per scene
+        near = points_near_set(points, inst, point_dist_thresh)
         return torch.cat([inst, points[~near]], dim=0)
-    out = torch.cat([inst, points], dim=0)
-    out[inst.shape[0]:, 0].masked_fill_(near, -1.0)
+    # the SET of completed points is all the voxelisers need: copies get scene id -1 in place (sv_dedup_rows) instead of a sort, a
+    # compaction and the host sync that sizes its result; object-contiguous rows also give k_points_near_set tight tile boxes
+    lib = _lib.load()
+    rows = rows.float().contiguous()
+    n = rows.shape[0]
+    scratch = _lib.workspace.scratch("dedup_rows", lib.sv_dedup_rows_scratch_bytes(n), rows.device)
+    _lib.check(lib.sv_dedup_rows(_lib.ptr(rows) if n else None, n, _lib.ptr(scratch), _lib.stream()), "sv_dedup_rows")
+    near = points_near_set(points, rows, point_dist_thresh)
+    out = torch.cat([rows, points], dim=0)
+    out[n:, 0].masked_fill_(near, -1.0)
     return out

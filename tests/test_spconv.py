@@ -263,8 +263,9 @@ def test_hip_weight_fragments_follow_the_weights_even_under_a_fused_optimizer(cu
 
 
 @pytest.mark.gpu
-def test_hip_table_plan_is_a_permutation_into_regions_with_balanced_waves(cuda, hip_lib):
-    """Structure of a plan at bench size: every row appears exactly once, inside its own region; tile_of covers every tile exactly once per
+@pytest.mark.parametrize("fused", [True, False])
+def test_hip_table_plan_is_a_permutation_into_regions_with_balanced_waves(cuda, hip_lib, fused, monkeypatch):
+    """(fused: the one-launch builder k_plan_region; otherwise the four separate kernels.)  Structure of a plan at bench size: every row appears exactly once, inside its own region; tile_of covers every tile exactly once per
     region; rows of a tile share their mask class in >= 85 % of the tiles; the busiest wave has <= 1.15x the mean work."""
     import seevcn_amd.synth as synth
     from seevcn_amd.pcdet.ops import voxel_ops
@@ -272,6 +273,7 @@ def test_hip_table_plan_is_a_permutation_into_regions_with_balanced_waves(cuda, 
     bs = 8
     pts, _ = synth.make_scene_batch(bs, seed=2000)
     feats, coords, _ = voxel_ops.voxelize_dynamic(torch.from_numpy(pts).to(cuda), [0, -40, -3, 70.4, 40, 1], [0.05, 0.05, 0.1], [1408, 1600, 40], bs)
+    monkeypatch.setattr(Fsp, "FUSED_PLAN", fused)
     rb = Fsp.build_subm_rulebook(coords, bs, [41, 1600, 1408], [3, 3, 3])                                # ~120 k rows: 7-8 quads per CU bin
     n = rb.n_out
     tp, tile_of, g, rev = rb.plan("fwd", 64, 64)
