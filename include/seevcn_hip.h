@@ -202,6 +202,11 @@ int sv_debug_conv_trace(void* buf);
 size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout);
 int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
                          int Cin, int Cout, void* scratch, void* stream);
+/* The same with element (k, c_in, c_out) written at dW[k * stride_k + c_in * stride_cin + c_out * stride_cout] -- the layout of the
+ * caller's parameter (spconv's (C_out, kz, ky, kx, C_in)), so that no transposing copy of the gradient is needed.  The strides must
+ * address a permutation of the K * C_in * C_out slab. */
+int sv_sparse_conv_wgrad_strided(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin, int Cout,
+                                 int64_t stride_k, int64_t stride_cin, int64_t stride_cout, void* scratch, void* stream);
 
 /* SparseConvTensor.dense(): (N,C) + coords -> (B, C, D, H, W), every element written once */
 size_t sv_sparse_to_dense_scratch_bytes(int batch, int D, int H, int W);

@@ -1341,17 +1341,30 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_valu(WgradArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nchunks, int64_t slab, float* __restrict__ dW) {
+// where element (k, c_in, c_out) of the weight gradient goes: contiguous (K, C_in, C_out) or the strides of the caller's parameter layout
+// (spconv keeps (C_out, kz, ky, kx, C_in): writing the gradient there directly spares the framework a transposing copy per layer and step)
+struct WgradOut {
+  int64_t sk, si, so;
+  int Cin, Cout, dense;
+  __device__ __forceinline__ int64_t at(int64_t e) const {
+    if (dense) return e;
+    const int co = (int)(e % Cout);
+    const int64_t t = e / Cout;
+    return (t / Cin) * sk + (t % Cin) * si + co * so;
+  }
+};
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nchunks, int64_t slab, float* __restrict__ dW, WgradOut o) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < slab; e += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * slab + e];
-    dW[e] = s;
+    dW[o.at(e)] = s;
   }
 }
 
 // slab % 4 == 0: 64 float4 columns x 4 quarters of the chunk range per workgroup -- four times the loads in flight of the scalar
 // kernel, partial sums combined in a fixed order ((q0 + q1) + (q2 + q3)): still bitwise reproducible
-__global__ __launch_bounds__(256) void k_wgrad_reduce4(const float* __restrict__ partial, int nchunks, int64_t slab4, float* __restrict__ dW) {
+__global__ __launch_bounds__(256) void k_wgrad_reduce4(const float* __restrict__ partial, int nchunks, int64_t slab4, float* __restrict__ dW, WgradOut o) {
   __shared__ f32x4 s_q[4][64];
   const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t e = (int64_t)blockIdx.x * 64 + col;
@@ -1364,7 +1377,15 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce4(const float* __restrict__
   }
   s_q[q][col] = s;
   __syncthreads();
-  if (q == 0 && e < slab4) reinterpret_cast<f32x4*>(dW)[e] = (s_q[0][col] + s_q[1][col]) + (s_q[2][col] + s_q[3][col]);
+  if (q == 0 && e < slab4) {
+    const f32x4 v = (s_q[0][col] + s_q[1][col]) + (s_q[2][col] + s_q[3][col]);
+    if (o.dense) {
+      reinterpret_cast<f32x4*>(dW)[e] = v;
+    } else {                                                  // C_out % 4 == 0 here: the four values are consecutive output channels of one (k, c_in)
+      const int64_t b = o.at(e * 4);
+      dW[b] = v.x, dW[b + o.so] = v.y, dW[b + 2 * o.so] = v.z, dW[b + 3 * o.so] = v.w;
+    }
+  }
 }
 
 extern "C" size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout) {
@@ -1380,13 +1401,13 @@ static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL>), dim3(blocks), dim3(256), 0, st, a);
 }
 
-extern "C" int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
-                                    int Cin, int Cout, void* scratch, void* stream) {
+static int wgrad_run(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
+                                    int Cin, int Cout, void* scratch, void* stream, WgradOut out) {
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Cin > 0 && Cout > 0 && dW, "sparse_conv_wgrad: bad arguments");
   hipStream_t st = sv_stream(stream);
   const int64_t slab = (int64_t)K * Cin * Cout;
   if (n_rows == 0) {
-    SV_HIP(hipMemsetAsync(dW, 0, (size_t)slab * 4, st));
+    SV_HIP(hipMemsetAsync(dW, 0, (size_t)slab * 4, st));      // every element, whatever the layout (the strided form is a permutation of the slab)
     return SV_OK;
   }
   SV_CHECK_ARG(X && nbr && dY && scratch, "sparse_conv_wgrad: null pointer");
@@ -1415,10 +1436,22 @@ extern "C" int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const fl
     hipLaunchKernelGGL(k_spconv_wgrad_valu, dim3(a.nchunks, K), dim3(256), 0, st, a);
     nslabs = a.nchunks;
   }
-  if (slab % 4 == 0 && (uintptr_t)dW % 16 == 0 && (uintptr_t)a.partial % 16 == 0)
-    hipLaunchKernelGGL(k_wgrad_reduce4, dim3(sv_div_up(slab / 4, 64)), dim3(256), 0, st, a.partial, nslabs, slab / 4, dW);
+  if (slab % 4 == 0 && Cout % 4 == 0 && (uintptr_t)dW % 16 == 0 && (uintptr_t)a.partial % 16 == 0)
+    hipLaunchKernelGGL(k_wgrad_reduce4, dim3(sv_div_up(slab / 4, 64)), dim3(256), 0, st, a.partial, nslabs, slab / 4, dW, out);
   else
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(sv_grid_1d(slab, 256)), dim3(256), 0, st, a.partial, nslabs, slab, dW);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(sv_grid_1d(slab, 256)), dim3(256), 0, st, a.partial, nslabs, slab, dW, out);
   SV_LAUNCH_CHECK();
   return SV_OK;
+}
+
+extern "C" int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
+                                    int Cin, int Cout, void* scratch, void* stream) {
+  return wgrad_run(X, nbr, dY, dW, n_rows, K, Cin, Cout, scratch, stream, WgradOut{0, 0, 0, Cin, Cout, 1});
+}
+
+// the same with the gradient written at element strides (stride_k, stride_cin, stride_cout) of dW -- a permutation of the K * C_in * C_out slab
+extern "C" int sv_sparse_conv_wgrad_strided(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
+                                    int Cin, int Cout, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, void* scratch, void* stream) {
+  SV_CHECK_ARG(stride_k > 0 && stride_cin > 0 && stride_cout > 0, "sparse_conv_wgrad_strided: strides must be positive");
+  return wgrad_run(X, nbr, dY, dW, n_rows, K, Cin, Cout, scratch, stream, WgradOut{stride_k, stride_cin, stride_cout, Cin, Cout, 0});
 }

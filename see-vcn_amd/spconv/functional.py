@@ -279,15 +279,36 @@ def gather_gemm(x, nbr, wt, n_rows, bias=None, scale=None, shift=None, residual=
     return y
 
 
-def wgrad(x, nbr, dy, K, cin, cout):
+def wgrad(x, nbr, dy, K, cin, cout, like=None):
+    """dW (K, C_in, C_out).  `like`: a (K, C_in, C_out) VIEW of the parameter (SparseConvolution.weight_kio()); the gradient is then written
+    in that view's memory layout (same strides over a fresh dense buffer), so that autograd's way back through the permute / reshape of the
+    view is a view again instead of a transposing copy (one small launch per layer and step otherwise)."""
     lib = _lib.load()
     n_rows = dy.shape[0]
-    dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dy.device)
     scratch = _lib.workspace.scratch("wgrad", lib.sv_sparse_conv_wgrad_scratch_bytes(n_rows, K, cin, cout), dy.device)
-    rc = lib.sv_sparse_conv_wgrad(_lib.ptr(x) if x.numel() else None, _lib.ptr(nbr) if nbr.numel() else None,
-                                  _lib.ptr(dy) if n_rows else None, _lib.ptr(dw), n_rows, K, cin, cout, _lib.ptr(scratch), _lib.stream())
+    xs, ns, ds = (_lib.ptr(x) if x.numel() else None), (_lib.ptr(nbr) if nbr.numel() else None), (_lib.ptr(dy) if n_rows else None)
+    st = None if like is None else tuple(int(v) for v in like.stride())
+    if st is not None and not like.is_contiguous() and min(st) > 0 and sorted(st)[0] == 1 and _dense_permutation(tuple(like.shape), st):
+        dw = torch.empty_strided((K, cin, cout), st, dtype=torch.float32, device=dy.device)
+        rc = lib.sv_sparse_conv_wgrad_strided(xs, ns, ds, dw.data_ptr(), n_rows, K, cin, cout, st[0], st[1], st[2], _lib.ptr(scratch), _lib.stream())
+        _lib.check(rc, "sv_sparse_conv_wgrad_strided")
+        return dw
+    dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dy.device)
+    rc = lib.sv_sparse_conv_wgrad(xs, ns, ds, _lib.ptr(dw), n_rows, K, cin, cout, _lib.ptr(scratch), _lib.stream())
     _lib.check(rc, "sv_sparse_conv_wgrad")
     return dw
+
+
+def _dense_permutation(shape, strides):
+    """True when (shape, strides) address every element of a dense buffer of prod(shape) elements exactly once."""
+    expect = 1
+    for sz, st in sorted(zip(shape, strides), key=lambda t: t[1]):
+        if sz == 1:
+            continue
+        if st != expect:
+            return False
+        expect *= sz
+    return True
 
 
 class SparseConvFunction(torch.autograd.Function):
@@ -327,7 +348,7 @@ class SparseConvFunction(torch.autograd.Function):
             else:
                 gf = gather_gemm(grad_out, rb.table_for_backward_data(), weight_kio.detach(), rb.n_in)
         if ctx.needs_input_grad[1]:
-            gw = wgrad(features, rb.nbr_out, grad_out, K, cin, cout)
+            gw = wgrad(features, rb.nbr_out, grad_out, K, cin, cout, like=weight_kio)
         return gf, gw, None
 
 
