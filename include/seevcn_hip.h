@@ -188,6 +188,10 @@ int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc, int64_t n_src);
  * weight version; either may be null). */
 int sv_conv_weight_fragments(const float* W, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, int K, int Cin, int Cout, float* frag_fwd,
                              float* frag_bwd, void* stream);
+/* The same for n_layers weights in one launch.  descs_device: (n_layers, 10) int64 ON THE DEVICE, per layer {W pointer, stride_k, stride_cin,
+ * stride_cout, K, C_in, C_out, frag_fwd pointer, frag_bwd pointer, first unit}; a layer has 2 * K * C_in * C_out / 4 units (float4, forward
+ * then backward view), "first unit" is the running sum of the layers before it, total_units the sum over all layers. */
+int sv_conv_weight_fragments_batch(const void* descs_device, int n_layers, int64_t total_units, void* stream);
 /* table_k_reversed: offset k reads table entry K-1-k (a submanifold table serving its own data gradient, no flipped copy). */
 int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src, const int32_t* table_rows, const int32_t* perm, const int32_t* masks_p,
                                        const int32_t* tile_of, int tiles_per_wave,

@@ -53,6 +53,7 @@ SIGNATURES = {
     "sv_debug_conv_trace": (c_i, [c_p]),
     "sv_conv_tiles_per_wave": (c_i, [c_i64, c_i, c_i]),
     "sv_conv_plan_tiles_bytes": (c_sz, [c_i64, c_i]),
+    "sv_conv_weight_fragments_batch": (c_i, [c_p, c_i, c_i64, c_p]),
     "sv_conv_plan_build_dealt": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p]),
     "sv_conv_plan_tiles": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
     "sv_conv_mfma_kernel_applies": (c_i, [c_i, c_i, c_i, c_i64]),

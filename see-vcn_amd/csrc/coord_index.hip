@@ -79,23 +79,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const int32_t*
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_sums(int32_t* __restrict__ block_sums, int nblocks,
-                                                    int32_t* __restrict__ total_out) {
-  int carry = 0;
-  for (int t0 = 0; t0 < nblocks; t0 += 1024) {
-    const int i = t0 + threadIdx.x;
-    const int v = i < nblocks ? block_sums[i] : 0;
-    int tot;
-    const int ex = block_excl_scan<1024>(v, &tot);
-    if (i < nblocks) block_sums[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0 && total_out) *total_out = carry;
-}
-
+// Every workgroup adds up the sums of the blocks before it by itself (a few hundred values, coalesced) instead of reading them from a
+// scan made by a one-workgroup kernel in between: two launches per scan instead of three.  The last block also writes the grand total.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_downsweep(const int32_t* __restrict__ in, int64_t n,
                                                                  const int32_t* __restrict__ block_sums,
-                                                                 int32_t* __restrict__ out) {
+                                                                 int32_t* __restrict__ out, int32_t* __restrict__ total_out) {
+  int before = 0;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) before += block_sums[j];
+  int block_off;
+  block_excl_scan<SCAN_THREADS>(before, &block_off);
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   int v[SCAN_ITEMS];
   const bool full = base + SCAN_ITEMS <= n;
@@ -114,7 +106,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_downsweep(const int32_t* 
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) { const int t = v[i]; v[i] = s; s += t; }
   int tot;
-  const int off = block_excl_scan<SCAN_THREADS>(s, &tot) + block_sums[blockIdx.x];
+  const int off = block_excl_scan<SCAN_THREADS>(s, &tot) + block_off;
+  if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = block_off + tot;
   if (full) {
     int4* q = reinterpret_cast<int4*>(out + base);
 #pragma unroll
@@ -141,9 +134,8 @@ int sv_index_scan_launch(const SvIndexView& ix, int32_t* total_out, void* scan_t
   const int nblocks = (int)((nchunks + SCAN_TILE - 1) / SCAN_TILE);
   int32_t* sums = reinterpret_cast<int32_t*>(scan_tmp);
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(SCAN_THREADS), 0, st, ix.chunk_cnt, nchunks, sums);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, sums, nblocks, total_out);
   hipLaunchKernelGGL(k_scan_downsweep, dim3(nblocks), dim3(SCAN_THREADS), 0, st, ix.chunk_cnt, nchunks, sums,
-                     ix.chunk_base);
+                     ix.chunk_base, total_out);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

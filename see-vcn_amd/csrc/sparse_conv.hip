@@ -749,6 +749,49 @@ extern "C" int sv_conv_weight_fragments(const float* W, int64_t stride_k, int64_
   return SV_OK;
 }
 
+// All layers of a network in ONE launch: descs (n, 10) int64 on the device = {W, stride_k, stride_cin, stride_cout, K, C_in, C_out, frag_fwd,
+// frag_bwd, first float4 unit of the layer in the launch}; a step of the bench re-lays 11 layers (the fragments follow the weights every
+// forward, see spconv/functional.py), one 4 us launch each before.
+struct FragDesc {
+  const float* w;
+  int64_t sk, si, so, K, Cin, Cout;
+  float* fwd;
+  float* bwd;
+  int64_t unit0;
+};
+__global__ __launch_bounds__(256) void k_weight_fragments_batch(const FragDesc* __restrict__ descs, int n, int64_t total_units) {
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total_units; u += (int64_t)gridDim.x * 256) {
+    int l = 0;
+    while (l + 1 < n && descs[l + 1].unit0 <= u) ++l;
+    const FragDesc d = descs[l];
+    const int K = (int)d.K, Cin = (int)d.Cin, Cout = (int)d.Cout;
+    const int total = K * Cin * Cout / 4;
+    const int i = (int)(u - d.unit0);
+    const bool bwd = i >= total;
+    const int e = bwd ? i - total : i;
+    const int Nc = bwd ? Cin : Cout, Kd = bwd ? Cout : Cin;
+    const int64_t sn = bwd ? d.si : d.so, sc = bwd ? d.so : d.si;
+    const int KQ = Kd / 16, NT = Nc / 16;
+    const int lane = e & 63, t = (e >> 6) % NT, q = ((e >> 6) / NT) % KQ, k = (e >> 6) / (NT * KQ);
+    const int li = lane & 15, kk = lane >> 4;
+    const float* src = d.w + k * d.sk + (t * 16 + li) * sn + (q * 16 + kk * 4) * sc;
+    float4 v;
+    if (sc == 1 && (((uintptr_t)src) & 15) == 0) v = *reinterpret_cast<const float4*>(src);
+    else v = make_float4(src[0], src[sc], src[2 * sc], src[3 * sc]);
+    reinterpret_cast<float4*>(bwd ? d.bwd : d.fwd)[e] = v;
+  }
+}
+
+extern "C" int sv_conv_weight_fragments_batch(const void* descs_device, int n_layers, int64_t total_units, void* stream) {
+  SV_CHECK_ARG(n_layers >= 0 && total_units >= 0, "sv_conv_weight_fragments_batch: bad sizes");
+  if (n_layers == 0 || total_units == 0) return SV_OK;
+  SV_CHECK_ARG(descs_device, "sv_conv_weight_fragments_batch: null pointer");
+  hipLaunchKernelGGL(k_weight_fragments_batch, dim3(sv_grid_1d(total_units, 256, 2048)), dim3(256), 0, sv_stream(stream),
+                     static_cast<const FragDesc*>(descs_device), n_layers, total_units);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The MFMA kernel on a plan.  Register-stationary like k_spconv_rs above, plus:
 //   * PMC on k_spconv_rs: matrix core busy 38 %, waves waiting for operands that were requested only one 64-MFMA step (~2000 cycles)

@@ -71,6 +71,8 @@ class _BackBone8xBase(nn.Module):
                                                   indice_dict=batch_dict.get('spconv_indice_dict'))      # seevcn: rulebooks built ahead (pipeline.front)
         # all rulebooks + conv plans first: their host syncs then wait for index kernels only, and the layer loop below is enqueued without one
         spconv.prebuild_rulebooks(self, input_sp_tensor, with_backward=self.training and torch.is_grad_enabled())
+        # the MFMA fragment copies of all layer weights in one launch (they follow the weights every forward; spconv/functional.py)
+        spconv.refresh_weight_fragments(self)
         x = self.conv_input(input_sp_tensor)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)

@@ -7,7 +7,7 @@ generators the dataloader binds (datasets/processor/data_processor.py:17-59).
 """
 from . import conv  # noqa: F401
 from . import utils  # noqa: F401  (spconv.utils.VoxelGeneratorV2 / VoxelGenerator / Point2VoxelCPU3d, data_processor.py:17-26)
-from .conv import SparseConv3d, SparseConvolution, SparseInverseConv3d, SubMConv3d, prebuild_rulebooks  # noqa: F401
+from .conv import SparseConv3d, SparseConvolution, SparseInverseConv3d, SubMConv3d, prebuild_rulebooks, refresh_weight_fragments  # noqa: F401
 from .core import SparseConvTensor  # noqa: F401
 from .modules import SparseModule, SparseSequential  # noqa: F401
 

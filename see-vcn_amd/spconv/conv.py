@@ -137,3 +137,12 @@ def prebuild_rulebooks(root, x, with_backward=True):
             rb.plan("bwd", m.out_channels, m.in_channels)
         if not m.subm:
             idx, shape = rb.out_indices, list(rb.out_shape)
+
+
+def refresh_weight_fragments(root):
+    """One launch that re-lays the MFMA fragment copies of every planned-kernel convolution under `root` (Fsp.fragment_cache.refresh_all)."""
+    if not Fsp.USE_PLAN:
+        return
+    ws = [m.weight_kio() for m in root.modules() if isinstance(m, SparseConvolution) and m.weight.is_cuda]
+    with torch.no_grad():
+        Fsp.fragment_cache.refresh_all(ws)

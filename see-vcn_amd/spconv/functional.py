@@ -184,7 +184,7 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
     cap = max(min(n_in * per_in, ncells), 1)
     out_coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     nbr_in = torch.empty((K, n_in), dtype=torch.int32, device=dev)
-    num_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+    num_out = torch.empty((1,), dtype=torch.int32, device=dev)      # zeroed by sv_rulebook_sparse
     with_rows = K <= 27 and n_in > 0
     in_block = torch.empty((33 * n_in,), dtype=torch.int32, device=dev) if with_rows else None     # [rows (n_in, 32) | masks (n_in)]
     rc = lib.sv_rulebook_sparse(_lib.ptr(indices), n_in, int(batch_size), _i3(spatial_shape), _i3(ksize), _i3(stride),
@@ -219,30 +219,65 @@ class _FragmentCache:
 
     def __init__(self):
         self._d = {}
+        self._fresh = set()          # entries re-laid by refresh_all and not yet taken by their layer's forward
+        self._tables = {}            # descriptor tables of refresh_all, by the identity of the weight set
 
-    def get(self, weight_kio, refresh=True):
+    def _entry(self, weight_kio):
         base = weight_kio._base if weight_kio._base is not None else weight_kio
         K, cin, cout = weight_kio.shape
         key = id(base)
         hit = self._d.get(key)
-        fwd = bwd = None
         if hit is not None and hit[0]() is base and hit[1].numel() == K * cin * cout and hit[1].device == weight_kio.device:
-            fwd, bwd = hit[1], hit[2]
-            if not refresh:
-                return fwd, bwd
-        if fwd is None:
-            fwd = torch.empty((K * cin * cout,), dtype=torch.float32, device=weight_kio.device)
-            bwd = torch.empty_like(fwd)
+            return key, hit[1], hit[2], True
+        fwd = torch.empty((K * cin * cout,), dtype=torch.float32, device=weight_kio.device)
+        bwd = torch.empty_like(fwd)
+        d = self._d
+        self._d[key] = (weakref.ref(base, lambda _r, k=key: (d.pop(k, None), self._fresh.discard(k))), fwd, bwd)
+        return key, fwd, bwd, False
+
+    def refresh_all(self, weights):
+        """Re-lay the fragments of every (K, C_in, C_out) weight view in `weights` in ONE launch (a backbone calls this at the top of its
+        forward); each layer's get() of this forward then takes its pair without a launch of its own.  An entry stays fresh only until it is
+        taken once or the next refresh_all."""
+        lib = _lib.load()
+        self._fresh.clear()
+        weights = [w for w in weights if w.is_cuda and w.dtype == torch.float32 and w.shape[1] % 16 == 0 and w.shape[2] % 16 == 0]
+        if not weights:
+            return
+        rows, keys, unit0 = [], [], 0
+        for w in weights:
+            key, fwd, bwd, _ = self._entry(w)
+            K, cin, cout = w.shape
+            sk, si, so = w.stride()
+            rows.append([w.data_ptr(), sk, si, so, K, cin, cout, fwd.data_ptr(), bwd.data_ptr(), unit0])
+            unit0 += 2 * K * cin * cout // 4
+            keys.append(key)
+        sig = tuple(tuple(r) for r in rows)
+        table = self._tables.get(sig)
+        if table is None:
+            if len(self._tables) > 16:
+                self._tables.clear()
+            table = torch.tensor(rows, dtype=torch.int64).to(weights[0].device)
+            self._tables[sig] = table
+        _lib.check(lib.sv_conv_weight_fragments_batch(_lib.ptr(table), len(rows), unit0, _lib.stream()), "sv_conv_weight_fragments_batch")
+        self._fresh.update(keys)
+
+    def get(self, weight_kio, refresh=True):
+        K, cin, cout = weight_kio.shape
+        key, fwd, bwd, hit = self._entry(weight_kio)
+        if hit and (not refresh or key in self._fresh):
+            self._fresh.discard(key)
+            return fwd, bwd
         lib = _lib.load()
         sk, si, so = weight_kio.stride()
         _lib.check(lib.sv_conv_weight_fragments(ctypes.c_void_p(weight_kio.data_ptr()), sk, si, so, K, cin, cout, _lib.ptr(fwd), _lib.ptr(bwd), _lib.stream()),
                    "sv_conv_weight_fragments")
-        d = self._d
-        self._d[key] = (weakref.ref(base, lambda _r, k=key: d.pop(k, None)), fwd, bwd)
         return fwd, bwd
 
     def clear(self):
         self._d.clear()
+        self._fresh.clear()
+        self._tables.clear()
 
 
 fragment_cache = _FragmentCache()
