@@ -29,7 +29,11 @@ __device__ __forceinline__ int64_t vox_key(const float* __restrict__ p, const Vo
 }
 
 __global__ __launch_bounds__(VOX_THREADS) void k_vox_mark(const float* __restrict__ points, int64_t n, int stride,
-                                                          VoxGeom g, SvIndexView ix, int64_t* __restrict__ keys) {
+                                                          VoxGeom g, SvIndexView ix, int64_t* __restrict__ keys, int32_t* __restrict__ cnt,
+                                                          int64_t capacity, float* __restrict__ feats, int64_t feat_words) {
+  // the accumulators of k_vox_accum (two launches later) start from zero: cleared here instead of by two memsets
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * blockDim.x) cnt[i] = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < feat_words; i += (int64_t)gridDim.x * blockDim.x) feats[i] = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float p[4];
     if (stride == 4) {
@@ -142,11 +146,14 @@ extern "C" int sv_voxelize_dynamic(const float* points, int64_t num_points, int 
   s += align256((size_t)capacity * 4);
   void* scan_tmp = s;
 
-  SV_HIP(hipMemsetAsync(cnt, 0, (size_t)capacity * 4, st));
-  SV_HIP(hipMemsetAsync(voxel_features, 0, (size_t)capacity * num_features * 4, st));
   const int grid = sv_grid_1d(num_points, VOX_THREADS);
-  if (num_points > 0)
-    hipLaunchKernelGGL(k_vox_mark, dim3(grid), dim3(VOX_THREADS), 0, st, points, num_points, point_stride, g, ix, keys);
+  if (num_points > 0) {
+    hipLaunchKernelGGL(k_vox_mark, dim3(grid), dim3(VOX_THREADS), 0, st, points, num_points, point_stride, g, ix, keys, cnt, capacity, voxel_features,
+                       capacity * num_features);
+  } else {
+    SV_HIP(hipMemsetAsync(cnt, 0, (size_t)capacity * 4, st));
+    SV_HIP(hipMemsetAsync(voxel_features, 0, (size_t)capacity * num_features * 4, st));
+  }
   int rc = sv_index_scan_launch(ix, num_voxels, scan_tmp, st);
   if (rc) return rc;
   if (num_points > 0) {
