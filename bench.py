@@ -64,7 +64,12 @@ class _MeanSquare(torch.autograd.Function):
     def forward(ctx, x):
         ctx.save_for_backward(x)
         flat = x.reshape(-1)
-        return torch.dot(flat, flat) / flat.numel()
+        n = flat.numel()
+        if n % 1024 == 0 and os.environ.get("SEEVCN_BENCH_DOT") != "1":
+            # row norms of a (n / 1024, 1024) view, squared and summed: 111 us for the 577 MB BEV tensor (5.2 TB/s); rocBLAS' dot takes
+            # 216 us, vector_norm over the whole tensor 150 us (measured on MI355X)
+            return torch.linalg.vector_norm(flat.view(-1, 1024), dim=1).square().sum() / n
+        return torch.dot(flat, flat) / n
 
     @staticmethod
     def backward(ctx, g):
@@ -116,45 +121,102 @@ def device_spinup(seconds, device):
 
 
 class Prefetch:
-    """The input side of batch N + 1 (SceneStep.front: stage A, voxelisation, rulebooks, plans -- no weights involved) on a side stream while
-    batch N trains on the main stream: the role of the reference's dataloader workers + offline completion, which also run beside the training
-    step (tools/train_utils/train_utils.py:22-29 fetches the next batch while the GPU works).  Every step still does one front and one compute;
-    the front's device -> host reads (voxel / site counts) wait for the side stream only, so the main stream never drains."""
+    """The input side of batch N + 1 (SceneStep.front: stage A, voxelisation, rulebooks, plans -- no weights involved) on a side stream AND a
+    host thread of its own while batch N trains on the main stream / main thread: the role of the reference's dataloader workers + offline
+    completion, which also run beside the training step (tools/train_utils/train_utils.py:22-29 fetches the next batch while the GPU works).
+    Every step still does one front and one compute.  The front's device -> host reads (voxel / site counts) block only its own thread and
+    wait for the side stream only; measured before the thread: the step was bound by the ONE host thread that enqueued the trained side
+    (~2.5 ms) and then sat in the front's reads (~3 ms) while the main stream ran dry (trained side alone: 3.9 ms per step)."""
 
-    def __init__(self, model, inputs):
+    def __init__(self, model, inputs, threaded=False):
+        from concurrent.futures import ThreadPoolExecutor
         self.model, self.inputs = model, inputs
         self.side = torch.cuda.Stream(priority=-1)
-        self.ready = None
+        self.device = torch.cuda.current_device()
+        self.pool = ThreadPoolExecutor(max_workers=1) if threaded else None
+        if threaded:
+            sys.setswitchinterval(float(os.environ.get("SEEVCN_BENCH_SWITCH_S", "2e-5")))   # default 5 ms: two launch-bound threads would take turns in 5 ms slices
+        self.pending = None
+        self.first = True
 
-    def issue(self):
-        from seevcn_amd.pipeline import record_stream_tree
-        main = torch.cuda.current_stream()
-        if self.ready is None:
-            self.side.wait_stream(main)                                       # first call: inputs / weights were produced on the main stream
+    def _front(self):
+        torch.cuda.set_device(self.device)
         with torch.cuda.stream(self.side):
             bd = self.model.front(*self.inputs, SCENES_PER_GPU)
             ev = self.side.record_event()
-        record_stream_tree(bd, main)
-        self.ready = (bd, ev)
+        return bd, ev
+
+    def issue(self):
+        if self.pending is not None and os.environ.get("SEEVCN_BENCH_REUSE_FRONT") == "1":
+            return              # measurement aid ONLY (how long is the trained side alone?): the step is incomplete, its time is not a result
+        if self.first:
+            self.side.wait_stream(torch.cuda.current_stream())               # inputs / weights were produced on the main stream
+            self.first = False
+        self.pending = self.pool.submit(self._front) if self.pool is not None else self._front()
 
     def take(self):
-        if self.ready is None:
+        from seevcn_amd.pipeline import record_stream_tree
+        if self.pending is None:
             self.issue()
-        bd, ev = self.ready
-        torch.cuda.current_stream().wait_event(ev)
+        if os.environ.get("SEEVCN_BENCH_REUSE_FRONT") == "1" and isinstance(self.pending, tuple):
+            return self.pending[0]
+        bd, ev = self.pending.result() if self.pool is not None else self.pending
+        if os.environ.get("SEEVCN_BENCH_REUSE_FRONT") == "1":
+            self.pending = (bd, ev)
+        main = torch.cuda.current_stream()
+        main.wait_event(ev)
+        record_stream_tree(bd, main)          # made on the side stream, read on the main one: the allocator must not hand the memory out early
         return bd
 
+    def wait_issued(self):
+        """Block until the worker thread has enqueued everything of the pending front (its GPU work is then covered by a device sync)."""
+        if self.pool is not None and self.pending is not None and not isinstance(self.pending, tuple):
+            self.pending.result()
 
-def run_step_prefetched(model, opt, params, pre, world):
-    """compute(N) on the main stream, then front(N + 1) on the side stream (issued after, so the main stream's queue is already full)."""
-    bd = pre.take()
+    def close(self):
+        if self.pool is not None:
+            if self.pending is not None and not isinstance(self.pending, tuple):
+                self.pending.result()
+            self.pool.shutdown(wait=True)
+
+
+def _compute_gen(model, opt, params, bd, world, out):
+    """The trained side of one batch as a generator: yields between pieces so that the caller can enqueue them one at a time."""
     opt.zero_grad(set_to_none=True)
-    loss = loss_fn(model.compute(bd))
+    res = yield from model.compute_stages(bd)
+    loss = loss_fn(res)
+    yield
     loss.backward()
+    yield
     allreduce_grads(params, world)
     opt.step()
-    pre.issue()
-    return loss
+    out.append(loss)
+
+
+def run_step_prefetched(model, opt, params, pre, world, interleave=True):
+    """One step = compute(N) on the main stream + front(N + 1) on the side stream, enqueued by ONE host thread.  The step is bound by that
+    thread (measured: 2.6 ms to enqueue the trained side, 2.4 ms in the input side, most of the latter spent WAITING in its seven device ->
+    host reads): so the pieces of compute(N) are enqueued exactly there -- each read of the front first runs the next piece (sync hook of
+    seevcn_amd._lib.host_int), after the kernels that produce the value it is about to read were launched."""
+    from seevcn_amd import _lib
+    bd = pre.take()
+    out = []
+    gen = _compute_gen(model, opt, params, bd, world, out)
+    main = torch.cuda.current_stream()
+
+    def piece():
+        with torch.cuda.stream(main), torch.enable_grad():    # the hook runs inside the front's side-stream / no_grad context
+            next(gen, None)
+
+    next(gen, None)                                           # first piece right away: the main stream has work from the start
+    prev = _lib.set_sync_hook(piece if interleave else None)
+    try:
+        pre.issue()
+    finally:
+        _lib.set_sync_hook(prev)
+    for _ in gen:                                             # whatever the front's reads did not take
+        pass
+    return out[0]
 
 
 def measure_dominant_kernel(model, inputs, reps=5):
@@ -350,6 +412,9 @@ def main():
     ap.add_argument("--no-kernel-rooflines", action="store_true", help="skip the per-kernel event timing after the timed region (tests)")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only control flow of the multi-rank path (gloo), no kernels")
     ap.add_argument("--no-prefetch", action="store_true", help="run the input side (stage A, voxelise, rulebooks) in line on the main stream")
+    ap.add_argument("--no-interleave", action="store_true", help="enqueue the trained side before the input side instead of inside its reads (A/B)")
+    ap.add_argument("--prefetch-thread", action="store_true", help="input side issued by a host thread of its own (A/B: measured slower, "
+                    "two launch-bound Python threads take turns on the GIL)")
     ap.add_argument("--spinup", type=float, default=0.0, help="seconds of untimed device spin-up (dense GEMMs) before the warm-up steps (A/B switch: a GPU "
                     "that idled may start below its sustained clocks; measured here: no effect, default off)")
     ap.add_argument("--config", default="main", choices=("main", "stageA", "second", "pvrcnn", "centerpoint"),
@@ -399,21 +464,27 @@ def main():
     inputs = (points, objects, scene)
 
     device_spinup(args.spinup, device)
-    pre = None if args.no_prefetch else Prefetch(model, inputs)
-    step = (lambda: run_step(model, opt, params, inputs, world)) if pre is None else (lambda: run_step_prefetched(model, opt, params, pre, world))
+    pre = None if args.no_prefetch else Prefetch(model, inputs, threaded=args.prefetch_thread)
+    step = (lambda: run_step(model, opt, params, inputs, world)) if pre is None else (lambda: run_step_prefetched(model, opt, params, pre, world, not args.no_interleave))
     for _ in range(args.warmup):
         step()
+    if pre is not None:
+        pre.wait_issued()              # the front of the first timed batch: enqueued and (next line) finished before the clock starts
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if pre is not None:
+        pre.wait_issued()              # K steps = K computes + K fronts: the last front issued belongs to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if pre is not None:
+        pre.close()
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -64,7 +64,9 @@ class _BackBone8xBase(nn.Module):
         batch_dict.update({'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})
         return batch_dict
 
-    def forward(self, batch_dict):
+    def forward_stages(self, batch_dict):
+        """forward() as a generator that yields between the backbone's stages (a caller with other work to enqueue in between, bench.py, steps
+        through it); the value of the StopIteration is the batch_dict."""
         voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         input_sp_tensor = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(),
                                                   spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'],
@@ -75,11 +77,22 @@ class _BackBone8xBase(nn.Module):
         spconv.refresh_weight_fragments(self)
         x = self.conv_input(input_sp_tensor)
         x_conv1 = self.conv1(x)
+        yield
         x_conv2 = self.conv2(x_conv1)
+        yield
         x_conv3 = self.conv3(x_conv2)
+        yield
         x_conv4 = self.conv4(x_conv3)
         out = self.conv_out(x_conv4)
         return self._finish(batch_dict, x_conv1, x_conv2, x_conv3, x_conv4, out)
+
+    def forward(self, batch_dict):
+        g = self.forward_stages(batch_dict)
+        try:
+            while True:
+                next(g)
+        except StopIteration as done:
+            return done.value
 
 
 class VoxelBackBone8x(_BackBone8xBase):

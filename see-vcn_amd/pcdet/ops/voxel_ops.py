@@ -46,7 +46,7 @@ def voxelize_dynamic(points, pc_range, voxel_size, grid_size, batch_size, num_fe
     _lib.check(rc, "sv_voxelize_dynamic")
     if not sync:
         return feats, coords, p2v, nvox
-    n = int(nvox.item())
+    n = _lib.host_int(nvox)
     return feats[:n], coords[:n], p2v
 
 

@@ -73,6 +73,11 @@ class SceneStep(nn.Module):
         bd = self.map_to_bev(bd)
         return bd
 
+    def compute_stages(self, bd):
+        """compute() as a generator yielding between the backbone's stages (see _BackBone8xBase.forward_stages)."""
+        bd = yield from self.backbone_3d.forward_stages(bd)
+        return self.map_to_bev(bd)
+
     def forward(self, points, objects, object_scene, batch_size):
         return self.compute(self.front(points, objects, object_scene, batch_size))
 

@@ -109,6 +109,17 @@ class SparseInverseConv3d(SparseConvolution):
         return SparseConvTensor(feats, rb.in_indices, rb.in_shape, x.batch_size, x.grid, x.indice_dict)
 
 
+def _sparse_convs(root):
+    """The SparseConvolution modules under `root` in definition order; the walk over nn.Module.modules() is cached on the root (0.25 ms per
+    step otherwise) and redone when the number of submodules changes."""
+    n = sum(1 for _ in root.children())
+    hit = root.__dict__.get('_seevcn_sparse_convs')
+    if hit is None or hit[0] != n:
+        hit = (n, [m for m in root.modules() if isinstance(m, SparseConvolution)])
+        root.__dict__['_seevcn_sparse_convs'] = hit
+    return hit[1]
+
+
 def prebuild_rulebooks(root, x, with_backward=True):
     """Build every rulebook (and conv plan) a network will need on `x` BEFORE its layers run.  A strided rulebook needs the number of output
     sites on the host (to allocate the next level), i.e. a device -> host sync; done lazily inside the layer loop, each of those syncs waits
@@ -117,9 +128,7 @@ def prebuild_rulebooks(root, x, with_backward=True):
     by layer: spconv_backbone.py:141-157 is the caller).  `root` is walked in definition order, which is the execution order of the
     reference's backbones; convolutions without an indice_key or inverse convolutions end the walk (they are then handled lazily)."""
     idx, shape = x.indices, list(x.spatial_shape)
-    for m in root.modules():
-        if not isinstance(m, SparseConvolution):
-            continue
+    for m in _sparse_convs(root):
         if m.inverse or m.indice_key is None:
             return
         rb = x.indice_dict.get(m.indice_key)
@@ -143,6 +152,6 @@ def refresh_weight_fragments(root):
     """One launch that re-lays the MFMA fragment copies of every planned-kernel convolution under `root` (Fsp.fragment_cache.refresh_all)."""
     if not Fsp.USE_PLAN:
         return
-    ws = [m.weight_kio() for m in root.modules() if isinstance(m, SparseConvolution) and m.weight.is_cuda]
+    ws = [m.weight_kio() for m in _sparse_convs(root) if m.weight.is_cuda]
     with torch.no_grad():
         Fsp.fragment_cache.refresh_all(ws)

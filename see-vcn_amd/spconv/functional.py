@@ -103,6 +103,16 @@ class Rulebook:
         kernel does not take the layer (sv_conv_mfma_kernel_applies is the single source of truth; SEEVCN_SPCONV_PLAN=0 forces the plain
         kernels for A/B runs).  direction 'fwd' = output-major table, 'bwd' = input-major table; a submanifold table serves its own data
         gradient with the offsets read in reverse, so it has one plan."""
+        hit = self._plan_results.get((direction, kd, nc, USE_PLAN)) if hasattr(self, "_plan_results") else None
+        if hit is not None:
+            return hit[0]
+        out = self._plan_uncached(direction, kd, nc)
+        if not hasattr(self, "_plan_results"):
+            self._plan_results = {}
+        self._plan_results[(direction, kd, nc, USE_PLAN)] = (out,)          # asked 60 times per step; two ctypes calls each before
+        return out
+
+    def _plan_uncached(self, direction, kd, nc):
         assert direction in ("fwd", "bwd")
         kd, nc = int(kd), int(nc)
         n_rows = self.n_out if direction == "fwd" else self.n_in
@@ -191,7 +201,7 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
                                 _i3(padding), _i3(dilation), _lib.ptr(ws), _lib.ptr(scratch), _lib.ptr(out_coords),
                                 _lib.ptr(nbr_in) if n_in else None, _lib.ptr(in_block), cap, _lib.ptr(num_out), _lib.stream())
     _lib.check(rc, "sv_rulebook_sparse")
-    n_out = int(num_out.item())  # host needs the size to allocate the output rows (spconv syncs here too)
+    n_out = _lib.host_int(num_out)  # host needs the size to allocate the output rows (spconv syncs here too)
     out_coords = out_coords[:n_out]
     if not with_rows or n_out == 0:
         nbr_out = torch.empty((K, n_out), dtype=torch.int32, device=dev)

@@ -7,9 +7,14 @@ import torch.nn as nn
 from .. import _lib
 
 
+_SCRATCH_BYTES = {}
+
+
 def _scratch(channels, device):
-    lib = _lib.load()
-    return _lib.workspace.scratch(f"bn{channels}", lib.sv_batchnorm_scratch_bytes(channels), device)
+    n = _SCRATCH_BYTES.get(channels)
+    if n is None:
+        n = _SCRATCH_BYTES[channels] = _lib.load().sv_batchnorm_scratch_bytes(channels)
+    return _lib.workspace.scratch(f"bn{channels}", n, device)
 
 
 class _BatchNormReLU(torch.autograd.Function):

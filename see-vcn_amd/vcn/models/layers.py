@@ -106,7 +106,7 @@ def distinct_rows(x):
     total = torch.empty((1,), dtype=torch.int32, device=x.device)
     _lib.check(lib.sv_unique_rows_compact(_lib.ptr(idx), _lib.ptr(cnt), B, n, _lib.ptr(sel), _lib.ptr(row_group), _lib.ptr(total), _lib.stream()),
                "sv_unique_rows_compact")
-    u = int(total.item())                                                                                     # sync: U rows
+    u = _lib.host_int(total)                                                                                     # sync: U rows
     sel, row_group = sel[:u], row_group[:u]
     return sel, row_group
 

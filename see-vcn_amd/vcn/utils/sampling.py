@@ -54,7 +54,7 @@ def get_largest_cluster_batch_device(pc, eps=0.4, min_points=1, total_pts=1024):
     cnt = torch.empty((B,), dtype=torch.int32, device=x.device)
     _lib.check(lib.sv_vcn_largest_cluster(_lib.ptr(x), B, x.shape[1], float(eps), int(min_points), int(total_pts), _lib.ptr(out), _lib.ptr(cnt),
                                           _lib.stream()), "sv_vcn_largest_cluster")
-    if B and int(cnt.min().item()) == 0:
+    if B and _lib.host_int(cnt.min()) == 0:
         raise ValueError("attempt to get argmax of an empty sequence")
     return out, cnt
 
