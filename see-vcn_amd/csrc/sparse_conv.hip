@@ -660,9 +660,12 @@ __global__ __launch_bounds__(1024) void k_plan_region(PlanFusedArgs a) {
 // Tiles a wave holds in registers at a time: 2 for the 64-column kernels (113 VGPRs: four waves per SIMD), 4 for the narrow ones (their
 // MFMA work per weight load is small).  The weight loads are shared by the G tiles of a pass.
 static int conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc) {
-  (void)n_rows;
   (void)Kd;
-  return (Nc > 32) ? 2 : 4;
+  if (Nc <= 32) return 4;
+  // 64-column kernels: 2 tiles per pass, but a table with no more tiles than the launch has waves (8 x 512) gives every wave ONE tile --
+  // with 2 per wave half the SIMD slots stay empty and the waves that run have nobody to hide their load latency behind
+  static const int64_t g1_tiles = getenv("SEEVCN_CONV_G1_TILES") ? atoll(getenv("SEEVCN_CONV_G1_TILES")) : (int64_t)PL_REGIONS * PL_REGION_WAVES * 9 / 8;
+  return (n_rows + 15) / 16 <= g1_tiles ? 1 : 2;
 }
 extern "C" int sv_conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc) { return conv_tiles_per_wave(n_rows < 0 ? 0 : n_rows, Kd, Nc); }
 extern "C" size_t sv_conv_plan_tiles_bytes(int64_t n_rows, int tiles_per_wave) {
@@ -949,7 +952,11 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       else if constexpr (RS_G == 3 && NT == 1) RS3_WAIT(8, V(As[0]), V(As[1]), V(As[2]), V(Bs[0]));
       else if constexpr (RS_G == 2 && NT == 4) RS3_WAIT(12, V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3]));
       else if constexpr (RS_G == 2 && NT == 2) RS3_WAIT(8, V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1]));
-      else RS3_WAIT(6, V(As[0]), V(As[1]), V(Bs[0]));
+      else if constexpr (RS_G == 1 && NT == 4) RS3_WAIT(10, V(As[0]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3]));
+      else {
+        static_assert(RS_G == 2 && NT == 1, "no counted wait for this (tiles per wave, column tiles) pair");
+        RS3_WAIT(6, V(As[0]), V(As[1]), V(Bs[0]));
+      }
 #undef V
 #undef RS3_WAIT
       // per tile: 4 passes over the NT column tiles, so that consecutive MFMAs never share an accumulator (a dependent
@@ -1033,8 +1040,12 @@ extern "C" int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc, int64_t n_src)
 template <int NT, int KQ>
 static void launch_rs3_g(const ConvArgs& a, const PlanView& pv, const float* wfrag, uint32_t xb, uint32_t wb, dim3 grid, hipStream_t st) {
   // tiles per pass: conv_tiles_per_wave (2 for the 64-column kernels, 4 for the narrow ones)
-  if constexpr (NT == 4) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
-  else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 4>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+  if constexpr (NT == 4) {
+    if (pv.d.G == 1) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 1>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+    else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+  } else {
+    hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 4>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+  }
 }
 template <int NT>
 static void launch_rs3_kq(const ConvArgs& a, const PlanView& pv, const float* wfrag, uint32_t xb, uint32_t wb, dim3 grid, hipStream_t st) {
