@@ -2,6 +2,10 @@
 // post_act_block (detector3d/pcdet/models/backbones_3d/spconv_backbone.py:9-27,73: BatchNorm1d eps 1e-3, momentum 0.01).
 // HBM-bound: forward = read x twice + write y, backward = read x,dy twice + write dx.  Three launches each way: row-chunk
 // partial sums, a per-channel fp64 combine in a fixed order (deterministic), one elementwise pass.
+// (Round 2 tried twice to let the workgroup that arrives last do the combine inside the reduce launch: with a release fence per workgroup
+// it took 67-71 us instead of 12 + 5; with write-through (sc1) partials, a drained arrival counter and an acquire in the last arriver only
+// it took 30-34 us -- one workgroup reading 1024 x 2 x C partials from memory is slower than C workgroups doing it in a launch of their
+// own -- and one test saw a stale partial at 4 workgroups per CU.  A kernel boundary costs 1.5 us here; three launches it is.)
 #include "common.h"
 
 #define BN_THREADS 256
