@@ -563,7 +563,7 @@ def kernel_rooflines(out, model, opt, params, inputs):
     # dominant kernel by time in the step: the register-stationary sparse-conv gather-GEMM (forward + data gradient)
     name, c_ms, c_flop, c_bytes, c_launches, c_step_ms = measure_spconv_kernel(model, opt, params, inputs, 1)
     c_ach = c_flop / (c_ms * 1e-3) / 1e12
-    out["roofline"] = {"bound": "mfma", "kernel": f"{name}G> (sv_sparse_conv_gather_gemm_planned, v_mfma_f32_16x16x4_f32; G = tiles per wave, 2-4 by layer size)",
+    out["roofline"] = {"bound": "mfma", "kernel": f"{name}G> (sv_sparse_conv_gather_gemm_planned, v_mfma_f32_16x16x4_f32; G = tiles per wave, 1-4 by layer size)",
                        "achieved": round(c_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(c_ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                        "launches_per_step": c_launches, "avg_launch_ms": round(c_ms, 4), "ms_per_step": round(c_step_ms, 3),
