@@ -74,6 +74,23 @@ class SparseConvolution(SparseModule):
         out = SparseConvTensor(feats, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.indice_dict)
         return out
 
+    def fusable_with(self, bn, x):
+        """True when forward_bn_relu may replace self -> bn (-> ReLU): no bias, not an inverse conv, a training-mode nn.BatchNorm1d with
+        affine parameters and running statistics on a channel count the fused kernels take, fp32 CUDA features, at least two output rows."""
+        from . import norm
+        return (not self.inverse and self.bias is None and type(bn) is nn.BatchNorm1d and bn.training and bn.affine and bn.track_running_stats
+                and bn.momentum is not None and norm.channels_fusable(self.out_channels) and x.features.is_cuda
+                and x.features.dtype == torch.float32 and x.features.shape[0] > 1)
+
+    def forward_bn_relu(self, x, bn, relu):
+        """self -> bn (-> ReLU) as one autograd node (Fsp.SparseConvBNReLUFunction)."""
+        rb = self.get_rulebook(x)
+        if rb.n_out < 2:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {(rb.n_out, self.out_channels)}")
+        feats = Fsp.SparseConvBNReLUFunction.apply(x.features, self.weight_kio(), rb, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                   bn.momentum, bn.eps, bool(relu), bn.num_batches_tracked)
+        return SparseConvTensor(feats, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.indice_dict)
+
 
 class SubMConv3d(SparseConvolution):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,

@@ -356,6 +356,33 @@ def _dense_permutation(shape, strides):
     return True
 
 
+def _conv_forward(features, weight_kio, rulebook):
+    """-> (out (N_out, C_out), frag_bwd or None): the forward of one sparse convolution on contiguous fp32 features."""
+    w = weight_kio.detach()
+    K, cin, cout = w.shape
+    plan = rulebook.plan("fwd", cin, cout)
+    if plan is not None:
+        frag_fwd, frag_bwd = fragment_cache.get(weight_kio)     # not the detached copy: the cache keys on ._base
+        return gather_gemm_planned(features, plan, frag_fwd, rulebook.n_out, K, cin, cout), frag_bwd
+    return gather_gemm(features, rulebook.nbr_out, w.permute(0, 2, 1), rulebook.n_out), None      # (K, C_out, C_in)
+
+
+def _conv_backward(features, weight_kio, rb, frag_bwd, grad_out, need_input, need_weight):
+    K, cin, cout = weight_kio.shape
+    gf = gw = None
+    if need_input:
+        # dX[i] = sum_k dY[nbr_in[k][i]] @ W[k]^T  -> Wt[k][n=c_in][c=c_out] = W[k][c_in][c_out]: weight_kio itself
+        plan = rb.plan("bwd", cout, cin)
+        if plan is not None:
+            fb = frag_bwd if frag_bwd is not None else fragment_cache.get(weight_kio)[1]
+            gf = gather_gemm_planned(grad_out, plan, fb, rb.n_in, K, cout, cin)
+        else:
+            gf = gather_gemm(grad_out, rb.table_for_backward_data(), weight_kio.detach(), rb.n_in)
+    if need_weight:
+        gw = wgrad(features, rb.nbr_out, grad_out, K, cin, cout, like=weight_kio)
+    return gf, gw
+
+
 class SparseConvFunction(torch.autograd.Function):
     """features (N_in,C_in), weight_kio (K,C_in,C_out) -> (N_out,C_out). Backward: gather-GEMM over the input-major
     table for the data gradient and a deterministic row reduction for the weight gradient."""
@@ -364,15 +391,7 @@ class SparseConvFunction(torch.autograd.Function):
     def forward(ctx, features, weight_kio, rulebook):
         _lib.require_cuda(features, weight_kio)
         features = features.contiguous().float()
-        w = weight_kio.detach()
-        K, cin, cout = w.shape
-        plan = rulebook.plan("fwd", cin, cout)
-        ctx.frag_bwd = None
-        if plan is not None:
-            frag_fwd, ctx.frag_bwd = fragment_cache.get(weight_kio)     # not the detached copy: the cache keys on ._base
-            out = gather_gemm_planned(features, plan, frag_fwd, rulebook.n_out, K, cin, cout)
-        else:
-            out = gather_gemm(features, rulebook.nbr_out, w.permute(0, 2, 1), rulebook.n_out)      # (K, C_out, C_in)
+        out, ctx.frag_bwd = _conv_forward(features, weight_kio, rulebook)
         ctx.rulebook = rulebook
         ctx.save_for_backward(features, weight_kio)
         return out
@@ -380,21 +399,35 @@ class SparseConvFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         features, weight_kio = ctx.saved_tensors
-        rb = ctx.rulebook
-        grad_out = grad_out.contiguous().float()
-        K, cin, cout = weight_kio.shape
-        gf = gw = None
-        if ctx.needs_input_grad[0]:
-            # dX[i] = sum_k dY[nbr_in[k][i]] @ W[k]^T  -> Wt[k][n=c_in][c=c_out] = W[k][c_in][c_out]: weight_kio itself
-            plan = rb.plan("bwd", cout, cin)
-            if plan is not None:
-                frag_bwd = ctx.frag_bwd if ctx.frag_bwd is not None else fragment_cache.get(weight_kio)[1]
-                gf = gather_gemm_planned(grad_out, plan, frag_bwd, rb.n_in, K, cout, cin)
-            else:
-                gf = gather_gemm(grad_out, rb.table_for_backward_data(), weight_kio.detach(), rb.n_in)
-        if ctx.needs_input_grad[1]:
-            gw = wgrad(features, rb.nbr_out, grad_out, K, cin, cout, like=weight_kio)
+        gf, gw = _conv_backward(features, weight_kio, ctx.rulebook, ctx.frag_bwd, grad_out.contiguous().float(), ctx.needs_input_grad[0],
+                                ctx.needs_input_grad[1])
         return gf, gw, None
+
+
+class SparseConvBNReLUFunction(torch.autograd.Function):
+    """SparseConvFunction followed by training-mode BatchNorm1d (+ ReLU) as ONE autograd node: the same five kernels per direction, half the
+    Python / autograd bookkeeping per layer (the bench step is bound by the host thread that enqueues it).  Used by SparseSequential for a
+    bias-free convolution directly followed by a fusable BatchNorm1d in training mode; the modules, their parameters and running statistics
+    are the plain torch ones."""
+
+    @staticmethod
+    def forward(ctx, features, weight_kio, rulebook, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked):
+        from . import norm
+        _lib.require_cuda(features, weight_kio)
+        features = features.contiguous().float()
+        conv_out, ctx.frag_bwd = _conv_forward(features, weight_kio, rulebook)
+        y, mean, invstd = norm.bn_forward_raw(conv_out, gamma, beta, running_mean, running_var, momentum, eps, True, relu, num_batches_tracked)
+        ctx.rulebook, ctx.relu = rulebook, relu
+        ctx.save_for_backward(features, weight_kio, conv_out, gamma, beta, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import norm
+        features, weight_kio, conv_out, gamma, beta, mean, invstd = ctx.saved_tensors
+        dconv, dgamma, dbeta = norm.bn_backward_raw(conv_out, dy.contiguous().float(), gamma, beta, mean, invstd, ctx.relu)
+        gf, gw = _conv_backward(features, weight_kio, ctx.rulebook, ctx.frag_bwd, dconv, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gf, gw, None, (dgamma if gamma is not None else None), (dbeta if beta is not None else None), None, None, None, None, None, None
 
 
 class DenseFunction(torch.autograd.Function):

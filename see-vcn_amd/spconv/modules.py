@@ -1,6 +1,10 @@
 from collections import OrderedDict
 
+import os
+
 import torch.nn as nn
+
+FUSE_CONV_BN = os.environ.get("SEEVCN_FUSE_CONV_BN", "1") != "0"      # 0: conv and BatchNorm as two autograd nodes (A/B runs, tests)
 
 
 class SparseModule(nn.Module):
@@ -52,6 +56,13 @@ class SparseSequential(SparseModule):
         i = 0
         while i < len(mods):
             module = mods[i]
+            if (FUSE_CONV_BN and i + 1 < len(mods) and hasattr(module, "fusable_with") and isinstance(input, SparseConvTensor)
+                    and input.indices.shape[0] != 0 and module.fusable_with(mods[i + 1], input)):
+                # conv -> BatchNorm1d [-> ReLU] as one autograd node (same kernels, half the host-side bookkeeping)
+                relu = i + 2 < len(mods) and type(mods[i + 2]) is nn.ReLU
+                input = module.forward_bn_relu(input, mods[i + 1], relu)
+                i += 3 if relu else 2
+                continue
             if _is_sparse(module):
                 input = module(input)
             elif isinstance(input, SparseConvTensor):

@@ -17,21 +17,40 @@ def _scratch(channels, device):
     return _lib.workspace.scratch(f"bn{channels}", n, device)
 
 
+def bn_forward_raw(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, num_batches_tracked=None):
+    """y, save_mean, save_invstd (the last two None in eval mode) of the fused BatchNorm(+ReLU) forward on a contiguous (N, C) matrix."""
+    lib = _lib.load()
+    n, c = x.shape
+    y = torch.empty_like(x)
+    if training:
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    else:
+        mean = invstd = None
+    _lib.check(lib.sv_batchnorm_relu_forward(_lib.ptr(x), n, c, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                             float(momentum), float(eps), int(training), int(relu), _lib.ptr(_scratch(c, x.device)), _lib.ptr(y),
+                                             _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(num_batches_tracked), _lib.stream()), "sv_batchnorm_relu_forward")
+    return y, mean, invstd
+
+
+def bn_backward_raw(x, dy, gamma, beta, mean, invstd, relu):
+    """dx, dgamma, dbeta of the training-mode fused BatchNorm(+ReLU); x is the BatchNorm INPUT (the ReLU mask is recomputed from it)."""
+    lib = _lib.load()
+    n, c = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    _lib.check(lib.sv_batchnorm_relu_backward(_lib.ptr(x), _lib.ptr(dy), n, c, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(invstd),
+                                              int(relu), _lib.ptr(_scratch(c, x.device)), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                              _lib.stream()), "sv_batchnorm_relu_backward")
+    return dx, dgamma, dbeta
+
+
 class _BatchNormReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, num_batches_tracked=None):
-        lib = _lib.load()
         x = x.contiguous()
-        n, c = x.shape
-        y = torch.empty_like(x)
-        if training:
-            mean = torch.empty(c, dtype=torch.float32, device=x.device)
-            invstd = torch.empty(c, dtype=torch.float32, device=x.device)
-        else:
-            mean = invstd = None
-        _lib.check(lib.sv_batchnorm_relu_forward(_lib.ptr(x), n, c, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var),
-                                                 float(momentum), float(eps), int(training), int(relu), _lib.ptr(_scratch(c, x.device)), _lib.ptr(y),
-                                                 _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(num_batches_tracked), _lib.stream()), "sv_batchnorm_relu_forward")
+        y, mean, invstd = bn_forward_raw(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, num_batches_tracked)
         ctx.relu, ctx.training = relu, training
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         return y
@@ -39,17 +58,13 @@ class _BatchNormReLU(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         assert ctx.training, "fused BatchNorm backward is only defined for training mode"
-        lib = _lib.load()
         x, gamma, beta, mean, invstd = ctx.saved_tensors
-        n, c = x.shape
-        dy = dy.contiguous()
-        dx = torch.empty_like(x)
-        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
-        _lib.check(lib.sv_batchnorm_relu_backward(_lib.ptr(x), _lib.ptr(dy), n, c, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(invstd),
-                                                  int(ctx.relu), _lib.ptr(_scratch(c, x.device)), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta),
-                                                  _lib.stream()), "sv_batchnorm_relu_backward")
+        dx, dgamma, dbeta = bn_backward_raw(x, dy.contiguous(), gamma, beta, mean, invstd, ctx.relu)
         return dx, (dgamma if gamma is not None else None), (dbeta if beta is not None else None), None, None, None, None, None, None, None
+
+
+def channels_fusable(c):
+    return 4 <= c <= 512 and c % 4 == 0 and 256 % (c // 4) == 0
 
 
 def fusable(bn, x):
