@@ -532,6 +532,7 @@ struct PlanFusedArgs {
   int32_t* tile_of;
   PlanDims d;
   int max_tiles;          // tiles of the largest region (LDS layout)
+  int debug;              // measurement only (SEEVCN_PLAN_DEBUG): 1 no histogram pass, 2 no perm / masks_p stores, 4 no deal
 };
 
 __global__ __launch_bounds__(1024) void k_plan_region(PlanFusedArgs a) {
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(1024) void k_plan_region(PlanFusedArgs a) {
   // pass 1: class histogram of the region.  PLR_B masks per thread are requested before the first is used: one workgroup has ~31 rows per
   // thread and nothing else to hide the load latency behind (one load at a time: 30 us per plan, most of it waiting)
   constexpr int PLR_B = 8;
-  for (int64_t base = row0; base < row1; base += 1024 * PLR_B) {
+  for (int64_t base = row0; base < row1 && !(a.debug & 1); base += 1024 * PLR_B) {
     unsigned m[PLR_B];
 #pragma unroll
     for (int u = 0; u < PLR_B; ++u) {
@@ -607,13 +608,16 @@ __global__ __launch_bounds__(1024) void k_plan_region(PlanFusedArgs a) {
         pos = row;                                            // padding positions n_rows .. n_pad - 1
       }
       if (pos >= row0 && pos < n_pad) {
-        a.perm[pos] = live ? (int32_t)row : -1;
-        a.masks_p[pos] = live ? (int32_t)m[u] : 0;
+        if (!(a.debug & 2)) {
+          a.perm[pos] = live ? (int32_t)row : -1;
+          a.masks_p[pos] = live ? (int32_t)m[u] : 0;
+        }
         if (live && m[u]) atomicOr(&s_tmask[(pos - row0) >> 4], m[u]);
       }
     }
   }
   __syncthreads();
+  if (a.debug & 4) return;
   // pass 4: tiles by descending cost, quads dealt to the 32 CU bins in snake order (k_plan_deal).  Neighbouring tiles are of neighbouring
   // classes and cost about the same: a wave's 64 tiles hit 2-4 of the 32 counters, so the wave groups its keys before the LDS atomic
   for (int base = 0; base < nt; base += 1024) {
@@ -695,6 +699,8 @@ extern "C" int sv_conv_plan_build_dealt(const int32_t* masks, int64_t n_rows, in
   PlanFusedArgs a;
   a.masks = masks, a.n_rows = n_rows, a.perm = perm, a.masks_p = masks_p, a.tile_of = tile_of;
   a.d = plan_dims(n_rows, tiles_per_wave);
+  static const int plan_debug = getenv("SEEVCN_PLAN_DEBUG") ? atoi(getenv("SEEVCN_PLAN_DEBUG")) : 0;
+  a.debug = plan_debug;
   a.max_tiles = 1;
   for (int r = 0; r < PL_REGIONS; ++r) {
     SV_CHECK_ARG(a.d.tiles[r] <= PL_MAX_REGION_TILES, "sv_conv_plan_build_dealt: at most %d tiles per region", PL_MAX_REGION_TILES);
