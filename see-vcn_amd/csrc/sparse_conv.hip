@@ -904,11 +904,15 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     for (int t = 0; t < NT; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (active) {
-    f32x4 A[3][RS_G], B[3][NT];
+    // ring depth 3 = two steps of loads in flight.  Tried: 5 stages for the one-tile-per-wave instance (its registers allow it) -- slower,
+    // 64->64 at 66 k rows 78 -> 85 us, 64->128 28 -> 39 us: the extra dummy loads of the tail and the longer prologue cost more than the
+    // lookahead buys (round 1 found the same on the narrow kernels)
+    constexpr int RING = 3;
+    f32x4 A[RING][RS_G], B[RING][NT];
     // defined here so that their live ranges start inside the pass (the asm waits below read-modify them: left undefined, hipcc keeps all
     // 18-24 stage registers alive across the whole pass loop, prologue and epilogue included, and spills 55 VGPRs at four waves per SIMD)
 #pragma unroll
-    for (int st = 0; st < 3; ++st) {
+    for (int st = 0; st < RING; ++st) {
 #pragma unroll
       for (int g = 0; g < RS_G; ++g) A[st][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -986,18 +990,18 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
         if (kc >= 0) mc = (unsigned)__builtin_amdgcn_readlane((int)maskreg, kc);
       }
     };
-    issue(A[0], B[0]);
-    issue(A[1], B[1]);
-    while (true) {
-      issue(A[2], B[2]);
-      compute(A[0], B[0]);
-      if (kc < 0) break;
-      issue(A[0], B[0]);
-      compute(A[1], B[1]);
-      if (kc < 0) break;
-      issue(A[1], B[1]);
-      compute(A[2], B[2]);
-      if (kc < 0) break;
+#pragma unroll
+    for (int st = 0; st < RING - 1; ++st) issue(A[st], B[st]);
+    for (bool more = true; more;) {
+#pragma unroll
+      for (int st = 0; st < RING; ++st) {
+        issue(A[(st + RING - 1) % RING], B[(st + RING - 1) % RING]);
+        compute(A[st], B[st]);
+        if (kc < 0) {
+          more = false;
+          break;
+        }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // retire the dummy loads before the registers are reused
   }
