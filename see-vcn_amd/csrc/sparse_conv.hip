@@ -839,7 +839,8 @@ struct PlanView {
   PlanDims d;
   int k_flip;               // read table entry K-1-k for offset k (a submanifold table serving its own data gradient)
   int nc_total;             // columns of Y and of the weight fragments (a.Nc is the block's share)
-  int debug;                // measurement only (SEEVCN_RS3_DEBUG): bit 0 = no gathered-row loads, bit 1 = no weight loads (results are wrong)
+  int debug;                // measurement only (SEEVCN_RS3_DEBUG; results are wrong): 1 no gathered-row loads, 2 no weight loads, 4 no MFMAs,
+                            // 8 / 16 weight / row loads of a wave all at ONE address (one cache line per load instead of 16)
   unsigned long long* trace;   // measurement only (sv_debug_conv_trace): 8 words per wave, or null
 };
 
@@ -931,12 +932,12 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       const bool live = kl >= 0;
 #pragma unroll
       for (int g = 0; g < RS_G; ++g) {
-        const uint32_t off = (live && jl[g] >= 0 && !(pv.debug & 1)) ? (uint32_t)((jl[g] * Kd + ql * 16 + kk * 4) * 4) : 0xfffffff0u;
+        const uint32_t off = (live && jl[g] >= 0 && !(pv.debug & 1)) ? ((pv.debug & 16) ? 0u : (uint32_t)((jl[g] * Kd + ql * 16 + kk * 4) * 4)) : 0xfffffff0u;
         As[g] = buf_load_b128(srd_x, off);
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const uint32_t off = (live && !(pv.debug & 2)) ? (uint32_t)(((((kl * KQ + ql) * nt_total + col_tile0 + t) * 64 + lane) * 4) * 4) : 0xfffffff0u;
+        const uint32_t off = (live && !(pv.debug & 2)) ? (uint32_t)(((((kl * KQ + ql) * nt_total + col_tile0 + t) * 64 + ((pv.debug & 8) ? 0 : lane)) * 4) * 4) : 0xfffffff0u;
         Bs[t] = buf_load_b128(srd_w, off);
       }
       if (live && ++ql == KQ) {
