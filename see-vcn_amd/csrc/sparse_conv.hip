@@ -830,6 +830,14 @@ __device__ __forceinline__ f32x4 buf_load_b128(i32x4 srd, uint32_t voff) {
   asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(srd) : "memory");
   return v;
 }
+// address = base + soff (SGPR) + voff (VGPR) + IMM; the range check looks at voff + IMM only, so an out-of-range voff still returns zeros
+// without a memory access whatever soff is
+template <int IMM>
+__device__ __forceinline__ f32x4 buf_load_b128_s(i32x4 srd, uint32_t voff, uint32_t soff) {
+  f32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(srd), "s"(soff), "i"(IMM) : "memory");
+  return v;
+}
 
 struct PlanView {
   const int32_t* tab;       // (n_rows, PL_ROW) row-major table, natural row order
@@ -844,7 +852,7 @@ struct PlanView {
   unsigned long long* trace;   // measurement only (sv_debug_conv_trace): 8 words per wave, or null
 };
 
-template <int NT, int KQ, int RS_G>
+template <int NT, int KQ, int RS_G, bool DBG = false>
 __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs a, PlanView pv, const float* __restrict__ wfrag, uint32_t x_bytes,
                                                                         uint32_t w_bytes) {
   constexpr int Kd = KQ * 16;
@@ -922,29 +930,50 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     // load iterator (two steps ahead of the compute iterator)
     unsigned long long la = active;
     int kl = __ffsll((long long)la) - 1, ql = 0;
-    int32_t jl[RS_G];
+    // Per offset: rowoff[g] = byte offset of the lane's gathered row (+ its 4-channel column), or an out-of-range value when the row has no
+    // neighbour there / the list has ended.  Per 16-channel step the loads then need NO vector arithmetic: rows at rowoff + (scalar) 64 * q,
+    // weights at one constant per-lane offset + (scalar) fragment base of (offset, q) + (immediate) 1 KiB * column tile.  (The first version
+    // recomputed every load's offset each step: 74 scalar + 25 vector instructions per step next to its 32 MFMAs.)
+    constexpr uint32_t OOB = 0xfffffff0u;
+    uint32_t rowoff[RS_G];
+    const uint32_t wlane = (uint32_t)lane * 16u;
+    uint32_t wvoff = wlane;                                          // OOB once the list has ended (dummy loads)
     auto read_j = [&]() {
 #pragma unroll
-      for (int g = 0; g < RS_G; ++g) jl[g] = s_idx[pv.k_flip ? a.K - 1 - kl : kl][g * 16 + li];
+      for (int g = 0; g < RS_G; ++g) {
+        const int32_t j = s_idx[pv.k_flip ? a.K - 1 - kl : kl][g * 16 + li];
+        rowoff[g] = j >= 0 ? (uint32_t)(j * (Kd * 4) + kk * 16) : OOB;
+        if constexpr (DBG) {
+          if (pv.debug & 1) rowoff[g] = OOB;
+          else if ((pv.debug & 16) && j >= 0) rowoff[g] = 0u;
+        }
+      }
     };
     read_j();
+    if constexpr (DBG) {
+      if (pv.debug & 2) wvoff = OOB;
+      else if (pv.debug & 8) wvoff = 0u;
+    }
     auto issue = [&](f32x4 (&As)[RS_G], f32x4 (&Bs)[NT]) {       // exactly NLOAD loads, always
-      const bool live = kl >= 0;
+      const uint32_t sa = (uint32_t)ql * 64u;                       // wave-uniform: scalar offset operands
+      const uint32_t sw = (uint32_t)(((kl < 0 ? 0 : kl) * KQ + ql) * nt_total + col_tile0) * 1024u;
 #pragma unroll
-      for (int g = 0; g < RS_G; ++g) {
-        const uint32_t off = (live && jl[g] >= 0 && !(pv.debug & 1)) ? ((pv.debug & 16) ? 0u : (uint32_t)((jl[g] * Kd + ql * 16 + kk * 4) * 4)) : 0xfffffff0u;
-        As[g] = buf_load_b128(srd_x, off);
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const uint32_t off = (live && !(pv.debug & 2)) ? (uint32_t)(((((kl * KQ + ql) * nt_total + col_tile0 + t) * 64 + ((pv.debug & 8) ? 0 : lane)) * 4) * 4) : 0xfffffff0u;
-        Bs[t] = buf_load_b128(srd_w, off);
-      }
-      if (live && ++ql == KQ) {
+      for (int g = 0; g < RS_G; ++g) As[g] = buf_load_b128_s<0>(srd_x, rowoff[g], sa);
+      if constexpr (NT >= 1) Bs[0] = buf_load_b128_s<0>(srd_w, wvoff, sw);
+      if constexpr (NT >= 2) Bs[1] = buf_load_b128_s<1024>(srd_w, wvoff, sw);
+      if constexpr (NT >= 3) Bs[2] = buf_load_b128_s<2048>(srd_w, wvoff, sw);
+      if constexpr (NT >= 4) Bs[3] = buf_load_b128_s<3072>(srd_w, wvoff, sw);
+      if (kl >= 0 && ++ql == KQ) {
         ql = 0;
         la &= la - 1;
         kl = la ? __ffsll((long long)la) - 1 : -1;
-        if (kl >= 0) read_j();
+        if (kl >= 0) {
+          read_j();
+        } else {                                                   // the list has ended: every further load is an out-of-range dummy
+          wvoff = OOB;
+#pragma unroll
+          for (int g = 0; g < RS_G; ++g) rowoff[g] = OOB;
+        }
       }
     };
     // compute iterator
@@ -974,7 +1003,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       // v_mfma_f32_16x16x4_f32 issues 47 cycles after its producer, an independent one after 32)
 #pragma unroll
       for (int g = 0; g < RS_G; ++g)
-        if (((mc >> g) & 1u) && !(pv.debug & 4)) {
+        if (((mc >> g) & 1u) && !(DBG && (pv.debug & 4))) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g].x, Bs[t].x, acc[g][t], 0, 0, 0);
 #pragma unroll
@@ -1050,7 +1079,17 @@ extern "C" int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc, int64_t n_src)
 
 template <int NT, int KQ>
 static void launch_rs3_g(const ConvArgs& a, const PlanView& pv, const float* wfrag, uint32_t xb, uint32_t wb, dim3 grid, hipStream_t st) {
-  // tiles per pass: conv_tiles_per_wave (2 for the 64-column kernels, 4 for the narrow ones)
+  // tiles per pass: conv_tiles_per_wave (1 or 2 for the 64-column kernels, 4 for the narrow ones); the measurement switches of
+  // SEEVCN_RS3_DEBUG live in instances of their own so that the production loop carries none of their tests
+  if (pv.debug) {
+    if constexpr (NT == 4) {
+      if (pv.d.G == 1) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 1, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+      else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+    } else {
+      hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 4, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+    }
+    return;
+  }
   if constexpr (NT == 4) {
     if (pv.d.G == 1) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 1>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
     else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
