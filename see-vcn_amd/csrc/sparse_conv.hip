@@ -954,25 +954,31 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       if (pv.debug & 2) wvoff = OOB;
       else if (pv.debug & 8) wvoff = 0u;
     }
+    // running scalar offsets: sa = 64 * q (rows), sw = fragment base of (offset, q) (weights)
+    constexpr uint32_t WSTEP = 1024u;                                // one (offset, q, column tile) fragment
+    const uint32_t wq = (uint32_t)nt_total * WSTEP;                   // q -> q + 1
+    uint32_t sa = 0u, sw = (uint32_t)((kl < 0 ? 0 : kl) * KQ * nt_total + col_tile0) * WSTEP;
     auto issue = [&](f32x4 (&As)[RS_G], f32x4 (&Bs)[NT]) {       // exactly NLOAD loads, always
-      const uint32_t sa = (uint32_t)ql * 64u;                       // wave-uniform: scalar offset operands
-      const uint32_t sw = (uint32_t)(((kl < 0 ? 0 : kl) * KQ + ql) * nt_total + col_tile0) * 1024u;
 #pragma unroll
       for (int g = 0; g < RS_G; ++g) As[g] = buf_load_b128_s<0>(srd_x, rowoff[g], sa);
       if constexpr (NT >= 1) Bs[0] = buf_load_b128_s<0>(srd_w, wvoff, sw);
       if constexpr (NT >= 2) Bs[1] = buf_load_b128_s<1024>(srd_w, wvoff, sw);
       if constexpr (NT >= 3) Bs[2] = buf_load_b128_s<2048>(srd_w, wvoff, sw);
       if constexpr (NT >= 4) Bs[3] = buf_load_b128_s<3072>(srd_w, wvoff, sw);
-      if (kl >= 0 && ++ql == KQ) {
-        ql = 0;
-        la &= la - 1;
-        kl = la ? __ffsll((long long)la) - 1 : -1;
-        if (kl >= 0) {
-          read_j();
-        } else {                                                   // the list has ended: every further load is an out-of-range dummy
-          wvoff = OOB;
+      if (kl >= 0) {
+        sa += 64u, sw += wq;
+        if (++ql == KQ) {
+          ql = 0, sa = 0u;
+          la &= la - 1;
+          kl = la ? __ffsll((long long)la) - 1 : -1;
+          if (kl >= 0) {
+            sw = (uint32_t)(kl * KQ * nt_total + col_tile0) * WSTEP;
+            read_j();
+          } else {                                                 // the list has ended: every further load is an out-of-range dummy
+            wvoff = OOB;
 #pragma unroll
-          for (int g = 0; g < RS_G; ++g) rowoff[g] = OOB;
+            for (int g = 0; g < RS_G; ++g) rowoff[g] = OOB;
+          }
         }
       }
     };
@@ -1040,16 +1046,23 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     for (int k = 0; k < a.K; ++k) trace_work += __popc((unsigned)__builtin_amdgcn_readlane((int)maskreg, k));
   }
   // D layout (16x16): col = lane&15, row = 4*(lane>>4) + reg
+  const bool plain_out = !a.bias && !a.scale && !a.residual && !a.relu;       // the training layers: BatchNorm follows, nothing fused here
 #pragma unroll
   for (int g = 0; g < RS_G; ++g)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t row = s_idx[RS3_KMAX][g * 16 + kk * 4 + r];
       if (row < 0) continue;
+      if (plain_out) {
+        float* yrow = a.Y + row * pv.nc_total + col_tile0 * 16 + li;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int col = (col_tile0 + t) * 16 + li;
-        a.Y[row * pv.nc_total + col] = conv_epilogue(acc[g][t][r], col, row, a);
+        for (int t = 0; t < NT; ++t) yrow[t * 16] = acc[g][t][r];
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int col = (col_tile0 + t) * 16 + li;
+          a.Y[row * pv.nc_total + col] = conv_epilogue(acc[g][t][r], col, row, a);
+        }
       }
     }
   }   // pass
