@@ -1267,10 +1267,13 @@ constexpr int WG_SUB = 4;           // 64-row blocks a wave compacts per pass
 constexpr int WG_DEPTH = 4;         // operand ring depth (MFMA steps)
 
 struct WgradArgs;
-static int wgrad_chunk_rows(int64_t n_rows, int K, int groups) {
-  // aim at ~2048 workgroups: chunk = n_rows*K*groups/2048 rounded up to one pass of the four waves (4 x WG_SUB x 64 rows)
+static int wgrad_chunk_rows(int64_t n_rows, int K, int groups, int Cin) {
+  // aim at ~2048 workgroups (4096 for the narrow layers, whose workgroups are short: measured 16->16 47 -> 36 us, 32->32 112 -> 98 us; the
+  // 64-channel layers lose with more, 156 -> 167 us): chunk = n_rows*K*groups/target rounded up to one pass of the four waves
   constexpr int64_t pass = 256 * WG_SUB;
-  int64_t c = (n_rows * K * groups + 2047) / 2048;
+  static const int64_t forced = getenv("SEEVCN_WGRAD_WGS") ? atoll(getenv("SEEVCN_WGRAD_WGS")) : 0;      // measurement switch
+  const int64_t target = forced > 0 ? forced : (Cin <= 32 ? 4096 : 2048);
+  int64_t c = (n_rows * K * groups + target - 1) / target;
   c = (c + pass - 1) / pass * pass;
   if (c < pass) c = pass;
   if (c > WG_CHUNK_MAX) c = WG_CHUNK_MAX;
@@ -1539,7 +1542,7 @@ static int wgrad_run(const float* X, const int32_t* nbr, const float* dY, float*
     else if (nt % 2 == 0) { tiles_c = 1; tiles_n = 2; }
   }
   const int groups = mfma ? (ct / tiles_c) * (nt / tiles_n) : 1;
-  const int chunk_rows = wgrad_chunk_rows(n_rows, K, groups);
+  const int chunk_rows = wgrad_chunk_rows(n_rows, K, groups, Cin);
   static const int xcd_order = (getenv("SEEVCN_WGRAD_XCD") && atoi(getenv("SEEVCN_WGRAD_XCD")) == 1) ? 1 : 0;
   WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, (int)((n_rows + chunk_rows - 1) / chunk_rows), chunk_rows, xcd_order};
   int nslabs = a.nchunks;
