@@ -49,8 +49,7 @@ def make_inputs(rank, device):
 
 def build_model(device, seed=0):
     from seevcn_amd.pipeline import SceneStep
-    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    from seeding import seeded_state_dict
+    from seevcn_amd.seeding import seeded_state_dict
     m = SceneStep()
     m.load_state_dict(seeded_state_dict(m, seed=seed))
     return m.to(device)
@@ -205,8 +204,14 @@ def run_step_prefetched(model, opt, params, pre, world, interleave=True):
     main = torch.cuda.current_stream()
 
     def piece():
-        with torch.cuda.stream(main), torch.enable_grad():    # the hook runs inside the front's side-stream / no_grad context
-            next(gen, None)
+        # the hook is off while a piece runs: a device -> host read inside the trained side (a rulebook built lazily, distinct_rows) must not
+        # re-enter the generator that is executing it
+        mine = _lib.set_sync_hook(None)
+        try:
+            with torch.cuda.stream(main), torch.enable_grad():    # the hook runs inside the front's side-stream / no_grad context
+                next(gen, None)
+        finally:
+            _lib.set_sync_hook(mine)
 
     next(gen, None)                                           # first piece right away: the main stream has work from the start
     prev = _lib.set_sync_hook(piece if interleave else None)
@@ -293,8 +298,7 @@ def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1, warmup=3, t
     from oracle import vcn as ovcn, voxelize as ovox, postprocess as opp, spconv_train as ost
     from seevcn_amd.pipeline import KITTI
     from seevcn_amd.pcdet.models import backbones_3d
-    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    from seeding import seeded_state_dict
+    from seevcn_amd.seeding import seeded_state_dict
     import seevcn_amd.vcn as V
     threads = torch.get_num_threads()
     vsd = seeded_state_dict(V.MODELS.build({'NAME': 'VCN_VC'}), seed=0)

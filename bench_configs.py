@@ -18,15 +18,14 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for sub in ("tests", os.path.join("tests", "golden")):
-    if os.path.join(ROOT, sub) not in sys.path:
-        sys.path.insert(0, os.path.join(ROOT, sub))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 CONFIGS = ("stageA", "second", "pvrcnn", "centerpoint")
 
 
 def _detector(cfg, num_class, ds, device, seed):
-    from seeding import seeded_state_dict
+    from seevcn_amd.seeding import seeded_state_dict
     from seevcn_amd.pcdet.models import detectors
     net = detectors.build_detector(cfg, num_class=num_class, dataset=ds)
     net.load_state_dict(seeded_state_dict(net, seed=seed))
@@ -48,7 +47,7 @@ def build(config, rank, device, scenes=None):
     from seevcn_amd.pcdet import model_cfgs as C
     if config == "stageA":
         import seevcn_amd.vcn as V
-        from seeding import seeded_state_dict
+        from seevcn_amd.seeding import seeded_state_dict
         from seevcn_amd.vcn.utils import sampling
         n_obj = scenes or 64
         objs, _ = synth.make_object_batch(n_obj, seed=1000 + 1000 * rank)
@@ -76,7 +75,7 @@ def build(config, rank, device, scenes=None):
         workload = (f"BASELINE configs[2]: SECONDNet train step (DynMeanVFE, VoxelBackBone8x, HeightCompression, BaseBEVBackbone, AnchorHeadSingle, "
                     f"losses, backward, SGD), {n} KITTI-shaped scenes per GPU ({len(pts) / n / 1e3:.1f}k returns each)")
     elif config == "pvrcnn":
-        import config_inputs as ci
+        import seevcn_amd.config_inputs as ci
         n = scenes or 4
         pts, gt = ci.pvrcnn_scene_batch(n, seed=3000 + 1000 * rank, n_az=350)
         gt = gt.copy()
@@ -87,7 +86,7 @@ def build(config, rank, device, scenes=None):
         workload = (f"BASELINE configs[3]: SEE-VCN PV-RCNN train step, DA geometry [41,1504,1504], 4096 keypoints, 512 proposals -> 128 RoIs x 216 grid "
                     f"points, {n} 360-degree scenes per GPU ({len(pts) / n / 1e3:.1f}k returns each; bs 32 = 8 GPUs x 4)")
     elif config == "centerpoint":
-        import config_inputs as ci
+        import seevcn_amd.config_inputs as ci
         from seevcn_amd.pcdet.ops import voxel_ops
         n = scenes or 1
         clouds, boxes = [], []

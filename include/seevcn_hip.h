@@ -368,12 +368,6 @@ int sv_three_interpolate_batch(int batch, int c, int m, int n, const float* poin
                                void* stream);
 int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float* grad_out, const int32_t* idx, const float* weight,
                                     float* grad_points, void* stream);
-int sv_three_nn_stack(int batch, int64_t n_unknown, const float* unknown, const int32_t* unknown_batch_cnt, const float* known,
-                      const int32_t* known_batch_cnt, float* dist2, int32_t* idx, void* stream);
-int sv_three_interpolate_stack(int64_t n, int channels, const float* features, const int32_t* idx, const float* weight, float* out,
-                               void* stream);
-int sv_three_interpolate_grad_stack(int64_t n, int channels, int64_t m, const float* grad_out, const int32_t* idx, const float* weight,
-                                    float* grad_features, void* stream);
 
 /* ---- BatchNorm1d (+ReLU) on (N,C) voxel features: the norm_fn -> ReLU tail of post_act_block
  * (detector3d/pcdet/models/backbones_3d/spconv_backbone.py:9-27,73; torch.nn.BatchNorm1d semantics: biased batch variance for

@@ -114,9 +114,6 @@ SIGNATURES = {
     "sv_three_nn_batch": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_three_interpolate_batch": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_three_interpolate_grad_batch": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
-    "sv_three_nn_stack": (c_i, [c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "sv_three_interpolate_stack": (c_i, [c_i64, c_i, c_p, c_p, c_p, c_p, c_p]),
-    "sv_three_interpolate_grad_stack": (c_i, [c_i64, c_i, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "sv_chamfer_forward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_chamfer_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_batchnorm_scratch_bytes": (c_sz, [c_i]),
@@ -208,17 +205,19 @@ def host_array(ctype, values):
 
 
 class Workspace:
-    """Grow-only device byte buffers, one set per device.
+    """Grow-only device byte buffers, one set per (device, stream).
 
     `persistent(name, nbytes)` returns a zero-initialised buffer that the kernels keep zeroed between calls
-    (coordinate-index bitmaps); `scratch(name, nbytes)` returns uninitialised bytes.
+    (coordinate-index bitmaps); `scratch(name, nbytes)` returns uninitialised bytes.  Every buffer is used inside ONE op call on the
+    calling thread's current stream; the key holds that stream's raw handle, so two streams (bench.py runs the input side of batch N + 1
+    beside the trained side of batch N) never share a buffer, and a grow-realloc frees a buffer only on the stream that used it.
     """
 
     def __init__(self):
         self._bufs = {}
 
     def _get(self, kind, name, nbytes, device, zero):
-        key = (kind, name, device.index)
+        key = (kind, name, device.index, _raw_stream(device.index if device.index is not None else _get_device()))
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             n = int(nbytes * 1.25) + 256 if buf is not None else int(nbytes)

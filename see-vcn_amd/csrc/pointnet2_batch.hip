@@ -85,24 +85,7 @@ __global__ __launch_bounds__(256) void k_three_nn_batch(int n, int m, const floa
   three_nn_scan(u[0], u[1], u[2], known + (size_t)b * m * 3, m, 0, dist2 + ((size_t)b * n + p) * 3, idx + ((size_t)b * n + p) * 3);
 }
 
-__global__ __launch_bounds__(256) void k_three_nn_stack(int batch, int N, const float* __restrict__ unknown, const int32_t* __restrict__ ucnt,
-                                                      const float* __restrict__ known, const int32_t* __restrict__ kcnt,
-                                                      float* __restrict__ dist2, int32_t* __restrict__ idx) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= N) return;
-  int bs = 0, acc = ucnt[0];
-  for (int k = 1; k < batch; ++k) {
-    if (p < acc) break;
-    acc += ucnt[k];
-    bs = k;
-  }
-  int start = 0;
-  for (int k = 0; k < bs; ++k) start += kcnt[k];
-  three_nn_scan(unknown[p * 3], unknown[p * 3 + 1], unknown[p * 3 + 2], known + (size_t)start * 3, kcnt[bs], start, dist2 + (size_t)p * 3,
-                idx + (size_t)p * 3);
-}
-
-// three_interpolate: batch layout points (B,C,M) -> out (B,C,N); stack layout features (M,C) -> out (N,C)
+// three_interpolate: batch layout points (B,C,M) -> out (B,C,N)
 __global__ __launch_bounds__(256) void k_three_interp_batch(int c, int m, int n, const float* __restrict__ points, const int32_t* __restrict__ idx,
                                                           const float* __restrict__ w, float* __restrict__ out) {
   const int b = blockIdx.z, ch = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
@@ -123,32 +106,6 @@ __global__ __launch_bounds__(256) void k_three_interp_grad_batch(int c, int n, i
   const float g = grad_out[((size_t)b * c + ch) * n + p];
   float* dst = grad_points + ((size_t)b * c + ch) * m;
   atomicAdd(&dst[i3[0]], g * w3[0]), atomicAdd(&dst[i3[1]], g * w3[1]), atomicAdd(&dst[i3[2]], g * w3[2]);
-}
-
-__global__ __launch_bounds__(256) void k_three_interp_stack(int64_t N, int C, const float* __restrict__ feat, const int32_t* __restrict__ idx,
-                                                          const float* __restrict__ w, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread per (point, channel), channels fastest: coalesced rows
-  if (i >= N * C) return;
-  const int64_t p = i / C;
-  const int ch = (int)(i - p * C);
-  const int32_t* i3 = idx + p * 3;
-  const float* w3 = w + p * 3;
-  out[i] = w3[0] * feat[(int64_t)i3[0] * C + ch] + w3[1] * feat[(int64_t)i3[1] * C + ch] + w3[2] * feat[(int64_t)i3[2] * C + ch];
-}
-
-__global__ __launch_bounds__(256) void k_three_interp_grad_stack(int64_t N, int C, const float* __restrict__ grad_out,
-                                                               const int32_t* __restrict__ idx, const float* __restrict__ w,
-                                                               float* __restrict__ grad_feat) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= N * C) return;
-  const int64_t p = i / C;
-  const int ch = (int)(i - p * C);
-  const int32_t* i3 = idx + p * 3;
-  const float* w3 = w + p * 3;
-  const float g = grad_out[i];
-  atomicAdd(&grad_feat[(int64_t)i3[0] * C + ch], g * w3[0]);
-  atomicAdd(&grad_feat[(int64_t)i3[1] * C + ch], g * w3[1]);
-  atomicAdd(&grad_feat[(int64_t)i3[2] * C + ch], g * w3[2]);
 }
 
 extern "C" int sv_ball_query_batch(int batch, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int32_t* idx,
@@ -204,16 +161,6 @@ extern "C" int sv_three_nn_batch(int batch, int n, int m, const float* unknown, 
   return SV_OK;
 }
 
-extern "C" int sv_three_nn_stack(int batch, int64_t n_unknown, const float* unknown, const int32_t* unknown_batch_cnt, const float* known,
-                                 const int32_t* known_batch_cnt, float* dist2, int32_t* idx, void* stream) {
-  if (batch <= 0 || n_unknown <= 0) return SV_OK;
-  SV_CHECK_ARG(unknown && unknown_batch_cnt && known && known_batch_cnt && dist2 && idx, "sv_three_nn_stack: null pointer");
-  hipLaunchKernelGGL(k_three_nn_stack, dim3(sv_div_up(n_unknown, 256)), dim3(256), 0, sv_stream(stream), batch, (int)n_unknown, unknown,
-                     unknown_batch_cnt, known, known_batch_cnt, dist2, idx);
-  SV_LAUNCH_CHECK();
-  return SV_OK;
-}
-
 extern "C" int sv_three_interpolate_batch(int batch, int c, int m, int n, const float* points, const int32_t* idx, const float* weight,
                                           float* out, void* stream) {
   if (batch <= 0 || c <= 0 || n <= 0) return SV_OK;
@@ -232,28 +179,6 @@ extern "C" int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, c
   if (n <= 0) return SV_OK;
   hipLaunchKernelGGL(k_three_interp_grad_batch, dim3(sv_div_up(n, 256), c, batch), dim3(256), 0, sv_stream(stream), c, n, m, grad_out, idx,
                      weight, grad_points);
-  SV_LAUNCH_CHECK();
-  return SV_OK;
-}
-
-extern "C" int sv_three_interpolate_stack(int64_t n, int channels, const float* features, const int32_t* idx, const float* weight,
-                                          float* out, void* stream) {
-  if (n <= 0 || channels <= 0) return SV_OK;
-  SV_CHECK_ARG(features && idx && weight && out, "sv_three_interpolate_stack: null pointer");
-  hipLaunchKernelGGL(k_three_interp_stack, dim3(sv_div_up(n * channels, 256)), dim3(256), 0, sv_stream(stream), n, channels, features, idx,
-                     weight, out);
-  SV_LAUNCH_CHECK();
-  return SV_OK;
-}
-
-extern "C" int sv_three_interpolate_grad_stack(int64_t n, int channels, int64_t m, const float* grad_out, const int32_t* idx,
-                                               const float* weight, float* grad_features, void* stream) {
-  if (m <= 0 || channels <= 0) return SV_OK;
-  SV_CHECK_ARG(grad_features && (n == 0 || (grad_out && idx && weight)), "sv_three_interpolate_grad_stack: null pointer");
-  SV_HIP(hipMemsetAsync(grad_features, 0, (size_t)m * channels * sizeof(float), sv_stream(stream)));
-  if (n <= 0) return SV_OK;
-  hipLaunchKernelGGL(k_three_interp_grad_stack, dim3(sv_div_up(n * channels, 256)), dim3(256), 0, sv_stream(stream), n, channels, grad_out,
-                     idx, weight, grad_features);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

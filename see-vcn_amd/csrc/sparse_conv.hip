@@ -935,6 +935,9 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     // weights at one constant per-lane offset + (scalar) fragment base of (offset, q) + (immediate) 1 KiB * column tile.  (The first version
     // recomputed every load's offset each step: 74 scalar + 25 vector instructions per step next to its 32 MFMAs.)
     constexpr uint32_t OOB = 0xfffffff0u;
+    // the weight loads add immediates of up to 3 KiB to their vector offset: an out-of-range value that cannot wrap around 2^32 with them
+    // (the fragment buffer is a few MB)
+    constexpr uint32_t WOOB = 0x80000000u;
     uint32_t rowoff[RS_G];
     const uint32_t wlane = (uint32_t)lane * 16u;
     uint32_t wvoff = wlane;                                          // OOB once the list has ended (dummy loads)
@@ -951,7 +954,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     };
     read_j();
     if constexpr (DBG) {
-      if (pv.debug & 2) wvoff = OOB;
+      if (pv.debug & 2) wvoff = WOOB;
       else if (pv.debug & 8) wvoff = 0u;
     }
     // running scalar offsets: sa = 64 * q (rows), sw = fragment base of (offset, q) (weights)
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
             sw = (uint32_t)(kl * KQ * nt_total + col_tile0) * WSTEP;
             read_j();
           } else {                                                 // the list has ended: every further load is an out-of-range dummy
-            wvoff = OOB;
+            wvoff = WOOB;
 #pragma unroll
             for (int g = 0; g < RS_G; ++g) rowoff[g] = OOB;
           }

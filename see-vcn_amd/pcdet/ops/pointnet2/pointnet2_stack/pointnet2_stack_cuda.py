@@ -76,29 +76,20 @@ def stack_farthest_point_sampling(points, xyz_batch_cnt, npoint, max_n=None):
     return idx
 
 
-def three_nn_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx):
-    """pointnet2_stack/src/interpolate.cpp three_nn_wrapper_stack: idx are GLOBAL rows of `known`."""
-    lib = _lib.load()
-    _lib.require_cuda(unknown, known, dist2, idx)
-    rc = lib.sv_three_nn_stack(int(unknown_batch_cnt.shape[0]), int(unknown.shape[0]), _lib.ptr(unknown), _lib.ptr(unknown_batch_cnt.int().contiguous()),
-                               _lib.ptr(known), _lib.ptr(known_batch_cnt.int().contiguous()), _lib.ptr(dist2), _lib.ptr(idx), _lib.stream())
-    _lib.check(rc, "sv_three_nn_stack")
-    return 1
+def _outside_hot_path(name):
+    def stub(*args, **kwargs):
+        raise NotImplementedError(f"pointnet2_stack_cuda.{name} is outside the SEE-VCN hot path (SURVEY.md 2: PV-RCNN++ / PartA2 / PointRCNN-style "
+                                  f"heads) and not built; see INTEGRATION.md 'Unsupported surface'")
+    stub.__name__ = name
+    return stub
 
 
-def three_interpolate_wrapper(features, idx, weight, out):
-    lib = _lib.load()
-    _lib.require_cuda(features, idx, weight, out)
-    rc = lib.sv_three_interpolate_stack(int(idx.shape[0]), int(features.shape[1]), _lib.ptr(features), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(out),
-                                        _lib.stream())
-    _lib.check(rc, "sv_three_interpolate_stack")
-    return 1
-
-
-def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
-    lib = _lib.load()
-    _lib.require_cuda(grad_out, idx, weight, grad_features)
-    rc = lib.sv_three_interpolate_grad_stack(int(idx.shape[0]), int(grad_out.shape[1]), int(grad_features.shape[0]), _lib.ptr(grad_out), _lib.ptr(idx),
-                                             _lib.ptr(weight), _lib.ptr(grad_features), _lib.stream())
-    _lib.check(rc, "sv_three_interpolate_grad_stack")
-    return 1
+# names the reference's extension exports (src/pointnet2_api.cpp:12-31) that no SEE-VCN configuration reaches
+three_nn_wrapper = _outside_hot_path("three_nn_wrapper")
+three_interpolate_wrapper = _outside_hot_path("three_interpolate_wrapper")
+three_interpolate_grad_wrapper = _outside_hot_path("three_interpolate_grad_wrapper")
+voxel_query_wrapper = _outside_hot_path("voxel_query_wrapper")
+vector_pool_wrapper = _outside_hot_path("vector_pool_wrapper")
+vector_pool_grad_wrapper = _outside_hot_path("vector_pool_grad_wrapper")
+query_stacked_local_neighbor_idxs_wrapper_stack = _outside_hot_path("query_stacked_local_neighbor_idxs_wrapper_stack")
+query_three_nn_by_stacked_local_idxs_wrapper_stack = _outside_hot_path("query_three_nn_by_stacked_local_idxs_wrapper_stack")

@@ -168,43 +168,3 @@ class FarthestPointSampling(Function):
 
 farthest_point_sample = furthest_point_sample = FarthestPointSampling.apply
 stack_farthest_point_sample = pointnet2.stack_farthest_point_sampling
-
-
-class ThreeNN(Function):
-    @staticmethod
-    def forward(ctx, unknown, unknown_batch_cnt, known, known_batch_cnt):
-        """unknown (N1+N2..,3), known (M1+M2..,3) -> (dist (N,3) L2 distances, idx (N,3) global rows of known) (reference :228-258)"""
-        assert unknown.dim() == 2 and unknown.shape[1] == 3 and known.dim() == 2 and known.shape[1] == 3
-        assert len(unknown_batch_cnt) == len(known_batch_cnt)
-        dist2 = unknown.new_zeros(unknown.shape)
-        idx = torch.zeros(unknown.shape, dtype=torch.int32, device=unknown.device)
-        pointnet2.three_nn_wrapper(unknown.contiguous(), unknown_batch_cnt.contiguous(), known.contiguous(), known_batch_cnt.contiguous(), dist2, idx)
-        return torch.sqrt(dist2), idx
-
-    @staticmethod
-    def backward(ctx, a=None, b=None):
-        return None, None
-
-
-three_nn = ThreeNN.apply
-
-
-class ThreeInterpolate(Function):
-    @staticmethod
-    def forward(ctx, features, idx, weight):
-        """features (M,C), idx / weight (N,3) -> (N,C) (reference :264-303)"""
-        assert idx.shape[0] == weight.shape[0] and idx.shape[1] == weight.shape[1] == 3
-        ctx.three_interpolate_for_backward = (idx, weight, features.shape[0])
-        output = features.new_zeros((idx.shape[0], features.shape[1]))
-        pointnet2.three_interpolate_wrapper(features.contiguous(), idx.contiguous(), weight.contiguous(), output)
-        return output
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        idx, weight, M = ctx.three_interpolate_for_backward
-        grad_features = grad_out.new_zeros((M, grad_out.shape[1]))
-        pointnet2.three_interpolate_grad_wrapper(grad_out.contiguous(), idx.contiguous(), weight.contiguous(), grad_features)
-        return grad_features, None, None
-
-
-three_interpolate = ThreeInterpolate.apply

@@ -29,3 +29,12 @@ def points_in_boxes_gpu(points, boxes):
     box_idxs_of_pts = torch.full((batch_size, num_points), -1, dtype=torch.int32, device=points.device)
     roiaware_pool3d_cuda.points_in_boxes_gpu(boxes.contiguous().float(), points.contiguous().float(), box_idxs_of_pts)
     return box_idxs_of_pts
+
+
+class RoIAwarePool3d(torch.nn.Module):
+    """Name kept so that `roiaware_pool3d_utils.RoIAwarePool3d` resolves (roiaware_pool3d_utils.py:44-53; built by partA2_head.py only,
+    SURVEY.md 2: outside the hot path).  Constructing one fails at model-build time instead of at the first forward."""
+
+    def __init__(self, out_size, max_pts_each_voxel=128):
+        raise NotImplementedError("RoIAwarePool3d (PartA2 RoI-aware pooling) is outside the SEE-VCN hot path and not built; "
+                                  "see INTEGRATION.md 'Unsupported surface'")

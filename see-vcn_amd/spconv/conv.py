@@ -21,8 +21,8 @@ class SparseConvolution(SparseModule):
     def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
                  bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None, **kwargs):
         super().__init__()
-        assert ndim == 3 and groups == 1 and not transposed, "only 3-D (sub)manifold, strided and inverse convs are built"
-        self.inverse = inverse
+        assert ndim == 3 and groups == 1 and not transposed, "only 3-D submanifold and strided convs are built"
+        assert not inverse, "inverse convolutions are not built"
         self.ndim = ndim
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride = _triple(kernel_size), _triple(stride)
@@ -60,7 +60,7 @@ class SparseConvolution(SparseModule):
         else:
             rb = Fsp.build_sparse_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding,
                                            self.dilation)
-        rb.in_indices, rb.in_shape = x.indices, list(x.spatial_shape)      # what SparseInverseConv3d restores
+        rb.in_indices, rb.in_shape = x.indices, list(x.spatial_shape)
         if self.indice_key is not None:
             x.indice_dict[self.indice_key] = rb
         return rb
@@ -75,10 +75,10 @@ class SparseConvolution(SparseModule):
         return out
 
     def fusable_with(self, bn, x):
-        """True when forward_bn_relu may replace self -> bn (-> ReLU): no bias, not an inverse conv, a training-mode nn.BatchNorm1d with
+        """True when forward_bn_relu may replace self -> bn (-> ReLU): no bias, a training-mode nn.BatchNorm1d with
         affine parameters and running statistics on a channel count the fused kernels take, fp32 CUDA features, at least two output rows."""
         from . import norm
-        return (not self.inverse and self.bias is None and type(bn) is nn.BatchNorm1d and bn.training and bn.affine and bn.track_running_stats
+        return (self.bias is None and type(bn) is nn.BatchNorm1d and bn.training and bn.affine and bn.track_running_stats
                 and bn.momentum is not None and norm.channels_fusable(self.out_channels) and x.features.is_cuda
                 and x.features.dtype == torch.float32 and x.features.shape[0] > 1)
 
@@ -107,29 +107,30 @@ class SparseConv3d(SparseConvolution):
 
 
 class SparseInverseConv3d(SparseConvolution):
-    """Undoes the sparsity change of the strided SparseConv3d that registered `indice_key` (spconv_backbone.py:16-18, the UNet
-    decoders): the output sites are that conv's INPUT sites and every (input row, output row, offset) pair of its rulebook is used
-    the other way round -- out[i] = sum over pairs (i, o, k) of W[k] . x[o].  No rulebook is built: the original's input-major
-    table is this layer's output-major table."""
+    """Name kept so that `spconv.SparseInverseConv3d` resolves (spconv_backbone.py:16-18 builds it for the UNet backbones only, SURVEY.md 2:
+    outside the hot path).  Constructing one fails at model-build time with a clear message."""
 
-    def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True, **kwargs):
-        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, subm=False, inverse=True, indice_key=indice_key, **kwargs)
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("SparseInverseConv3d (UNet decoders of UNetV2 / PartA2) is outside the SEE-VCN hot path and not built; "
+                                  "see INTEGRATION.md 'Unsupported surface'")
 
-    def forward(self, x):
-        assert isinstance(x, SparseConvTensor)
-        rb = x.find_indice_pair(self.indice_key)
-        assert rb is not None and not rb.subm, f"SparseInverseConv3d needs the rulebook of a strided conv under indice_key {self.indice_key!r}"
-        assert rb.ksize == self.kernel_size and rb.n_out == x.features.shape[0], "inverse conv applied to a tensor of another level"
-        feats = Fsp.SparseConvFunction.apply(x.features, self.weight_kio(), rb.inverse_view())
-        if self.bias is not None:
-            feats = feats + self.bias
-        return SparseConvTensor(feats, rb.in_indices, rb.in_shape, x.batch_size, x.grid, x.indice_dict)
+
+_registration_epoch = [0]
+
+
+def _bump_epoch(module, name, submodule):
+    _registration_epoch[0] += 1
+
+
+# fires on every add_module / register_module / attribute assignment of a submodule, anywhere: the cached walks below are keyed on it
+torch.nn.modules.module.register_module_module_registration_hook(_bump_epoch)
 
 
 def _sparse_convs(root):
     """The SparseConvolution modules under `root` in definition order; the walk over nn.Module.modules() is cached on the root (0.25 ms per
-    step otherwise) and redone when the number of submodules changes."""
-    n = sum(1 for _ in root.children())
+    step otherwise) and redone whenever a submodule was registered or replaced anywhere since (global registration hook above) or the
+    number of direct children changed (a deleted one)."""
+    n = (_registration_epoch[0], len(root._modules))
     hit = root.__dict__.get('_seevcn_sparse_convs')
     if hit is None or hit[0] != n:
         hit = (n, [m for m in root.modules() if isinstance(m, SparseConvolution)])
@@ -143,10 +144,10 @@ def prebuild_rulebooks(root, x, with_backward=True):
     for all the convolution work queued so far and then leaves the GPU idle until the host has enqueued the next layers.  Done here, the
     syncs wait for small index kernels only and the whole layer loop is enqueued without one (spconv builds its indice pairs lazily, layer
     by layer: spconv_backbone.py:141-157 is the caller).  `root` is walked in definition order, which is the execution order of the
-    reference's backbones; convolutions without an indice_key or inverse convolutions end the walk (they are then handled lazily)."""
+    reference's backbones; convolutions without an indice_key end the walk (they are then handled lazily)."""
     idx, shape = x.indices, list(x.spatial_shape)
     for m in _sparse_convs(root):
-        if m.inverse or m.indice_key is None:
+        if m.indice_key is None:
             return
         rb = x.indice_dict.get(m.indice_key)
         if rb is None:

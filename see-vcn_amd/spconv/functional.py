@@ -71,23 +71,12 @@ class Rulebook:
         self._nbr_in_subm = None
         self.rows_out = self.masks_out = self.rows_in = self.masks_in = None     # row-major twins + neighbour masks from the builders
         self._plans = {}
-        self._inverse = None
+        self._plan_results = {}
         self.in_indices = self.in_shape = None      # set by the conv that built the rulebook
 
     @property
     def K(self):
         return self.nbr_out.shape[0]
-
-    def inverse_view(self):
-        """The same pairs read the other way round (SparseInverseConv3d): the input-major table becomes the output-major one."""
-        assert not self.subm and self.nbr_in is not None
-        if self._inverse is None:
-            self._inverse = Rulebook(self.nbr_in, self.nbr_out, self.in_indices, self.in_shape, self.n_out, self.n_in, False, self.ksize)
-            inv = self._inverse
-            inv.rows_out, inv.masks_out, inv.rows_in, inv.masks_in = self.rows_in, self.masks_in, self.rows_out, self.masks_out
-            self._inverse._plans = {"fwd": self._plans.get("bwd"), "bwd": self._plans.get("fwd")}
-            self._inverse._plans = {k: v for k, v in self._inverse._plans.items() if v is not None}
-        return self._inverse
 
     def table_for_backward_data(self):
         """Input-major k-major table (the plain kernels). For SubM it is the output-major table with the offsets reversed
@@ -103,12 +92,10 @@ class Rulebook:
         kernel does not take the layer (sv_conv_mfma_kernel_applies is the single source of truth; SEEVCN_SPCONV_PLAN=0 forces the plain
         kernels for A/B runs).  direction 'fwd' = output-major table, 'bwd' = input-major table; a submanifold table serves its own data
         gradient with the offsets read in reverse, so it has one plan."""
-        hit = self._plan_results.get((direction, kd, nc, USE_PLAN)) if hasattr(self, "_plan_results") else None
+        hit = self._plan_results.get((direction, kd, nc, USE_PLAN))
         if hit is not None:
             return hit[0]
         out = self._plan_uncached(direction, kd, nc)
-        if not hasattr(self, "_plan_results"):
-            self._plan_results = {}
         self._plan_results[(direction, kd, nc, USE_PLAN)] = (out,)          # asked 60 times per step; two ctypes calls each before
         return out
 

@@ -15,6 +15,11 @@ def _is_sparse(m):
     return isinstance(m, SparseModule)
 
 
+def _hooked(*mods):
+    """A module with forward (pre-)hooks must run through its own __call__: the fused paths below call kernels directly."""
+    return any(m._forward_hooks or m._forward_pre_hooks for m in mods)
+
+
 class SparseSequential(SparseModule):
     """Sequential that feeds SparseModules the sparse tensor and plain nn.Modules (BatchNorm1d, ReLU) the
     `.features` matrix — the behaviour post_act_block relies on (spconv_backbone.py:21-25)."""
@@ -57,7 +62,8 @@ class SparseSequential(SparseModule):
         while i < len(mods):
             module = mods[i]
             if (FUSE_CONV_BN and i + 1 < len(mods) and hasattr(module, "fusable_with") and isinstance(input, SparseConvTensor)
-                    and input.indices.shape[0] != 0 and module.fusable_with(mods[i + 1], input)):
+                    and input.indices.shape[0] != 0 and module.fusable_with(mods[i + 1], input)
+                    and not _hooked(module, mods[i + 1], *mods[i + 2:i + 3])):
                 # conv -> BatchNorm1d [-> ReLU] as one autograd node (same kernels, half the host-side bookkeeping)
                 relu = i + 2 < len(mods) and type(mods[i + 2]) is nn.ReLU
                 input = module.forward_bn_relu(input, mods[i + 1], relu)
@@ -67,7 +73,7 @@ class SparseSequential(SparseModule):
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
-                    if norm.fusable(module, input.features):
+                    if norm.fusable(module, input.features) and not _hooked(module, *mods[i + 1:i + 2]):
                         # BatchNorm1d [-> ReLU] in one pass over the features (sv_batchnorm_relu_forward)
                         relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
                         input = input.replace_feature(norm.batch_norm_relu(module, input.features, relu))

@@ -191,33 +191,6 @@ def test_hip_pointnet2_batch_ops_vs_oracle(cuda, hip_lib):
 
 
 @pytest.mark.gpu
-def test_hip_three_nn_interpolate_stack_vs_oracle(cuda, hip_lib):
-    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as PS
-    rng = np.random.default_rng(13)
-    ucnt, kcnt = [300, 0, 451], [120, 40, 77]
-    unknown = rng.uniform(-3, 3, (sum(ucnt), 3)).astype(np.float32)
-    known = rng.uniform(-3, 3, (sum(kcnt), 3)).astype(np.float32)
-    t = lambda a: torch.from_numpy(a).to(cuda)
-    dist, idx = PS.three_nn(t(unknown), torch.tensor(ucnt, dtype=torch.int32, device=cuda), t(known), torch.tensor(kcnt, dtype=torch.int32, device=cuda))
-    u0 = k0 = 0
-    for nu, nk in zip(ucnt, kcnt):
-        if nu:
-            d2, i3 = op2.three_nn(unknown[u0:u0 + nu], known[k0:k0 + nk])
-            assert np.array_equal(idx[u0:u0 + nu].cpu().numpy(), i3 + k0) and np.array_equal(dist[u0:u0 + nu].cpu().numpy(), np.sqrt(d2))
-        u0, k0 = u0 + nu, k0 + nk
-    feats = t(rng.normal(size=(sum(kcnt), 24)).astype(np.float32)).requires_grad_(True)
-    weight = torch.softmax(-dist, dim=1).contiguous()
-    out = PS.three_interpolate(feats, idx, weight)
-    assert np.array_equal(out.detach().cpu().numpy(), op2.three_interpolate(feats.detach().cpu().numpy(), idx.cpu().numpy(), weight.cpu().numpy()))
-    gw = t(rng.normal(size=tuple(out.shape)).astype(np.float32))
-    (g1,) = torch.autograd.grad((out * gw).sum(), feats)
-    ref = torch.zeros_like(feats)
-    for j in range(3):
-        ref.index_add_(0, idx[:, j].long(), gw * weight[:, j:j + 1])
-    torch.testing.assert_close(g1, ref, rtol=1e-4, atol=1e-5)
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("c_in,mlps,nsamples", [(0, [[16, 16], [16, 16]], [16, 16]), (16, [[16, 16], [16, 32]], [16, 32]), (64, [[64, 64], [64, 64]], [16, 32]),
                                                  (128, [[64, 64], [64, 64]], [16, 16])])
 def test_hip_fused_set_abstraction_matches_the_unfused_path(cuda, hip_lib, c_in, mlps, nsamples):

@@ -37,27 +37,6 @@ GEOMS = [  # (ksize, stride, padding)
 
 
 # ---------------------------------------------------------------------------------- CPU: oracle vs dense conv3d
-@pytest.mark.parametrize("ksize,stride,padding", [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))])
-def test_oracle_inverse_conv_equals_conv_transpose3d_at_input_sites(ksize, stride, padding):
-    """SparseInverseConv3d semantics (the strided conv's pairs used the other way round) = the dense transposed convolution of the
-    densified tensor, read at the original input sites."""
-    rng = np.random.default_rng(2)
-    batch, shape, cin, cout = 2, (9, 14, 12), 6, 5
-    coords = _rand_coords(rng, 300, batch, shape)
-    oc, nbr_out, nbr_in, oshape = osp.rulebook_sparse(coords, shape, ksize, stride, padding)
-    x = rng.normal(size=(len(oc), cin)).astype(np.float32)                 # features living on the strided conv's outputs
-    w = rng.normal(size=(len(nbr_in), cin, cout)).astype(np.float32)       # (K, C_in, C_out)
-    got = osp.conv_forward(x, nbr_in, w)                                    # rows = the strided conv's input sites
-    dense_in = torch.from_numpy(osp.dense(x, oc, batch, oshape)).double()
-    wt = torch.from_numpy(w).double().reshape(*ksize, cin, cout).permute(3, 4, 0, 1, 2)          # conv_transpose3d: (C_in, C_out, kz, ky, kx)
-    full = F.conv_transpose3d(dense_in, wt, stride=osp._triple(stride), padding=osp._triple(padding),
-                              output_padding=[(d + 2 * p - k) % s for d, p, k, s in zip(shape, osp._triple(padding), ksize, osp._triple(stride))])
-    assert tuple(full.shape[2:]) == tuple(shape)
-    want = full.numpy()[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]]
-    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
-
-
-
 @pytest.mark.parametrize("ksize,stride,padding", GEOMS)
 def test_oracle_sparse_conv_equals_dense_conv3d(ksize, stride, padding):
     rng = np.random.default_rng(0)
@@ -586,34 +565,3 @@ def test_hip_sparse_conv_full_size_properties(cuda, hip_lib, config):
     assert torch.equal(t.features.grad, f)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("cin,cout", [(32, 16), (64, 64), (20, 12)])
-def test_hip_sparse_inverse_conv_vs_oracle(cuda, hip_lib, cin, cout):
-    """SparseConv3d(stride 2, indice_key) -> SparseInverseConv3d(same key): sites, values, all three gradients."""
-    import seevcn_amd.spconv as spconv
-    rng = np.random.default_rng(12)
-    batch, shape = 2, (9, 48, 40)
-    coords = _rand_coords(rng, 2500, batch, shape)
-    feats = rng.normal(size=(len(coords), 16)).astype(np.float32)
-    torch.manual_seed(0)
-    down = spconv.SparseConv3d(16, cin, 3, stride=2, padding=1, bias=False, indice_key="spconv2").to(cuda)
-    up = spconv.SparseInverseConv3d(cin, cout, 3, indice_key="spconv2", bias=True).to(cuda)
-    assert isinstance(up, spconv.conv.SparseConvolution) and up.weight.shape == (cout, 3, 3, 3, cin)
-    t = spconv.SparseConvTensor(torch.from_numpy(feats).to(cuda), torch.from_numpy(coords).to(cuda), list(shape), batch)
-    mid = down(t)
-    x = mid.features.detach().clone().requires_grad_(True)
-    out = up(mid.replace_feature(x))
-    assert torch.equal(out.indices, t.indices) and list(out.spatial_shape) == list(shape)
-    oc, nbr_out, nbr_in, _ = osp.rulebook_sparse(coords, shape, 3, 2, 1)
-    w = osp.weight_to_kio(up.weight.detach().cpu().numpy())
-    xn = x.detach().cpu().numpy()
-    want = osp.conv_forward(xn, nbr_in, w, up.bias.detach().cpu().numpy())
-    assert _ok(out.features.detach().cpu().numpy(), want, name='inverse conv forward')
-    go = rng.normal(size=want.shape).astype(np.float32)
-    out.features.backward(torch.from_numpy(go).to(cuda))
-    gf, gw = osp.conv_backward(xn, nbr_in, w, go)
-    assert _ok(x.grad.cpu().numpy(), gf, rtol=2e-3, atol_frac=2e-4, name='inverse conv data gradient')
-    assert _ok(osp.weight_to_kio(up.weight.grad.cpu().numpy()), gw, rtol=2e-3, atol_frac=5e-4, name='inverse conv weight gradient')
-    np.testing.assert_allclose(up.bias.grad.cpu().numpy(), go.sum(0), rtol=1e-3, atol=1e-3)
-    with pytest.raises(AssertionError):
-        spconv.SparseInverseConv3d(cin, cout, 3, indice_key="no_such_key").to(cuda)(mid)
