@@ -413,6 +413,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scenes-per-gpu", type=int, default=None, help="override the 16 scenes per GPU (tests)")
     ap.add_argument("--objects-per-gpu", type=int, default=None, help="override the 64 objects per GPU (tests)")
+    ap.add_argument("--no-side-modes", action="store_true", help="skip the brief runs of the other BASELINE configs after the headline")
     ap.add_argument("--no-kernel-rooflines", action="store_true", help="skip the per-kernel event timing after the timed region (tests)")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only control flow of the multi-rank path (gloo), no kernels")
     ap.add_argument("--no-prefetch", action="store_true", help="run the input side (stage A, voxelise, rulebooks) in line on the main stream")
@@ -516,10 +517,43 @@ def main():
             kernel_rooflines(out, model, opt, params, inputs)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pts_np, objs_np, scene_np)
+        if not args.no_side_modes and world == 1:
+            # the other BASELINE configs, a few steps each, AFTER the headline was measured (its numbers above are final): same protocol as
+            # `--config X`, so that the driver's one command sees them too
+            del model, opt, params, inputs, points, objects, scene, pre, step
+            out["side_modes"] = side_modes_brief(device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()             # the other ranks wait here while rank 0 measures and prints
         dist.destroy_process_group()
+
+
+def side_modes_brief(device, warmup=3, steps=5):
+    """{config: ms_per_step, ...} of bench_configs' detector train steps (second = BASELINE configs[2], pvrcnn = [3], centerpoint = [4]) and
+    stage A alone ([1]); N = 1 only, warm-up includes MIOpen's solver search."""
+    import gc
+    import bench_configs
+    sys.modules.setdefault("bench", sys.modules[__name__])
+    res = {}
+    for name in ("stageA", "second", "pvrcnn", "centerpoint"):
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            step, units, unit, metric, config = bench_configs.build(name, 0, device)
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            res[name] = {"ms_per_step": round(ms, 3), "value": round(units / (ms * 1e-3), 2), "unit": unit, "steps": steps, "warmup": warmup,
+                         "workload": config["workload"]}
+            del step
+        except Exception as e:                                     # a side mode must never take the headline line down with it
+            res[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return res
 
 
 def side_mode(args, rank, world, device):

@@ -56,6 +56,15 @@ PP_BACKBONE_2D = dict(NAME='BaseBEVBackbone', LAYER_NUMS=[3, 5, 5], LAYER_STRIDE
                       UPSAMPLE_STRIDES=[1, 2, 4], NUM_UPSAMPLE_FILTERS=[128, 128, 128])
 
 
+PP_DENSE_HEAD = dict(SECOND_DENSE_HEAD, ANCHOR_GENERATOR_CONFIG=[dict(a, feature_map_stride=2) for a in SECOND_DENSE_HEAD['ANCHOR_GENERATOR_CONFIG']])
+
+
+def pointpillar_model_cfg():
+    """MODEL section of kitti_models/pointpillar.yaml:48-140 (values as data)."""
+    return dict(NAME='PointPillar', VFE=PP_VFE, MAP_TO_BEV=PP_MAP_TO_BEV, BACKBONE_2D=PP_BACKBONE_2D, DENSE_HEAD=PP_DENSE_HEAD,
+                POST_PROCESSING=SECOND_POST_PROCESSING)
+
+
 def _sa(mlps, radii, nsample, factor=None):
     d = dict(MLPS=[list(m) for m in mlps], POOL_RADIUS=list(radii), NSAMPLE=list(nsample))
     if factor is not None:

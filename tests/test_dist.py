@@ -125,3 +125,82 @@ def test_bench_main_two_ranks_end_to_end_on_one_gpu():
                      {"SEEVCN_BENCH_SHARE_GPU": "1", "SEEVCN_BENCH_BACKEND": "gloo"}, timeout=900)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["achieved"] > 0
     assert out["config"]["scenes_per_gpu"] == 2
+
+
+def _dist_helper_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import seevcn_amd  # noqa: F401
+    from seevcn_amd.pcdet.utils import common_utils
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1")
+    os.environ.pop("MASTER_PORT", None)
+    assert common_utils.get_dist_info() == (0, 1)
+    n_gpus, r = common_utils.init_dist_pytorch(port, rank, backend="gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    out[rank] = (r, common_utils.get_dist_info(), float(t), n_gpus == torch.cuda.device_count())
+    dist.destroy_process_group()
+
+
+def test_init_dist_pytorch_world2_gloo():
+    """The reference's rendezvous helper (pcdet/utils/common_utils.py:164-182) with the same signature and return value."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dist_helper_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: (0, (0, 2), 3.0, True), 1: (1, (1, 2), 3.0, True)}
+
+
+def _ddp_worker(rank, world, port, sync_bn, out):
+    """tools/train.py:118-144 of the reference: build_network -> (convert_sync_batchnorm) -> .cuda() -> .train() -> DistributedDataParallel,
+    then train steps on per-rank scenes.  Two ranks share cuda:0 over gloo (RCCL refuses two ranks per device)."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import seevcn_amd.synth as synth
+    from seevcn_amd.pcdet import model_cfgs as C
+    from seevcn_amd.pcdet.models import detectors
+    from seevcn_amd.pcdet.utils import common_utils
+    from seevcn_amd.seeding import seeded_state_dict
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    common_utils.init_dist_pytorch(port, 0, backend="gloo")
+    device = torch.device("cuda", 0)
+    net = detectors.build_detector(C.second_model_cfg(dynamic_vfe=True), num_class=3, dataset=C.SyntheticDatasetInfo())
+    net.load_state_dict(seeded_state_dict(net, seed=5 + rank))              # DDP broadcasts rank 0's parameters and buffers at wrap time
+    if sync_bn:
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+    net.to(device).train()
+    ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0])
+    params = [p for p in ddp.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9)
+    pts, gt = synth.make_scene_batch(2, seed=2000 + 1000 * rank, n_az=96)
+    batch = {"batch_size": 2, "points": torch.from_numpy(pts).to(device), "gt_boxes": torch.from_numpy(gt).to(device)}
+    losses = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        ret, _, _ = ddp(dict(batch))
+        ret["loss"].backward()
+        opt.step()
+        losses.append(float(ret["loss"]))
+    torch.cuda.synchronize()
+    grads = torch.cat([p.grad.reshape(-1) for p in params]).cpu()
+    weights = torch.cat([p.detach().reshape(-1) for p in params]).cpu()
+    stats = torch.cat([b.detach().float().reshape(-1) for b in net.buffers()]).cpu()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (losses, grads, weights, stats))
+    out[rank] = (all(torch.equal(gathered[0][1], g[1]) for g in gathered), all(torch.equal(gathered[0][2], g[2]) for g in gathered),
+                 bool(torch.isfinite(grads).all() and np.isfinite(losses).all()), gathered[0][0] != gathered[1][0],
+                 (not sync_bn) or all(torch.equal(gathered[0][3], g[3]) for g in gathered))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_ddp_wrapped_second_net_two_ranks_on_one_gpu(sync_bn):
+    """The reference's own multi-GPU wrapper: a registered detector (custom autograd nodes, prefetched rulebooks, per-stream workspaces)
+    inside DistributedDataParallel for two steps -- no hang, averaged gradients and updated weights bit-identical on both ranks while
+    each saw different scenes.  With --sync_bn (train.py:118-119) the BatchNorm layers become torch SyncBatchNorm: SparseSequential then
+    runs conv and norm as separate nodes (the fused conv+BN node only takes a plain nn.BatchNorm1d) and the running statistics agree too."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_worker, args=(world, _free_port(), sync_bn, out), nprocs=world, join=True)
+    assert dict(out) == {0: (True, True, True, True, True), 1: (True, True, True, True, True)}

@@ -9,6 +9,7 @@ timeout 900 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}
 tail -c 600 gpurun_out/${TAG}_bench.json
 TOP=8 tools/profile.sh ${TAG}_main 20 2>&1 | head -10
 tools/traffic.sh ${TAG} 2>&1 | tail -6
+tools/mfma_busy.sh ${TAG} 2>&1 | tail -8
 : > gpurun_out/${TAG}_side_modes.jsonl
 for c in stageA second pvrcnn centerpoint; do
   timeout 600 python3 bench.py --config $c --steps 10 --warmup 5 2>/dev/null | grep '^{' >> gpurun_out/${TAG}_side_modes.jsonl

@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 rm -rf gpurun_out/prof_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --steps $STEPS --warmup 5 --no-cpu-baseline $EXTRA > gpurun_out/prof_$TAG.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-side-modes $EXTRA > gpurun_out/prof_$TAG.log 2>&1
 F=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$F" gpurun_out/${TAG}_kernel_stats.csv
 T=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)

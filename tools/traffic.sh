@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 for CNT in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/${TAG}_pmc_$CNT
-  rocprofv3 --pmc $CNT --output-format csv -d gpurun_out/${TAG}_pmc_$CNT -o pmc -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_pmc_$CNT.log 2>&1
+  rocprofv3 --pmc $CNT --output-format csv -d gpurun_out/${TAG}_pmc_$CNT -o pmc -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-side-modes > gpurun_out/${TAG}_pmc_$CNT.log 2>&1
 done
 python3 - <<PY
 import csv, glob, json, collections
@@ -27,7 +27,7 @@ for k, d in agg.items():
     fetch = d.get("FETCH_SIZE", 0.0) / max(calls[k]["FETCH_SIZE"], 1) * 1024 * 2
     write = d.get("WRITE_SIZE", 0.0) / max(calls[k]["WRITE_SIZE"], 1) * 1024
     out[k] = {"dispatches": n, "fetch_bytes_per_dispatch": fetch, "write_bytes_per_dispatch": write, "hbm_bytes_per_dispatch": fetch + write}
-json.dump({"command": "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline", "units": "bytes; FETCH_SIZE KiB x1024 x2 (gfx950), WRITE_SIZE KiB x1024",
+json.dump({"command": "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-side-modes", "units": "bytes; FETCH_SIZE KiB x1024 x2 (gfx950), WRITE_SIZE KiB x1024",
            "kernels": out}, open("gpurun_out/${TAG}_traffic.json", "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_dispatch"] * kv[1]["dispatches"])[:12]:
     print(f'{k[:70]:70s} n={v["dispatches"]:4d} fetch {v["fetch_bytes_per_dispatch"]/1e6:9.2f} MB write {v["write_bytes_per_dispatch"]/1e6:9.2f} MB')
