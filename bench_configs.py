@@ -82,7 +82,9 @@ def build(config, rank, device, scenes=None):
         gt[:, :, 7] = (gt[:, :, 3] > 0)
         ds = C.SyntheticDatasetInfo(class_names=["car"], point_cloud_range=C.DA_RANGE, voxel_size=C.DA_VOXEL, num_point_features=3)
         net = _detector(C.see_pvrcnn_model_cfg(), 1, ds, device, 6)
-        batch = {"batch_size": n, "points": torch.from_numpy(pts).to(device), "gt_boxes": torch.from_numpy(gt).to(device)}
+        # points_per_scene: what collate_batch hands over with the points (host-side counts: the keypoint sampling then starts without a read-back)
+        batch = {"batch_size": n, "points": torch.from_numpy(pts).to(device), "gt_boxes": torch.from_numpy(gt).to(device),
+                 "points_per_scene": np.bincount(pts[:, 0].astype(np.int64), minlength=n).tolist()}
         workload = (f"BASELINE configs[3]: SEE-VCN PV-RCNN train step, DA geometry [41,1504,1504], 4096 keypoints, 512 proposals -> 128 RoIs x 216 grid "
                     f"points, {n} 360-degree scenes per GPU ({len(pts) / n / 1e3:.1f}k returns each; bs 32 = 8 GPUs x 4)")
     elif config == "centerpoint":

@@ -241,6 +241,13 @@ int sv_stack_farthest_point_sampling(const float* xyz, const int32_t* xyz_batch_
 size_t sv_fps_multi_scratch_bytes(int batch);
 int sv_stack_farthest_point_sampling_multi(const float* xyz, const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int batch,
                                            int max_n, int m, float* temp, void* multi_scratch, int32_t* idx, void* stream);
+/* The same without the read-back (seevcn extension, for a sampling that runs on a side stream beside the backbone): ONE attempt -- write_through 0:
+ * records kept in one XCD's L2 (fast, relies on the observed dispatch order), 1: write-through records (any placement) -- and nothing is
+ * synchronised.  The int32 error word at multi_scratch + sv_fps_multi_error_offset(batch) is 0 when every partner workgroup arrived; the
+ * caller reads it when it next synchronises with `stream` and, if non-zero, samples again with write_through = 1. */
+size_t sv_fps_multi_error_offset(int batch);
+int sv_stack_farthest_point_sampling_multi_async(const float* xyz, const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int batch, int max_n,
+                                                 int m, float* temp, void* multi_scratch, int32_t* idx, int write_through, void* stream);
 /* ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx) (src/ball_query.cpp:31-47,
  * kernel ball_query_gpu.cu:16-66): idx (M,nsample) scene-local indices of the first nsample points with d^2 < r^2 in index
  * order, padded with the first hit; idx[m][0] = -1 for an empty ball. */
@@ -258,6 +265,32 @@ int sv_sa_prepare_weights(const float* weight, const float* bn_weight, const flo
                           const float* running_var, float eps, int c_out, int c_in, int xyz_first, float* w_out, float* b_out, void* stream);
 int sv_sa_mlp_max(const float* xyz, const float* features, const float* new_xyz, const int32_t* idx, const int32_t* row_start, int64_t M, int C,
                   int nsample, const float* w1, const float* b1, int C1, const float* w2, const float* b2, int C2, float* out, void* stream);
+/* ---- set abstraction, TRAINING mode (csrc/set_abstraction_train.hip): one radius scale of StackSAModuleMSG.forward
+ * (pointnet2_modules.py:78-112) with batch-statistics BatchNorm2d, and its backward, as chains of persistent MFMA launches over 16-row tiles;
+ * no (M, C+3, nsample) tensor, no library GEMM.  Same operands as sv_sa_mlp_max, weights in the PARAMETER layouts: w1 (C1, 3 + C) with the xyz
+ * columns first (QueryAndGroup's concatenation order, pointnet2_utils.py:147-152), w2 (C2, C1); gamma / beta / running_* / tracked = the two
+ * nn.BatchNorm2d's weight, bias, running_mean, running_var, num_batches_tracked (updated like torch: biased variance to normalise, unbiased
+ * into running_var).  R = M * nsample rows.
+ * forward:  writes z1 (R, C1), z2 (R, C2) [pre-BatchNorm activations, kept for the backward], save_mean* / save_invstd*, sel (M, C2) = the z2
+ *           that makes each output, arg (M, C2) = its slot, out (M, C2); aux (M, C2) floats and aux_arg (M, C2) bytes are work buffers.
+ * backward: grad_out (M, C2) -> grad_w1 (C1, 3 + C), grad_w2 (C2, C1), dgamma* / dbeta*, scatter (N, C1) = per support point the sum of dz1 over
+ *           its (query, slot) pairs (zero-filled here; fp32 atomics like group_points_grad_kernel_stack, group_points_gpu.cu:38-41).  The
+ *           feature gradient is linear in the gathered row: grad_features (N, C) = scatter . w1[:, 3:] (null when not wanted or C == 0).
+ *           dy1 (R, C1) and aux (M, C2) are work buffers.
+ * scratch: sv_sa_train_scratch_bytes(C, C1, C2) bytes, not shared between a forward and a backward in flight on different streams. */
+size_t sv_sa_train_scratch_bytes(int C, int C1, int C2);
+int sv_sa_train_forward(const float* xyz, const float* features, const float* new_xyz, const int32_t* idx, const int32_t* row_start, int64_t M, int C,
+                        int nsample, const float* w1, const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
+                        int64_t* tracked1, int C1, const float* w2, const float* gamma2, const float* beta2, float* running_mean2,
+                        float* running_var2, int64_t* tracked2, int C2, float momentum, float eps, void* scratch, float* z1, float* z2,
+                        float* save_mean1, float* save_invstd1, float* save_mean2, float* save_invstd2, float* sel, float* aux, uint8_t* arg,
+                        uint8_t* aux_arg, float* out, void* stream);
+int sv_sa_train_backward(const float* xyz, const float* features, const float* new_xyz, const int32_t* idx, const int32_t* row_start, int64_t M,
+                         int64_t N, int C, int nsample, const float* w1, const float* gamma1, const float* beta1, int C1, const float* w2,
+                         const float* gamma2, const float* beta2, int C2, const float* z1, const float* z2, const float* save_mean1,
+                         const float* save_invstd1, const float* save_mean2, const float* save_invstd2, const float* sel, const uint8_t* arg,
+                         const float* out, const float* grad_out, void* scratch, float* dy1, float* aux, float* scatter, float* grad_features,
+                         float* grad_w1, float* grad_w2, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream);
 /* group_points_wrapper / group_points_grad_wrapper (src/group_points.cpp:31-69, kernels group_points_gpu.cu:15-102):
  * out (M,C,nsample)[m][c][s] = features[row_start[m] + idx[m][s]][c]; row_start[m] = first feature row of query m's scene.
  * The gradient zero-fills grad_features (N,C) and scatter-adds with fp32 atomics like the reference. */
@@ -265,15 +298,6 @@ int sv_group_points_stack(int M, int C, int nsample, const float* features, cons
                           float* out, void* stream);
 int sv_group_points_grad_stack(int M, int C, int N, int nsample, const float* grad_out, const int32_t* idx,
                                const int32_t* row_start, float* grad_features, void* stream);
-
-/* Neighbourhoods as rows (seevcn extension; the channel-last twin of QueryAndGroup.forward, pointnet2_utils.py:62-83):
- * out[(m * nsample + s), :] = [xyz[j] - new_xyz[m] | features[j]] (3 + C floats), j = row_start[m] + idx[m][s]; zero rows where idx[m][0] < 0
- * (empty ball, as ball_query leaves it).  features may be null when C == 0.  _grad: grad_features (N, C) = scatter-add of the feature
- * columns of grad_rows (zeroed inside). */
-int sv_group_rows_stack(int64_t M, int C, int nsample, const float* xyz, const float* features, const float* new_xyz, const int32_t* idx,
-                        const int32_t* row_start, float* out, void* stream);
-int sv_group_rows_grad_stack(int64_t M, int C, int64_t N, int nsample, const float* grad_rows, const int32_t* idx, const int32_t* row_start,
-                             float* grad_features, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Rotated-box geometry (detector3d/pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:12-17,

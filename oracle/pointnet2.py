@@ -119,3 +119,26 @@ def three_interpolate(features_mc, idx, weight):
     """stack layout: features (M,C) -> (N,C) = w0 f[i0] + w1 f[i1] + w2 f[i2] in fp32, left to right."""
     f, w = np.asarray(features_mc, F), np.asarray(weight, F)
     return (w[:, 0:1] * f[idx[:, 0]] + w[:, 1:2] * f[idx[:, 1]]) + w[:, 2:3] * f[idx[:, 2]]
+
+
+def sa_scale_train(xyz, features, new_xyz, idx, row_start, w1, g1, b1, w2, g2, b2, eps=1e-5):
+    """One radius scale of StackSAModuleMSG.forward in TRAINING mode (pointnet2_modules.py:96-110 on top of QueryAndGroup,
+    pointnet2_utils.py:112-159), in float64: grouped [xyz - new_xyz | features] with all-zero groups for empty balls (idx[m][0] < 0, as
+    ball_query leaves them), Conv2d 1x1 (no bias) -> BatchNorm2d with BATCH statistics over all M * nsample positions (biased variance) ->
+    ReLU, twice, then the maximum over nsample.  idx (M, ns) scene-local, row_start (M,) first support row of the query's scene;
+    w1 (C1, 3 + C), w2 (C2, C1).  -> (M, C2) float64."""
+    M, ns = idx.shape
+    empty = idx[:, 0] < 0
+    rows = row_start[:, None].astype(np.int64) + np.where(empty[:, None], 0, idx)
+    x = xyz[rows].astype(np.float64) - new_xyz[:, None, :].astype(np.float64)
+    if features is not None:
+        x = np.concatenate([x, features[rows].astype(np.float64)], axis=2)
+    x[empty] = 0.0
+    x = x.reshape(M * ns, -1)
+
+    def bn_relu(z, g, b):
+        return np.maximum((z - z.mean(0)) / np.sqrt(z.var(0) + eps) * g.astype(np.float64) + b.astype(np.float64), 0.0)
+
+    a1 = bn_relu(x @ w1.astype(np.float64).T, g1, b1)
+    a2 = bn_relu(a1 @ w2.astype(np.float64).T, g2, b2)
+    return a2.reshape(M, ns, -1).max(axis=1)

@@ -8,29 +8,7 @@
 // own -- and one test saw a stale partial at 4 workgroups per CU.  A kernel boundary costs 1.5 us here; three launches it is.)
 #include "common.h"
 
-#define BN_THREADS 256
-#define BN_MAX_C 512
-#define BN_MAX_WGS 1024
-
-struct BnArgs {
-  const float* x;       // (N, C) BN input
-  const float* dy;      // (N, C) gradient wrt the output (backward only)
-  float* out;           // y (forward) or dx (backward)
-  const float* gamma;   // may be null (1)
-  const float* beta;    // may be null (0)
-  float* running_mean;  // may be null
-  float* running_var;
-  float* save_mean;     // (C)
-  float* save_invstd;   // (C)
-  float* dgamma;        // (C)
-  float* dbeta;
-  float* partial;       // scratch: (wgs, 2, C)
-  float* coef;          // scratch: (4, C) per-channel constants of the elementwise pass
-  int64_t n;
-  int C, relu, wgs;
-  float momentum, eps;
-  int64_t* num_batches_tracked;   // nn.BatchNorm1d's counter, incremented by the training forward (may be null)
-};
+#include "norm.h"
 
 // per-thread: channels c4*4..c4*4+3 of rows (row0 + tid / C4) + k * R
 template <bool BWD>
@@ -239,3 +217,8 @@ extern "C" int sv_batchnorm_relu_backward(const float* x, const float* dy, int64
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
+
+// internal (norm.h): the per-channel combine of workgroup partials, for kernels that produce the partial sums in their own epilogue
+// (set_abstraction_train.hip).  a.partial (wgs, 2, C), a.coef (4, C), a.n = number of rows the statistics run over.
+void sv_bn_finalize_fwd(const BnArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_bn_finalize<false>, dim3(a.C), dim3(BN_THREADS), 0, st, a); }
+void sv_bn_finalize_bwd(const BnArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_bn_finalize<true>, dim3(a.C), dim3(BN_THREADS), 0, st, a); }

@@ -302,8 +302,11 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_multi(const float* __restri
   }
 }
 
+// async_mode < 0: the multi-workgroup path ends synchronised (error word read back, retry with write-through records).  async_mode 0 / 1: ONE
+// attempt (0: one-XCD records, 1: write-through records), nothing is read back -- the caller reads the error word at the end of multi_scratch
+// (sv_fps_multi_error_offset) whenever it next synchronises and re-runs with mode 1 if it is non-zero.
 static int fps_launch(const float* xyz, const int32_t* starts, const int32_t* counts, int batch, int fixed_n, int max_n, int m,
-                      float* temp, int32_t* idx, int add_offset, hipStream_t st, void* multi_scratch = nullptr) {
+                      float* temp, int32_t* idx, int add_offset, hipStream_t st, void* multi_scratch = nullptr, int async_mode = -1) {
   if (batch <= 0 || m <= 0) return SV_OK;
   static unsigned nonce = 0;
   static const bool multi_off = getenv("SEEVCN_FPS_MULTI") && atoi(getenv("SEEVCN_FPS_MULTI")) == 0;
@@ -316,7 +319,7 @@ static int fps_launch(const float* xyz, const int32_t* starts, const int32_t* co
     // first with the scene's workgroups on one XCD and its L2 as the meeting point (1.9 us per round); were the dispatch order ever not
     // "workgroup i -> XCD i % 8" a partner would poll a stale line of its own L2, time out and raise the error word: then once more with
     // write-through records, which hold for any placement (2.8 us per round).  The error word is read back, so this path ends synchronised.
-    for (int one_xcd = first_mode; one_xcd >= 0; --one_xcd) {
+    for (int one_xcd = async_mode < 0 ? first_mode : 1 - async_mode; one_xcd >= 0; --one_xcd) {
       SV_HIP(hipMemsetAsync(err, 0, 4, st));
       nonce = (nonce + 1) & 0xffffu;
       if (nonce == 0) nonce = 1;
@@ -327,6 +330,7 @@ static int fps_launch(const float* xyz, const int32_t* starts, const int32_t* co
       else if (p <= 4) hipLaunchKernelGGL(k_fps_multi<4>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset, rec, nonce, err, batch, one_xcd, spin_limit);
       else hipLaunchKernelGGL(k_fps_multi<8>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset, rec, nonce, err, batch, one_xcd, spin_limit);
       SV_LAUNCH_CHECK();
+      if (async_mode >= 0) return SV_OK;
       int32_t host_err = 0;
       SV_HIP(hipMemcpyAsync(&host_err, err, 4, hipMemcpyDeviceToHost, st));
       SV_HIP(hipStreamSynchronize(st));
@@ -335,6 +339,8 @@ static int fps_launch(const float* xyz, const int32_t* starts, const int32_t* co
     sv_set_error("farthest_point_sampling: a partner workgroup never arrived (GPU shared with another process?); SEEVCN_FPS_MULTI=0 selects one workgroup per scene");
     return SV_ERR_HIP;
   }
+  if (async_mode >= 0 && multi_scratch)      // the single-workgroup kernels cannot fail: the error word the caller will read is 0
+    SV_HIP(hipMemsetAsync(reinterpret_cast<char*>(multi_scratch) + (size_t)batch * 2 * FPS_W * sizeof(FpsRecord), 0, 4, st));
   const int p = (max_n + FPS_THREADS - 1) / FPS_THREADS;
   dim3 grid(batch), block(FPS_THREADS);
   if (p <= 4) hipLaunchKernelGGL(k_fps_reg<4>, grid, block, 0, st, xyz, starts, counts, fixed_n, m, idx, add_offset);
@@ -353,6 +359,8 @@ static int fps_launch(const float* xyz, const int32_t* starts, const int32_t* co
 
 // scratch of the multi-workgroup path: 2 x FPS_W records per scene + an error word (read it back to detect a missing partner; 0 = fine)
 extern "C" size_t sv_fps_multi_scratch_bytes(int batch) { return (size_t)(batch > 0 ? batch : 0) * 2 * FPS_W * sizeof(FpsRecord) + 64; }
+
+extern "C" size_t sv_fps_multi_error_offset(int batch) { return (size_t)(batch > 0 ? batch : 0) * 2 * FPS_W * sizeof(FpsRecord); }
 
 extern "C" int sv_farthest_point_sampling(const float* xyz, int b, int n, int m, float* temp, int32_t* idx, void* stream) {
   SV_CHECK_ARG(b >= 0 && n > 0 && m >= 0 && (b == 0 || (xyz && idx)), "farthest_point_sampling: bad arguments");
@@ -374,6 +382,15 @@ extern "C" int sv_stack_farthest_point_sampling_multi(const float* xyz, const in
   if (batch == 0 || m == 0) return SV_OK;
   SV_CHECK_ARG(xyz && xyz_batch_start && xyz_batch_cnt && idx, "stack_farthest_point_sampling: null pointer");
   return fps_launch(xyz, xyz_batch_start, xyz_batch_cnt, batch, 0, max_n, m, temp, idx, 1, sv_stream(stream), multi_scratch);
+}
+
+extern "C" int sv_stack_farthest_point_sampling_multi_async(const float* xyz, const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int batch,
+                                                            int max_n, int m, float* temp, void* multi_scratch, int32_t* idx, int write_through,
+                                                            void* stream) {
+  SV_CHECK_ARG(batch >= 0 && m >= 0 && max_n >= 0, "stack_farthest_point_sampling: bad arguments");
+  if (batch == 0 || m == 0) return SV_OK;
+  SV_CHECK_ARG(xyz && xyz_batch_start && xyz_batch_cnt && idx && multi_scratch, "stack_farthest_point_sampling: null pointer");
+  return fps_launch(xyz, xyz_batch_start, xyz_batch_cnt, batch, 0, max_n, m, temp, idx, 1, sv_stream(stream), multi_scratch, write_through ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,51 +524,6 @@ __global__ __launch_bounds__(256) void k_group_points_grad(int64_t pairs, int C,
   }
 }
 
-// ---- neighbourhoods as ROWS: out[(m * nsample + s), :] = [xyz[j] - new_xyz[m] (3) | features[j] (C)] with j = row_start[m] + idx[m][s];
-// an empty ball (idx[m][0] < 0) gives zero rows.  The channel-last twin of QueryAndGroup's (M, 3 + C, nsample) tensor
-// (pointnet2_utils.py:62-83): the shared MLP of a set-abstraction scale is then ONE (M * nsample, 3 + C) x (3 + C, C') GEMM.
-__global__ __launch_bounds__(256) void k_group_rows(int64_t total, int C, int nsample, const float* __restrict__ xyz, const float* __restrict__ features,
-                                                    const float* __restrict__ new_xyz, const int32_t* __restrict__ idx,
-                                                    const int32_t* __restrict__ row_start, float* __restrict__ out) {
-  const int cg = C + 3;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(e % cg);
-    const int64_t r = e / cg;
-    const int64_t m = r / nsample;
-    const int32_t j0 = idx[m * nsample];
-    float v = 0.f;
-    if (j0 >= 0) {
-      const int64_t row = (int64_t)row_start[m] + idx[r];
-      v = c < 3 ? xyz[row * 3 + c] - new_xyz[m * 3 + c] : features[row * C + (c - 3)];
-    }
-    out[e] = v;
-  }
-}
-
-// gradient of the feature part of k_group_rows: one thread per (query, channel), lanes over channels, repeats of the first neighbour summed first
-__global__ __launch_bounds__(256) void k_group_rows_grad(int64_t pairs, int C, int nsample, const float* __restrict__ grad_rows,
-                                                         const int32_t* __restrict__ idx, const int32_t* __restrict__ row_start,
-                                                         float* __restrict__ grad_features) {
-  const int cg = C + 3;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < pairs; t += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(t % C);
-    const int64_t m = t / C;
-    const int32_t* id = idx + m * nsample;
-    const int32_t j0 = id[0];
-    if (j0 < 0) continue;
-    const float* g = grad_rows + m * nsample * cg + 3 + c;
-    const int64_t row0 = row_start[m];
-    float acc = g[0];
-    for (int s = 1; s < nsample; ++s) {
-      const int32_t j = id[s];
-      const float v = g[(int64_t)s * cg];
-      if (j == j0) acc += v;
-      else atomicAdd(&grad_features[(row0 + j) * C + c], v);
-    }
-    atomicAdd(&grad_features[(row0 + j0) * C + c], acc);
-  }
-}
-
 extern "C" int sv_group_points_stack(int M, int C, int nsample, const float* features, const int32_t* idx, const int32_t* row_start,
                                      float* out, void* stream) {
   SV_CHECK_ARG(M >= 0 && C > 0 && nsample > 0, "group_points: bad arguments");
@@ -577,34 +549,6 @@ extern "C" int sv_group_points_grad_stack(int M, int C, int N, int nsample, cons
   const int64_t pairs = (int64_t)M * C;
   hipLaunchKernelGGL(k_group_points_grad, dim3(sv_grid_1d(pairs, 256, 256 * 64)), dim3(256), 0, st, pairs, C, nsample, grad_out, idx, row_start,
                      grad_features);
-  SV_LAUNCH_CHECK();
-  return SV_OK;
-}
-
-extern "C" int sv_group_rows_stack(int64_t M, int C, int nsample, const float* xyz, const float* features, const float* new_xyz, const int32_t* idx,
-                                   const int32_t* row_start, float* out, void* stream) {
-  SV_CHECK_ARG(M >= 0 && C >= 0 && nsample > 0, "group_rows: bad arguments");
-  if (M == 0) return SV_OK;
-  SV_CHECK_ARG(xyz && new_xyz && idx && row_start && out && (C == 0 || features), "group_rows: null pointer");
-  const int64_t total = M * nsample * (C + 3);
-  hipLaunchKernelGGL(k_group_rows, dim3(sv_grid_1d(total, 256, 256 * 64)), dim3(256), 0, sv_stream(stream), total, C, nsample, xyz, features, new_xyz, idx,
-                     row_start, out);
-  SV_LAUNCH_CHECK();
-  return SV_OK;
-}
-
-extern "C" int sv_group_rows_grad_stack(int64_t M, int C, int64_t N, int nsample, const float* grad_rows, const int32_t* idx, const int32_t* row_start,
-                                        float* grad_features, void* stream) {
-  SV_CHECK_ARG(M >= 0 && C > 0 && nsample > 0 && N >= 0, "group_rows_grad: bad arguments");
-  hipStream_t st = sv_stream(stream);
-  if (N > 0) {
-    SV_CHECK_ARG(grad_features, "group_rows_grad: null pointer");
-    SV_HIP(hipMemsetAsync(grad_features, 0, (size_t)N * C * 4, st));
-  }
-  if (M == 0) return SV_OK;
-  SV_CHECK_ARG(grad_rows && idx && row_start, "group_rows_grad: null pointer");
-  const int64_t pairs = M * C;
-  hipLaunchKernelGGL(k_group_rows_grad, dim3(sv_grid_1d(pairs, 256, 256 * 64)), dim3(256), 0, st, pairs, C, nsample, grad_rows, idx, row_start, grad_features);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -28,6 +28,10 @@ def collate_batch(batch_list, _unused=False):
             elif key in ['points', 'voxel_coords']:
                 # prepend the sample index as column 0: points (P, 1+C) [b,x,y,z,...], voxel_coords (V,4) [b,z,y,x]
                 ret[key] = np.concatenate([np.pad(c, ((0, 0), (1, 0)), mode='constant', constant_values=i) for i, c in enumerate(val)], axis=0)
+                if key == 'points':
+                    # seevcn extension: the per-scene counts are known here for free; with them on the host the detector needs no device -> host
+                    # read to size its keypoint sampling (VoxelSetAbstraction.prefetch_keypoints)
+                    ret['points_per_scene'] = [len(c) for c in val]
             elif key in ['gt_boxes', 'gt_boxes2d']:
                 max_gt = max(len(x) for x in val)
                 out = np.zeros((batch_size, max_gt, val[0].shape[-1]), dtype=np.float32)

@@ -3,7 +3,7 @@ import torch
 import torch.nn as nn
 
 from .... import _lib
-from ...utils import box_coder_utils, loss_utils
+from ...utils import box_coder_utils, common_utils, loss_utils
 from ...utils.common_utils import cfg_get
 from .target_assigner.anchor_generator import AnchorGenerator
 from .target_assigner.axis_aligned_target_assigner import AxisAlignedTargetAssigner
@@ -84,7 +84,7 @@ class AnchorHeadTemplate(nn.Module):
         one_hot.scatter_(-1, cls_targets.unsqueeze(-1), 1.0)
         cls_loss_src = self.cls_loss_func(cls_preds.view(batch_size, -1, self.num_class), one_hot[..., 1:], weights=cls_weights)
         cls_loss = cls_loss_src.sum() / batch_size * cfg_get(self.model_cfg, 'LOSS_CONFIG')['LOSS_WEIGHTS']['cls_weight']
-        return cls_loss, {'rpn_loss_cls': cls_loss.item()}
+        return cls_loss, {'rpn_loss_cls': common_utils.tb_value(cls_loss)}
 
     @staticmethod
     def add_sin_difference(boxes1, boxes2, dim=6):
@@ -123,7 +123,7 @@ class AnchorHeadTemplate(nn.Module):
         loss_w = cfg_get(self.model_cfg, 'LOSS_CONFIG')['LOSS_WEIGHTS']
         loc_loss = self.reg_loss_func(box_preds_sin, reg_targets_sin, weights=reg_weights).sum() / batch_size * loss_w['loc_weight']
         box_loss = loc_loss
-        tb_dict = {'rpn_loss_loc': loc_loss.item()}
+        tb_dict = {'rpn_loss_loc': common_utils.tb_value(loc_loss)}
         if box_dir_cls_preds is not None:
             nb = cfg_get(self.model_cfg, 'NUM_DIR_BINS')
             dir_targets = self.get_direction_target(anchors, box_reg_targets, dir_offset=cfg_get(self.model_cfg, 'DIR_OFFSET'), num_bins=nb)
@@ -132,7 +132,7 @@ class AnchorHeadTemplate(nn.Module):
             weights = weights / torch.clamp(weights.sum(-1, keepdim=True), min=1.0)
             dir_loss = self.dir_loss_func(dir_logits, dir_targets, weights=weights).sum() / batch_size * loss_w['dir_weight']
             box_loss = box_loss + dir_loss
-            tb_dict['rpn_loss_dir'] = dir_loss.item()
+            tb_dict['rpn_loss_dir'] = common_utils.tb_value(dir_loss)
         return box_loss, tb_dict
 
     def get_loss(self):
@@ -140,7 +140,7 @@ class AnchorHeadTemplate(nn.Module):
         box_loss, tb_dict_box = self.get_box_reg_layer_loss()
         tb_dict.update(tb_dict_box)
         rpn_loss = cls_loss + box_loss
-        tb_dict['rpn_loss'] = rpn_loss.item()
+        tb_dict['rpn_loss'] = common_utils.tb_value(rpn_loss)
         return rpn_loss, tb_dict
 
     @torch.no_grad()

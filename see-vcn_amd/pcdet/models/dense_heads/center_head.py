@@ -6,7 +6,7 @@ import torch.nn as nn
 from torch.nn.init import kaiming_normal_
 
 from .... import _lib
-from ...utils import loss_utils
+from ...utils import common_utils, loss_utils
 from ...utils.common_utils import cfg_get
 from ..model_utils import centernet_utils, model_nms_utils
 
@@ -81,7 +81,7 @@ class CenterHead(nn.Module):
                     tab[h, self.class_names.index(n) + 1] = li + 1
             ncls = np.array([len(n) for n in self.class_names_each_head], np.int32)
             off = (np.cumsum(ncls) - ncls).astype(np.int32)
-            self._tables[dev] = tuple(torch.from_numpy(x).to(dev) for x in (tab, ncls, off)) + (int(ncls.sum()),)
+            self._tables[dev] = tuple(torch.from_numpy(x).to(dev) for x in (tab, ncls, off)) + (int(ncls.sum()), off.tolist())
         return self._tables[dev]
 
     def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
@@ -93,7 +93,7 @@ class CenterHead(nn.Module):
         gt = gt_boxes.contiguous().float()
         B, G, D = gt.shape
         dev = gt.device
-        tab, ncls, off, total = self._device_tables(dev)
+        tab, ncls, off, total, off_host = self._device_tables(dev)
         nh, nmax = len(self.class_names_each_head), cfg_get(tcfg, 'NUM_MAX_OBJS')
         heat = torch.empty((B, total, H, W), dtype=torch.float32, device=dev)
         tbox = torch.empty((nh, B, nmax, D), dtype=torch.float32, device=dev)
@@ -104,7 +104,7 @@ class CenterHead(nn.Module):
                                           float(cfg_get(tcfg, 'FEATURE_MAP_STRIDE')), nmax, float(cfg_get(tcfg, 'GAUSSIAN_OVERLAP')),
                                           int(cfg_get(tcfg, 'MIN_RADIUS')), _lib.ptr(heat), _lib.ptr(tbox), _lib.ptr(inds), _lib.ptr(masks), _lib.stream())
         _lib.check(rc, "sv_center_assign_targets")
-        offs = off.tolist() + [total]
+        offs = off_host + [total]
         return {'heatmaps': [heat[:, offs[h]:offs[h + 1]] for h in range(nh)], 'target_boxes': [tbox[h] for h in range(nh)],
                 'inds': [inds[h] for h in range(nh)], 'masks': [masks[h] for h in range(nh)], 'heatmap_masks': []}
 
@@ -121,11 +121,11 @@ class CenterHead(nn.Module):
             hm_loss = self.hm_loss_func(pred['hm'], target_dicts['heatmaps'][idx]) * lw['cls_weight']
             pred_boxes = torch.cat([pred[name] for name in cfg_get(self.separate_head_cfg, 'HEAD_ORDER')], dim=1)
             reg_loss = self.reg_loss_func(pred_boxes, target_dicts['masks'][idx], target_dicts['inds'][idx], target_dicts['target_boxes'][idx])
-            loc_loss = (reg_loss * reg_loss.new_tensor(lw['code_weights'])).sum() * lw['loc_weight']
+            loc_loss = (reg_loss * common_utils.const_tensor(lw['code_weights'], reg_loss.device, reg_loss.dtype)).sum() * lw['loc_weight']
             loss = loss + hm_loss + loc_loss
-            tb_dict['hm_loss_head_%d' % idx] = hm_loss.item()
-            tb_dict['loc_loss_head_%d' % idx] = loc_loss.item()
-        tb_dict['rpn_loss'] = loss.item()
+            tb_dict['hm_loss_head_%d' % idx] = common_utils.tb_value(hm_loss)
+            tb_dict['loc_loss_head_%d' % idx] = common_utils.tb_value(loc_loss)
+        tb_dict['rpn_loss'] = common_utils.tb_value(loss)
         return loss, tb_dict
 
     @torch.no_grad()

@@ -18,7 +18,8 @@ class PointHeadSimple(PointHeadTemplate):
         batch_size = gt_boxes.shape[0]
         extend = box_utils.enlarge_box3d(gt_boxes.view(-1, gt_boxes.shape[-1]),
                                          extra_width=cfg_get(self.model_cfg, 'TARGET_CONFIG')['GT_EXTRA_WIDTH']).view(batch_size, -1, gt_boxes.shape[-1])
-        return self.assign_stack_targets(points=point_coords, gt_boxes=gt_boxes, extend_gt_boxes=extend, set_ignore_flag=True)
+        return self.assign_stack_targets(points=point_coords, gt_boxes=gt_boxes, extend_gt_boxes=extend, set_ignore_flag=True,
+                                         points_per_scene=input_dict.get('point_coords_per_scene'))
 
     def get_loss(self, tb_dict=None):
         tb_dict = {} if tb_dict is None else tb_dict

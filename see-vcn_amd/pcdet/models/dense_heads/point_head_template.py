@@ -2,7 +2,7 @@ import torch
 import torch.nn as nn
 
 from ...ops.roiaware_pool3d import roiaware_pool3d_utils
-from ...utils import loss_utils
+from ...utils import common_utils, loss_utils
 from ...utils.common_utils import cfg_get
 
 
@@ -25,15 +25,17 @@ class PointHeadTemplate(nn.Module):
         layers.append(nn.Linear(c_in, output_channels, bias=True))
         return nn.Sequential(*layers)
 
-    def assign_stack_targets(self, points, gt_boxes, extend_gt_boxes=None, set_ignore_flag=True):
+    def assign_stack_targets(self, points, gt_boxes, extend_gt_boxes=None, set_ignore_flag=True, points_per_scene=None):
         """points (N,4) [b,x,y,z] stacked scene by scene with equal counts or ragged; gt_boxes (B,M,8).
         Labels: class (or 1) inside a box, -1 inside the enlarged box only, 0 elsewhere (reference :49-129,
         set_ignore_flag branch).  One batched points-in-boxes launch per box set instead of a python loop over scenes."""
         assert len(points.shape) == 2 and points.shape[1] == 4 and len(gt_boxes.shape) == 3 and gt_boxes.shape[2] == 8
         assert set_ignore_flag, "ball-constraint targets are outside the built path"
         B = gt_boxes.shape[0]
-        cnt = torch.bincount(points[:, 0].long(), minlength=B)
-        m = int(cnt.max().item()) if points.shape[0] else 0
+        cnt = common_utils.batch_counts(points[:, 0].long(), B).long()
+        # rows of the padded (B, m, 3) block: the per-scene count when the producer of the points stated it (VoxelSetAbstraction: NUM_KEYPOINTS per
+        # scene), else an upper bound that needs no device -> host read (all points in one scene)
+        m = int(points_per_scene) if points_per_scene else int(points.shape[0])
         padded = points.new_full((B, max(m, 1), 3), 1e8)                     # far-away filler for ragged scenes
         pos = torch.arange(points.shape[0], device=points.device) - (torch.cumsum(cnt, 0) - cnt)[points[:, 0].long()]
         padded[points[:, 0].long(), pos] = points[:, 1:4]
@@ -41,12 +43,12 @@ class PointHeadTemplate(nn.Module):
         ext_idx = roiaware_pool3d_utils.points_in_boxes_gpu(padded, extend_gt_boxes[:, :, 0:7].contiguous()).long()
         box_idx, ext_idx = box_idx[points[:, 0].long(), pos], ext_idx[points[:, 0].long(), pos]
         fg = box_idx >= 0
-        labels = points.new_zeros(points.shape[0]).long()
-        labels[fg ^ (ext_idx >= 0)] = -1
+        # selects instead of masked assignments (an index list made from a mask is a device -> host read of its length)
+        labels = torch.where(fg ^ (ext_idx >= 0), -torch.ones_like(box_idx), torch.zeros_like(box_idx))
         if self.num_class == 1:
-            labels[fg] = 1
+            labels = torch.where(fg, torch.ones_like(labels), labels)
         else:
-            labels[fg] = gt_boxes[points[fg, 0].long(), box_idx[fg], -1].long()
+            labels = torch.where(fg, gt_boxes[points[:, 0].long(), box_idx.clamp(min=0), -1].long(), labels)
         return {'point_cls_labels': labels, 'point_box_labels': None, 'point_part_labels': None}
 
     def get_cls_layer_loss(self, tb_dict=None):
@@ -61,7 +63,7 @@ class PointHeadTemplate(nn.Module):
         loss = self.cls_loss_func(preds, one_hot[..., 1:], weights=cls_weights).sum()
         loss = loss * cfg_get(self.model_cfg, 'LOSS_CONFIG')['LOSS_WEIGHTS']['point_cls_weight']
         tb_dict = {} if tb_dict is None else tb_dict
-        tb_dict.update({'point_loss_cls': loss.item(), 'point_pos_num': pos_normalizer.item()})
+        tb_dict.update({'point_loss_cls': common_utils.tb_value(loss), 'point_pos_num': common_utils.tb_value(pos_normalizer)})
         return loss, tb_dict
 
     def forward(self, **kwargs):

@@ -6,6 +6,7 @@ from ..backbones_2d import map_to_bev
 from ..backbones_3d import pfe, vfe
 from ..model_utils import model_nms_utils
 from ...ops.iou3d_nms import iou3d_nms_utils
+from ...utils import common_utils
 from ...utils.common_utils import cfg_get
 from ...utils.spconv_utils import find_all_spconv_keys
 
@@ -140,6 +141,8 @@ class Detector3DTemplate(nn.Module):
     LOSS_HEADS = ('dense_head',)
 
     def run_modules(self, batch_dict):
+        if getattr(self, 'pfe', None) is not None and hasattr(self.pfe, 'prefetch_keypoints'):
+            self.pfe.prefetch_keypoints(batch_dict)                        # keypoint sampling on a side stream, beside the backbone
         for module in self.module_list:
             batch_dict = module(batch_dict)
         return batch_dict
@@ -147,12 +150,14 @@ class Detector3DTemplate(nn.Module):
     def get_training_loss(self):
         """sum of the LOSS_HEADS' losses -> (loss, tb_dict, disp_dict), the reference detectors' return convention"""
         total, tb_dict = None, None
-        for name in self.LOSS_HEADS:
-            head = getattr(self, name)
-            term, tb_dict = head.get_loss() if tb_dict is None else head.get_loss(tb_dict)
-            total = term if total is None else total + term
-        if len(self.LOSS_HEADS) == 1:
-            tb_dict = {'loss_rpn': total.item(), **tb_dict}
+        with common_utils.deferred_tb():                                   # the heads' loss scalars stay tensors ...
+            for name in self.LOSS_HEADS:
+                head = getattr(self, name)
+                term, tb_dict = head.get_loss() if tb_dict is None else head.get_loss(tb_dict)
+                total = term if total is None else total + term
+            if len(self.LOSS_HEADS) == 1:
+                tb_dict = {'loss_rpn': common_utils.tb_value(total), **tb_dict}
+        common_utils.materialize_tb(tb_dict)                               # ... and become Python floats with ONE device -> host read
         return total, tb_dict, {}
 
     def forward(self, batch_dict):

@@ -24,3 +24,16 @@ def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
         original_idxs = scores_mask.nonzero().view(-1)
         selected = original_idxs[selected]
     return selected, src_box_scores[selected]
+
+
+def class_agnostic_nms_padded(box_scores, box_preds, nms_config):
+    """class_agnostic_nms without a score threshold as a fixed-size result: (selected (NMS_POST_MAXSIZE,) indices into the original arrays,
+    valid (NMS_POST_MAXSIZE,) bool); the survivors come first, in score order.  No device -> host read."""
+    post = cfg_get(nms_config, 'NMS_POST_MAXSIZE')
+    if box_scores.shape[0] == 0:
+        z = torch.zeros((post,), dtype=torch.int64, device=box_scores.device)
+        return z, z.bool()
+    box_scores_nms, indices = torch.topk(box_scores, k=min(cfg_get(nms_config, 'NMS_PRE_MAXSIZE'), box_scores.shape[0]))
+    keep, valid = iou3d_nms_utils.nms_gpu_padded(box_preds[indices][:, 0:7], box_scores_nms, cfg_get(nms_config, 'NMS_THRESH'), post,
+                                                 normal=cfg_get(nms_config, 'NMS_TYPE') == 'nms_normal_gpu')
+    return indices[keep], valid

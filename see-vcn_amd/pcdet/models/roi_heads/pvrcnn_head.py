@@ -40,7 +40,10 @@ class PVRCNNHead(RoIHeadTemplate):
 
     @staticmethod
     def get_dense_grid_points(rois, batch_size_rcnn, grid_size):
-        dense_idx = rois.new_ones((grid_size, grid_size, grid_size)).nonzero().repeat(batch_size_rcnn, 1, 1).float()   # (B, g^3, 3)
+        # rois.new_ones((g, g, g)).nonzero() of the reference = the g^3 index triples in C order: a constant, made once per device
+        import numpy as np
+        dense_idx = common_utils.const_tensor(np.stack(np.meshgrid(*([np.arange(grid_size)] * 3), indexing='ij'), axis=-1).reshape(-1, 3), rois.device,
+                                              rois.dtype).repeat(batch_size_rcnn, 1, 1)                               # (B, g^3, 3)
         size = rois.view(batch_size_rcnn, -1)[:, 3:6]
         return (dense_idx + 0.5) / grid_size * size.unsqueeze(1) - (size.unsqueeze(1) / 2)
 
@@ -58,7 +61,7 @@ class PVRCNNHead(RoIHeadTemplate):
         glob, _ = self.get_global_grid_points_of_roi(rois, grid_size=self.grid_size)
         glob = glob.view(batch_size, -1, 3)
         xyz = point_coords[:, 1:4]
-        xyz_batch_cnt = torch.bincount(point_coords[:, 0].long(), minlength=batch_size).int()
+        xyz_batch_cnt = common_utils.batch_counts(point_coords[:, 0].long(), batch_size)
         new_xyz = glob.view(-1, 3)
         new_xyz_batch_cnt = xyz.new_zeros(batch_size).int().fill_(glob.shape[1])
         _, pooled = self.roi_grid_pool_layer(xyz=xyz.contiguous(), xyz_batch_cnt=xyz_batch_cnt, new_xyz=new_xyz.contiguous(),

@@ -5,7 +5,7 @@ import torch.nn.functional as F
 
 from ...utils import box_coder_utils, common_utils, loss_utils
 from ...utils.common_utils import cfg_get
-from ..model_utils.model_nms_utils import class_agnostic_nms
+from ..model_utils.model_nms_utils import class_agnostic_nms, class_agnostic_nms_padded  # noqa: F401
 from .target_assigner.proposal_target_layer import ProposalTargetLayer
 
 
@@ -63,10 +63,11 @@ class RoIHeadTemplate(nn.Module):
             mask = (batch_dict['batch_index'] == i) if batch_dict.get('batch_index', None) is not None else i
             box_preds, cls_preds = box_preds_all[mask], cls_preds_all[mask]
             cur_scores, cur_labels = torch.max(cls_preds, dim=1)
-            selected, _ = class_agnostic_nms(box_scores=cur_scores, box_preds=box_preds, nms_config=nms_config)
-            rois[i, :len(selected)] = box_preds[selected]
-            roi_scores[i, :len(selected)] = cur_scores[selected]
-            roi_labels[i, :len(selected)] = cur_labels[selected]
+            # the survivors of the NMS in a fixed-size block, the rest zeros: no read of the survivor count on the host
+            selected, valid = class_agnostic_nms_padded(box_scores=cur_scores, box_preds=box_preds, nms_config=nms_config)
+            rois[i] = box_preds[selected] * valid.view(-1, 1)
+            roi_scores[i] = cur_scores[selected] * valid
+            roi_labels[i] = cur_labels[selected] * valid
         batch_dict['rois'], batch_dict['roi_scores'], batch_dict['roi_labels'] = rois, roi_scores, roi_labels + 1
         batch_dict['has_class_labels'] = True if cls_preds_all.shape[-1] > 1 else False
         batch_dict.pop('batch_index', None)
@@ -85,9 +86,8 @@ class RoIHeadTemplate(nn.Module):
         gt = common_utils.rotate_points_along_z(points=gt.view(-1, 1, gt.shape[-1]), angle=-roi_ry.view(-1)).view(batch_size, -1, gt.shape[-1])
         heading = gt[:, :, 6] % (2 * np.pi)
         opp = (heading > np.pi * 0.5) & (heading < np.pi * 1.5)
-        heading[opp] = (heading[opp] + np.pi) % (2 * np.pi)
-        flag = heading > np.pi
-        heading[flag] = heading[flag] - np.pi * 2
+        heading = torch.where(opp, (heading + np.pi) % (2 * np.pi), heading)        # masked assignment as a select: no index list, no host read
+        heading = torch.where(heading > np.pi, heading - np.pi * 2, heading)
         gt[:, :, 6] = torch.clamp(heading, min=-np.pi / 2, max=np.pi / 2)
         t['gt_of_rois'] = gt
         return t
@@ -102,7 +102,8 @@ class RoIHeadTemplate(nn.Module):
         rcnn_reg, roi_boxes3d = forward_ret_dict['rcnn_reg'], forward_ret_dict['rois']
         n = gt_ct.view(-1, code).shape[0]
         fg_mask = reg_valid_mask > 0
-        fg_sum = fg_mask.long().sum().item()
+        fg_sum = fg_mask.long().sum()                                              # stays on the device: no host read
+        fg_norm = torch.clamp(fg_sum, min=1).float()
         tb = {}
         assert cfg_get(lc, 'REG_LOSS') == 'smooth-l1'
         anchors = roi_boxes3d.clone().detach().view(-1, code)
@@ -110,20 +111,22 @@ class RoIHeadTemplate(nn.Module):
         anchors[:, 6] = 0
         reg_targets = self.box_coder.encode_torch(gt_ct.view(n, code), anchors)
         loss = self.reg_loss_func(rcnn_reg.view(n, -1).unsqueeze(0), reg_targets.unsqueeze(0))
-        loss = (loss.view(n, -1) * fg_mask.unsqueeze(-1).float()).sum() / max(fg_sum, 1) * lw['rcnn_reg_weight']
-        tb['rcnn_loss_reg'] = loss.item()
-        if cfg_get(lc, 'CORNER_LOSS_REGULARIZATION') and fg_sum > 0:
-            fg_reg = rcnn_reg.view(n, -1)[fg_mask]
-            fg_rois = roi_boxes3d.view(-1, code)[fg_mask].view(1, -1, code)
-            batch_anchors = fg_rois.clone().detach()
-            roi_ry, roi_xyz = fg_rois[:, :, 6].view(-1), fg_rois[:, :, 0:3].view(-1, 3)
+        loss = (loss.view(n, -1) * fg_mask.unsqueeze(-1).float()).sum() / fg_norm * lw['rcnn_reg_weight']
+        tb['rcnn_loss_reg'] = common_utils.tb_value(loss)
+        if cfg_get(lc, 'CORNER_LOSS_REGULARIZATION'):
+            # the reference gathers the foreground RoIs (a host read of their number) and averages over them; here every RoI is decoded and the
+            # background ones are masked out of the mean: the same value, 0 when there is no foreground RoI
+            all_rois = roi_boxes3d.view(1, -1, code)
+            batch_anchors = all_rois.clone().detach()
+            roi_ry, roi_xyz = all_rois[:, :, 6].view(-1), all_rois[:, :, 0:3].view(-1, 3)
             batch_anchors[:, :, 0:3] = 0
-            boxes = self.box_coder.decode_torch(fg_reg.view(batch_anchors.shape[0], -1, code), batch_anchors).view(-1, code)
+            boxes = self.box_coder.decode_torch(rcnn_reg.view(1, -1, code), batch_anchors).view(-1, code)
             boxes = common_utils.rotate_points_along_z(boxes.unsqueeze(1), roi_ry).squeeze(1)
-            boxes[:, 0:3] += roi_xyz
-            corner = loss_utils.get_corner_loss_lidar(boxes[:, 0:7], gt_src[fg_mask][:, 0:7]).mean() * lw['rcnn_corner_weight']
+            boxes = torch.cat([boxes[:, 0:3] + roi_xyz, boxes[:, 3:]], dim=1)
+            per_roi = loss_utils.get_corner_loss_lidar(boxes[:, 0:7], gt_src[:, 0:7])
+            corner = (per_roi * fg_mask.float()).sum() / fg_norm * lw['rcnn_corner_weight']
             loss = loss + corner
-            tb['rcnn_loss_corner'] = corner.item()
+            tb['rcnn_loss_corner'] = common_utils.tb_value(corner)
         return loss, tb
 
     def get_box_cls_layer_loss(self, forward_ret_dict):
@@ -138,7 +141,7 @@ class RoIHeadTemplate(nn.Module):
             raise NotImplementedError
         valid = (labels >= 0).float()
         loss = (batch_loss * valid).sum() / torch.clamp(valid.sum(), min=1.0) * cfg_get(lc, 'LOSS_WEIGHTS')['rcnn_cls_weight']
-        return loss, {'rcnn_loss_cls': loss.item()}
+        return loss, {'rcnn_loss_cls': common_utils.tb_value(loss)}
 
     def get_loss(self, tb_dict=None):
         tb_dict = {} if tb_dict is None else tb_dict
@@ -147,7 +150,7 @@ class RoIHeadTemplate(nn.Module):
         tb_dict.update(tb1)
         tb_dict.update(tb2)
         rcnn_loss = cls_loss + reg_loss
-        tb_dict['rcnn_loss'] = rcnn_loss.item()
+        tb_dict['rcnn_loss'] = common_utils.tb_value(rcnn_loss)
         return rcnn_loss, tb_dict
 
     def generate_predicted_boxes(self, batch_size, rois, cls_preds, box_preds):

@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ...utils import loss_utils
+from ...utils import common_utils, loss_utils
 from ...utils.common_utils import cfg_get
 from .roi_head_template import RoIHeadTemplate
 
@@ -88,7 +88,7 @@ class SECONDHead(RoIHeadTemplate):
         tb_dict = {} if tb_dict is None else tb_dict
         rcnn_loss, cls_tb_dict = self.get_box_iou_layer_loss(self.forward_ret_dict)
         tb_dict.update(cls_tb_dict)
-        tb_dict['rcnn_loss'] = rcnn_loss.item()
+        tb_dict['rcnn_loss'] = common_utils.tb_value(rcnn_loss)
         return rcnn_loss, tb_dict
 
     def get_box_iou_layer_loss(self, forward_ret_dict):
@@ -107,4 +107,4 @@ class SECONDHead(RoIHeadTemplate):
         valid = (labels >= 0).float()
         loss = (batch_loss * valid).sum() / torch.clamp(valid.sum(), min=1.0)
         loss = loss * cfg_get(loss_cfgs, 'LOSS_WEIGHTS')['rcnn_iou_weight']
-        return loss, {'rcnn_loss_iou': loss.item()}
+        return loss, {'rcnn_loss_iou': common_utils.tb_value(loss)}

@@ -24,13 +24,14 @@ class ProposalTargetLayer(nn.Module):
         st = self._c('CLS_SCORE_TYPE')
         if st == 'cls':
             cls_labels = (ious > self._c('CLS_FG_THRESH')).long()
-            cls_labels[(ious > self._c('CLS_BG_THRESH')) & (ious < self._c('CLS_FG_THRESH'))] = -1
+            ignore = (ious > self._c('CLS_BG_THRESH')) & (ious < self._c('CLS_FG_THRESH'))
+            cls_labels = torch.where(ignore, -torch.ones_like(cls_labels), cls_labels)        # a select: no index list from the mask
         elif st == 'roi_iou':
             bg, fg = self._c('CLS_BG_THRESH'), self._c('CLS_FG_THRESH')
             fg_mask, bg_mask = ious > fg, ious < bg
             interval = (fg_mask == 0) & (bg_mask == 0)
             cls_labels = (fg_mask > 0).float()
-            cls_labels[interval] = (ious[interval] - bg) / (fg - bg)
+            cls_labels = torch.where(interval, (ious - bg) / (fg - bg), cls_labels)
         elif st == 'raw_roi_iou':
             cls_labels = ious
         else:
@@ -39,80 +40,72 @@ class ProposalTargetLayer(nn.Module):
                 'reg_valid_mask': reg_valid_mask, 'rcnn_cls_labels': cls_labels}
 
     def sample_rois_for_rcnn(self, batch_dict):
+        """Same selection as the reference (:82-128) with ONE device -> host read instead of ~30 per scene: the RoI x ground-truth overlaps of every
+        scene are computed on the device against ALL rows of the padded gt block (rows past the last non-zero one are masked out instead of being
+        cut off after reading their number), the (B, P) maximum overlaps are read once, the fg / hard-bg / easy-bg draws run on the host in the
+        reference's order (np.random.permutation, then torch.randint for hard and easy background, scene after scene -- the same numbers from the
+        same seeds), and the chosen indices go back in one copy."""
         batch_size = batch_dict['batch_size']
         rois, roi_scores, roi_labels, gt_boxes = batch_dict['rois'], batch_dict['roi_scores'], batch_dict['roi_labels'], batch_dict['gt_boxes']
-        n, code = self._c('ROI_PER_IMAGE'), rois.shape[-1]
-        b_rois = rois.new_zeros(batch_size, n, code)
-        b_gt = rois.new_zeros(batch_size, n, code + 1)
-        b_iou = rois.new_zeros(batch_size, n)
-        b_scores = rois.new_zeros(batch_size, n)
-        b_labels = rois.new_zeros((batch_size, n), dtype=torch.long)
+        n, G = self._c('ROI_PER_IMAGE'), gt_boxes.shape[1]
+        dev = rois.device
+        # valid gt rows: up to the last row whose entries do not sum to zero (reference :95-98); an empty scene keeps one all-zero row
+        pos = torch.arange(G, device=dev).view(1, -1)
+        last = ((gt_boxes.sum(dim=2) != 0).long() * (pos + 1)).max(dim=1)[0]                  # (B,) rows kept
+        valid = pos < torch.clamp(last, min=1).view(-1, 1)                                   # (B, G)
+        by_class = self._c('SAMPLE_ROI_BY_EACH_CLASS', False)
+        overlaps, assignment = [], []
         for i in range(batch_size):
-            cur_roi, cur_gt, cur_labels, cur_scores = rois[i], gt_boxes[i], roi_labels[i], roi_scores[i]
-            k = len(cur_gt) - 1
-            while k >= 0 and cur_gt[k].sum() == 0:
-                k -= 1
-            cur_gt = cur_gt[:k + 1]
-            cur_gt = cur_gt.new_zeros((1, cur_gt.shape[1])) if len(cur_gt) == 0 else cur_gt
-            if self._c('SAMPLE_ROI_BY_EACH_CLASS', False):
-                max_overlaps, gt_assignment = self.get_max_iou_with_same_class(cur_roi, cur_labels, cur_gt[:, 0:7], cur_gt[:, -1].long())
-            else:
-                max_overlaps, gt_assignment = torch.max(iou3d_nms_utils.boxes_iou3d_gpu(cur_roi, cur_gt[:, 0:7]), dim=1)
-            sel = self.subsample_rois(max_overlaps=max_overlaps)
-            b_rois[i], b_labels[i], b_iou[i], b_scores[i] = cur_roi[sel], cur_labels[sel], max_overlaps[sel], cur_scores[sel]
-            b_gt[i] = cur_gt[gt_assignment[sel]]
-        return b_rois, b_gt, b_iou, b_scores, b_labels
+            iou = iou3d_nms_utils.boxes_iou3d_gpu(rois[i], gt_boxes[i][:, 0:7])                 # (P, G)
+            ok = valid[i].view(1, -1)
+            if by_class:                                                                     # get_max_iou_with_same_class (:210-230) as a mask
+                ok = ok & (roi_labels[i].view(-1, 1) == gt_boxes[i][:, -1].long().view(1, -1))
+            best, arg = torch.where(ok, iou, -torch.ones_like(iou)).max(dim=1)
+            none = best < 0                                                                  # no ground truth (of its class): overlap 0, row 0
+            overlaps.append(torch.where(none, torch.zeros_like(best), best))
+            assignment.append(torch.where(none, torch.zeros_like(arg), arg))
+        max_overlaps, gt_assignment = torch.stack(overlaps), torch.stack(assignment)         # (B, P)
+        host = max_overlaps.cpu().numpy()                                                    # the one read
+        sel = torch.from_numpy(np.stack([self.subsample_rois_host(host[i]) for i in range(batch_size)])).to(dev)      # (B, n)
+        b_rois = torch.gather(rois, 1, sel.unsqueeze(-1).expand(-1, -1, rois.shape[-1]))
+        b_gt = torch.gather(gt_boxes, 1, torch.gather(gt_assignment, 1, sel).unsqueeze(-1).expand(-1, -1, gt_boxes.shape[-1]))
+        return b_rois, b_gt, torch.gather(max_overlaps, 1, sel), torch.gather(roi_scores, 1, sel), torch.gather(roi_labels, 1, sel)
 
-    def subsample_rois(self, max_overlaps):
+    def subsample_rois_host(self, max_overlaps):
+        """subsample_rois (:130-171) on a host array (P,) float32 -> (ROI_PER_IMAGE,) int64; float32 comparisons and the order of the random
+        draws as in the reference."""
         n = self._c('ROI_PER_IMAGE')
         fg_per_image = int(np.round(self._c('FG_RATIO') * n))
-        fg_thresh = min(self._c('REG_FG_THRESH'), self._c('CLS_FG_THRESH'))
-        fg_inds = (max_overlaps >= fg_thresh).nonzero().view(-1)
-        easy_bg = (max_overlaps < self._c('CLS_BG_THRESH_LO')).nonzero().view(-1)
-        hard_bg = ((max_overlaps < self._c('REG_FG_THRESH')) & (max_overlaps >= self._c('CLS_BG_THRESH_LO'))).nonzero().view(-1)
-        n_fg, n_bg = fg_inds.numel(), hard_bg.numel() + easy_bg.numel()
+        fg_thresh = np.float32(min(self._c('REG_FG_THRESH'), self._c('CLS_FG_THRESH')))
+        lo, reg = np.float32(self._c('CLS_BG_THRESH_LO')), np.float32(self._c('REG_FG_THRESH'))
+        fg_inds = np.nonzero(max_overlaps >= fg_thresh)[0]
+        easy_bg = np.nonzero(max_overlaps < lo)[0]
+        hard_bg = np.nonzero((max_overlaps < reg) & (max_overlaps >= lo))[0]
+        n_fg, n_bg = fg_inds.size, hard_bg.size + easy_bg.size
         if n_fg > 0 and n_bg > 0:
             fg_this = min(fg_per_image, n_fg)
-            perm = torch.from_numpy(np.random.permutation(n_fg)).to(max_overlaps.device).long()
-            fg_inds = fg_inds[perm[:fg_this]]
-            bg_inds = self.sample_bg_inds(hard_bg, easy_bg, n - fg_this, self._c('HARD_BG_RATIO'))
+            fg_inds = fg_inds[np.random.permutation(n_fg)[:fg_this]]
+            bg_inds = self.sample_bg_inds_host(hard_bg, easy_bg, n - fg_this, self._c('HARD_BG_RATIO'))
         elif n_fg > 0 and n_bg == 0:
-            r = torch.from_numpy(np.floor(np.random.rand(n) * n_fg)).to(max_overlaps.device).long()
-            fg_inds = fg_inds[r]
+            fg_inds = fg_inds[np.floor(np.random.rand(n) * n_fg).astype(np.int64)]
             bg_inds = fg_inds[fg_inds < 0]
         elif n_bg > 0 and n_fg == 0:
-            bg_inds = self.sample_bg_inds(hard_bg, easy_bg, n, self._c('HARD_BG_RATIO'))
+            fg_inds = fg_inds[:0]
+            bg_inds = self.sample_bg_inds_host(hard_bg, easy_bg, n, self._c('HARD_BG_RATIO'))
         else:
             raise NotImplementedError('no RoIs to sample: FG=%d, BG=%d' % (n_fg, n_bg))
-        return torch.cat((fg_inds, bg_inds), dim=0)
+        return np.concatenate((fg_inds, bg_inds)).astype(np.int64)
 
     @staticmethod
-    def sample_bg_inds(hard_bg_inds, easy_bg_inds, bg_rois_per_this_image, hard_bg_ratio):
-        dev = hard_bg_inds.device
-
+    def sample_bg_inds_host(hard_bg_inds, easy_bg_inds, bg_rois_per_this_image, hard_bg_ratio):
         def draw(pool, k):
-            return pool[torch.randint(low=0, high=pool.numel(), size=(k,)).long().to(dev)]
+            return pool[torch.randint(low=0, high=pool.size, size=(k,)).long().numpy()]
 
-        if hard_bg_inds.numel() > 0 and easy_bg_inds.numel() > 0:
+        if hard_bg_inds.size > 0 and easy_bg_inds.size > 0:
             n_hard = min(int(bg_rois_per_this_image * hard_bg_ratio), len(hard_bg_inds))
-            hard = draw(hard_bg_inds, n_hard)
-            easy = draw(easy_bg_inds, bg_rois_per_this_image - n_hard)
-            return torch.cat([hard, easy], dim=0)
-        if hard_bg_inds.numel() > 0:
+            return np.concatenate([draw(hard_bg_inds, n_hard), draw(easy_bg_inds, bg_rois_per_this_image - n_hard)])
+        if hard_bg_inds.size > 0:
             return draw(hard_bg_inds, bg_rois_per_this_image)
-        if easy_bg_inds.numel() > 0:
+        if easy_bg_inds.size > 0:
             return draw(easy_bg_inds, bg_rois_per_this_image)
         raise NotImplementedError
-
-    @staticmethod
-    def get_max_iou_with_same_class(rois, roi_labels, gt_boxes, gt_labels):
-        max_overlaps = rois.new_zeros(rois.shape[0])
-        gt_assignment = roi_labels.new_zeros(roi_labels.shape[0])
-        for k in range(gt_labels.min().item(), gt_labels.max().item() + 1):
-            roi_mask, gt_mask = roi_labels == k, gt_labels == k
-            if roi_mask.sum() > 0 and gt_mask.sum() > 0:
-                orig = gt_mask.nonzero().view(-1)
-                cur_max, cur_arg = torch.max(iou3d_nms_utils.boxes_iou3d_gpu(rois[roi_mask], gt_boxes[gt_mask]), dim=1)
-                max_overlaps[roi_mask] = cur_max
-                gt_assignment[roi_mask] = orig[cur_arg]
-        return max_overlaps, gt_assignment

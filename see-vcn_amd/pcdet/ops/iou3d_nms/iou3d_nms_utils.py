@@ -55,7 +55,7 @@ def boxes_iou3d_gpu(boxes_a, boxes_b):
     return overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-6)
 
 
-def _nms(boxes, scores, thresh, pre_maxsize, normal, max_keep=None):
+def _nms(boxes, scores, thresh, pre_maxsize, normal, max_keep=None, padded=None):
     lib = _lib.load()
     _lib.require_cuda(boxes, scores)
     assert boxes.shape[1] == 7
@@ -65,12 +65,18 @@ def _nms(boxes, scores, thresh, pre_maxsize, normal, max_keep=None):
     sorted_boxes = boxes[order].contiguous().float()
     n = sorted_boxes.shape[0]
     dev = boxes.device
-    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
+    keep = torch.empty((max(n, 1, padded or 0),), dtype=torch.int64, device=dev)
     num_out = torch.zeros((1,), dtype=torch.int32, device=dev)
     scratch = _lib.workspace.scratch("nms", lib.sv_nms_scratch_bytes(n), dev)
     rc = lib.sv_nms_prefix(_lib.ptr(sorted_boxes) if n else None, n, float(thresh), int(normal), n if max_keep is None else min(n, int(max_keep)),
                            _lib.ptr(scratch), _lib.ptr(keep), _lib.ptr(num_out), _lib.stream())
     _lib.check(rc, "sv_nms_prefix")
+    if padded is not None:
+        # no device -> host read: `padded` slots, the survivors first (score order), the rest index 0 with valid = False
+        valid = torch.arange(padded, device=dev) < torch.clamp(num_out, max=padded)
+        if n == 0:
+            return torch.zeros((padded,), dtype=torch.int64, device=dev), valid
+        return order[torch.where(valid, keep[:padded], torch.zeros_like(keep[:padded]))], valid
     return order[keep[:int(num_out.item())]].contiguous(), None
 
 
@@ -82,3 +88,10 @@ def nms_gpu(boxes, scores, thresh, pre_maxsize=None, max_keep=None, **kwargs):
 
 def nms_normal_gpu(boxes, scores, thresh, max_keep=None, **kwargs):
     return _nms(boxes, scores, thresh, None, True, max_keep)
+
+
+def nms_gpu_padded(boxes, scores, thresh, slots, pre_maxsize=None, normal=False):
+    """(seevcn extension) the first `slots` survivors of nms_gpu / nms_normal_gpu as a fixed-size result: (indices (slots,) int64, valid (slots,)
+    bool) -- no device -> host read of the survivor count, for callers that fill a zero-padded (slots, .) block anyway
+    (RoIHeadTemplate.proposal_layer, roi_head_template.py:46-102)."""
+    return _nms(boxes, scores, thresh, pre_maxsize, normal, slots, padded=int(slots))

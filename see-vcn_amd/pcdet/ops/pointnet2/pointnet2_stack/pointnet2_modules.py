@@ -11,7 +11,7 @@ from . import pointnet2_stack_cuda, pointnet2_utils
 import os
 
 FUSED_SA_OFF = os.environ.get("SEEVCN_FUSED_SA", "1") == "0"      # 0: always the torch path (A/B runs, tests)
-ROWS_SA_OFF = os.environ.get("SEEVCN_ROWS_SA", "1") == "0"        # 0: training goes through the (M, C, nsample) Conv2d path of the reference
+TRAIN_SA_OFF = os.environ.get("SEEVCN_TRAIN_SA", "1") == "0"      # 0: training goes through the (M, C, nsample) Conv2d path of the reference
 
 
 def _cfg(config, key, default=None):
@@ -118,47 +118,40 @@ class StackSAModuleMSG(nn.Module):
                    "sv_sa_mlp_max")
         return out
 
-    def _rows_ok(self, k, xyz, new_xyz, features):
-        """The channel-last path takes this scale: conv-BN-ReLU layers without conv bias, channel counts the fused BatchNorm kernels take,
-        max pooling, fp32 on the GPU, with xyz in the features (QueryAndGroup use_xyz)."""
-        from .....spconv import norm
-        if ROWS_SA_OFF or self.pool_method != 'max_pool' or not (xyz.is_cuda and new_xyz.is_cuda) or not self.groupers[k].use_xyz:
+    def _train_ok(self, k, xyz, new_xyz, features):
+        """The training kernels (sv_sa_train_forward / _backward) take this scale: two conv-BN-ReLU layers of 16..64 channels without conv bias,
+        16 or 32 neighbours, max pooling, feature channels a multiple of 16 up to 128 (or none), fp32 on the GPU, xyz in the features,
+        BatchNorm2d in training mode with affine parameters and running statistics."""
+        if (TRAIN_SA_OFF or not self.training or self.pool_method != 'max_pool' or not (xyz.is_cuda and new_xyz.is_cuda) or not self.groupers[k].use_xyz
+                or new_xyz.shape[0] * self.groupers[k].nsample < 2):
             return False
         layers = list(self.mlps[k])
-        if len(layers) % 3 != 0 or (features is not None and features.dtype != torch.float32):
+        if len(layers) != 6 or (features is not None and features.dtype != torch.float32):
             return False
-        if not self.training and torch.is_grad_enabled() and ((features is not None and features.requires_grad)
-                                                              or any(p.requires_grad for p in self.mlps[k].parameters())):
-            return False                                      # the fused BatchNorm has no eval-mode backward
-        for i in range(0, len(layers), 3):
+        for i in (0, 3):
             conv, bn = layers[i], layers[i + 1]
-            if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(layers[i + 2], nn.ReLU) and conv.bias is None):
+            if not (isinstance(conv, nn.Conv2d) and type(bn) is nn.BatchNorm2d and isinstance(layers[i + 2], nn.ReLU) and conv.bias is None
+                    and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None):
                 return False
-            c = conv.out_channels
-            if not (4 <= c <= 512 and c % 4 == 0 and 256 % (c // 4) == 0 and bn.momentum is not None and bn.track_running_stats and bn.affine):
+            if conv._forward_hooks or conv._forward_pre_hooks or bn._forward_hooks or bn._forward_pre_hooks:
                 return False
-        return True
+        c = 0 if features is None else features.shape[1]
+        c1, c2 = layers[0].out_channels, layers[3].out_channels
+        return (c % 16 == 0 and c <= 128 and layers[0].in_channels == c + 3 and layers[3].in_channels == c1 and self.groupers[k].nsample in (16, 32)
+                and all(v % 16 == 0 and 16 <= v <= 64 for v in (c1, c2)) and layers[1].eps == layers[4].eps and layers[1].momentum == layers[4].momentum)
 
-    def _rows_scale(self, k, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features):
-        """ball query -> neighbourhood ROWS (M * nsample, 3 + C) -> per layer one GEMM + the fused BatchNorm/ReLU kernels of the sparse backbone
-        -> max over the nsample rows of each query.  Same arithmetic as Conv2d(1x1) / BatchNorm2d / ReLU / max_pool2d over (1, C, M, nsample)
-        (pointnet2_modules.py:96-110: statistics over all M * nsample positions), same parameters and running statistics; the Conv2d route hands
-        MIOpen a non-packed (1, C, M, nsample) view, for which it only has its naive kernels (65-100 ms per layer at PV-RCNN sizes)."""
-        from .....spconv.norm import _BatchNormReLU
+    def _train_scale(self, k, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features):
+        """ball query (HIP) -> SAScaleTrain: the whole scale (gather, both MLP layers with batch-statistics BatchNorm, max over the neighbours) and its
+        backward on the hand-written MFMA kernels; same parameters, running statistics and num_batches_tracked as the Conv2d / BatchNorm2d path."""
         g = self.groupers[k]
         M, B = new_xyz.shape[0], xyz_batch_cnt.shape[0]
         idx = torch.zeros((M, g.nsample), dtype=torch.int32, device=new_xyz.device)
         pointnet2_stack_cuda.ball_query_wrapper(B, M, g.radius, g.nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
         row_start = pointnet2_stack_cuda._row_start(new_xyz_batch_cnt, xyz_batch_cnt, M)
-        x = pointnet2_utils.group_rows(xyz, features, new_xyz, idx, row_start)                    # (M * ns, 3 + C)
-        layers = list(self.mlps[k])
-        for i in range(0, len(layers), 3):
-            conv, bn = layers[i], layers[i + 1]
-            x = pointnet2_utils.rows_linear(x, conv.weight.view(conv.out_channels, conv.in_channels))
-            training = bn.training
-            x = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, training, True,
-                                     bn.num_batches_tracked if training else None)
-        return x.view(M, g.nsample, x.shape[1]).max(dim=1)[0]
+        conv1, bn1, _, conv2, bn2, _ = list(self.mlps[k])
+        return pointnet2_utils.sa_scale_train(xyz, features, new_xyz, idx, row_start, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias,
+                                              bn1.running_mean, bn1.running_var, bn1.num_batches_tracked, bn2.running_mean, bn2.running_var,
+                                              bn2.num_batches_tracked, bn1.momentum, bn1.eps)
 
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True):
         outs = []
@@ -168,8 +161,8 @@ class StackSAModuleMSG(nn.Module):
             if self._fused_ok(k, xyz, new_xyz, feats_c):
                 outs.append(self._fused_scale(k, xyz, xyz_batch_cnt.contiguous(), new_xyz, new_xyz_batch_cnt.contiguous(), feats_c))
                 continue
-            if self._rows_ok(k, xyz, new_xyz, feats_c):
-                outs.append(self._rows_scale(k, xyz, xyz_batch_cnt.contiguous(), new_xyz, new_xyz_batch_cnt.contiguous(), feats_c))
+            if self._train_ok(k, xyz, new_xyz, feats_c):
+                outs.append(self._train_scale(k, xyz, xyz_batch_cnt.contiguous(), new_xyz, new_xyz_batch_cnt.contiguous(), feats_c))
                 continue
             grouped, _ = self.groupers[k](xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)    # (M, C, nsample)
             x = self.mlps[k](grouped.permute(1, 0, 2).unsqueeze(dim=0))                               # (1, C', M, nsample)

@@ -76,6 +76,50 @@ def stack_farthest_point_sampling(points, xyz_batch_cnt, npoint, max_n=None):
     return idx
 
 
+class FpsHandle:
+    """A stacked farthest point sampling in flight (stack_farthest_point_sampling_async).  result() returns the (batch, npoint) int32 GLOBAL row
+    indices; it reads the kernel's error word on the stream the sampling ran on (so only that stream is waited for) and samples once more with
+    write-through records if a partner workgroup did not arrive."""
+
+    def __init__(self, idx, err, stream, rerun):
+        self.idx, self.err, self.stream, self._rerun = idx, err, stream, rerun
+
+    def result(self):
+        with torch.cuda.stream(self.stream):
+            bad = int(self.err.item())
+            if bad:
+                self._rerun()
+                bad = int(self.err.item())
+        if bad:
+            raise _lib.SeevcnHipError("farthest_point_sampling: a partner workgroup never arrived (GPU shared with another process?); "
+                                      "SEEVCN_FPS_MULTI=0 selects one workgroup per scene")
+        return self.idx
+
+
+def stack_farthest_point_sampling_async(points, xyz_batch_cnt, npoint, max_n):
+    """stack_farthest_point_sampling without the read-back: enqueues on the current stream and returns an FpsHandle (seevcn extension, used to
+    sample the keypoints on a side stream while the backbone runs).  max_n (largest scene) must come from the host."""
+    lib = _lib.load()
+    _lib.require_cuda(points)
+    starts, cnt = _starts(xyz_batch_cnt)
+    batch = cnt.shape[0]
+    idx = torch.empty((batch, npoint), dtype=torch.int32, device=points.device)
+    temp = torch.empty((points.shape[0],), dtype=torch.float32, device=points.device) if max_n > 24576 else None
+    nbytes = int(lib.sv_fps_multi_scratch_bytes(batch))
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=points.device)
+    off = int(lib.sv_fps_multi_error_offset(batch))
+    err = scratch[off:off + 4].view(torch.int32)
+    stream = torch.cuda.current_stream()
+
+    def launch(write_through):
+        _lib.check(lib.sv_stack_farthest_point_sampling_multi_async(_lib.ptr(points), _lib.ptr(starts), _lib.ptr(cnt), batch, int(max_n), int(npoint),
+                                                                    _lib.ptr(temp), _lib.ptr(scratch), _lib.ptr(idx), int(write_through), _lib.stream()),
+                   "sv_stack_farthest_point_sampling_multi_async")
+
+    launch(0)
+    return FpsHandle(idx, err, stream, lambda: launch(1))
+
+
 def _outside_hot_path(name):
     def stub(*args, **kwargs):
         raise NotImplementedError(f"pointnet2_stack_cuda.{name} is outside the SEE-VCN hot path (SURVEY.md 2: PV-RCNN++ / PartA2 / PointRCNN-style "

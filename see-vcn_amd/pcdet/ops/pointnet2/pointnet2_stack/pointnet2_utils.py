@@ -59,71 +59,70 @@ class GroupingOperation(Function):
 grouping_operation = GroupingOperation.apply
 
 
-class GroupRows(Function):
-    """Neighbourhoods as rows (seevcn extension): (M * nsample, 3 + C) = [xyz[j] - new_xyz[m] | features[j]], zero rows for empty balls --
-    the channel-last twin of QueryAndGroup's (M, 3 + C, nsample) tensor, so that a scale's shared MLP is one GEMM over all rows.
-    idx (M, nsample) int32 as ball_query_wrapper leaves it (idx[m][0] == -1 marks an empty ball); row_start (M,) first row of the query's scene."""
+class SAScaleTrain(Function):
+    """One radius scale of StackSAModuleMSG in TRAINING mode as one autograd node over the hand-written MFMA kernels
+    (sv_sa_train_forward / sv_sa_train_backward, csrc/set_abstraction_train.hip): gather -> Conv2d 1x1 -> BatchNorm2d(batch statistics) ->
+    ReLU, twice -> max over nsample (pointnet2_modules.py:96-110), without the (M, C+3, nsample) tensor; running statistics and
+    num_batches_tracked of the two norms are updated like nn.BatchNorm2d does.  idx / row_start as ball_query_wrapper leaves them."""
 
     @staticmethod
-    def forward(ctx, xyz, features, new_xyz, idx, row_start):
+    def forward(ctx, xyz, features, new_xyz, idx, row_start, w1, g1, b1, w2, g2, b2, rm1, rv1, nbt1, rm2, rv2, nbt2, momentum, eps):
         from ..... import _lib
         lib = _lib.load()
+        dev = xyz.device
         M, ns = idx.shape
         C = 0 if features is None else features.shape[1]
-        out = torch.empty((M * ns, 3 + C), dtype=torch.float32, device=xyz.device)
-        _lib.check(lib.sv_group_rows_stack(M, C, ns, _lib.ptr(xyz), _lib.ptr(features) if C else None, _lib.ptr(new_xyz), _lib.ptr(idx), _lib.ptr(row_start),
-                                           _lib.ptr(out), _lib.stream()), "sv_group_rows_stack")
-        ctx.n = 0 if features is None else features.shape[0]
-        ctx.c = C
-        ctx.save_for_backward(idx, row_start)
+        C1, C2 = w1.shape[0], w2.shape[0]
+        w1c, w2c = w1.detach().reshape(C1, C + 3).contiguous(), w2.detach().reshape(C2, C1).contiguous()
+        R = M * ns
+        f32 = dict(dtype=torch.float32, device=dev)
+        z1, z2 = torch.empty((R, C1), **f32), torch.empty((R, C2), **f32)
+        stats = torch.empty((2 * C1 + 2 * C2,), **f32)
+        sm1, si1, sm2, si2 = stats[:C1], stats[C1:2 * C1], stats[2 * C1:2 * C1 + C2], stats[2 * C1 + C2:]
+        sel, aux, out = torch.empty((M, C2), **f32), torch.empty((M, C2), **f32), torch.empty((M, C2), **f32)
+        arg, aux_arg = torch.empty((M, C2), dtype=torch.uint8, device=dev), torch.empty((M, C2), dtype=torch.uint8, device=dev)
+        scratch = _lib.workspace.scratch("sa_train", lib.sv_sa_train_scratch_bytes(C, C1, C2), dev)
+        _lib.check(lib.sv_sa_train_forward(_lib.ptr(xyz), _lib.ptr(features) if C else None, _lib.ptr(new_xyz), _lib.ptr(idx), _lib.ptr(row_start), M, C, ns,
+                                           _lib.ptr(w1c), _lib.ptr(g1.detach()), _lib.ptr(b1.detach()), _lib.ptr(rm1), _lib.ptr(rv1), _lib.ptr(nbt1), C1,
+                                           _lib.ptr(w2c), _lib.ptr(g2.detach()), _lib.ptr(b2.detach()), _lib.ptr(rm2), _lib.ptr(rv2), _lib.ptr(nbt2), C2,
+                                           float(momentum), float(eps), _lib.ptr(scratch), _lib.ptr(z1), _lib.ptr(z2), _lib.ptr(sm1), _lib.ptr(si1),
+                                           _lib.ptr(sm2), _lib.ptr(si2), _lib.ptr(sel), _lib.ptr(aux), _lib.ptr(arg), _lib.ptr(aux_arg), _lib.ptr(out),
+                                           _lib.stream()), "sv_sa_train_forward")
+        ctx.save_for_backward(xyz, features, new_xyz, idx, row_start, w1c, g1, b1, w2c, g2, b2, z1, z2, stats, sel, arg, out)
+        ctx.w_shapes = (w1.shape, w2.shape)
+        ctx.mark_non_differentiable(idx)
         return out
 
     @staticmethod
-    def backward(ctx, grad_rows):
+    def backward(ctx, grad_out):
         from ..... import _lib
-        if ctx.c == 0 or not ctx.needs_input_grad[1]:
-            return None, None, None, None, None
         lib = _lib.load()
-        idx, row_start = ctx.saved_tensors
+        xyz, features, new_xyz, idx, row_start, w1c, g1, b1, w2c, g2, b2, z1, z2, stats, sel, arg, out = ctx.saved_tensors
+        dev = xyz.device
         M, ns = idx.shape
-        grad = torch.empty((ctx.n, ctx.c), dtype=torch.float32, device=grad_rows.device)
-        _lib.check(lib.sv_group_rows_grad_stack(M, ctx.c, ctx.n, ns, _lib.ptr(grad_rows.contiguous()), _lib.ptr(idx), _lib.ptr(row_start), _lib.ptr(grad),
-                                                _lib.stream()), "sv_group_rows_grad_stack")
-        return None, grad, None, None, None
+        C = 0 if features is None else features.shape[1]
+        N = xyz.shape[0]
+        C1, C2 = w1c.shape[0], w2c.shape[0]
+        sm1, si1, sm2, si2 = stats[:C1], stats[C1:2 * C1], stats[2 * C1:2 * C1 + C2], stats[2 * C1 + C2:]
+        f32 = dict(dtype=torch.float32, device=dev)
+        dy1, aux = torch.empty((M * ns, C1), **f32), torch.empty((M, C2), **f32)
+        scatter = torch.empty((N, C1), **f32) if C else None
+        gf = torch.empty((N, C), **f32) if C and ctx.needs_input_grad[1] else None
+        gw1, gw2 = torch.empty((C1, C + 3), **f32), torch.empty((C2, C1), **f32)
+        gbn = torch.empty((2 * C1 + 2 * C2,), **f32)
+        dg1, db1, dg2, db2 = gbn[:C1], gbn[C1:2 * C1], gbn[2 * C1:2 * C1 + C2], gbn[2 * C1 + C2:]
+        scratch = _lib.workspace.scratch("sa_train", lib.sv_sa_train_scratch_bytes(C, C1, C2), dev)
+        _lib.check(lib.sv_sa_train_backward(_lib.ptr(xyz), _lib.ptr(features) if C else None, _lib.ptr(new_xyz), _lib.ptr(idx), _lib.ptr(row_start), M, N, C,
+                                            ns, _lib.ptr(w1c), _lib.ptr(g1.detach()), _lib.ptr(b1.detach()), C1, _lib.ptr(w2c), _lib.ptr(g2.detach()),
+                                            _lib.ptr(b2.detach()), C2, _lib.ptr(z1), _lib.ptr(z2), _lib.ptr(sm1), _lib.ptr(si1), _lib.ptr(sm2), _lib.ptr(si2),
+                                            _lib.ptr(sel), _lib.ptr(arg), _lib.ptr(out), _lib.ptr(grad_out.contiguous()), _lib.ptr(scratch), _lib.ptr(dy1),
+                                            _lib.ptr(aux), _lib.ptr(scatter), _lib.ptr(gf), _lib.ptr(gw1), _lib.ptr(gw2), _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dg2),
+                                            _lib.ptr(db2), _lib.stream()), "sv_sa_train_backward")
+        s1, s2 = ctx.w_shapes
+        return (None, gf, None, None, None, gw1.view(s1), dg1, db1, gw2.view(s2), dg2, db2, None, None, None, None, None, None, None, None)
 
 
-group_rows = GroupRows.apply
-
-
-class RowsLinear(Function):
-    """y = x @ w.T for a tall x (R rows, R ~ 10^5..10^6, 16..259 columns).  The weight gradient dy.T @ x contracts over R into a tiny
-    (C_out, C_in) result: as ONE library GEMM that is a single output tile walking all R rows (7.6 ms at R = 1.77 M on MI355X); here R is cut
-    into S slices contracted by one batched GEMM and summed (split-K), S chosen so every slice still has >= 1024 rows."""
-
-    @staticmethod
-    def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
-        return x @ w.t()
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = dy @ w if ctx.needs_input_grad[0] else None
-        dw = None
-        if ctx.needs_input_grad[1]:
-            r = x.shape[0]
-            s = 1
-            while s < 256 and r % (2 * s) == 0 and r // (2 * s) >= 1024:
-                s *= 2
-            if s == 1:
-                dw = dy.t() @ x
-            else:
-                dw = torch.bmm(dy.view(s, r // s, -1).transpose(1, 2), x.view(s, r // s, -1)).sum(dim=0)
-        return dx, dw
-
-
-rows_linear = RowsLinear.apply
+sa_scale_train = SAScaleTrain.apply
 
 
 class QueryAndGroup(nn.Module):

@@ -36,12 +36,34 @@ def rotate_points_along_z(points, angle):
     return out.numpy() if is_numpy else out
 
 
+def batch_counts(batch_indices, batch_size):
+    """rows per scene (batch_size,) int32 from the scene-index column -- torch.bincount(..., minlength=B) without its device -> host read
+    (bincount sizes its output from the largest index)."""
+    b = torch.arange(batch_size, device=batch_indices.device, dtype=batch_indices.dtype).view(1, -1)
+    return (batch_indices.view(-1, 1) == b).sum(dim=0, dtype=torch.int32)
+
+
+_const_cache = {}
+
+
+def const_tensor(values, device, dtype=torch.float32):
+    """A small constant as a device tensor, made once per (values, device, dtype): torch.tensor(list, device=cuda) is a blocking host -> device
+    copy that waits for everything queued on the stream, and the reference's helpers make such constants on every call."""
+    import numpy as np
+    arr = np.asarray(values, dtype=np.float64)
+    key = (arr.tobytes(), arr.shape, str(device), dtype)
+    t = _const_cache.get(key)
+    if t is None:
+        t = _const_cache[key] = torch.tensor(arr, dtype=dtype, device=device)
+    return t
+
+
 def get_voxel_centers(voxel_coords, downsample_times, voxel_size, point_cloud_range):
     """voxel_coords (N,3) [z,y,x] -> centres (N,3) [x,y,z] (common_utils.py:144-161)."""
     assert voxel_coords.shape[1] == 3
-    centers = voxel_coords[:, [2, 1, 0]].float()
-    vs = torch.tensor(voxel_size, device=centers.device).float() * downsample_times
-    pc = torch.tensor(point_cloud_range[0:3], device=centers.device).float()
+    centers = voxel_coords.flip(1).float()                              # [z,y,x] -> [x,y,z]; indexing with a Python list copies an index tensor host -> device
+    vs = const_tensor(voxel_size, centers.device) * downsample_times
+    pc = const_tensor(list(point_cloud_range[0:3]), centers.device)
     return (centers + 0.5) * vs + pc
 
 
@@ -75,3 +97,35 @@ def get_dist_info(return_gpu_per_machine=False):
     if return_gpu_per_machine:
         return rank, world_size, torch.cuda.device_count()
     return rank, world_size
+
+
+# ---- loss scalars for tb_dict without one device -> host read each --------------------------------------------------------------------
+# The reference fills tb_dict with `loss.item()` at every term (anchor_head_template.py:87-143, roi_head_template.py:114-150, ...): each
+# .item() waits for the whole stream.  Inside `deferred_tb()` (the detectors' get_training_loss) tb_value() keeps the 0-dim tensor and
+# materialize_tb() turns all of them into Python floats with ONE read at the end; called outside, tb_value() is `.item()` as before.
+_tb_deferred = [0]
+
+
+class deferred_tb:
+    def __enter__(self):
+        _tb_deferred[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _tb_deferred[0] -= 1
+        return False
+
+
+def tb_value(t):
+    if _tb_deferred[0] and torch.is_tensor(t):
+        return t.detach()
+    return t.item() if torch.is_tensor(t) else t
+
+
+def materialize_tb(*dicts):
+    keys = [(d, k) for d in dicts for k, v in d.items() if torch.is_tensor(v)]
+    if keys:
+        vals = torch.stack([d[k].reshape(()).float() for d, k in keys]).tolist()
+        for (d, k), v in zip(keys, vals):
+            d[k] = v
+    return dicts[0] if len(dicts) == 1 else dicts

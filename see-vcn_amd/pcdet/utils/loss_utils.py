@@ -45,7 +45,9 @@ class WeightedSmoothL1Loss(nn.Module):
         target = torch.where(torch.isnan(target), input, target)  # ignore nan targets
         diff = input - target
         if self.code_weights is not None:
-            diff = diff * self.code_weights.to(diff.device).view(1, 1, -1)
+            if self.code_weights.device != diff.device:                  # moved once, not copied host -> device at every call
+                self.code_weights = self.code_weights.to(diff.device)
+            diff = diff * self.code_weights.view(1, 1, -1)
         loss = self.smooth_l1_loss(diff, self.beta)
         if weights is not None:
             assert weights.shape[0] == loss.shape[0] and weights.shape[1] == loss.shape[1]
@@ -87,7 +89,9 @@ def neg_loss_cornernet(pred, gt, mask=None):
     else:
         num_pos = pos_inds.float().sum()
     pos_loss, neg_loss = pos_loss.sum(), neg_loss.sum()
-    return -neg_loss if num_pos == 0 else -(pos_loss + neg_loss) / num_pos
+    # `-neg_loss if num_pos == 0 else -(pos_loss + neg_loss) / num_pos` of the reference as a select: the Python branch reads num_pos on the host.
+    # With num_pos == 0 there is no positive term: pos_loss is 0 and both forms give -neg_loss
+    return torch.where(num_pos == 0, -neg_loss, -(pos_loss + neg_loss) / torch.clamp(num_pos, min=1.0))
 
 
 class FocalLossCenterNet(nn.Module):

@@ -50,14 +50,17 @@ def test_hip_config1_vcn_on_the_demo_crops(golden_dir, cuda, hip_lib):
     with torch.no_grad():
         ret = net({"input": x})
     for k in ("coarse", "reg_rot", "reg_centre"):
-        assert_close_per_channel(ret[k].cpu().numpy(), g[k], rtol=1e-3, atol_frac=2e-4, name="config1 " + k)
+        assert_close_per_channel(ret[k].cpu().numpy(), g[k], rtol=1e-3, atol_frac=1e-4, name="config1 " + k)
     # surface selection on the REFERENCE's coarse output: index sets must be identical -> bit-exact points
     surface, _ = sampling.get_partial_mesh_batch_device(x, torch.from_numpy(g["coarse"]).to(cuda), k=30)
     assert np.array_equal(surface.cpu().numpy(), g["surface"])
     # and on this build's own coarse output (differs in the last bits): the selected sets may differ only where two distances nearly tie
+    # (one index more or less re-orders the whole CPython-set walk, so the comparison is between the point SETS of each object)
     mine, _ = sampling.get_partial_mesh_batch_device(x, ret["coarse"], k=30)
-    same = (mine.cpu().numpy() == g["surface"]).all(axis=2).mean()
-    assert same >= 0.98, same
+    for b in range(len(g["surface"])):
+        want = {tuple(r) for r in g["surface"][b].tolist()}
+        got = {tuple(r) for r in mine[b].cpu().numpy().tolist()}
+        assert len(want & got) >= 0.98 * len(want | got), (b, len(want), len(got), len(want & got))
 
 
 @pytest.mark.gpu
@@ -89,17 +92,16 @@ def test_hip_config1_pointpillar_detector_on_the_demo_scene(golden_dir, cuda, hi
         m.register_forward_hook(lambda mod, i, o, seen=seen: seen.update({type(mod).__name__: dict(o)}))
     with torch.no_grad():
         preds, recall = net({"batch_size": 1, "voxels": vox[0, :n].contiguous(), "voxel_coords": coords, "voxel_num_points": nmp[0, :n].contiguous()})
-    assert_close_per_channel(seen["PillarVFE"]["pillar_features"][::4].cpu().numpy(), g["pillar_features"], rtol=1e-3, atol_frac=2e-4, name="pillar_features")
+    assert_close_per_channel(seen["PillarVFE"]["pillar_features"][::4].cpu().numpy(), g["pillar_features"], rtol=1e-3, atol_frac=1e-4, name="pillar_features")
     sf = seen["BaseBEVBackbone"]["spatial_features_2d"]
     assert list(sf.shape) == list(g["sf2d_shape"]) == [1, 384, 248, 216]
-    # MIOpen picks Winograd / implicit-GEMM kernels for the 16 stacked 3x3 layers: ~1e-4 of the channel's scale per element
-    assert_close_per_channel(sf[0, :, ::8, ::8].cpu().numpy(), g["sf2d_sample"], rtol=1e-3, atol_frac=1e-3, name="spatial_features_2d", channel_axis=0)
+    assert_close_per_channel(sf[0, :, ::8, ::8].cpu().numpy(), g["sf2d_sample"], rtol=1e-3, atol_frac=1e-4, name="spatial_features_2d", channel_axis=0)
     np.testing.assert_allclose(sf.double().sum((0, 2, 3)).cpu().numpy(), g["sf2d_channel_sum"], rtol=1e-3, atol=1e-2 * np.abs(g["sf2d_channel_sum"]).max())
     hd = seen["AnchorHeadSingle"]
     assert hd["batch_box_preds"].shape[1] == int(g["n_anchors"]) == 248 * 216 * 6
     pick = torch.from_numpy(g["anchor_pick"]).to(cuda)
-    assert_close_per_channel(hd["batch_cls_preds"][0, pick].cpu().numpy(), g["cls_preds"], rtol=1e-3, atol_frac=1e-3, name="batch_cls_preds")
-    assert_close_per_channel(hd["batch_box_preds"][0, pick].cpu().numpy(), g["box_preds"], rtol=1e-3, atol_frac=1e-3, name="batch_box_preds")
+    assert_close_per_channel(hd["batch_cls_preds"][0, pick].cpu().numpy(), g["cls_preds"], rtol=1e-3, atol_frac=1e-4, name="batch_cls_preds")
+    assert_close_per_channel(hd["batch_box_preds"][0, pick].cpu().numpy(), g["box_preds"], rtol=1e-3, atol_frac=1e-4, name="batch_box_preds")
     # final boxes: NMS at 0.01 over scores that differ in the last bits between the CPU and GPU convolutions -> compare as sets
     pb, ps = preds[0]["pred_boxes"].cpu().numpy(), preds[0]["pred_scores"].cpu().numpy()
     gb, gs = g["pred_boxes"], g["pred_scores"]

@@ -159,6 +159,17 @@ def test_hip_pvrcnn_train_step_at_config4_size(cuda, hip_lib):
         s1 = int(c3n[0])
         want = op2.ball_query(radius, ns, xyz3[s1:s1 + int(c3n[1])].cpu().numpy(), [int(c3n[1])], new_xyz[sl].cpu().numpy(), [300])
         assert np.array_equal(idx[sl].cpu().numpy(), want), radius
+        # D16 features at size: the training-mode set-abstraction kernels (gather, MFMA MLP, batch-statistics BatchNorm, max) of this scale,
+        # ALL 16 384 queries, against the float64 oracle on the same neighbour lists (the statistics need every row)
+        k = 0 if ns == 16 else 1
+        conv1, bn1, _, conv2, bn2, _ = list(net.pfe.SA_layers[0].mlps[k])
+        n = lambda p: p.detach().cpu().numpy()
+        row_start = torch.repeat_interleave(torch.cumsum(c3, 0) - c3, 4096).int().cpu().numpy()
+        want_f = op2.sa_scale_train(xyz3.cpu().numpy(), t3.features.detach().cpu().numpy(), new_xyz.cpu().numpy(), idx.cpu().numpy(), row_start,
+                                    n(conv1.weight).reshape(64, 67), n(bn1.weight), n(bn1.bias), n(conv2.weight).reshape(64, 64), n(bn2.weight), n(bn2.bias),
+                                    eps=bn1.eps)
+        got_f = bd["point_features_before_fusion"][:, 288 + 64 * k:288 + 64 * (k + 1)].detach().cpu().numpy()
+        assert_close_per_channel(got_f, want_f, rtol=1e-3, atol_frac=1e-4, name=f"x_conv3 set-abstraction features, radius {radius}")
     # D19 at size: the 9000 -> 512 proposal NMS of scene 0 against the oracle sweep
     scores = bd["batch_cls_preds"][0].detach().max(dim=1)[0]
     boxes = bd["batch_box_preds"][0].detach()

@@ -57,8 +57,7 @@ def test_hip_bev_backbone_matches_reference_golden(golden_dir, cuda, hip_lib):
     bb = bb.to(cuda).eval()
     with torch.no_grad():
         out = bb({"spatial_features": torch.from_numpy(g["spatial_features"]).to(cuda)})["spatial_features_2d"].cpu().numpy()
-    # MIOpen picks Winograd kernels for the 3x3 layers: per-element error ~1e-4 of the channel's scale after 6 stacked convs
-    assert_close_per_channel(out, g["spatial_features_2d"], rtol=1e-3, atol_frac=5e-4, name="spatial_features_2d", channel_axis=1)
+    assert_close_per_channel(out, g["spatial_features_2d"], rtol=1e-3, atol_frac=1e-4, name="spatial_features_2d", channel_axis=1)
 
 
 @pytest.mark.gpu

@@ -108,9 +108,9 @@ def test_hip_dyn_pillar_vfe_matches_reference_golden(golden_dir, cuda, hip_lib):
     assert np.array_equal(bd['voxel_coords'].cpu().numpy(), g['voxel_coords'])
     feat = bd['pillar_features']
     ref = g['pillar_features']
-    assert_close_per_channel(feat.detach().cpu().numpy(), ref, rtol=1e-3, atol_frac=2e-4, name="pillar_features")
+    assert_close_per_channel(feat.detach().cpu().numpy(), ref, rtol=1e-3, atol_frac=1e-4, name="pillar_features")
     w = torch.from_numpy(np.random.default_rng(3).normal(size=ref.shape).astype(np.float32)).to(cuda)
     (feat * w).sum().backward()
     for name, grad in (("grad_linear0", m.pfn_layers[0].linear.weight.grad), ("grad_linear1", m.pfn_layers[1].linear.weight.grad)):
-        assert_close_per_channel(grad.cpu().numpy(), g[name], rtol=2e-3, atol_frac=5e-4, name=name)
+        assert_close_per_channel(grad.cpu().numpy(), g[name], rtol=1e-3, atol_frac=1e-4, name=name)
     np.testing.assert_allclose(m.pfn_layers[0].norm.running_mean.cpu().numpy(), g['running_mean0'], rtol=1e-3, atol=1e-5)

@@ -224,11 +224,11 @@ def test_hip_fused_set_abstraction_matches_the_unfused_path(cuda, hip_lib, c_in,
     with torch.no_grad():
         assert m._fused_ok(0, args[0], args[2], f) and m._fused_ok(1, args[0], args[2], f)
         _, fused = m(*args, features=f)
-        saved, pm.FUSED_SA_OFF, pm.ROWS_SA_OFF = (pm.FUSED_SA_OFF, pm.ROWS_SA_OFF), True, True
+        saved, pm.FUSED_SA_OFF, pm.TRAIN_SA_OFF = (pm.FUSED_SA_OFF, pm.TRAIN_SA_OFF), True, True
         try:
             _, plain = m(*args, features=f)
         finally:
-            pm.FUSED_SA_OFF, pm.ROWS_SA_OFF = saved
+            pm.FUSED_SA_OFF, pm.TRAIN_SA_OFF = saved
     assert fused.shape == plain.shape == (sum(qcnt), mlps[0][-1] + mlps[1][-1])
     assert_close_per_channel(fused.cpu().numpy(), plain.cpu().numpy(), rtol=1e-3, atol_frac=1e-4, name="fused SA output")
     # the empty ball: relu(BN shift) through both layers, identical rows for every empty query
@@ -239,11 +239,14 @@ def test_hip_fused_set_abstraction_matches_the_unfused_path(cuda, hip_lib, c_in,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("c_in,mlps,nsamples", [(0, [[16, 16], [16, 16]], [16, 16]), (64, [[64, 64], [64, 128]], [16, 32]), (128, [[64, 64], [64, 64]], [16, 16])])
-def test_hip_rows_set_abstraction_train_step_matches_the_conv2d_path(cuda, hip_lib, c_in, mlps, nsamples):
-    """Train-mode StackSAModuleMSG: neighbourhood rows -> GEMM -> fused BatchNorm/ReLU -> max against the reference-shaped path (QueryAndGroup ->
-    Conv2d / BatchNorm2d / ReLU -> max_pool2d over (1, C, M, nsample)): outputs, running statistics, and the gradients of the point features and of
-    every weight, element-wise per channel.  Includes an empty ball and balls padded with their first neighbour."""
+@pytest.mark.parametrize("c_in,mlps,nsamples", [(0, [[16, 16], [16, 16]], [16, 16]), (64, [[64, 64], [32, 64]], [16, 32]), (128, [[64, 64], [64, 64]], [16, 16]),
+                                                 (32, [[32, 32], [48, 16]], [32, 16]), (16, [[16, 16], [16, 32]], [16, 32])])
+def test_hip_set_abstraction_train_kernels_match_the_conv2d_path(cuda, hip_lib, c_in, mlps, nsamples):
+    """Train-mode StackSAModuleMSG on the hand-written kernels (sv_sa_train_forward / _backward: gather -> MFMA MLP with batch-statistics BatchNorm in
+    the passes' epilogues -> max, and the backward chain) against the reference-shaped path (QueryAndGroup -> Conv2d / BatchNorm2d / ReLU ->
+    max_pool2d over (1, C, M, nsample)): outputs, running statistics, num_batches_tracked, and the gradients of the point features and of every
+    weight, element-wise per channel.  Includes an empty ball, balls padded with their first neighbour and negative BatchNorm scales (the
+    maximum over the neighbours is then made by the SMALLEST pre-activation)."""
     import copy
     import seevcn_amd.synth as synth
     from tolerances import assert_close_per_channel
@@ -259,30 +262,71 @@ def test_hip_rows_set_abstraction_train_step_matches_the_conv2d_path(cuda, hip_l
     feats = rng.normal(size=(len(xyz), c_in)).astype(np.float32) if c_in else None
     torch.manual_seed(c_in)
     m1 = pm.StackSAModuleMSG(radii=[0.4, 1.2], nsamples=nsamples, mlps=[[c_in] + list(x) for x in mlps], use_xyz=True, pool_method='max_pool').to(cuda).train()
+    with torch.no_grad():
+        for mod in m1.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.weight[::5] *= -1.0                                    # negative scales
+                mod.bias.uniform_(-0.3, 0.3)
     m2 = copy.deepcopy(m1)
     t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(cuda) if dt is None else torch.tensor(a, dtype=dt, device=cuda)
     args = (t(xyz), t(counts.tolist(), torch.int32), t(new), t(qcnt, torch.int32))
     f1 = t(feats).requires_grad_(True) if c_in else None
     f2 = t(feats).requires_grad_(True) if c_in else None
-    assert m1._rows_ok(0, args[0], args[2], f1) and m1._rows_ok(1, args[0], args[2], f1)
+    assert m1._train_ok(0, args[0], args[2], f1) and m1._train_ok(1, args[0], args[2], f1)
     _, rows = m1(*args, features=f1)
-    saved, pm.ROWS_SA_OFF = pm.ROWS_SA_OFF, True
+    saved, pm.TRAIN_SA_OFF = pm.TRAIN_SA_OFF, True
     try:
         _, conv = m2(*args, features=f2)
     finally:
-        pm.ROWS_SA_OFF = saved
+        pm.TRAIN_SA_OFF = saved
     assert rows.shape == conv.shape == (sum(qcnt), mlps[0][-1] + mlps[1][-1])
-    assert_close_per_channel(rows.detach().cpu().numpy(), conv.detach().cpu().numpy(), rtol=1e-3, atol_frac=1e-4, name="rows SA output")
+    assert_close_per_channel(rows.detach().cpu().numpy(), conv.detach().cpu().numpy(), rtol=1e-3, atol_frac=1e-4, name="train-kernel SA output")
+    for (n1, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+        np.testing.assert_allclose(b1.cpu().numpy(), b2.cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=n1)
+        assert "num_batches_tracked" not in n1 or int(b1) == int(b2) == 1
+    # the same scale as plain torch ops over the same neighbour lists (gathered rows -> matmul -> F.batch_norm(training) -> relu, twice -> max):
+    # the fp32 torch reference of the op; every gradient element-wise per channel
+    import torch.nn.functional as F
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as raw
+    f3 = t(feats).requires_grad_(True) if c_in else None
+    leaves, outs = [], []
+    for k in range(2):
+        gq = m2.groupers[k]
+        idx = torch.zeros((sum(qcnt), gq.nsample), dtype=torch.int32, device=cuda)
+        raw.ball_query_wrapper(3, sum(qcnt), gq.radius, gq.nsample, args[2], args[3], args[0], args[1], idx)
+        row_start = raw._row_start(args[3], args[1], sum(qcnt))
+        empty = idx[:, 0] < 0
+        rows_i = row_start[:, None].long() + torch.where(empty[:, None], torch.zeros_like(idx), idx).long()
+        x = args[0][rows_i] - args[2][:, None, :]
+        if c_in:
+            x = torch.cat([x, f3[rows_i]], dim=2)
+        x = (x * (~empty)[:, None, None]).reshape(-1, c_in + 3)
+        for i in (0, 3):
+            conv_i, bn_i = m2.mlps[k][i], m2.mlps[k][i + 1]
+            ps = [p.detach().clone().requires_grad_(True) for p in (conv_i.weight.reshape(conv_i.out_channels, -1), bn_i.weight, bn_i.bias)]
+            leaves += ps
+            x = torch.relu(F.batch_norm(x @ ps[0].t(), None, None, ps[1], ps[2], True, 0.1, bn_i.eps))
+        outs.append(x.view(sum(qcnt), gq.nsample, -1).max(dim=1)[0])
+    plain = torch.cat(outs, dim=1)
+    assert_close_per_channel(rows.detach().cpu().numpy(), plain.detach().cpu().numpy(), rtol=1e-3, atol_frac=1e-4, name="train-kernel SA output vs plain torch ops")
     w = torch.from_numpy(rng.normal(size=tuple(rows.shape)).astype(np.float32)).to(cuda)
     (rows * w).sum().backward()
     (conv * w).sum().backward()
-    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
-        a, b = p1.grad.reshape(p1.shape[0], -1).cpu().numpy(), p2.grad.reshape(p2.shape[0], -1).cpu().numpy()
-        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3 * float(np.abs(b).max()) + 1e-6, err_msg=n1)
-    for (n1, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
-        np.testing.assert_allclose(b1.cpu().numpy(), b2.cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=n1)
+    (plain * w).sum().backward()
+    for (n1, p1), p3 in zip(m1.named_parameters(), leaves):
+        assert_close_per_channel(p1.grad.reshape(p1.shape[0], -1).cpu().numpy(), p3.grad.reshape(p1.shape[0], -1).cpu().numpy(), rtol=1e-3, atol_frac=1e-4, name=n1)
     if c_in:
-        assert_close_per_channel(f1.grad.cpu().numpy(), f2.grad.cpu().numpy(), rtol=2e-3, atol_frac=1e-3, name="feature gradient")
+        assert_close_per_channel(f1.grad.cpu().numpy(), f3.grad.cpu().numpy(), rtol=1e-3, atol_frac=1e-4, name="feature gradient")
+    # against the Conv2d path (MIOpen BatchNorm / pooling kernels): a last-bit difference in a pre-activation can flip a ReLU mask or an arg-max at a
+    # near-tie there, which moves one gradient contribution and, through the BatchNorm backward sums, shifts every element a little -- both are
+    # valid gradients, so this comparison is norm-wise (the element-wise one is the plain-torch reference above)
+    def norm_close(a, b, name):
+        assert np.linalg.norm(a - b) <= 2e-2 * np.linalg.norm(b) + 1e-6, (name, float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)))
+    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        norm_close(p1.grad.reshape(p1.shape[0], -1).cpu().numpy(), p2.grad.reshape(p2.shape[0], -1).cpu().numpy(), n1)
+    if c_in:
+        norm_close(f1.grad.cpu().numpy(), f2.grad.cpu().numpy(), "feature gradient vs the Conv2d path")
 
 
 @pytest.mark.gpu

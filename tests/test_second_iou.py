@@ -51,8 +51,7 @@ def test_hip_second_iou_head_and_post_processing_match_reference_golden(golden_d
     fr = head.forward_ret_dict
     np.testing.assert_allclose(fr['rois'].cpu().numpy(), g['train_rois'], rtol=0, atol=0)            # same NMS survivors, same random sample
     np.testing.assert_allclose(fr['rcnn_cls_labels'].cpu().numpy(), g['rcnn_cls_labels'], rtol=1e-3, atol=1e-4)
-    # same stated reason as tests/test_pvrcnn.py: the 256-wide FC stack behind a 7x7x(C) RoI grid accumulates ~1e-4 of the output scale
-    assert_close_per_channel(fr['rcnn_iou'].detach().cpu().numpy(), g['rcnn_iou'], rtol=1e-3, atol_frac=1e-3, name="rcnn_iou")
+    assert_close_per_channel(fr['rcnn_iou'].detach().cpu().numpy(), g['rcnn_iou'], rtol=1e-3, atol_frac=1e-4, name="rcnn_iou")
     loss, tb = head.get_loss()
     assert abs(tb['rcnn_loss_iou'] - float(g['rcnn_loss_iou'])) <= 1e-3 * float(g['rcnn_loss_iou'])
     loss.backward()
@@ -63,7 +62,7 @@ def test_hip_second_iou_head_and_post_processing_match_reference_golden(golden_d
     np.testing.assert_allclose(bd['rois'].cpu().numpy(), g['eval_rois'], rtol=0, atol=0)
     assert np.array_equal(bd['roi_labels'].cpu().numpy(), g['eval_roi_labels'])
     np.testing.assert_allclose(bd['roi_scores'].cpu().numpy(), g['eval_roi_scores'], rtol=1e-6, atol=0)
-    assert_close_per_channel(bd['batch_cls_preds'].cpu().numpy(), g['eval_batch_cls_preds'], rtol=1e-3, atol_frac=1e-3, name="eval_batch_cls_preds")
+    assert_close_per_channel(bd['batch_cls_preds'].cpu().numpy(), g['eval_batch_cls_preds'], rtol=1e-3, atol_frac=1e-4, name="eval_batch_cls_preds")
     fake = SimpleNamespace(model_cfg=dict(POST_PROCESSING=C.SECOND_IOU_POST), num_class=3, class_names=C.CLASS_NAMES,
                            generate_recall_record=Detector3DTemplate.generate_recall_record)
     with torch.no_grad():

@@ -1,0 +1,90 @@
+"""Debug aid: sv_sa_train_* called directly against an explicit torch graph over the same neighbour lists; reports the rows whose dy1 differs."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import seevcn_amd  # noqa: F401
+import seevcn_amd.synth as synth
+from seevcn_amd import _lib
+from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as raw
+
+cuda = torch.device("cuda:0")
+lib = _lib.load()
+c_in, C1, C2, ns, radius = 64, 64, 64, 16, 0.4
+pts, _ = synth.make_scene_batch(3, seed=2000, n_az=60)
+counts = np.bincount(pts[:, 0].astype(int), minlength=3)
+xyz = np.ascontiguousarray(pts[:, 1:4])
+rng = np.random.default_rng(c_in + 5)
+qcnt = [700, 513, 64]
+starts = np.cumsum(counts) - counts
+new = np.concatenate([xyz[starts[b]:starts[b] + counts[b]][rng.integers(0, counts[b], q)] + rng.normal(0, 0.3, (q, 3)) for b, q in enumerate(qcnt)]).astype(np.float32)
+new[7] = [500, 500, 500]
+feats = rng.normal(size=(len(xyz), c_in)).astype(np.float32)
+t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(cuda) if dt is None else torch.tensor(a, dtype=dt, device=cuda)
+X, NX, Fe = t(xyz), t(new), t(feats)
+M = NX.shape[0]
+idx = torch.zeros((M, ns), dtype=torch.int32, device=cuda)
+raw.ball_query_wrapper(3, M, radius, ns, NX, t(qcnt, torch.int32), X, t(counts.tolist(), torch.int32), idx)
+row_start = raw._row_start(t(qcnt, torch.int32), t(counts.tolist(), torch.int32), M)
+from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as pm
+torch.manual_seed(c_in)
+m1 = pm.StackSAModuleMSG(radii=[0.4, 1.2], nsamples=[16, 32], mlps=[[c_in, 64, 64], [c_in, 32, 64]], use_xyz=True, pool_method='max_pool').to(cuda).train()
+with torch.no_grad():
+    for mod in m1.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.uniform_(0.5, 1.5)
+            mod.weight[::5] *= -1.0
+            mod.bias.uniform_(-0.3, 0.3)
+conv1, bn1, _, conv2, bn2, _ = list(m1.mlps[0])
+w1, w2 = conv1.weight.detach().reshape(C1, c_in + 3).contiguous(), conv2.weight.detach().reshape(C2, C1).contiguous()
+g1, b1, g2, b2 = bn1.weight.detach().clone(), bn1.bias.detach().clone(), bn2.weight.detach().clone(), bn2.bias.detach().clone()
+wfull = torch.from_numpy(rng.normal(size=(M, 128)).astype(np.float32)).to(cuda)
+gout = wfull[:, :64].contiguous()
+R = M * ns
+f32 = dict(dtype=torch.float32, device=cuda)
+z1, z2 = torch.empty((R, C1), **f32), torch.empty((R, C2), **f32)
+sm1, si1, sm2, si2 = (torch.empty(64, **f32) for _ in range(4))
+sel, aux, out = (torch.empty((M, C2), **f32) for _ in range(3))
+arg, aux_arg = (torch.empty((M, C2), dtype=torch.uint8, device=cuda) for _ in range(2))
+rm = [torch.zeros(64, **f32) for _ in range(4)]
+nbt = [torch.zeros((), dtype=torch.int64, device=cuda) for _ in range(2)]
+scratch = torch.empty(lib.sv_sa_train_scratch_bytes(c_in, C1, C2), dtype=torch.uint8, device=cuda)
+P = _lib.ptr
+_lib.check(lib.sv_sa_train_forward(P(X), P(Fe), P(NX), P(idx), P(row_start), M, c_in, ns, P(w1), P(g1), P(b1), P(rm[0]), P(rm[1]), P(nbt[0]), C1, P(w2), P(g2), P(b2),
+                                   P(rm[2]), P(rm[3]), P(nbt[1]), C2, 0.1, 1e-5, P(scratch), P(z1), P(z2), P(sm1), P(si1), P(sm2), P(si2), P(sel), P(aux), P(arg), P(aux_arg),
+                                   P(out), _lib.stream()), "fwd")
+dy1, aux2 = torch.empty((R, C1), **f32), torch.empty((M, C2), **f32)
+scatter = torch.empty((X.shape[0], C1), **f32)
+gw1, gw2 = torch.empty((C1, c_in + 3), **f32), torch.empty((C2, C1), **f32)
+dg = [torch.empty(64, **f32) for _ in range(4)]
+_lib.check(lib.sv_sa_train_backward(P(X), P(Fe), P(NX), P(idx), P(row_start), M, X.shape[0], c_in, ns, P(w1), P(g1), P(b1), C1, P(w2), P(g2), P(b2), C2, P(z1), P(z2),
+                                    P(sm1), P(si1), P(sm2), P(si2), P(sel), P(arg), P(out), P(gout), P(scratch), P(dy1), P(aux2), P(scatter), None, P(gw1), P(gw2),
+                                    P(dg[0]), P(dg[1]), P(dg[2]), P(dg[3]), _lib.stream()), "bwd")
+# explicit torch graph
+empty = idx[:, 0] < 0
+rows = (row_start[:, None].long() + torch.where(empty[:, None], torch.zeros_like(idx), idx).long())
+xr = torch.cat([X[rows] - NX[:, None, :], Fe[rows]], dim=2)
+xr[empty] = 0
+xr = xr.view(R, -1)
+W1, W2, G1, B1, G2, B2 = (p.clone().requires_grad_(True) for p in (w1, w2, g1, b1, g2, b2))
+Z1 = xr @ W1.t()
+Y1 = F.batch_norm(Z1, None, None, G1, B1, True, 0.1, 1e-5); Y1.retain_grad()
+Z2 = torch.relu(Y1) @ W2.t(); Z2.retain_grad()
+Y2 = F.batch_norm(Z2, None, None, G2, B2, True, 0.1, 1e-5)
+O, am = torch.relu(Y2).view(M, ns, C2).max(dim=1)
+print("out maxdiff", float((O - out).abs().max()), "z1", float((Z1 - z1).abs().max()), "z2", float((Z2 - z2).abs().max()))
+(O * gout).sum().backward()
+print("gw2 err", float((W2.grad - gw2).abs().max()), "gw1 err", float((W1.grad - gw1).abs().max()), "dg2", float((G2.grad - dg[2]).abs().max()), "dg1", float((G1.grad - dg[0]).abs().max()))
+e = (Y1.grad - dy1).abs()
+bad = torch.nonzero(e.max(dim=1)[0] > 1e-3 * float(Y1.grad.abs().max())).view(-1)
+print("dy1 rows wrong:", bad.tolist()[:40], "max err", float(e.max()))
+pos = (O > 0)
+mism = torch.nonzero((am != arg.long()) & pos)
+print("slot mismatches with positive output:", mism.shape[0])
+for q, c in mism.tolist()[:10]:
+    print("  q", q, "c", c, "torch slot", int(am[q, c]), "mine", int(arg[q, c]), "idx row", idx[q].tolist(), "z2 col", [round(float(v), 6) for v in z2.view(M, ns, C2)[q, :, c]],
+          "sc2 sign", float(g2[c]), "out", float(out[q, c]))
