@@ -254,6 +254,14 @@ int sv_stack_farthest_point_sampling_multi_async(const float* xyz, const int32_t
 int sv_ball_query_stack(int batch, int M, int max_queries_per_scene, float radius, int nsample, const float* new_xyz,
                         const int32_t* new_xyz_batch_start, const int32_t* new_xyz_batch_cnt, const float* xyz,
                         const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int32_t* idx, void* stream);
+/* The same result, element for element, over a cell hash of the support points instead of the reference's scan of the whole scene per query
+ * (seevcn extension): cells of edge radius * 1.0001 counting-sorted into hash buckets, a wave per query tests the candidates of the 27 cells
+ * around it with the reference's own distance expression and writes the nsample smallest indices in ascending order.  n_points = rows of xyz;
+ * scratch: sv_ball_query_hash_scratch_bytes(n_points) bytes (any content); nsample <= 64. */
+size_t sv_ball_query_hash_scratch_bytes(int64_t n_points);
+int sv_ball_query_stack_hashed(int batch, int M, int64_t n_points, float radius, int nsample, const float* new_xyz, const int32_t* new_xyz_batch_start,
+                               const int32_t* new_xyz_batch_cnt, const float* xyz, const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt,
+                               void* scratch, int32_t* idx, void* stream);
 /* ---- fused set-abstraction reduction, eval mode (csrc/set_abstraction.hip): the tail of StackSAModuleMSG.forward
  * (ops/pointnet2/pointnet2_stack/pointnet2_modules.py:78-112) for one radius scale -- QueryAndGroup's gather (xyz relative to the query in
  * front of the features, an empty ball = zeros; pointnet2_utils.py:112-159) -> two Conv2d 1x1 + BatchNorm2d(eval) + ReLU -> max over nsample --
@@ -271,7 +279,8 @@ int sv_sa_mlp_max(const float* xyz, const float* features, const float* new_xyz,
  * columns first (QueryAndGroup's concatenation order, pointnet2_utils.py:147-152), w2 (C2, C1); gamma / beta / running_* / tracked = the two
  * nn.BatchNorm2d's weight, bias, running_mean, running_var, num_batches_tracked (updated like torch: biased variance to normalise, unbiased
  * into running_var).  R = M * nsample rows.
- * forward:  writes z1 (R, C1), z2 (R, C2) [pre-BatchNorm activations, kept for the backward], save_mean* / save_invstd*, sel (M, C2) = the z2
+ * forward:  N = rows of xyz / features; proj (N, C1) is a work buffer (null when C == 0: the feature part of layer 1, made once per support
+ *           point).  Writes z1 (R, C1), z2 (R, C2) [pre-BatchNorm activations, kept for the backward], save_mean* / save_invstd*, sel (M, C2) = the z2
  *           that makes each output, arg (M, C2) = its slot, out (M, C2); aux (M, C2) floats and aux_arg (M, C2) bytes are work buffers.
  * backward: grad_out (M, C2) -> grad_w1 (C1, 3 + C), grad_w2 (C2, C1), dgamma* / dbeta*, scatter (N, C1) = per support point the sum of dz1 over
  *           its (query, slot) pairs (zero-filled here; fp32 atomics like group_points_grad_kernel_stack, group_points_gpu.cu:38-41).  The
@@ -279,10 +288,11 @@ int sv_sa_mlp_max(const float* xyz, const float* features, const float* new_xyz,
  *           dy1 (R, C1) and aux (M, C2) are work buffers.
  * scratch: sv_sa_train_scratch_bytes(C, C1, C2) bytes, not shared between a forward and a backward in flight on different streams. */
 size_t sv_sa_train_scratch_bytes(int C, int C1, int C2);
-int sv_sa_train_forward(const float* xyz, const float* features, const float* new_xyz, const int32_t* idx, const int32_t* row_start, int64_t M, int C,
-                        int nsample, const float* w1, const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
+int sv_sa_train_forward(const float* xyz, const float* features, const float* new_xyz, const int32_t* idx, const int32_t* row_start, int64_t M,
+                        int64_t N, int C, int nsample, const float* w1, const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
                         int64_t* tracked1, int C1, const float* w2, const float* gamma2, const float* beta2, float* running_mean2,
-                        float* running_var2, int64_t* tracked2, int C2, float momentum, float eps, void* scratch, float* z1, float* z2,
+                        float* running_var2, int64_t* tracked2, int C2, float momentum, float eps, void* scratch, float* proj, float* z1,
+                        float* z2,
                         float* save_mean1, float* save_invstd1, float* save_mean2, float* save_invstd2, float* sel, float* aux, uint8_t* arg,
                         uint8_t* aux_arg, float* out, void* stream);
 int sv_sa_train_backward(const float* xyz, const float* features, const float* new_xyz, const int32_t* idx, const int32_t* row_start, int64_t M,

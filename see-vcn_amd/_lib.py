@@ -71,11 +71,13 @@ SIGNATURES = {
     "sv_fps_multi_error_offset": (c_sz, [c_i]),
     "sv_stack_farthest_point_sampling_multi_async": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
     "sv_ball_query_stack": (c_i, [c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sv_ball_query_hash_scratch_bytes": (c_sz, [c_i64]),
+    "sv_ball_query_stack_hashed": (c_i, [c_i, c_i, c_i64, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_sa_prepare_weights": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_sa_mlp_max": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p]),
     "sv_sa_train_scratch_bytes": (c_sz, [c_i, c_i, c_i]),
-    "sv_sa_train_forward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f,
-                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sv_sa_train_forward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f,
+                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_sa_train_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p,
                                    c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_group_points_stack": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

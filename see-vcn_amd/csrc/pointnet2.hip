@@ -552,3 +552,287 @@ extern "C" int sv_group_points_grad_stack(int M, int C, int N, int nsample, cons
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Ball query over a cell hash (same result as k_ball_query, element for element).  The reference scans every point of the scene for every query
+// (ball_query_gpu.cu:47-65: O(M N)); here the support points are counting-sorted into hash buckets of cubic cells of edge r (1 + 1e-4) -- a hit
+// differs from its query by less than r in every coordinate, so it lives in one of the 27 cells around the query's -- and a wave per query
+// gathers the candidates of those 27 buckets, keeps the ones of the right scene and cell that pass the reference's own distance test
+// ((qx-x)^2 + (qy-y)^2 + (qz-z)^2 < r^2, same operation order), and writes the nsample SMALLEST indices in ascending order: exactly "the first
+// nsample hits in index order", padded with the first hit, idx[0] = -1 for an empty ball.
+// Build: count (one atomic per point) -> exclusive scan over the buckets (one workgroup) -> fill (entries {x, y, z, index}, 16 B, so that a
+// bucket is one contiguous read).  Query: lanes 0..26 fetch their bucket's range, the candidates are enumerated flat over the 27 ranges, hits
+// are compacted into a wave-private LDS list and the nsample smallest are taken by a 64-lane bitonic sort (<= 64 hits) or by repeated
+// minimum extraction (more).
+// ------------------------------------------------------------------------------------------------
+constexpr int BQH_LIST = 1024;         // hits kept per wave (more: the list is reduced to its nsample smallest and refilled)
+
+__device__ __forceinline__ void bqh_cell(float x, float y, float z, float inv, int& cx, int& cy, int& cz) {
+  cx = (int)floorf(x * inv), cy = (int)floorf(y * inv), cz = (int)floorf(z * inv);
+}
+__device__ __forceinline__ uint32_t bqh_bucket(int b, int cx, int cy, int cz, uint32_t mask) {
+  return (((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u) ^ ((uint32_t)cz * 83492791u) ^ ((uint32_t)b * 2654435761u)) & mask;
+}
+__device__ __forceinline__ int bqh_scene(int i, const int32_t* __restrict__ start, const int32_t* __restrict__ cnt, int batch) {
+  int b = 0;
+  while (b + 1 < batch && i >= start[b] + cnt[b]) ++b;
+  return b;
+}
+
+__global__ __launch_bounds__(256) void k_bqh_count(int N, const float* __restrict__ xyz, const int32_t* __restrict__ p_start,
+                                                   const int32_t* __restrict__ p_cnt, int batch, float inv, uint32_t mask,
+                                                   int32_t* __restrict__ count, int32_t* __restrict__ bucket_of) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  int cx, cy, cz;
+  bqh_cell(xyz[(int64_t)i * 3], xyz[(int64_t)i * 3 + 1], xyz[(int64_t)i * 3 + 2], inv, cx, cy, cz);
+  const uint32_t bk = bqh_bucket(bqh_scene(i, p_start, p_cnt, batch), cx, cy, cz, mask);
+  bucket_of[i] = (int32_t)bk;
+  atomicAdd(&count[bk], 1);
+}
+
+// exclusive scan of count[0..T) -> start[0..T], start[T] = total; one workgroup, tiles of 4096 buckets; cursor[] (= count's memory) is zeroed
+__global__ __launch_bounds__(1024) void k_bqh_scan(int32_t* __restrict__ count, int T, int32_t* __restrict__ start) {
+  __shared__ int32_t s_wave[16];
+  __shared__ int32_t s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 4096) {
+    const int e = t0 + tid * 4;
+    int4 v = make_int4(0, 0, 0, 0);
+    if (e < T) v = *reinterpret_cast<const int4*>(count + e);           // T is a power of two >= 4096
+    const int local = v.x + v.y + v.z + v.w;
+    int inc = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(inc, off);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wid] = inc;
+    __syncthreads();
+    int base = s_carry;
+    for (int w = 0; w < wid; ++w) base += s_wave[w];
+    const int ex = base + inc - local;
+    if (e < T) {
+      *reinterpret_cast<int4*>(start + e) = make_int4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
+      *reinterpret_cast<int4*>(count + e) = make_int4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    if (tid == 1023) s_carry = ex + local;
+    __syncthreads();
+  }
+  if (tid == 0) start[T] = s_carry;
+}
+
+__global__ __launch_bounds__(256) void k_bqh_fill(int N, const float* __restrict__ xyz, const int32_t* __restrict__ p_start,
+                                                  const int32_t* __restrict__ p_cnt, int batch, const int32_t* __restrict__ bucket_of,
+                                                  const int32_t* __restrict__ start, int32_t* __restrict__ cursor, float4* __restrict__ entries) {
+  (void)p_start, (void)p_cnt, (void)batch;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int bk = bucket_of[i];
+  const int pos = start[bk] + atomicAdd(&cursor[bk], 1);
+  entries[pos] = make_float4(xyz[(int64_t)i * 3], xyz[(int64_t)i * 3 + 1], xyz[(int64_t)i * 3 + 2], __int_as_float(i));      // global row
+}
+
+// ascending 64-lane bitonic sort of one int per lane
+__device__ __forceinline__ int bqh_sort64(int v, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int o = __shfl_xor(v, j);
+      const bool up = ((lane & k) == 0), lower = ((lane & j) == 0);
+      v = (lower == up) ? min(v, o) : max(v, o);
+    }
+  return v;
+}
+
+// the smallest value of list[0..L) for the whole wave; that entry is then marked taken
+__device__ __forceinline__ int bqh_take_min(int32_t* list, int L, int lane) {
+  int best = 0x7fffffff, at = -1;
+  for (int t = lane; t < L; t += 64) {
+    const int v = list[t];
+    if (v < best) best = v, at = t;
+  }
+  int wb = best;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) wb = min(wb, __shfl_xor(wb, off));
+  const unsigned long long own = __ballot(best == wb && at >= 0);
+  if (own && lane == __ffsll((long long)own) - 1) list[at] = 0x7fffffff;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  return wb;
+}
+
+__global__ __launch_bounds__(256) void k_bqh_query(int M, const float* __restrict__ new_xyz, const int32_t* __restrict__ q_start,
+                                                   const int32_t* __restrict__ q_cnt, const float* __restrict__ xyz,
+                                                   const int32_t* __restrict__ p_start, const int32_t* __restrict__ p_cnt, int batch,
+                                                   const int32_t* __restrict__ start, const float4* __restrict__ entries, float inv, uint32_t mask,
+                                                   float radius2, int nsample, int32_t* __restrict__ idx) {
+  __shared__ int32_t s_list[4][BQH_LIST];
+  __shared__ int32_t s_pre[4][32], s_beg[4][32];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int32_t* list = s_list[wid];
+  int32_t* pre = s_pre[wid];
+  int32_t* beg = s_beg[wid];
+  for (int q = blockIdx.x * 4 + wid; q < M; q += gridDim.x * 4) {
+    const int b = bqh_scene(q, q_start, q_cnt, batch);
+    const int ps = p_start[b], pn = p_cnt[b];
+    const float qx = new_xyz[(int64_t)q * 3], qy = new_xyz[(int64_t)q * 3 + 1], qz = new_xyz[(int64_t)q * 3 + 2];
+    int32_t* out = idx + (int64_t)q * nsample;
+    int qcx, qcy, qcz;
+    bqh_cell(qx, qy, qz, inv, qcx, qcy, qcz);
+    // lanes 0..26: the bucket ranges of the 27 cells around the query's
+    int n = 0;
+    if (lane < 27) {
+      const uint32_t bk = bqh_bucket(b, qcx + lane % 3 - 1, qcy + (lane / 3) % 3 - 1, qcz + lane / 9 - 1, mask);
+      const int s = start[bk];
+      n = start[bk + 1] - s;
+      beg[lane] = s;
+    }
+    int inc = n;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int o = __shfl_up(inc, off);
+      if (lane >= off) inc += o;
+    }
+    if (lane < 27) pre[lane + 1] = inc;
+    if (lane == 0) pre[0] = 0;
+    const int total = __shfl(inc, 26);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    int L = 0;                                                        // hits in the list
+    bool scan = false;
+    for (int c0 = 0; c0 < total; c0 += 256) {                         // 256 candidates per round: four independent loads per lane
+      int hit[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = c0 + u * 64 + lane;
+        hit[u] = -1;
+        if (i < total) {
+          int lo = 0, hi = 27;                                        // the cell k with pre[k] <= i < pre[k + 1]
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= i) lo = mid; else hi = mid;
+          }
+          const float4 e = entries[beg[lo] + (i - pre[lo])];
+          int ex, ey, ez;
+          bqh_cell(e.x, e.y, e.z, inv, ex, ey, ez);
+          const float d2 = (qx - e.x) * (qx - e.x) + (qy - e.y) * (qy - e.y) + (qz - e.z) * (qz - e.z);
+          // an entry counts in its own cell only (a bucket can hold several cells, and two of the 27 cells can share a bucket) and in the
+          // query's scene only (scenes share the coordinate frame; the scene is hashed in, but buckets collide)
+          const int j = __float_as_int(e.w) - ps;
+          if (j >= 0 && j < pn && ex == qcx + lo % 3 - 1 && ey == qcy + (lo / 3) % 3 - 1 && ez == qcz + lo / 9 - 1 && d2 < radius2) hit[u] = j;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned long long m = __ballot(hit[u] >= 0);
+        if (m) {
+          const int cntm = __popcll(m);
+          if (L + cntm > BQH_LIST) {                                  // list full: keep its nsample smallest and go on (nsample <= 64)
+            const int kept = min(nsample, L);
+            int keep = 0x7fffffff;
+            for (int r = 0; r < kept; ++r) {
+              const int wb = bqh_take_min(list, L, lane);
+              if (lane == r) keep = wb;
+            }
+            if (lane < kept) list[lane] = keep;
+            L = kept;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          }
+          if (hit[u] >= 0) list[L + __popcll(m & ((1ull << lane) - 1ull))] = hit[u];
+          L += cntm;
+        }
+      }
+      if (c0 == 0 && total > 1024) {
+        // a crowded neighbourhood: from the hit rate of the first 256 candidates, would the reference's own scan in index order (which stops at
+        // the nsample-th hit) need fewer rounds than the rest of the candidates?  Both in rounds of 256 points.
+        const float est_hits = fmaxf((float)L, 0.5f) * (float)total * (1.f / 256.f);
+        const float scan_rounds = (float)pn * (float)nsample / (est_hits * 256.f), hash_rounds = (float)(total - 256) * (1.f / 256.f);
+        if (scan_rounds < hash_rounds) {
+          scan = true;
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (scan) {
+      int cnt = 0;
+      for (int p0 = 0; p0 < pn && cnt < nsample; p0 += 256) {
+        bool h[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = p0 + u * 64 + lane;
+          h[u] = false;
+          if (k < pn) {
+            const float* p = xyz + (int64_t)(ps + k) * 3;
+            const float x = p[0], y = p[1], z = p[2];
+            h[u] = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z) < radius2;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned long long m = __ballot(h[u]);
+          if (m && cnt < nsample) {
+            const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+            if (cnt == 0) {                                           // first hit: the whole row is pre-filled with it (the reference's padding)
+              const int first = p0 + u * 64 + (__ffsll((long long)m) - 1);
+              if (lane < nsample) out[lane] = first;
+            }
+            if (h[u] && pos < nsample) out[pos] = p0 + u * 64 + lane;
+            cnt += __popcll(m);
+          }
+        }
+      }
+      if (cnt == 0 && lane == 0) out[0] = -1;
+      continue;
+    }
+    if (L == 0) {
+      if (lane == 0) out[0] = -1;
+    } else if (L <= 64) {
+      const int v = bqh_sort64(lane < L ? list[lane] : 0x7fffffff, lane);
+      const int first = __shfl(v, 0);
+      if (lane < nsample) out[lane] = lane < L ? v : first;            // nsample <= 64
+    } else {
+      for (int r = 0; r < nsample; ++r) {                              // more than 64 hits: every slot has a hit of its own
+        const int wb = bqh_take_min(list, L, lane);
+        if (lane == 0) out[r] = wb;
+      }
+    }
+  }
+}
+
+extern "C" size_t sv_ball_query_hash_scratch_bytes(int64_t n_points) {
+  int64_t T = 4096;
+  while (T < 2 * n_points) T <<= 1;
+  return (size_t)(2 * T + 8) * 4 + (size_t)n_points * 4 + (size_t)n_points * 16 + 64;
+}
+
+// same arguments and result as sv_ball_query_stack + the number of support points and a scratch of sv_ball_query_hash_scratch_bytes(N) bytes
+extern "C" int sv_ball_query_stack_hashed(int batch, int M, int64_t N, float radius, int nsample, const float* new_xyz,
+                                          const int32_t* new_xyz_batch_start, const int32_t* new_xyz_batch_cnt, const float* xyz,
+                                          const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, void* scratch, int32_t* idx, void* stream) {
+  SV_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0 && nsample > 0 && nsample <= 64 && radius > 0.f, "ball_query_hashed: bad arguments (nsample <= 64, radius > 0)");
+  if (batch == 0 || M == 0) return SV_OK;
+  SV_CHECK_ARG(new_xyz && new_xyz_batch_start && new_xyz_batch_cnt && xyz_batch_start && xyz_batch_cnt && idx && scratch && (xyz || N == 0),
+               "ball_query_hashed: null pointer");
+  SV_CHECK_ARG(N < (1ll << 30), "ball_query_hashed: too many points");
+  hipStream_t st = sv_stream(stream);
+  int64_t T = 4096;
+  while (T < 2 * N) T <<= 1;
+  int32_t* count = reinterpret_cast<int32_t*>(scratch);            // T     (bucket sizes, then the fill cursors)
+  int32_t* start = count + T;                                      // T + 1 (+ padding to 8)
+  int32_t* bucket_of = start + T + 8;                              // N
+  float4* entries = reinterpret_cast<float4*>(reinterpret_cast<char*>(bucket_of + N) + ((16 - ((uintptr_t)(bucket_of + N) & 15)) & 15));
+  const float inv = 1.0f / (radius * 1.0001f);
+  const uint32_t mask = (uint32_t)(T - 1);
+  SV_HIP(hipMemsetAsync(count, 0, (size_t)T * 4, st));
+  if (N > 0) hipLaunchKernelGGL(k_bqh_count, dim3(sv_div_up(N, 256)), dim3(256), 0, st, (int)N, xyz, xyz_batch_start, xyz_batch_cnt, batch, inv, mask, count, bucket_of);
+  hipLaunchKernelGGL(k_bqh_scan, dim3(1), dim3(1024), 0, st, count, (int)T, start);
+  if (N > 0) hipLaunchKernelGGL(k_bqh_fill, dim3(sv_div_up(N, 256)), dim3(256), 0, st, (int)N, xyz, xyz_batch_start, xyz_batch_cnt, batch, bucket_of, start, count, entries);
+  hipLaunchKernelGGL(k_bqh_query, dim3(sv_grid_1d(M, 4, 256 * 8)), dim3(256), 0, st, M, new_xyz, new_xyz_batch_start, new_xyz_batch_cnt, xyz,
+                     xyz_batch_start, xyz_batch_cnt, batch, start, entries, inv, mask, radius * radius, nsample, idx);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

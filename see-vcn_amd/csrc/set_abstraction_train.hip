@@ -7,7 +7,9 @@
 //
 // BatchNorm in training mode needs every row's pre-activation before any row can be normalised, so a scale is a chain of passes over
 // 16-row tiles (a query's nsample neighbours = 1 or 2 tiles), each pass one persistent launch whose waves keep their accumulators in registers:
-//   fwd1   gather [features | dx dy dz | 0] rows -> layer-1 GEMM (v_mfma_f32_16x16x4_f32) -> z1 (R, C1) + per-channel sum / sum of squares
+//   proj   layer 1 is linear in the gathered row, and the feature part of a gathered row is a COPY of a support point's row: P = F . W1[:, 3:]^T
+//          is made once per support point (N x C x C1 on the matrix core instead of R x C x C1, R = M * nsample = 27 .. 108 N here)
+//   fwd1   z1[row] = P[source of row] + W1[:, :3] . (xyz[source] - query)  (R, C1) + per-channel sum / sum of squares: a gather, no GEMM
 //   (fin)  k_bn_finalize (norm.hip): batch mean / invstd, running statistics, scale / shift
 //   fwd2   z1 -> scale, shift, ReLU fused into the operand load -> layer-2 GEMM -> z2 (R, C2) + statistics + per query and channel the largest
 //          and the smallest z2 with their slots: max over slots of relu(s * z + t) = relu(s * (s >= 0 ? max z : min z) + t), bit for bit
@@ -15,12 +17,14 @@
 //   bwd0   the gradient enters at ONE slot per (query, channel): BatchNorm-2 backward sums over (M, C2) only
 //   bwd2   tiles: dz2 (BatchNorm-2 backward, dense) -> weight gradient 2 (contraction over rows on the matrix core, accumulators stay in
 //          registers for the whole launch) and da1 = dz2 . W2 -> ReLU mask -> dy1 (R, C1) + BatchNorm-1 backward sums
-//   bwd1   tiles: dz1 -> weight gradient 1 against the re-gathered rows, and S[source row] += dz1 (float atomics, one 256-byte row per
-//          instruction); the feature gradient is linear in the gathered row, so dF = S . W1[:, features] is one small GEMM over the N support
-//          points instead of a (R, C) gradient tensor.  (The reference scatters with atomicAdd too: group_points_gpu.cu:38-41.)
+//   bwd1   tiles: dz1 -> S[source row] += dz1 (float atomics, one 256-byte row per instruction; the reference scatters with atomicAdd too:
+//          group_points_gpu.cu:38-41) and the xyz columns of the weight gradient (sum of dz1 x relative coordinate).  Everything else of
+//          layer 1's backward is linear in the gathered row and happens per SUPPORT POINT afterwards: dW1[:, 3:] = S^T . F (wgp) and
+//          dF = S . W1[:, 3:] (fgrad) are small GEMMs over the N points instead of passes over (R, C) tensors.
 // Only C1- / C2-wide per-row tensors touch HBM (z1, z2, dy1: 256 B per row at 64 channels); the (C+3)-wide gathered rows never do.
-// Bounds at the RoI-grid pool (pvrcnn_head.py:64-109: 110 592 queries x 16 neighbours, C = 128, 64/64 channels): 109 GFLOP per scale
-// forward + backward on the fp32 matrix core against 9 x 453 MB of per-row traffic -> fp32 MFMA bound.
+// At the RoI-grid pool (pvrcnn_head.py:64-109: 110 592 queries x 16 neighbours, C = 128, 64/64 channels): 43.5 GFLOP per scale on the fp32
+// matrix core (layer 2 forward, its data and weight gradients) instead of the 109 GFLOP of the literal formulation, 9 x 453 MB of per-row
+// traffic (z1, z2, dy1).
 #include "norm.h"
 
 typedef float st_f4 __attribute__((ext_vector_type(4)));
@@ -30,11 +34,9 @@ constexpr int ST_WAVES = ST_THREADS / 64;
 constexpr int ST_MAXC = 64;                  // widest MLP layer
 constexpr int ST_NT = ST_MAXC / 16;
 constexpr int ST_MAXF = 128;                 // most feature channels
-constexpr int ST_MAXKP = ST_MAXF + 16;       // padded contraction length of layer 1
-constexpr int ST_NV = ST_MAXKP / 16;         // 9 feature tiles
-constexpr int ST_NVH = (ST_NV + 1) / 2;      // per wave of a pair in bwd1
+
 constexpr int ST_PITCH = ST_MAXC + 4;        // LDS row pitch of a 16-row tile
-constexpr int ST_GRID = 256;
+constexpr int ST_GRID = 512;                 // two workgroups per CU: four waves per SIMD (kernels hold <= 128 VGPRs, <= 80 KB LDS)
 
 struct SaT {
   const float* xyz;          // (N, 3)
@@ -62,7 +64,8 @@ struct SaT {
   const float* dout;         // (M, C2)
   float* wpart;              // weight-gradient partials
   float* S;                  // (N, C1) scatter target of bwd1
-  int64_t M;
+  float* P;                  // (N, C1) layer-1 feature part per support point (forward)
+  int64_t M, N;
   int C, Kp, C1, C2, ns;
 };
 
@@ -115,77 +118,128 @@ __device__ __forceinline__ void stats_to_partial(float (&s0)[ST_NT], float (&s1)
 }
 
 // ------------------------------------------------------------------------------------------------ forward, layer 1
-__global__ __launch_bounds__(ST_THREADS) void k_sa_fwd1(SaT a) {
-  __shared__ __attribute__((aligned(16))) float s_w1[ST_MAXC * (ST_MAXKP + 4)];          // (C1, p1): [features | xyz | 0]
-  __shared__ __attribute__((aligned(16))) float s_t[ST_WAVES][16 * ST_PITCH];
-  __shared__ float s_red[ST_WAVES][2][ST_MAXC];
+// P (N, C1) = F . W1[:, 3:]^T on the matrix core: 16 support points per wave tile
+constexpr int SP_THREADS = 256;
+__global__ __launch_bounds__(SP_THREADS) void k_sa_point_proj(SaT a) {
+  __shared__ __attribute__((aligned(16))) float s_w[ST_MAXC * (ST_MAXF + 4)];             // (C1, C + 4): feature columns of W1
+  __shared__ __attribute__((aligned(16))) float s_t[SP_THREADS / 64][16 * ST_PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, kk = lane >> 4;
-  const int p1 = a.Kp + 4, cin = a.C + 3;
-  for (int e = tid; e < a.C1 * a.Kp; e += ST_THREADS) {
-    const int n = e / a.Kp, k = e - n * a.Kp;
-    s_w1[n * p1 + k] = k < a.C ? a.w1[n * cin + 3 + k] : (k < a.C + 3 ? a.w1[n * cin + (k - a.C)] : 0.f);
-  }
+  const int pw = a.C + 4, cin = a.C + 3;
+  for (int e = tid; e < a.C1 * a.C; e += SP_THREADS) s_w[(e / a.C) * pw + e % a.C] = a.w1[(e / a.C) * cin + 3 + e % a.C];
   __syncthreads();
   float* T = s_t[wid];
-  const int nt1 = a.C1 / 16, nq1 = a.Kp / 16, nqf = a.C / 16, G = a.ns / 16;
-  float s0[ST_NT] = {0.f, 0.f, 0.f, 0.f}, s1[ST_NT] = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t q = (int64_t)blockIdx.x * ST_WAVES + wid; q < a.M; q += (int64_t)gridDim.x * ST_WAVES) {
+  const int nt1 = a.C1 / 16, nqf = a.C / 16;
+  const int64_t ntiles = (a.N + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * (SP_THREADS / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (SP_THREADS / 64)) {
+    const int64_t n = tile * 16 + li;
+    st_f4 acc[ST_NT];
+#pragma unroll
+    for (int t = 0; t < ST_NT; ++t) acc[t] = (st_f4){0.f, 0.f, 0.f, 0.f};
+    for (int qs = 0; qs < nqf; ++qs) {
+      st_f4 A = (st_f4){0.f, 0.f, 0.f, 0.f};
+      if (n < a.N) A = *reinterpret_cast<const st_f4*>(a.feat + n * a.C + qs * 16 + kk * 4);
+#pragma unroll
+      for (int t = 0; t < ST_NT; ++t)
+        if (t < nt1) acc[t] = mfma4(A, *reinterpret_cast<const st_f4*>(s_w + (t * 16 + li) * pw + qs * 16 + kk * 4), acc[t]);
+    }
+    acc_to_lds(T, acc, nt1, li, kk);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const int rows = (int)min((int64_t)16, a.N - tile * 16);           // the last tile may be short
+    const int c4n = a.C1 >> 2;
+    for (int f = lane; f < rows * c4n; f += 64) {
+      const int row = f / c4n, c4 = f - row * c4n;
+      reinterpret_cast<st_f4*>(a.P + tile * 16 * a.C1)[f] = *reinterpret_cast<const st_f4*>(T + row * ST_PITCH + c4 * 4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+}
+
+// z1[row] = P[source] + W1[:, :3] . (xyz[source] - query), 0 for an empty ball; per-channel sum / sum of squares.  Lane (row li, columns
+// 16 qs + 4 kk .. + 3): 16-byte pieces of the P rows in, 16-byte pieces of z1 out; no matrix work.
+constexpr int SG_THREADS = 256;
+template <int NT1, int NT2>   // channel tiles of the two layers at compile time (0: read from the arguments)
+__global__ __launch_bounds__(SG_THREADS) void k_sa_fwd1(SaT a_in) {
+  SaT a = a_in;
+  if (NT1) a.C1 = NT1 * 16;
+  if (NT2) a.C2 = NT2 * 16;
+  __shared__ __attribute__((aligned(16))) float s_wx[3][ST_MAXC];                        // xyz columns of W1, by coordinate
+  __shared__ float s_red[SG_THREADS / 64][2][ST_MAXC];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, kk = lane >> 4;
+  for (int e = tid; e < 3 * ST_MAXC; e += SG_THREADS) s_wx[e / ST_MAXC][e % ST_MAXC] = (e % ST_MAXC) < a.C1 ? a.w1[(e % ST_MAXC) * (a.C + 3) + e / ST_MAXC] : 0.f;
+  __syncthreads();
+  const int nt1 = NT1 ? NT1 : a.C1 / 16, G = a.ns / 16;
+  st_f4 s0[ST_NT], s1[ST_NT];
+#pragma unroll
+  for (int qs = 0; qs < ST_NT; ++qs) s0[qs] = s1[qs] = (st_f4){0.f, 0.f, 0.f, 0.f};
+  for (int64_t q = (int64_t)blockIdx.x * (SG_THREADS / 64) + wid; q < a.M; q += (int64_t)gridDim.x * (SG_THREADS / 64)) {
     const bool empty = a.idx[q * a.ns] < 0;
     const int64_t base = a.row_start[q];
     const float qx = a.new_xyz[q * 3], qy = a.new_xyz[q * 3 + 1], qz = a.new_xyz[q * 3 + 2];
     for (int g = 0; g < G; ++g) {
-      const int64_t nrow = empty ? -1 : base + a.idx[q * a.ns + g * 16 + li];
-      st_f4 acc[ST_NT];
-#pragma unroll
-      for (int t = 0; t < ST_NT; ++t) acc[t] = (st_f4){0.f, 0.f, 0.f, 0.f};
-      for (int qs = 0; qs < nq1; ++qs) {
-        st_f4 A = (st_f4){0.f, 0.f, 0.f, 0.f};
-        if (nrow >= 0) {
-          if (qs < nqf) {
-            A = *reinterpret_cast<const st_f4*>(a.feat + nrow * a.C + qs * 16 + kk * 4);
-          } else if (kk == 0) {
-            const float* p = a.xyz + nrow * 3;
-            A = (st_f4){p[0] - qx, p[1] - qy, p[2] - qz, 0.f};
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < ST_NT; ++t)
-          if (t < nt1) acc[t] = mfma4(A, *reinterpret_cast<const st_f4*>(s_w1 + (t * 16 + li) * p1 + qs * 16 + kk * 4), acc[t]);
+      const int64_t row = q * a.ns + g * 16 + li;
+      float dx = 0.f, dy = 0.f, dz = 0.f;
+      int64_t src = -1;
+      if (!empty) {
+        src = base + a.idx[row];
+        const float* p = a.xyz + src * 3;
+        dx = p[0] - qx, dy = p[1] - qy, dz = p[2] - qz;
       }
 #pragma unroll
-      for (int t = 0; t < ST_NT; ++t)
+      for (int qs = 0; qs < ST_NT; ++qs)
+        if (qs < nt1) {
+          const int c = qs * 16 + kk * 4;
+          st_f4 z = (st_f4){0.f, 0.f, 0.f, 0.f};
+          if (!empty) {
+            if (a.P) z = *reinterpret_cast<const st_f4*>(a.P + src * a.C1 + c);
+            const st_f4 wx = *reinterpret_cast<const st_f4*>(s_wx[0] + c), wy = *reinterpret_cast<const st_f4*>(s_wx[1] + c),
+                        wz = *reinterpret_cast<const st_f4*>(s_wx[2] + c);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s0[t] += acc[t][r], s1[t] += acc[t][r] * acc[t][r];
-      acc_to_lds(T, acc, nt1, li, kk);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      tile_to_global(T, a.z1 + (q * a.ns + g * 16) * a.C1, a.C1, lane);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (int i = 0; i < 4; ++i) z[i] = fmaf(wz[i], dz, fmaf(wy[i], dy, fmaf(wx[i], dx, z[i])));
+          }
+          *reinterpret_cast<st_f4*>(a.z1 + row * a.C1 + c) = z;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s0[qs][i] += z[i], s1[qs][i] += z[i] * z[i];
+        }
     }
   }
-  stats_to_partial(s0, s1, nt1, a.C1, s_red, a.part, wid, lane);
+  // column sums: over the 16 rows of a wave by shuffles, over the waves in a fixed order
+#pragma unroll
+  for (int qs = 0; qs < ST_NT; ++qs)
+    if (qs < nt1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float u = s0[qs][i], v = s1[qs][i];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) u += __shfl_xor(u, off), v += __shfl_xor(v, off);
+        if (li == 0) s_red[wid][0][qs * 16 + kk * 4 + i] = u, s_red[wid][1][qs * 16 + kk * 4 + i] = v;
+      }
+    }
+  __syncthreads();
+  for (int e = tid; e < 2 * a.C1; e += SG_THREADS) {
+    const int which = e / a.C1, c = e - which * a.C1;
+    float v = 0.f;
+    for (int w = 0; w < SG_THREADS / 64; ++w) v += s_red[w][which][c];
+    a.part[(size_t)blockIdx.x * 2 * a.C1 + which * a.C1 + c] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ forward, layer 2
-__global__ __launch_bounds__(ST_THREADS) void k_sa_fwd2(SaT a) {
+template <int NT1, int NT2>   // channel tiles of the two layers at compile time (0: read from the arguments)
+__global__ __launch_bounds__(ST_THREADS, 4) void k_sa_fwd2(SaT a_in) {
+  SaT a = a_in;
+  if (NT1) a.C1 = NT1 * 16;
+  if (NT2) a.C2 = NT2 * 16;
   __shared__ __attribute__((aligned(16))) float s_w2[ST_MAXC * (ST_MAXC + 4)];            // (C2, p2)
   __shared__ __attribute__((aligned(16))) float s_t[ST_WAVES][16 * ST_PITCH];
   __shared__ float s_red[ST_WAVES][2][ST_MAXC];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, kk = lane >> 4;
+  __shared__ __attribute__((aligned(16))) float s_c1[2][ST_MAXC];                         // BatchNorm-1 scale / shift (read per operand load: registers are short)
   const int p2 = a.C1 + 4;
   for (int e = tid; e < a.C2 * a.C1; e += ST_THREADS) s_w2[(e / a.C1) * p2 + e % a.C1] = a.w2[e];
+  for (int e = tid; e < a.C1; e += ST_THREADS) s_c1[0][e] = a.coef1[e], s_c1[1][e] = a.coef1[a.C1 + e];
   __syncthreads();
   float* T = s_t[wid];
-  const int nt1 = a.C1 / 16, nt2 = a.C2 / 16, G = a.ns / 16;
-  // BatchNorm-1 scale / shift of this lane's operand columns 16 qs + 4 kk .. + 3
-  st_f4 sc[ST_NT], sh[ST_NT];
-#pragma unroll
-  for (int qs = 0; qs < ST_NT; ++qs) {
-    sc[qs] = sh[qs] = (st_f4){0.f, 0.f, 0.f, 0.f};
-    if (qs < nt1) {
-      sc[qs] = *reinterpret_cast<const st_f4*>(a.coef1 + qs * 16 + kk * 4);
-      sh[qs] = *reinterpret_cast<const st_f4*>(a.coef1 + a.C1 + qs * 16 + kk * 4);
-    }
-  }
+  const int nt1 = NT1 ? NT1 : a.C1 / 16, nt2 = NT2 ? NT2 : a.C2 / 16, G = a.ns / 16;
   float s0[ST_NT] = {0.f, 0.f, 0.f, 0.f}, s1[ST_NT] = {0.f, 0.f, 0.f, 0.f};
   for (int64_t q = (int64_t)blockIdx.x * ST_WAVES + wid; q < a.M; q += (int64_t)gridDim.x * ST_WAVES) {
     float vmax[ST_NT], vmin[ST_NT];
@@ -197,12 +251,19 @@ __global__ __launch_bounds__(ST_THREADS) void k_sa_fwd2(SaT a) {
       st_f4 acc[ST_NT];
 #pragma unroll
       for (int t = 0; t < ST_NT; ++t) acc[t] = (st_f4){0.f, 0.f, 0.f, 0.f};
+      st_f4 Az[ST_NT];                                               // the tile's z1 rows, all requested before the first use
+#pragma unroll
+      for (int qs = 0; qs < ST_NT; ++qs) {
+        Az[qs] = (st_f4){0.f, 0.f, 0.f, 0.f};
+        if (qs < nt1) Az[qs] = *reinterpret_cast<const st_f4*>(a.z1 + (rowbase + li) * a.C1 + qs * 16 + kk * 4);
+      }
 #pragma unroll
       for (int qs = 0; qs < ST_NT; ++qs)
         if (qs < nt1) {
-          st_f4 A = *reinterpret_cast<const st_f4*>(a.z1 + (rowbase + li) * a.C1 + qs * 16 + kk * 4);
-          A.x = fmaxf(fmaf(A.x, sc[qs].x, sh[qs].x), 0.f), A.y = fmaxf(fmaf(A.y, sc[qs].y, sh[qs].y), 0.f);
-          A.z = fmaxf(fmaf(A.z, sc[qs].z, sh[qs].z), 0.f), A.w = fmaxf(fmaf(A.w, sc[qs].w, sh[qs].w), 0.f);
+          const st_f4 sc = *reinterpret_cast<const st_f4*>(s_c1[0] + qs * 16 + kk * 4), sh = *reinterpret_cast<const st_f4*>(s_c1[1] + qs * 16 + kk * 4);
+          st_f4 A = Az[qs];
+          A.x = fmaxf(fmaf(A.x, sc.x, sh.x), 0.f), A.y = fmaxf(fmaf(A.y, sc.y, sh.y), 0.f);
+          A.z = fmaxf(fmaf(A.z, sc.z, sh.z), 0.f), A.w = fmaxf(fmaf(A.w, sc.w, sh.w), 0.f);
 #pragma unroll
           for (int t = 0; t < ST_NT; ++t)
             if (t < nt2) acc[t] = mfma4(A, *reinterpret_cast<const st_f4*>(s_w2 + (t * 16 + li) * p2 + qs * 16 + kk * 4), acc[t]);
@@ -288,37 +349,46 @@ __global__ __launch_bounds__(256) void k_sa_bwd0(SaT a) {
 
 // bwd2.  coef2 = k_bn_finalize<true>'s {gamma*invstd, mean(dy), mean(dy*xhat), mean} of BatchNorm 2; coef1 = {scale, shift} of BatchNorm 1.
 // dz2 = k * (dy - md - xhat * mx) = k * dy + A * z + B  with  A = -k * mx * invstd,  B = k * (mx * invstd * mean - md)
-__global__ __launch_bounds__(ST_THREADS) void k_sa_bwd2(SaT a) {
+// Waves w and w + 4 of a workgroup take the same queries and split the layer-1 channels (the columns of da1 / dy1 / dW2) between them: each
+// makes the cheap dz2 tile for itself and runs half of the matrix work, with its 32 + 16 accumulator registers instead of 64 + 32 --
+// four waves per SIMD instead of two with spills.
+constexpr int ST_NTH = ST_NT / 2;
+template <int NT1, int NT2>   // channel tiles of the two layers at compile time (0: read from the arguments)
+__global__ __launch_bounds__(ST_THREADS, 4) void k_sa_bwd2(SaT a_in) {
+  SaT a = a_in;
+  if (NT1) a.C1 = NT1 * 16;
+  if (NT2) a.C2 = NT2 * 16;
   __shared__ __attribute__((aligned(16))) float s_w2t[ST_MAXC * (ST_MAXC + 4)];           // (C1, pT): W2 transposed
   __shared__ __attribute__((aligned(16))) float s_t[ST_WAVES][16 * ST_PITCH];
   __shared__ float s_red[ST_WAVES][2][ST_MAXC];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, kk = lane >> 4;
+  const int pair = wid & 3, half = wid >> 2;
   const int pT = a.C2 + 4;
   for (int e = tid; e < a.C2 * a.C1; e += ST_THREADS) s_w2t[(e % a.C1) * pT + e / a.C1] = a.w2[e];
   __syncthreads();
   float* T = s_t[wid];
-  const int nt1 = a.C1 / 16, nt2 = a.C2 / 16, G = a.ns / 16;
-  float k2[ST_NT], A2[ST_NT], B2[ST_NT], sc1[ST_NT], sh1[ST_NT], is1[ST_NT], nm1[ST_NT];
-#pragma unroll
-  for (int t = 0; t < ST_NT; ++t) {
-    k2[t] = A2[t] = B2[t] = sc1[t] = sh1[t] = is1[t] = nm1[t] = 0.f;
-    if (t < nt2) {
-      const int c = t * 16 + li;
-      const float k = a.coef2[c], md = a.coef2[a.C2 + c], mx = a.coef2[2 * a.C2 + c], m = a.coef2[3 * a.C2 + c], is = a.istd2[c];
-      k2[t] = k, A2[t] = -k * mx * is, B2[t] = k * (mx * is * m - md);
+  const int nt1 = NT1 ? NT1 : a.C1 / 16, nt2 = NT2 ? NT2 : a.C2 / 16, G = a.ns / 16;
+  const int u0 = half ? (nt1 + 1) / 2 : 0, u1 = half ? nt1 : (nt1 + 1) / 2;              // this wave's layer-1 channel tiles
+  // per-channel constants live in LDS (seven per channel would cost 28 registers a lane): s_k[0..2] = k2, A2, B2; s_k[3..6] = scale1, shift1,
+  // invstd1, -mean1 * invstd1
+  __shared__ float s_k[7][ST_MAXC];
+  for (int c = tid; c < ST_MAXC; c += ST_THREADS) {
+    float k = 0.f, A = 0.f, B = 0.f, s1v = 0.f, h1 = 0.f, i1 = 0.f, n1 = 0.f;
+    if (c < a.C2) {
+      const float md = a.coef2[a.C2 + c], mx = a.coef2[2 * a.C2 + c], m = a.coef2[3 * a.C2 + c], is = a.istd2[c];
+      k = a.coef2[c], A = -k * mx * is, B = k * (mx * is * m - md);
     }
-    if (t < nt1) {
-      const int c = t * 16 + li;
-      sc1[t] = a.coef1[c], sh1[t] = a.coef1[a.C1 + c], is1[t] = a.istd1[c], nm1[t] = -a.mean1[c] * a.istd1[c];
-    }
+    if (c < a.C1) s1v = a.coef1[c], h1 = a.coef1[a.C1 + c], i1 = a.istd1[c], n1 = -a.mean1[c] * a.istd1[c];
+    s_k[0][c] = k, s_k[1][c] = A, s_k[2][c] = B, s_k[3][c] = s1v, s_k[4][c] = h1, s_k[5][c] = i1, s_k[6][c] = n1;
   }
-  st_f4 accw[ST_NT][ST_NT];                                          // dW2[c2 = 16 t + 4 kk + r][c1 = 16 u + li]
+  __syncthreads();
+  st_f4 accw[ST_NT][ST_NTH];                                         // dW2[c2 = 16 t + 4 kk + r][c1 = 16 (u0 + j) + li]
 #pragma unroll
   for (int t = 0; t < ST_NT; ++t)
 #pragma unroll
-    for (int u = 0; u < ST_NT; ++u) accw[t][u] = (st_f4){0.f, 0.f, 0.f, 0.f};
-  float sd[ST_NT] = {0.f, 0.f, 0.f, 0.f}, sdx[ST_NT] = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t q = (int64_t)blockIdx.x * ST_WAVES + wid; q < a.M; q += (int64_t)gridDim.x * ST_WAVES) {
+    for (int j = 0; j < ST_NTH; ++j) accw[t][j] = (st_f4){0.f, 0.f, 0.f, 0.f};
+  float sd[ST_NTH] = {0.f, 0.f}, sdx[ST_NTH] = {0.f, 0.f};
+  for (int64_t q = (int64_t)blockIdx.x * 4 + pair; q < a.M; q += (int64_t)gridDim.x * 4) {
     float dq[ST_NT];
     int aq[ST_NT];
 #pragma unroll
@@ -337,36 +407,46 @@ __global__ __launch_bounds__(ST_THREADS) void k_sa_bwd2(SaT a) {
           for (int r = 0; r < 4; ++r) {
             const float z = a.z2[(rowbase + kk * 4 + r) * a.C2 + t * 16 + li];
             const float dy = aq[t] == g * 16 + kk * 4 + r ? dq[t] : 0.f;
-            dz2[t][r] = fmaf(k2[t], dy, fmaf(A2[t], z, B2[t]));
+            dz2[t][r] = fmaf(s_k[0][t * 16 + li], dy, fmaf(s_k[1][t * 16 + li], z, s_k[2][t * 16 + li]));
           }
+        }
+      }
+      st_f4 z1v[ST_NTH];                                             // this wave's z1 columns, requested before the matrix work
+#pragma unroll
+      for (int j = 0; j < ST_NTH; ++j) {
+        z1v[j] = (st_f4){0.f, 0.f, 0.f, 0.f};
+        if (u0 + j < u1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z1v[j][r] = a.z1[(rowbase + kk * 4 + r) * a.C1 + (u0 + j) * 16 + li];
         }
       }
       acc_to_lds(T, dz2, nt2, li, kk);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      st_f4 da1[ST_NT];                                              // da1 = dz2 . W2: rows x C1
+      st_f4 da1[ST_NTH];                                             // da1 = dz2 . W2: rows x this wave's C1 columns
 #pragma unroll
-      for (int u = 0; u < ST_NT; ++u) da1[u] = (st_f4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < ST_NTH; ++j) da1[j] = (st_f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int qs = 0; qs < ST_NT; ++qs)
         if (qs < nt2) {
           const st_f4 A = *reinterpret_cast<const st_f4*>(T + li * ST_PITCH + qs * 16 + kk * 4);
 #pragma unroll
-          for (int u = 0; u < ST_NT; ++u)
-            if (u < nt1) da1[u] = mfma4(A, *reinterpret_cast<const st_f4*>(s_w2t + (u * 16 + li) * pT + qs * 16 + kk * 4), da1[u]);
+          for (int j = 0; j < ST_NTH; ++j)
+            if (u0 + j < u1) da1[j] = mfma4(A, *reinterpret_cast<const st_f4*>(s_w2t + ((u0 + j) * 16 + li) * pT + qs * 16 + kk * 4), da1[j]);
         }
-      st_f4 a1[ST_NT];
+      st_f4 a1[ST_NTH];
 #pragma unroll
-      for (int u = 0; u < ST_NT; ++u) {
-        a1[u] = (st_f4){0.f, 0.f, 0.f, 0.f};
-        if (u < nt1) {
+      for (int j = 0; j < ST_NTH; ++j) {
+        a1[j] = (st_f4){0.f, 0.f, 0.f, 0.f};
+        if (u0 + j < u1) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float z = a.z1[(rowbase + kk * 4 + r) * a.C1 + u * 16 + li];
-            const float y = fmaf(z, sc1[u], sh1[u]);
-            a1[u][r] = fmaxf(y, 0.f);
-            const float d = y > 0.f ? da1[u][r] : 0.f;
-            da1[u][r] = d;
-            sd[u] += d, sdx[u] += d * fmaf(z, is1[u], nm1[u]);
+            const int c = (u0 + j) * 16 + li;
+            const float z = z1v[j][r];
+            const float y = fmaf(z, s_k[3][c], s_k[4][c]);
+            a1[j][r] = fmaxf(y, 0.f);
+            const float d = y > 0.f ? da1[j][r] : 0.f;
+            da1[j][r] = d;
+            sd[j] += d, sdx[j] += d * fmaf(z, s_k[5][c], s_k[6][c]);
           }
         }
       }
@@ -375,142 +455,201 @@ __global__ __launch_bounds__(ST_THREADS) void k_sa_bwd2(SaT a) {
       for (int t = 0; t < ST_NT; ++t)
         if (t < nt2) {
 #pragma unroll
-          for (int u = 0; u < ST_NT; ++u)
-            if (u < nt1) accw[t][u] = mfma4(dz2[t], a1[u], accw[t][u]);
+          for (int j = 0; j < ST_NTH; ++j)
+            if (u0 + j < u1) accw[t][j] = mfma4(dz2[t], a1[j], accw[t][j]);
         }
+      // dy1: this wave's columns of the tile -> LDS (rows 4 kk + r) -> whole 128-byte pieces of the (R, C1) matrix
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // the A-operand reads of T are done (in order) before it is rewritten
-      acc_to_lds(T, da1, nt1, li, kk);
+#pragma unroll
+      for (int j = 0; j < ST_NTH; ++j)
+        if (u0 + j < u1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T[(kk * 4 + r) * ST_PITCH + j * 16 + li] = da1[j][r];
+        }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      tile_to_global(T, a.dy1 + rowbase * a.C1, a.C1, lane);
+      const int c4n = (u1 - u0) * 4, nf = 16 * c4n;                    // float4 pieces per row of this wave's share
+      for (int f = lane; f < nf; f += 64) {
+        const int row = f / c4n, c4 = f - row * c4n;
+        *reinterpret_cast<st_f4*>(a.dy1 + (rowbase + row) * a.C1 + u0 * 16 + c4 * 4) = *reinterpret_cast<const st_f4*>(T + row * ST_PITCH + c4 * 4);
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
   }
-  // weight-gradient partial of the workgroup (grid, C2, C1): 16 gradient rows at a time through the waves' LDS tiles, summed over the waves in a
-  // fixed order
+  // weight-gradient partial of the workgroup (grid, C2, C1): 16 gradient rows at a time through the waves' LDS tiles; a column's sum runs over the
+  // four waves of the half that owns it, in a fixed order
   float* wp = a.wpart + (size_t)blockIdx.x * a.C2 * a.C1;
+  const int split = ((nt1 + 1) / 2) * 16;                              // first column of the second half
 #pragma unroll
   for (int t = 0; t < ST_NT; ++t)
     if (t < nt2) {
       __syncthreads();
-      acc_to_lds(T, accw[t], nt1, li, kk);
+#pragma unroll
+      for (int j = 0; j < ST_NTH; ++j)
+        if (u0 + j < u1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T[(kk * 4 + r) * ST_PITCH + (u0 + j) * 16 + li] = accw[t][j][r];
+        }
       __syncthreads();
       for (int e = tid; e < 16 * a.C1; e += ST_THREADS) {
         const int row = e / a.C1, col = e - row * a.C1;
+        const int w0 = col < split ? 0 : 4;
         float v = 0.f;
-        for (int w = 0; w < ST_WAVES; ++w) v += s_t[w][row * ST_PITCH + col];
+        for (int w = w0; w < w0 + 4; ++w) v += s_t[w][row * ST_PITCH + col];
         wp[(t * 16 + row) * a.C1 + col] = v;
       }
     }
   __syncthreads();
-  stats_to_partial(sd, sdx, nt1, a.C1, s_red, a.part, wid, lane);
+  // BatchNorm-1 backward sums: a wave holds its own channel tiles only
+  float f0[ST_NT] = {0.f, 0.f, 0.f, 0.f}, f1[ST_NT] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < ST_NTH; ++j)
+#pragma unroll
+    for (int t = 0; t < ST_NT; ++t)
+      if (t == u0 + j && u0 + j < u1) f0[t] = sd[j], f1[t] = sdx[j];
+  stats_to_partial(f0, f1, nt1, a.C1, s_red, a.part, wid, lane);
 }
 
-// bwd1.  coef1 = k_bn_finalize<true>'s {gamma*invstd, mean(dy), mean(dy*xhat), mean} of BatchNorm 1.  Waves w and w + 4 of a workgroup
-// take the same queries and split the feature tiles of the weight gradient between them (36 accumulator tiles do not fit one wave at two
-// waves per SIMD); the first of the pair also scatters dz1.
-__global__ __launch_bounds__(ST_THREADS) void k_sa_bwd1(SaT a) {
-  constexpr int WP = ST_MAXKP + 4;                                  // pitch of the weight-gradient staging rows
-  __shared__ __attribute__((aligned(16))) float s_t[ST_WAVES / 2][16 * WP];      // scatter tile (pitch ST_PITCH) / weight-gradient staging (pitch WP)
+// bwd1.  coef1 = k_bn_finalize<true>'s {gamma*invstd, mean(dy), mean(dy*xhat), mean} of BatchNorm 1: dz1 = k dy1 + A z1 + B per channel.
+// Lane (row li, columns 16 qs + 4 kk .. + 3).  Per tile: dz1 -> LDS -> S[source of row] += dz1 row (one C1-wide row per atomic instruction, the
+// repeats of the first neighbour summed in registers first), and wx[c][d] += dz1[row][c] * (xyz[source] - query)[d] -- the xyz columns of dW1.
+template <int NT1, int NT2>   // channel tiles of the two layers at compile time (0: read from the arguments)
+__global__ __launch_bounds__(SG_THREADS) void k_sa_bwd1(SaT a_in) {
+  SaT a = a_in;
+  if (NT1) a.C1 = NT1 * 16;
+  if (NT2) a.C2 = NT2 * 16;
+  __shared__ __attribute__((aligned(16))) float s_k[3][ST_MAXC];
+  __shared__ __attribute__((aligned(16))) float s_t[SG_THREADS / 64][16 * ST_PITCH];
+  __shared__ float s_wxr[SG_THREADS / 64][3][ST_MAXC];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, kk = lane >> 4;
-  const int pair = wid & 3, half = wid >> 2;
-  float* T = s_t[pair];
-  const int nt1 = a.C1 / 16, nv = a.Kp / 16, nvh = (nv + 1) / 2, G = a.ns / 16;
-  const int v0 = half ? nvh : 0, v1 = half ? nv : nvh;              // this wave's feature tiles
-  float k1[ST_NT], A1[ST_NT], B1[ST_NT];
-#pragma unroll
-  for (int t = 0; t < ST_NT; ++t) {
-    k1[t] = A1[t] = B1[t] = 0.f;
-    if (t < nt1) {
-      const int c = t * 16 + li;
-      const float k = a.coef1[c], md = a.coef1[a.C1 + c], mx = a.coef1[2 * a.C1 + c], m = a.coef1[3 * a.C1 + c], is = a.istd1[c];
-      k1[t] = k, A1[t] = -k * mx * is, B1[t] = k * (mx * is * m - md);
+  for (int c = tid; c < ST_MAXC; c += SG_THREADS) {
+    float k = 0.f, A = 0.f, B = 0.f;
+    if (c < a.C1) {
+      const float md = a.coef1[a.C1 + c], mx = a.coef1[2 * a.C1 + c], m = a.coef1[3 * a.C1 + c], is = a.istd1[c];
+      k = a.coef1[c], A = -k * mx * is, B = k * (mx * is * m - md);
     }
+    s_k[0][c] = k, s_k[1][c] = A, s_k[2][c] = B;
   }
-  st_f4 accw[ST_NT][ST_NVH];                                         // dW1[c1 = 16 t + 4 kk + r][k = 16 (v0 + j) + li]
+  __syncthreads();
+  float* T = s_t[wid];
+  const int nt1 = NT1 ? NT1 : a.C1 / 16, G = a.ns / 16;
+  st_f4 wx[ST_NT], wy[ST_NT], wz[ST_NT];
 #pragma unroll
-  for (int t = 0; t < ST_NT; ++t)
-#pragma unroll
-    for (int j = 0; j < ST_NVH; ++j) accw[t][j] = (st_f4){0.f, 0.f, 0.f, 0.f};
-  for (int64_t q = (int64_t)blockIdx.x * 4 + pair; q < a.M; q += (int64_t)gridDim.x * 4) {
+  for (int qs = 0; qs < ST_NT; ++qs) wx[qs] = wy[qs] = wz[qs] = (st_f4){0.f, 0.f, 0.f, 0.f};
+  for (int64_t q = (int64_t)blockIdx.x * (SG_THREADS / 64) + wid; q < a.M; q += (int64_t)gridDim.x * (SG_THREADS / 64)) {
     const bool empty = a.idx[q * a.ns] < 0;
     const int64_t base = a.row_start[q];
     const float qx = a.new_xyz[q * 3], qy = a.new_xyz[q * 3 + 1], qz = a.new_xyz[q * 3 + 2];
     const int64_t first = empty ? -1 : base + a.idx[q * a.ns];
     float acc0 = 0.f;                                                // repeats of the first neighbour (slots past the ball's count) summed here
     for (int g = 0; g < G; ++g) {
-      const int64_t rowbase = q * a.ns + g * 16;
-      st_f4 dz1[ST_NT];
-#pragma unroll
-      for (int t = 0; t < ST_NT; ++t) {
-        dz1[t] = (st_f4){0.f, 0.f, 0.f, 0.f};
-        if (t < nt1) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t o = (rowbase + kk * 4 + r) * a.C1 + t * 16 + li;
-            dz1[t][r] = fmaf(k1[t], a.dy1[o], fmaf(A1[t], a.z1[o], B1[t]));
-          }
-        }
+      const int64_t row = q * a.ns + g * 16 + li;
+      const int32_t my = a.idx[row];                                 // lane li (any kk) holds tile row li's neighbour
+      float dx = 0.f, dy = 0.f, dz = 0.f;
+      if (!empty) {
+        const float* p = a.xyz + (base + my) * 3;
+        dx = p[0] - qx, dy = p[1] - qy, dz = p[2] - qz;
       }
-      int64_t nr[4];                                                 // source rows of this lane's tile rows 4 kk + s
 #pragma unroll
-      for (int s = 0; s < 4; ++s) nr[s] = empty ? -1 : base + a.idx[q * a.ns + g * 16 + kk * 4 + s];
-      if (half == 0 && a.feat && !empty) {
-        // scatter: S[source] += dz1 row, one C1-wide row per instruction
-        acc_to_lds(T, dz1, nt1, li, kk);
+      for (int qs = 0; qs < ST_NT; ++qs)
+        if (qs < nt1) {
+          const int c = qs * 16 + kk * 4;
+          const st_f4 d = *reinterpret_cast<const st_f4*>(a.dy1 + row * a.C1 + c), z = *reinterpret_cast<const st_f4*>(a.z1 + row * a.C1 + c);
+          const st_f4 k = *reinterpret_cast<const st_f4*>(s_k[0] + c), A = *reinterpret_cast<const st_f4*>(s_k[1] + c),
+                      B = *reinterpret_cast<const st_f4*>(s_k[2] + c);
+          st_f4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = fmaf(k[i], d[i], fmaf(A[i], z[i], B[i]));
+            wx[qs][i] = fmaf(v[i], dx, wx[qs][i]), wy[qs][i] = fmaf(v[i], dy, wy[qs][i]), wz[qs][i] = fmaf(v[i], dz, wz[qs][i]);
+          }
+          *reinterpret_cast<st_f4*>(T + li * ST_PITCH + c) = v;
+        }
+      if (a.S && !empty) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        const int32_t my = a.idx[q * a.ns + g * 16 + li];           // lane li holds the tile row li's neighbour
-        for (int row = 0; row < 16; ++row) {
-          const int64_t src = base + __shfl(my, row);
-          const float v = lane < a.C1 ? T[row * ST_PITCH + lane] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const int64_t src = base + __shfl(my, r);
+          const float v = lane < a.C1 ? T[r * ST_PITCH + lane] : 0.f;
           if (src == first) acc0 += v;
           else if (lane < a.C1) atomicAdd(a.S + src * a.C1 + lane, v);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       }
-      // weight gradient 1 against the re-gathered rows in D layout: X[row 4 kk + s][16 v + li]
+    }
+    if (a.S && !empty && lane < a.C1) atomicAdd(a.S + first * a.C1 + lane, acc0);
+  }
+  // xyz columns of dW1: over the 16 rows of a wave by shuffles, over the waves in a fixed order -> partial (grid, C1, 4) [x y z -]
 #pragma unroll
-      for (int j = 0; j < ST_NVH; ++j) {
-        const int v = v0 + j;
-        if (v < v1) {
-          st_f4 X = (st_f4){0.f, 0.f, 0.f, 0.f};
-          const int k = v * 16 + li;
-          if (!empty) {
-            if (k < a.C) {
+  for (int qs = 0; qs < ST_NT; ++qs)
+    if (qs < nt1) {
 #pragma unroll
-              for (int s = 0; s < 4; ++s) X[s] = a.feat[nr[s] * a.C + k];
-            } else if (k < a.C + 3) {
-              const float qc = k == a.C ? qx : (k == a.C + 1 ? qy : qz);
+      for (int i = 0; i < 4; ++i) {
+        float u = wx[qs][i], v = wy[qs][i], w = wz[qs][i];
 #pragma unroll
-              for (int s = 0; s < 4; ++s) X[s] = a.xyz[nr[s] * 3 + (k - a.C)] - qc;
-            }
-          }
-#pragma unroll
-          for (int t = 0; t < ST_NT; ++t)
-            if (t < nt1) accw[t][j] = mfma4(dz1[t], X, accw[t][j]);
+        for (int off = 1; off < 16; off <<= 1) u += __shfl_xor(u, off), v += __shfl_xor(v, off), w += __shfl_xor(w, off);
+        if (li == 0) {
+          const int c = qs * 16 + kk * 4 + i;
+          s_wxr[wid][0][c] = u, s_wxr[wid][1][c] = v, s_wxr[wid][2][c] = w;
         }
       }
     }
-    if (half == 0 && a.feat && !empty && lane < a.C1) atomicAdd(a.S + first * a.C1 + lane, acc0);
+  __syncthreads();
+  for (int e = tid; e < a.C1 * 4; e += SG_THREADS) {
+    const int c = e >> 2, d = e & 3;
+    float v = 0.f;
+    if (d < 3)
+      for (int w = 0; w < SG_THREADS / 64; ++w) v += s_wxr[w][d][c];
+    a.wpart[(size_t)blockIdx.x * a.C1 * 4 + e] = v;
   }
-  // weight-gradient partial of the workgroup (grid, C1, Kp): 16 gradient rows at a time; the two waves of a pair fill disjoint columns of the
-  // pair's staging tile, the four pairs are summed in a fixed order
-  float* wp = a.wpart + (size_t)blockIdx.x * a.C1 * a.Kp;
+}
+
+// wgp: the feature columns of dW1 = S^T . F, a contraction over the N support points on the matrix core.  blockIdx.y = feature tile (16
+// columns of F), a wave takes 16 points at a time: A = S tile read column-wise (point 4 kk + s is the k index of MFMA s), B = F tile likewise.
+// Partial (gridDim.x, C1, C).
+__global__ __launch_bounds__(SP_THREADS) void k_sa_wgrad1_points(SaT a) {
+  __shared__ __attribute__((aligned(16))) float s_t[SP_THREADS / 64][16 * ST_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, kk = lane >> 4;
+  const int v = blockIdx.y, nt1 = a.C1 / 16;
+  st_f4 acc[ST_NT];
+#pragma unroll
+  for (int t = 0; t < ST_NT; ++t) acc[t] = (st_f4){0.f, 0.f, 0.f, 0.f};
+  const int64_t ntiles = (a.N + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * (SP_THREADS / 64) + wid; tile < ntiles; tile += (int64_t)gridDim.x * (SP_THREADS / 64)) {
+    st_f4 X = (st_f4){0.f, 0.f, 0.f, 0.f}, Sv[ST_NT];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int64_t n = tile * 16 + kk * 4 + s4;
+      if (n < a.N) X[s4] = a.feat[n * a.C + v * 16 + li];
+    }
+#pragma unroll
+    for (int t = 0; t < ST_NT; ++t) {
+      Sv[t] = (st_f4){0.f, 0.f, 0.f, 0.f};
+      if (t < nt1) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int64_t n = tile * 16 + kk * 4 + s4;
+          if (n < a.N) Sv[t][s4] = a.S[n * a.C1 + t * 16 + li];
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < ST_NT; ++t)
+      if (t < nt1) acc[t] = mfma4(Sv[t], X, acc[t]);
+  }
+  // acc[t][r] = dW1[c1 = 16 t + 4 kk + r][feature 16 v + li]: sum over the waves, then the workgroup's partial
+  float* wp = a.wpart + (size_t)blockIdx.x * a.C1 * a.C;
+  float* T = s_t[wid];
 #pragma unroll
   for (int t = 0; t < ST_NT; ++t)
     if (t < nt1) {
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < ST_NVH; ++j)
-        if (v0 + j < v1) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) T[(kk * 4 + r) * WP + (v0 + j) * 16 + li] = accw[t][j][r];
-        }
+      for (int r = 0; r < 4; ++r) T[(kk * 4 + r) * ST_PITCH + li] = acc[t][r];
       __syncthreads();
-      for (int e = tid; e < 16 * a.Kp; e += ST_THREADS) {
-        const int row = e / a.Kp, col = e - row * a.Kp;
-        float v = 0.f;
-        for (int w = 0; w < 4; ++w) v += s_t[w][row * WP + col];
-        wp[(t * 16 + row) * a.Kp + col] = v;
+      for (int e = tid; e < 256; e += SP_THREADS) {
+        const int row = e >> 4, col = e & 15;
+        float s4 = 0.f;
+        for (int w = 0; w < SP_THREADS / 64; ++w) s4 += s_t[w][row * ST_PITCH + col];
+        wp[(t * 16 + row) * a.C + v * 16 + col] = s4;
       }
     }
 }
@@ -540,23 +679,26 @@ __global__ __launch_bounds__(256) void k_sa_feat_grad(const float* __restrict__ 
   }
 }
 
-// sum of the workgroup partials in a fixed order -> the parameter's own layout.  first != 0: partial columns are [features | xyz | pad], the
-// parameter's are [xyz | features].  64 elements per block, 4 groups of partials per element, combined in LDS.
-__global__ __launch_bounds__(256) void k_sa_wreduce(const float* __restrict__ part, int nparts, int rows, int cols_p, int C, int first,
-                                                    float* __restrict__ out) {
-  __shared__ float s_r[4][64];
-  const int cols_o = first ? C + 3 : cols_p;
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+// sum of the workgroup partials in a fixed order: out[n * out_stride + out_col0 + k] = sum over p of part[(p * rows + n) * cols_p + k], k < ncols.
+// 16 elements per block, 16 groups of partials per element, combined in LDS in a fixed order.
+__global__ __launch_bounds__(256) void k_sa_wreduce(const float* __restrict__ part, int nparts, int rows, int cols_p, int ncols, float* __restrict__ out,
+                                                    int out_stride, int out_col0) {
+  __shared__ float s_r[16][16];
+  const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
   float v = 0.f;
-  if (e < rows * cols_o) {
-    const int n = e / cols_o, ko = e - n * cols_o;
-    const int kp = first ? (ko < 3 ? C + ko : ko - 3) : ko;
-    const int per = (nparts + 3) / 4, p0 = grp * per, p1 = min(nparts, p0 + per);
-    for (int p = p0; p < p1; ++p) v += part[((size_t)p * rows + n) * cols_p + kp];
+  const int n = e / ncols, k = e - n * ncols;
+  if (e < rows * ncols) {
+    const int per = (nparts + 15) / 16, p0 = grp * per, p1 = min(nparts, p0 + per);
+    for (int p = p0; p < p1; ++p) v += part[((size_t)p * rows + n) * cols_p + k];
   }
-  s_r[grp][threadIdx.x & 63] = v;
+  s_r[grp][el] = v;
   __syncthreads();
-  if (grp == 0 && e < rows * cols_o) out[e] = (s_r[0][threadIdx.x] + s_r[1][threadIdx.x]) + (s_r[2][threadIdx.x] + s_r[3][threadIdx.x]);
+  if (grp == 0 && e < rows * ncols) {
+    float t = 0.f;
+    for (int g = 0; g < 16; ++g) t += s_r[g][el];
+    out[(size_t)n * out_stride + out_col0 + k] = t;
+  }
 }
 
 // forward scale / shift of a BatchNorm from its saved batch statistics: o = {gamma * invstd, beta - mean * gamma * invstd}
@@ -584,11 +726,20 @@ static int sa_train_check(const char* who, int64_t M, int C, int ns, int C1, int
   return SV_OK;
 }
 
-// scratch layout (floats): coef1 (4 C1) | coef2 (4 C2) | stats partials (ST_GRID * 2 * 64) | weight partials (ST_GRID * max(C2*C1, C1*Kp))
+// grids: fwd1 / bwd1 (gather passes, 256 threads, no matrix work) up to SG_GRID workgroups; fwd2 / bwd2 up to ST_GRID; statistics partials sized for
+// the larger of the two
+constexpr int SG_GRID = 1024;
+constexpr int WGP_GRID = 64;
+static int sg_grid(int64_t M) {
+  const int64_t need = (M + SG_THREADS / 64 - 1) / (SG_THREADS / 64);
+  return (int)(need < SG_GRID ? (need < 1 ? 1 : need) : SG_GRID);
+}
+
+// scratch layout (floats): coef1 (4 C1) | coef2 (4 C2) | stats partials (SG_GRID * 2 * 64) | weight partials
 extern "C" size_t sv_sa_train_scratch_bytes(int C, int C1, int C2) {
-  const size_t Kp = 16 * ((size_t)C / 16 + 1);
-  const size_t w2 = (size_t)ST_GRID * C2 * C1, w1 = (size_t)ST_GRID * C1 * Kp;
-  return (4 * (size_t)(C1 + C2) + (size_t)ST_GRID * 2 * ST_MAXC + (w2 > w1 ? w2 : w1)) * sizeof(float);
+  const size_t w2 = (size_t)ST_GRID * C2 * C1, wx = (size_t)SG_GRID * C1 * 4, wf = (size_t)WGP_GRID * C1 * (C > 0 ? C : 1);
+  const size_t w = w2 > wx ? (w2 > wf ? w2 : wf) : (wx > wf ? wx : wf);
+  return (4 * (size_t)(C1 + C2) + (size_t)SG_GRID * 2 * ST_MAXC + w) * sizeof(float);
 }
 
 struct SaScratch {
@@ -599,20 +750,21 @@ static SaScratch sa_scratch(void* scratch, int C1, int C2) {
   s.coef1 = reinterpret_cast<float*>(scratch);
   s.coef2 = s.coef1 + 4 * C1;
   s.part = s.coef2 + 4 * C2;
-  s.wpart = s.part + (size_t)ST_GRID * 2 * ST_MAXC;
+  s.wpart = s.part + (size_t)SG_GRID * 2 * ST_MAXC;
   return s;
 }
 
 extern "C" int sv_sa_train_forward(const float* xyz, const float* features, const float* new_xyz, const int32_t* idx, const int32_t* row_start,
-                                   int64_t M, int C, int nsample, const float* w1, const float* gamma1, const float* beta1, float* running_mean1,
+                                   int64_t M, int64_t N, int C, int nsample, const float* w1, const float* gamma1, const float* beta1, float* running_mean1,
                                    float* running_var1, int64_t* tracked1, int C1, const float* w2, const float* gamma2, const float* beta2,
                                    float* running_mean2, float* running_var2, int64_t* tracked2, int C2, float momentum, float eps, void* scratch,
-                                   float* z1, float* z2, float* save_mean1, float* save_invstd1, float* save_mean2, float* save_invstd2,
+                                   float* proj, float* z1, float* z2, float* save_mean1, float* save_invstd1, float* save_mean2, float* save_invstd2,
                                    float* sel, float* aux, uint8_t* arg, uint8_t* aux_arg, float* out, void* stream) {
   if (int rc = sa_train_check("sv_sa_train_forward", M, C, nsample, C1, C2)) return rc;
   SV_CHECK_ARG(xyz && new_xyz && idx && row_start && w1 && w2 && scratch && z1 && z2 && save_mean1 && save_invstd1 && save_mean2 && save_invstd2 &&
-                   sel && aux && arg && aux_arg && out && (features || C == 0),
+                   sel && aux && arg && aux_arg && out && ((features && proj) || C == 0),
                "sv_sa_train_forward: null pointer");
+  SV_CHECK_ARG(N >= 0, "sv_sa_train_forward: bad point count");
   SV_CHECK_ARG(C == 0 || (uintptr_t)features % 16 == 0, "sv_sa_train_forward: features must be 16-byte aligned");
   hipStream_t st = sv_stream(stream);
   const SaScratch sc = sa_scratch(scratch, C1, C2);
@@ -620,14 +772,24 @@ extern "C" int sv_sa_train_forward(const float* xyz, const float* features, cons
   SaT a{};
   a.xyz = xyz, a.feat = C ? features : nullptr, a.new_xyz = new_xyz, a.idx = idx, a.row_start = row_start, a.w1 = w1, a.w2 = w2, a.z1 = z1, a.z2 = z2;
   a.part = sc.part, a.coef1 = sc.coef1, a.coef2 = sc.coef2, a.zmax = sel, a.zmin = aux, a.amax = arg, a.amin = aux_arg, a.out = out;
-  a.M = M, a.C = C, a.Kp = 16 * (C / 16 + 1), a.C1 = C1, a.C2 = C2, a.ns = nsample;
-  const int grid = sa_grid(M, ST_WAVES);
-  hipLaunchKernelGGL(k_sa_fwd1, dim3(grid), dim3(ST_THREADS), 0, st, a);
+  a.M = M, a.N = N, a.C = C, a.Kp = 16 * (C / 16 + 1), a.C1 = C1, a.C2 = C2, a.ns = nsample;
+  a.P = C ? proj : nullptr;
+  if (C && N > 0) hipLaunchKernelGGL(k_sa_point_proj, dim3(sv_grid_1d((N + 15) / 16, SP_THREADS / 64, 1024)), dim3(SP_THREADS), 0, st, a);
+  const int gridg = sg_grid(M);
+  if (C1 == 64 && C2 == 64) hipLaunchKernelGGL((k_sa_fwd1<4, 4>), dim3(gridg), dim3(SG_THREADS), 0, st, a);
+  else if (C1 == 32 && C2 == 32) hipLaunchKernelGGL((k_sa_fwd1<2, 2>), dim3(gridg), dim3(SG_THREADS), 0, st, a);
+  else if (C1 == 16 && C2 == 16) hipLaunchKernelGGL((k_sa_fwd1<1, 1>), dim3(gridg), dim3(SG_THREADS), 0, st, a);
+  else hipLaunchKernelGGL((k_sa_fwd1<0, 0>), dim3(gridg), dim3(SG_THREADS), 0, st, a);
   BnArgs b{};
   b.gamma = gamma1, b.beta = beta1, b.running_mean = running_mean1, b.running_var = running_var1, b.save_mean = save_mean1, b.save_invstd = save_invstd1;
-  b.partial = sc.part, b.coef = sc.coef1, b.n = R, b.C = C1, b.wgs = grid, b.momentum = momentum, b.eps = eps, b.num_batches_tracked = tracked1;
+  b.partial = sc.part, b.coef = sc.coef1, b.n = R, b.C = C1, b.wgs = gridg, b.momentum = momentum, b.eps = eps, b.num_batches_tracked = tracked1;
   sv_bn_finalize_fwd(b, st);
-  hipLaunchKernelGGL(k_sa_fwd2, dim3(grid), dim3(ST_THREADS), 0, st, a);
+  const int grid = sa_grid(M, ST_WAVES);
+  if (C1 == 64 && C2 == 64) hipLaunchKernelGGL((k_sa_fwd2<4, 4>), dim3(grid), dim3(ST_THREADS), 0, st, a);
+  else if (C1 == 32 && C2 == 32) hipLaunchKernelGGL((k_sa_fwd2<2, 2>), dim3(grid), dim3(ST_THREADS), 0, st, a);
+  else if (C1 == 16 && C2 == 16) hipLaunchKernelGGL((k_sa_fwd2<1, 1>), dim3(grid), dim3(ST_THREADS), 0, st, a);
+  else hipLaunchKernelGGL((k_sa_fwd2<0, 0>), dim3(grid), dim3(ST_THREADS), 0, st, a);
+  b.wgs = grid;
   b.gamma = gamma2, b.beta = beta2, b.running_mean = running_mean2, b.running_var = running_var2, b.save_mean = save_mean2, b.save_invstd = save_invstd2;
   b.coef = sc.coef2, b.C = C2, b.num_batches_tracked = tracked2;
   sv_bn_finalize_fwd(b, st);
@@ -659,7 +821,7 @@ extern "C" int sv_sa_train_backward(const float* xyz, const float* features, con
   a.z1 = const_cast<float*>(z1), a.z2 = const_cast<float*>(z2), a.dy1 = dy1, a.part = sc.part, a.coef1 = sc.coef1, a.coef2 = sc.coef2;
   a.istd1 = save_invstd1, a.mean1 = save_mean1, a.istd2 = save_invstd2, a.mean2 = save_mean2;
   a.zmax = const_cast<float*>(sel), a.zmin = aux, a.amax = const_cast<uint8_t*>(arg), a.out = const_cast<float*>(out), a.dout = grad_out;
-  a.wpart = sc.wpart, a.S = scatter, a.M = M, a.C = C, a.Kp = 16 * (C / 16 + 1), a.C1 = C1, a.C2 = C2, a.ns = nsample;
+  a.wpart = sc.wpart, a.S = C ? scatter : nullptr, a.M = M, a.N = N, a.C = C, a.Kp = 16 * (C / 16 + 1), a.C1 = C1, a.C2 = C2, a.ns = nsample;
   // BatchNorm 2 backward sums
   const int g0 = sa_grid(M, 64);
   hipLaunchKernelGGL(k_sa_bwd0, dim3(g0), dim3(256), 0, st, a);
@@ -669,17 +831,28 @@ extern "C" int sv_sa_train_backward(const float* xyz, const float* features, con
   sv_bn_finalize_bwd(b, st);
   // forward scale / shift of BatchNorm 1 (the ReLU mask and a1 are recomputed from z1)
   hipLaunchKernelGGL(k_sa_coef, dim3(1), dim3(64), 0, st, gamma1, beta1, save_mean1, save_invstd1, C1, sc.coef1);
-  const int grid = sa_grid(M, ST_WAVES);
-  hipLaunchKernelGGL(k_sa_bwd2, dim3(grid), dim3(ST_THREADS), 0, st, a);
-  hipLaunchKernelGGL(k_sa_wreduce, dim3(sv_div_up((int64_t)C2 * C1, 64)), dim3(256), 0, st, sc.wpart, grid, C2, C1, 0, 0, grad_w2);
+  const int grid = sa_grid(M, 4);
+  if (C1 == 64 && C2 == 64) hipLaunchKernelGGL((k_sa_bwd2<4, 4>), dim3(grid), dim3(ST_THREADS), 0, st, a);
+  else if (C1 == 32 && C2 == 32) hipLaunchKernelGGL((k_sa_bwd2<2, 2>), dim3(grid), dim3(ST_THREADS), 0, st, a);
+  else if (C1 == 16 && C2 == 16) hipLaunchKernelGGL((k_sa_bwd2<1, 1>), dim3(grid), dim3(ST_THREADS), 0, st, a);
+  else hipLaunchKernelGGL((k_sa_bwd2<0, 0>), dim3(grid), dim3(ST_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_sa_wreduce, dim3(sv_div_up((int64_t)C2 * C1, 16)), dim3(256), 0, st, sc.wpart, grid, C2, C1, C1, grad_w2, C1, 0);
   // BatchNorm 1 backward
   b.gamma = gamma1, b.beta = beta1, b.save_mean = const_cast<float*>(save_mean1), b.save_invstd = const_cast<float*>(save_invstd1);
   b.dgamma = dgamma1, b.dbeta = dbeta1, b.coef = sc.coef1, b.C = C1, b.wgs = grid;
   sv_bn_finalize_bwd(b, st);
   if (C) SV_HIP(hipMemsetAsync(scatter, 0, (size_t)N * C1 * sizeof(float), st));
-  const int grid1 = sa_grid(M, 4);
-  hipLaunchKernelGGL(k_sa_bwd1, dim3(grid1), dim3(ST_THREADS), 0, st, a);
-  hipLaunchKernelGGL(k_sa_wreduce, dim3(sv_div_up((int64_t)C1 * (C + 3), 64)), dim3(256), 0, st, sc.wpart, grid1, C1, a.Kp, C, 1, grad_w1);
+  const int grid1 = sg_grid(M);
+  if (C1 == 64 && C2 == 64) hipLaunchKernelGGL((k_sa_bwd1<4, 4>), dim3(grid1), dim3(SG_THREADS), 0, st, a);
+  else if (C1 == 32 && C2 == 32) hipLaunchKernelGGL((k_sa_bwd1<2, 2>), dim3(grid1), dim3(SG_THREADS), 0, st, a);
+  else if (C1 == 16 && C2 == 16) hipLaunchKernelGGL((k_sa_bwd1<1, 1>), dim3(grid1), dim3(SG_THREADS), 0, st, a);
+  else hipLaunchKernelGGL((k_sa_bwd1<0, 0>), dim3(grid1), dim3(SG_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_sa_wreduce, dim3(sv_div_up((int64_t)C1 * 3, 16)), dim3(256), 0, st, sc.wpart, grid1, C1, 4, 3, grad_w1, C + 3, 0);      // xyz columns
+  if (C) {                                                                                                                        // feature columns
+    const int gp = sv_grid_1d((N + 15) / 16, SP_THREADS / 64, WGP_GRID);
+    hipLaunchKernelGGL(k_sa_wgrad1_points, dim3(gp, C / 16), dim3(SP_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_sa_wreduce, dim3(sv_div_up((int64_t)C1 * C, 16)), dim3(256), 0, st, sc.wpart, gp, C1, C, C, grad_w1, C + 3, 3);
+  }
   if (C && grad_features) hipLaunchKernelGGL(k_sa_feat_grad, dim3(sv_grid_1d(N, 256 / (C / 4), 1024)), dim3(256), 0, st, scatter, w1, N, C, C1, grad_features);
   SV_LAUNCH_CHECK();
   return SV_OK;

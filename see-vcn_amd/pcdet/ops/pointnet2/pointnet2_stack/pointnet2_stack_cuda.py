@@ -1,6 +1,8 @@
 """Same entry-point names and argument order as the reference's compiled extension `pointnet2_stack_cuda`
 (detector3d/pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp:12-31), bound to libseevcn_hip.so.
 Outputs are caller-allocated torch tensors, every function returns 1 like the reference wrappers."""
+import os
+
 import torch
 
 from ..... import _lib
@@ -11,11 +13,22 @@ def _starts(cnt):
     return (torch.cumsum(cnt, 0, dtype=torch.int32) - cnt).contiguous(), cnt.contiguous()
 
 
+BALL_HASH_MIN_POINTS = int(os.environ.get("SEEVCN_BALL_HASH_MIN", "2048"))   # support sets below this (or nsample > 64) are scanned like the reference does
+
+
 def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
     lib = _lib.load()
     _lib.require_cuda(new_xyz, xyz, idx)
     qs, qc = _starts(new_xyz_batch_cnt)
     ps, pc = _starts(xyz_batch_cnt)
+    n = int(xyz.shape[0])
+    if n >= BALL_HASH_MIN_POINTS and nsample <= 64 and radius > 0:
+        # the same idx, element for element, from a cell hash of the support points (sv_ball_query_stack_hashed) instead of the O(M N) scan
+        scratch = _lib.workspace.scratch("ball_hash", lib.sv_ball_query_hash_scratch_bytes(n), xyz.device)
+        rc = lib.sv_ball_query_stack_hashed(int(B), int(M), n, float(radius), int(nsample), _lib.ptr(new_xyz), _lib.ptr(qs), _lib.ptr(qc), _lib.ptr(xyz),
+                                            _lib.ptr(ps), _lib.ptr(pc), _lib.ptr(scratch), _lib.ptr(idx), _lib.stream())
+        _lib.check(rc, "sv_ball_query_stack_hashed")
+        return 1
     max_q = int(M)  # upper bound of queries per scene without a host sync
     rc = lib.sv_ball_query_stack(int(B), int(M), max_q, float(radius), int(nsample), _lib.ptr(new_xyz), _lib.ptr(qs), _lib.ptr(qc),
                                  _lib.ptr(xyz), _lib.ptr(ps), _lib.ptr(pc), _lib.ptr(idx), _lib.stream())

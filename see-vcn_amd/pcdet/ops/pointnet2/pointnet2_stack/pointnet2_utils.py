@@ -76,16 +76,18 @@ class SAScaleTrain(Function):
         w1c, w2c = w1.detach().reshape(C1, C + 3).contiguous(), w2.detach().reshape(C2, C1).contiguous()
         R = M * ns
         f32 = dict(dtype=torch.float32, device=dev)
+        N = xyz.shape[0]
+        proj = torch.empty((N, C1), **f32) if C else None                     # layer 1's feature part, once per support point (work buffer)
         z1, z2 = torch.empty((R, C1), **f32), torch.empty((R, C2), **f32)
         stats = torch.empty((2 * C1 + 2 * C2,), **f32)
         sm1, si1, sm2, si2 = stats[:C1], stats[C1:2 * C1], stats[2 * C1:2 * C1 + C2], stats[2 * C1 + C2:]
         sel, aux, out = torch.empty((M, C2), **f32), torch.empty((M, C2), **f32), torch.empty((M, C2), **f32)
         arg, aux_arg = torch.empty((M, C2), dtype=torch.uint8, device=dev), torch.empty((M, C2), dtype=torch.uint8, device=dev)
         scratch = _lib.workspace.scratch("sa_train", lib.sv_sa_train_scratch_bytes(C, C1, C2), dev)
-        _lib.check(lib.sv_sa_train_forward(_lib.ptr(xyz), _lib.ptr(features) if C else None, _lib.ptr(new_xyz), _lib.ptr(idx), _lib.ptr(row_start), M, C, ns,
+        _lib.check(lib.sv_sa_train_forward(_lib.ptr(xyz), _lib.ptr(features) if C else None, _lib.ptr(new_xyz), _lib.ptr(idx), _lib.ptr(row_start), M, N, C, ns,
                                            _lib.ptr(w1c), _lib.ptr(g1.detach()), _lib.ptr(b1.detach()), _lib.ptr(rm1), _lib.ptr(rv1), _lib.ptr(nbt1), C1,
                                            _lib.ptr(w2c), _lib.ptr(g2.detach()), _lib.ptr(b2.detach()), _lib.ptr(rm2), _lib.ptr(rv2), _lib.ptr(nbt2), C2,
-                                           float(momentum), float(eps), _lib.ptr(scratch), _lib.ptr(z1), _lib.ptr(z2), _lib.ptr(sm1), _lib.ptr(si1),
+                                           float(momentum), float(eps), _lib.ptr(scratch), _lib.ptr(proj), _lib.ptr(z1), _lib.ptr(z2), _lib.ptr(sm1), _lib.ptr(si1),
                                            _lib.ptr(sm2), _lib.ptr(si2), _lib.ptr(sel), _lib.ptr(aux), _lib.ptr(arg), _lib.ptr(aux_arg), _lib.ptr(out),
                                            _lib.stream()), "sv_sa_train_forward")
         ctx.save_for_backward(xyz, features, new_xyz, idx, row_start, w1c, g1, b1, w2c, g2, b2, z1, z2, stats, sel, arg, out)

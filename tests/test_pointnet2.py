@@ -101,6 +101,38 @@ def test_hip_stack_fps_several_workgroups_per_scene_index_exact(cuda, hip_lib, c
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("radius,nsample", [(0.3, 16), (1.5, 32), (6.0, 64), (12.0, 16)])
+def test_hip_hashed_ball_query_equals_the_scan(cuda, hip_lib, radius, nsample):
+    """sv_ball_query_stack_hashed (cell hash, nsample smallest indices of the hits) == sv_ball_query_stack (the reference's scan in index order),
+    element for element: two scenes that share their coordinates (bucket collisions across scenes), balls with thousands of hits (the hit list
+    overflows and is reduced), empty balls, queries far outside the cloud."""
+    import seevcn_amd.synth as synth
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as raw
+    pts, _ = synth.make_scene_batch(1, seed=2100, n_az=300)
+    xyz1 = np.ascontiguousarray(pts[:, 1:4])
+    rng = np.random.default_rng(5)
+    xyz = np.concatenate([xyz1, xyz1[rng.permutation(len(xyz1))]]).astype(np.float32)      # scene 1 = scene 0 in another order
+    counts = [len(xyz1), len(xyz1)]
+    qcnt = [1500, 1300]
+    new = np.concatenate([xyz1[rng.integers(0, len(xyz1), q)] + rng.normal(0, 0.2, (q, 3)) for q in qcnt]).astype(np.float32)
+    new[3] = [900, -900, 50]
+    new[1700] = [-1e4, 0, 0]
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(cuda) if dt is None else torch.tensor(a, dtype=dt, device=cuda)
+    args = (2, len(new), radius, nsample, t(new), t(qcnt, torch.int32), t(xyz), t(counts, torch.int32))
+    hashed = torch.zeros((len(new), nsample), dtype=torch.int32, device=cuda)
+    scanned = torch.zeros((len(new), nsample), dtype=torch.int32, device=cuda)
+    assert len(xyz) >= raw.BALL_HASH_MIN_POINTS
+    raw.ball_query_wrapper(*args, hashed)
+    saved, raw.BALL_HASH_MIN_POINTS = raw.BALL_HASH_MIN_POINTS, 1 << 40
+    try:
+        raw.ball_query_wrapper(*args, scanned)
+    finally:
+        raw.BALL_HASH_MIN_POINTS = saved
+    assert torch.equal(hashed, scanned)
+    assert int((scanned[:, 0] == -1).sum()) >= 2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("radius,nsample", [(0.4, 16), (0.8, 16), (2.4, 32), (0.05, 4)])
 def test_hip_ball_query_group_vs_oracle(cuda, hip_lib, radius, nsample):
     import seevcn_amd.synth as synth

@@ -54,8 +54,8 @@ rm = [torch.zeros(64, **f32) for _ in range(4)]
 nbt = [torch.zeros((), dtype=torch.int64, device=cuda) for _ in range(2)]
 scratch = torch.empty(lib.sv_sa_train_scratch_bytes(c_in, C1, C2), dtype=torch.uint8, device=cuda)
 P = _lib.ptr
-_lib.check(lib.sv_sa_train_forward(P(X), P(Fe), P(NX), P(idx), P(row_start), M, c_in, ns, P(w1), P(g1), P(b1), P(rm[0]), P(rm[1]), P(nbt[0]), C1, P(w2), P(g2), P(b2),
-                                   P(rm[2]), P(rm[3]), P(nbt[1]), C2, 0.1, 1e-5, P(scratch), P(z1), P(z2), P(sm1), P(si1), P(sm2), P(si2), P(sel), P(aux), P(arg), P(aux_arg),
+_lib.check(lib.sv_sa_train_forward(P(X), P(Fe), P(NX), P(idx), P(row_start), M, X.shape[0], c_in, ns, P(w1), P(g1), P(b1), P(rm[0]), P(rm[1]), P(nbt[0]), C1, P(w2), P(g2), P(b2),
+                                   P(rm[2]), P(rm[3]), P(nbt[1]), C2, 0.1, 1e-5, P(scratch), P(torch.empty((X.shape[0], C1), **f32)), P(z1), P(z2), P(sm1), P(si1), P(sm2), P(si2), P(sel), P(aux), P(arg), P(aux_arg),
                                    P(out), _lib.stream()), "fwd")
 dy1, aux2 = torch.empty((R, C1), **f32), torch.empty((M, C2), **f32)
 scatter = torch.empty((X.shape[0], C1), **f32)
