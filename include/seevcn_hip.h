@@ -197,7 +197,11 @@ int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src, const int3
                                        const int32_t* tile_of, int tiles_per_wave,
                                        const float* wfrag, float* Y, int64_t n_rows, int K, int Kd, int Nc, const float* bias,
                                        const float* scale, const float* shift, const float* residual, int relu, int table_k_reversed,
-                                       void* stream);
+                                       float* bn_partial, void* stream);
+/* bn_partial (null or sv_conv_planned_partials() x 2 x Nc floats; plain epilogue only: no bias / scale / residual / relu): per-workgroup column
+ * sums and sums of squares of Y, the first pass of the training-mode BatchNorm behind the convolution (post_act_block, spconv_backbone.py:9-27)
+ * made in the epilogue that holds the values in registers anyway; consumed by sv_batchnorm_relu_forward_partial. */
+int sv_conv_planned_partials(void);
 /* Measurement aid (tools/conv_trace.py): while buf is non-null every wave of sv_sparse_conv_gather_gemm_planned writes 8 uint64 to it
  * (s_memtime at start / after the prologue / after the main loop / at the end, HW_ID, XCC_ID, tile-offset steps, block << 8 | wave);
  * buf holds grid.x * grid.y * 4 slots of 64 bytes (size it as 8 * (n_tiles + 64) * columns / 64 slots).  Not for production use. */
@@ -365,11 +369,14 @@ int sv_pillar_decorate(const float* voxels, const int32_t* num_points, const int
                        int with_distance, float* out, void* stream);
 
 /* interpolate_from_bev_features (detector3d/pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py:11-42,176-204):
- * keypoints (M,4) [b,x,y,z], bev (B,C,H,W) -> out (M,C); the gradient scatter-adds into grad_bev (zero-filled here). */
+ * keypoints (M,4) [b,x,y,z], bev (B,C,H,W) -> out (M,C); the gradient scatter-adds the taps into a channel-last staging map (scratch:
+ * sv_bev_interpolate_grad_scratch_bytes bytes; a tap is then one contiguous run of C floats for the float atomics) and transposes it into
+ * grad_bev (B,C,H,W), every element written. */
 int sv_bev_interpolate(const float* keypoints, int64_t num_keypoints, const float* bev, int batch, int C, int H, int W, float x_min,
                        float y_min, float voxel_x, float voxel_y, float bev_stride, float* out, void* stream);
+size_t sv_bev_interpolate_grad_scratch_bytes(int batch, int C, int H, int W);
 int sv_bev_interpolate_grad(const float* keypoints, int64_t num_keypoints, const float* grad_out, int batch, int C, int H, int W,
-                            float x_min, float y_min, float voxel_x, float voxel_y, float bev_stride, float* grad_bev, void* stream);
+                            float x_min, float y_min, float voxel_x, float voxel_y, float bev_stride, void* scratch, float* grad_bev, void* stream);
 
 /* CenterHead.assign_targets (detector3d/pcdet/models/dense_heads/center_head.py:103-213; gaussian_radius /
  * draw_gaussian_to_heatmap, models/model_utils/centernet_utils.py:9-69): all heads and scenes in one launch.
@@ -413,6 +420,11 @@ size_t sv_batchnorm_scratch_bytes(int channels);
 int sv_batchnorm_relu_forward(const float* x, int64_t n, int channels, const float* gamma, const float* beta, float* running_mean,
                               float* running_var, float momentum, float eps, int training, int relu, void* scratch, float* y,
                               float* save_mean, float* save_invstd, int64_t* num_batches_tracked, void* stream);
+/* the training forward with its statistics pass already done by the producer of x: scratch holds n_partials x 2 x channels partial sums behind its
+ * 4 * channels coefficient floats (sv_sparse_conv_gather_gemm_planned's bn_partial = (float*)scratch + 4 * channels) */
+int sv_batchnorm_relu_forward_partial(const float* x, int64_t n, int channels, const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, float momentum, float eps, int relu, void* scratch, int n_partials, float* y,
+                                      float* save_mean, float* save_invstd, int64_t* num_batches_tracked, void* stream);
 int sv_batchnorm_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, int relu, void* scratch, float* dx, float* dgamma,
                                float* dbeta, void* stream);

@@ -49,7 +49,9 @@ SIGNATURES = {
     "sv_conv_table_rows": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p]),
     "sv_conv_plan_perm_bytes": (c_sz, [c_i64]),
     "sv_conv_plan_build": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p]),
-    "sv_sparse_conv_gather_gemm_planned": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "sv_sparse_conv_gather_gemm_planned": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "sv_conv_planned_partials": (c_i, []),
+    "sv_batchnorm_relu_forward_partial": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_debug_conv_trace": (c_i, [c_p]),
     "sv_conv_tiles_per_wave": (c_i, [c_i64, c_i, c_i]),
     "sv_conv_plan_tiles_bytes": (c_sz, [c_i64, c_i]),
@@ -91,7 +93,8 @@ SIGNATURES = {
     "sv_voxelize_hard": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_pillar_decorate": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "sv_bev_interpolate": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
-    "sv_bev_interpolate_grad": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
+    "sv_bev_interpolate_grad_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "sv_bev_interpolate_grad": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     "sv_center_assign_targets": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_p, c_p, c_p,
                                        c_p, c_p]),
     "sv_vcn_surface_select_scratch_bytes": (c_sz, [c_i]),

@@ -199,6 +199,28 @@ extern "C" int sv_batchnorm_relu_forward(const float* x, int64_t n, int channels
   return SV_OK;
 }
 
+// The same training-mode forward with the statistics' first pass already done: `scratch` (laid out as for sv_batchnorm_relu_forward) holds
+// n_partials per-workgroup partial sums (n_partials, 2, C) behind its 4 * C coefficient floats -- written there by the epilogue of the kernel
+// that produced x (sv_sparse_conv_gather_gemm_planned's bn_partial).  Two launches instead of three, and x is read once instead of twice.
+extern "C" int sv_batchnorm_relu_forward_partial(const float* x, int64_t n, int channels, const float* gamma, const float* beta, float* running_mean,
+                                                 float* running_var, float momentum, float eps, int relu, void* scratch, int n_partials, float* y,
+                                                 float* save_mean, float* save_invstd, int64_t* num_batches_tracked, void* stream) {
+  if (int rc = bn_common_check("sv_batchnorm_relu_forward_partial", n, channels)) return rc;
+  SV_CHECK_ARG(x && y && scratch && save_mean && save_invstd, "sv_batchnorm_relu_forward_partial: null pointer");
+  SV_CHECK_ARG(n_partials >= 1 && n_partials <= BN_MAX_WGS, "sv_batchnorm_relu_forward_partial: 1..%d partials (got %d)", BN_MAX_WGS, n_partials);
+  BnArgs a{};
+  a.x = x, a.out = y, a.gamma = gamma, a.beta = beta, a.running_mean = running_mean, a.running_var = running_var;
+  a.save_mean = save_mean, a.save_invstd = save_invstd, a.n = n, a.C = channels, a.relu = relu, a.momentum = momentum, a.eps = eps;
+  a.wgs = n_partials;
+  a.num_batches_tracked = num_batches_tracked;
+  bn_scratch(a, scratch);
+  hipStream_t st = sv_stream(stream);
+  hipLaunchKernelGGL(k_bn_finalize<false>, dim3(channels), dim3(BN_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_bn_apply_fwd, dim3(sv_grid_1d(n * (channels / 4), BN_THREADS)), dim3(BN_THREADS), 0, st, a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 extern "C" int sv_batchnorm_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* gamma, const float* beta,
                                           const float* save_mean, const float* save_invstd, int relu, void* scratch, float* dx,
                                           float* dgamma, float* dbeta, void* stream) {

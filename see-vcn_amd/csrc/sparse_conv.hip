@@ -847,6 +847,7 @@ struct PlanView {
   PlanDims d;
   int k_flip;               // read table entry K-1-k for offset k (a submanifold table serving its own data gradient)
   int nc_total;             // columns of Y and of the weight fragments (a.Nc is the block's share)
+  float* bn_partial;        // (gridDim.x, 2, nc_total) per-workgroup column sums / sums of squares of Y, or null (BatchNorm statistics made here)
   int debug;                // measurement only (SEEVCN_RS3_DEBUG; results are wrong): 1 no gathered-row loads, 2 no weight loads, 4 no MFMAs,
                             // 8 / 16 weight / row loads of a wave all at ONE address (one cache line per load instead of 16)
   unsigned long long* trace;   // measurement only (sv_debug_conv_trace): 8 words per wave, or null
@@ -868,6 +869,9 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   const i32x4 srd_x = make_srd(a.X, x_bytes), srd_w = make_srd(wfrag, w_bytes);
   const int32_t* my_tiles = pv.tile_of + ((int64_t)region * PL_REGION_WAVES + lw) * (pv.d.n_pass * RS_G);
 
+  float bn0[NT], bn1[NT];                                  // this lane's column sums over all its rows (column 16 t + li)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bn0[t] = bn1[t] = 0.f;
 #pragma nounroll
   for (int pass = 0; pass < pv.d.n_pass; ++pass) {
   if (my_tiles[pass * RS_G] < 0) break;                    // slots are filled front to back: an empty first slot ends the wave's list
@@ -1050,25 +1054,69 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   }
   // D layout (16x16): col = lane&15, row = 4*(lane>>4) + reg
   const bool plain_out = !a.bias && !a.scale && !a.residual && !a.relu;       // the training layers: BatchNorm follows, nothing fused here
+  if (plain_out) {
+    // Whole rows out: a tile goes through wave-private LDS (rows 0..16 of the neighbour-index block, free now; row RS3_KMAX = the output rows
+    // stays) so that the 16 x NT lanes of a row store its 64 * NT bytes with one instruction.  Stored straight from the accumulators a row left
+    // as four 64-byte pieces in four instructions: 58 MB written for a 35.7 MB output on the 64-channel layers (PMC WRITE_SIZE, round 2).
+    float* T = reinterpret_cast<float*>(&s_idx[0][0]);
+    constexpr int TP = NT * 16 + 4;                                 // pitch: 68 floats at NT = 4 (17 index rows of 64 ints hold 16 of them)
+    static_assert(16 * TP <= 17 * 64, "the staging tile must fit under the output-row line of the index block");
 #pragma unroll
-  for (int g = 0; g < RS_G; ++g)
+    for (int g = 0; g < RS_G; ++g) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = s_idx[RS3_KMAX][g * 16 + kk * 4 + r];
-      if (row < 0) continue;
-      if (plain_out) {
-        float* yrow = a.Y + row * pv.nc_total + col_tile0 * 16 + li;
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) yrow[t * 16] = acc[g][t][r];
-      } else {
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[g][t][r];
+          T[(kk * 4 + r) * TP + t * 16 + li] = v;
+          bn0[t] += v, bn1[t] += v * v;                                // padding rows hold zeros
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      constexpr int C4N = NT * 4;                                     // 16-byte pieces per row
+#pragma unroll
+      for (int i = 0; i < (16 * C4N + 63) / 64; ++i) {
+        const int f = lane + 64 * i, rw = f / C4N, c4 = f % C4N;
+        if (16 * C4N % 64 == 0 || f < 16 * C4N) {
+          const int64_t row = s_idx[RS3_KMAX][g * 16 + rw];
+          if (row >= 0) *reinterpret_cast<f32x4*>(a.Y + row * pv.nc_total + col_tile0 * 16 + c4 * 4) = *reinterpret_cast<const f32x4*>(T + rw * TP + c4 * 4);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the next pass refills the index block
+  } else {
+#pragma unroll
+    for (int g = 0; g < RS_G; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = s_idx[RS3_KMAX][g * 16 + kk * 4 + r];
+        if (row < 0) continue;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int col = (col_tile0 + t) * 16 + li;
           a.Y[row * pv.nc_total + col] = conv_epilogue(acc[g][t][r], col, row, a);
         }
       }
-    }
+  }
   }   // pass
+  if (pv.bn_partial) {
+    // BatchNorm statistics of this launch's output: lane sums -> the wave (4 row groups) -> the workgroup (4 waves, fixed order) -> one partial
+    // per workgroup and column, combined by k_bn_finalize in a fixed order
+    __shared__ float s_bn[4][2][64];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float u = bn0[t], v = bn1[t];
+      u += __shfl_xor(u, 16), v += __shfl_xor(v, 16);
+      u += __shfl_xor(u, 32), v += __shfl_xor(v, 32);
+      if (kk == 0) s_bn[wid][0][t * 16 + li] = u, s_bn[wid][1][t * 16 + li] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * NT * 16; e += 256) {
+      const int which = e / (NT * 16), c = e % (NT * 16);
+      const float v = (s_bn[0][which][c] + s_bn[1][which][c]) + (s_bn[2][which][c] + s_bn[3][which][c]);
+      pv.bn_partial[((size_t)blockIdx.x * 2 + which) * pv.nc_total + col_tile0 * 16 + c] = v;
+    }
+  }
   if (pv.trace && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -1088,6 +1136,9 @@ static bool rs3_applies(int K, int Kd, int Nc) {
   const bool nc_ok = Nc == 16 || Nc == 32 || (Nc >= 64 && Nc % 64 == 0 && Nc <= 512);
   return kd_ok && nc_ok;
 }
+// workgroups along x of every planned launch = BatchNorm partials its epilogue writes
+extern "C" int sv_conv_planned_partials(void) { return PL_REGIONS * PL_REGION_WAVES / 4; }
+
 extern "C" int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc, int64_t n_src) {
   // the gathers address X through a 32-bit buffer descriptor
   return (rs3_applies(K, Kd, Nc) && (uint64_t)(n_src < 0 ? 0 : n_src) * Kd * 4 < 0xfffffff0ull) ? 1 : 0;
@@ -1134,8 +1185,9 @@ extern "C" int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src,
                                                   const int32_t* tile_of, int tiles_per_wave,
                                                   const float* wfrag, float* Y, int64_t n_rows, int K, int Kd, int Nc, const float* bias,
                                                   const float* scale, const float* shift, const float* residual, int relu, int table_k_reversed,
-                                                  void* stream) {
+                                                  float* bn_partial, void* stream) {
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Kd > 0 && Nc > 0, "sparse_conv (planned): bad sizes");
+  SV_CHECK_ARG(!bn_partial || (!bias && !scale && !residual && !relu), "sparse_conv (planned): BatchNorm partial sums are made by the plain epilogue only");
   if (n_rows == 0) return SV_OK;
   SV_CHECK_ARG(X && table_rows && perm && masks_p && tile_of && wfrag && Y, "sparse_conv (planned): null pointer");
   SV_CHECK_ARG((scale == nullptr) == (shift == nullptr), "sparse_conv: scale and shift go together");
@@ -1145,7 +1197,7 @@ extern "C" int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src,
   SV_CHECK_ARG((uintptr_t)X % 16 == 0 && (uintptr_t)wfrag % 16 == 0 && (uintptr_t)table_rows % 16 == 0, "sparse_conv (planned): 16-byte alignment");
   ConvArgs a{X, nullptr, nullptr, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc};
   PlanView pv;
-  pv.tab = table_rows, pv.perm = perm, pv.masks_p = masks_p, pv.tile_of = tile_of, pv.d = plan_dims(n_rows, tiles_per_wave), pv.k_flip = table_k_reversed ? 1 : 0, pv.nc_total = Nc;
+  pv.tab = table_rows, pv.perm = perm, pv.masks_p = masks_p, pv.tile_of = tile_of, pv.d = plan_dims(n_rows, tiles_per_wave), pv.k_flip = table_k_reversed ? 1 : 0, pv.nc_total = Nc, pv.bn_partial = bn_partial;
   static const int debug = getenv("SEEVCN_RS3_DEBUG") ? atoi(getenv("SEEVCN_RS3_DEBUG")) : 0;
   pv.debug = debug;
   pv.trace = g_conv_trace;

@@ -30,7 +30,9 @@ class _BevInterp(torch.autograd.Function):
         B, C, H, W, x0, y0, vx, vy, stride = ctx.meta
         g = grad_out.contiguous().float()
         gbev = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
-        rc = lib.sv_bev_interpolate_grad(_lib.ptr(kp), kp.shape[0], _lib.ptr(g), B, C, H, W, x0, y0, vx, vy, stride, _lib.ptr(gbev), _lib.stream())
+        scratch = _lib.workspace.scratch("bev_interp_grad", lib.sv_bev_interpolate_grad_scratch_bytes(B, C, H, W), g.device)
+        rc = lib.sv_bev_interpolate_grad(_lib.ptr(kp), kp.shape[0], _lib.ptr(g), B, C, H, W, x0, y0, vx, vy, stride, _lib.ptr(scratch), _lib.ptr(gbev),
+                                         _lib.stream())
         _lib.check(rc, "sv_bev_interpolate_grad")
         return gbev, None, None, None, None, None, None
 

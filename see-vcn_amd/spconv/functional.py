@@ -280,8 +280,9 @@ class _FragmentCache:
 fragment_cache = _FragmentCache()
 
 
-def gather_gemm_planned(x, plan, wfrag, n_rows, K, kd, nc, bias=None, scale=None, shift=None, residual=None, relu=False):
-    """Y (n_rows, nc) = epi(sum_k X[nbr[k]] @ W[k]) on a table plan (Rulebook.plan) with the weights in fragment order."""
+def gather_gemm_planned(x, plan, wfrag, n_rows, K, kd, nc, bias=None, scale=None, shift=None, residual=None, relu=False, bn_partial=None):
+    """Y (n_rows, nc) = epi(sum_k X[nbr[k]] @ W[k]) on a table plan (Rulebook.plan) with the weights in fragment order.  bn_partial: device address
+    (int) of sv_conv_planned_partials() x 2 x nc floats that receive the BatchNorm partial sums of Y (plain epilogue only)."""
     lib = _lib.load()
     tp, tile_of, g, rev = plan
     assert x.shape[1] == kd and x.dtype == torch.float32
@@ -290,7 +291,7 @@ def gather_gemm_planned(x, plan, wfrag, n_rows, K, kd, nc, bias=None, scale=None
     rc = lib.sv_sparse_conv_gather_gemm_planned(_lib.ptr(x) if x.numel() else None, x.shape[0], _lib.ptr(tp.rows), _lib.ptr(tp.perm), _lib.ptr(tp.masks_p),
                                                 _lib.ptr(tile_of), int(g), _lib.ptr(wfrag),
                                                 _lib.ptr(y) if n_rows else None, n_rows, int(K), int(kd), int(nc), _lib.ptr(bias), _lib.ptr(scale),
-                                                _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), int(bool(rev)), _lib.stream())
+                                                _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), int(bool(rev)), bn_partial, _lib.stream())
     _lib.check(rc, "sv_sparse_conv_gather_gemm_planned")
     return y
 
@@ -343,14 +344,15 @@ def _dense_permutation(shape, strides):
     return True
 
 
-def _conv_forward(features, weight_kio, rulebook):
-    """-> (out (N_out, C_out), frag_bwd or None): the forward of one sparse convolution on contiguous fp32 features."""
+def _conv_forward(features, weight_kio, rulebook, bn_partial=None):
+    """-> (out (N_out, C_out), frag_bwd or None): the forward of one sparse convolution on contiguous fp32 features.  bn_partial: a callable that
+    returns the device address for the BatchNorm partial sums; called (and the sums made) only when the planned kernel runs the layer."""
     w = weight_kio.detach()
     K, cin, cout = w.shape
     plan = rulebook.plan("fwd", cin, cout)
     if plan is not None:
         frag_fwd, frag_bwd = fragment_cache.get(weight_kio)     # not the detached copy: the cache keys on ._base
-        return gather_gemm_planned(features, plan, frag_fwd, rulebook.n_out, K, cin, cout), frag_bwd
+        return gather_gemm_planned(features, plan, frag_fwd, rulebook.n_out, K, cin, cout, bn_partial=bn_partial() if bn_partial else None), frag_bwd
     return gather_gemm(features, rulebook.nbr_out, w.permute(0, 2, 1), rulebook.n_out), None      # (K, C_out, C_in)
 
 
@@ -402,8 +404,12 @@ class SparseConvBNReLUFunction(torch.autograd.Function):
         from . import norm
         _lib.require_cuda(features, weight_kio)
         features = features.contiguous().float()
-        conv_out, ctx.frag_bwd = _conv_forward(features, weight_kio, rulebook)
-        y, mean, invstd = norm.bn_forward_raw(conv_out, gamma, beta, running_mean, running_var, momentum, eps, True, relu, num_batches_tracked)
+        # the planned conv kernel leaves the BatchNorm partial sums of its output in the norm's scratch: no statistics pass over conv_out
+        cout, used = weight_kio.shape[2], []
+        conv_out, ctx.frag_bwd = _conv_forward(features, weight_kio, rulebook, bn_partial=(lambda: used.append(1) or norm.partial_address(cout, features.device))
+                                               if norm.STATS_IN_CONV else None)
+        y, mean, invstd = norm.bn_forward_raw(conv_out, gamma, beta, running_mean, running_var, momentum, eps, True, relu, num_batches_tracked,
+                                              n_partials=_lib.load().sv_conv_planned_partials() if used else 0)
         ctx.rulebook, ctx.relu = rulebook, relu
         ctx.save_for_backward(features, weight_kio, conv_out, gamma, beta, mean, invstd)
         return y

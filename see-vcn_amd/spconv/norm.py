@@ -1,6 +1,8 @@
 """Fused BatchNorm1d(+ReLU) over voxel feature matrices, used by SparseSequential / SparseBasicBlock in place of the separate
 torch kernels for the `norm_fn -> ReLU` tail of the reference's post_act_block (spconv_backbone.py:9-27).  The modules stay
 plain `nn.BatchNorm1d` / `nn.ReLU` (same state_dict keys, same running-statistics semantics); only the arithmetic moves."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -17,8 +19,17 @@ def _scratch(channels, device):
     return _lib.workspace.scratch(f"bn{channels}", n, device)
 
 
-def bn_forward_raw(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, num_batches_tracked=None):
-    """y, save_mean, save_invstd (the last two None in eval mode) of the fused BatchNorm(+ReLU) forward on a contiguous (N, C) matrix."""
+STATS_IN_CONV = os.environ.get("SEEVCN_BN_STATS_IN_CONV", "1") != "0"      # 0: the fused conv + BatchNorm node runs the separate statistics pass (A/B runs)
+
+
+def partial_address(channels, device):
+    """Device address where the producer of a BatchNorm input leaves its partial sums: behind the 4 * C coefficient floats of the norm's scratch."""
+    return _scratch(channels, device).data_ptr() + 16 * channels
+
+
+def bn_forward_raw(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, num_batches_tracked=None, n_partials=0):
+    """y, save_mean, save_invstd (the last two None in eval mode) of the fused BatchNorm(+ReLU) forward on a contiguous (N, C) matrix.  n_partials > 0:
+    the statistics' first pass is already in the scratch (partial_address), written by the kernel that produced x."""
     lib = _lib.load()
     n, c = x.shape
     y = torch.empty_like(x)
@@ -27,6 +38,12 @@ def bn_forward_raw(x, gamma, beta, running_mean, running_var, momentum, eps, tra
         invstd = torch.empty(c, dtype=torch.float32, device=x.device)
     else:
         mean = invstd = None
+    if training and n_partials:
+        _lib.check(lib.sv_batchnorm_relu_forward_partial(_lib.ptr(x), n, c, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                                         float(momentum), float(eps), int(relu), _lib.ptr(_scratch(c, x.device)), int(n_partials), _lib.ptr(y),
+                                                         _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(num_batches_tracked), _lib.stream()),
+                   "sv_batchnorm_relu_forward_partial")
+        return y, mean, invstd
     _lib.check(lib.sv_batchnorm_relu_forward(_lib.ptr(x), n, c, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var),
                                              float(momentum), float(eps), int(training), int(relu), _lib.ptr(_scratch(c, x.device)), _lib.ptr(y),
                                              _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(num_batches_tracked), _lib.stream()), "sv_batchnorm_relu_forward")

@@ -565,3 +565,38 @@ def test_hip_sparse_conv_full_size_properties(cuda, hip_lib, config):
     assert torch.equal(t.features.grad, f)
 
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (64, 128)])
+def test_hip_batchnorm_statistics_from_the_conv_epilogue(cuda, hip_lib, cin, cout):
+    """conv -> BatchNorm1d(train) -> ReLU as one node: the statistics' first pass made in the planned conv kernel's epilogue (per-workgroup column
+    sums next to the whole-row stores) against the separate reduction pass over the conv output -- outputs, running statistics, gradients."""
+    import seevcn_amd.spconv as spconv
+    from seevcn_amd.spconv import norm
+    from tolerances import assert_close_per_channel
+    rng = np.random.default_rng(21)
+    batch, shape = 2, (21, 200, 176)
+    coords = _rand_coords(rng, 60000, batch, shape)
+    feats = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    res = []
+    for flag in (True, False):
+        torch.manual_seed(3)
+        seq = spconv.SparseSequential(spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="s"), torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01),
+                                      torch.nn.ReLU()).to(cuda).train()
+        x = torch.from_numpy(feats).to(cuda).requires_grad_(True)
+        saved, norm.STATS_IN_CONV = norm.STATS_IN_CONV, flag
+        try:
+            y = seq(spconv.SparseConvTensor(x, torch.from_numpy(coords).to(cuda), list(shape), batch)).features
+            (y * y).sum().backward()
+        finally:
+            norm.STATS_IN_CONV = saved
+        res.append((y.detach().cpu().numpy(), seq[1].running_mean.cpu().numpy(), seq[1].running_var.cpu().numpy(), x.grad.cpu().numpy(),
+                    seq[0].weight.grad.reshape(cout, -1).cpu().numpy(), int(seq[1].num_batches_tracked)))
+    a, b = res
+    assert a[5] == b[5] == 1
+    assert_close_per_channel(a[0], b[0], rtol=1e-4, atol_frac=1e-5, name="output")
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-5, atol=1e-7)
+    assert_close_per_channel(a[3], b[3], rtol=1e-3, atol_frac=1e-4, name="input gradient")
+    assert_close_per_channel(a[4], b[4], rtol=1e-3, atol_frac=1e-4, name="weight gradient")
