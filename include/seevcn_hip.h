@@ -410,6 +410,29 @@ int sv_three_interpolate_batch(int batch, int c, int m, int n, const float* poin
 int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float* grad_out, const int32_t* idx, const float* weight,
                                     float* grad_points, void* stream);
 
+/* ---- launch-list executor (csrc/sequencer.hip): enqueue a list of this library's operations with ONE call.  An operation is SV_OP_WORDS int64:
+ *   [0] code   [1..8] eight small integers i0..i7   [9..12] four sizes / strides n0..n3   [13..16] four doubles (bit patterns) f0..f3
+ *   [17..31] fifteen pointers p0..p14 (device addresses; 0 = null)
+ * executed in order on `stream`; the first failing operation's code is returned (sv_last_error names it).  Codes and their fields, in the
+ * argument order of the entry point each one calls:
+ *   SV_OP_CONV_PLANNED  sv_sparse_conv_gather_gemm_planned: p = X, table_rows, perm, masks_p, tile_of, wfrag, Y, bias, scale, shift, residual,
+ *                       bn_partial; n = n_src, n_rows; i = tiles_per_wave, K, Kd, Nc, relu, table_k_reversed
+ *   SV_OP_CONV_PLAIN    sv_sparse_conv_gather_gemm: p = X, nbr, Wt, Y, bias, scale, shift, residual; n = n_src, n_rows; i = K, Kd, Nc, relu
+ *   SV_OP_BN_FWD        sv_batchnorm_relu_forward (i3 = 0) / _forward_partial (i3 = number of partials): p = x, gamma, beta, running_mean,
+ *                       running_var, scratch, y, save_mean, save_invstd, num_batches_tracked; n = rows; i = channels, training, relu, n_partials;
+ *                       f = momentum, eps
+ *   SV_OP_BN_BWD        sv_batchnorm_relu_backward: p = x, dy, gamma, beta, save_mean, save_invstd, scratch, dx, dgamma, dbeta; n = rows; i = channels, relu
+ *   SV_OP_WGRAD         sv_sparse_conv_wgrad_strided: p = X, nbr, dY, dW, scratch; n = n_rows, stride_k, stride_cin, stride_cout; i = K, Cin, Cout
+ * Used by seevcn_amd/spconv/chain.py: the forward and the backward of a conv -> BatchNorm -> ReLU chain (VoxelBackBone8x, spconv_backbone.py:128-180)
+ * as two calls inside one autograd node. */
+#define SV_OP_WORDS 32
+#define SV_OP_CONV_PLANNED 1
+#define SV_OP_CONV_PLAIN 2
+#define SV_OP_BN_FWD 3
+#define SV_OP_BN_BWD 5
+#define SV_OP_WGRAD 6
+int sv_run_ops(const int64_t* ops, int n_ops, void* stream);
+
 /* ---- BatchNorm1d (+ReLU) on (N,C) voxel features: the norm_fn -> ReLU tail of post_act_block
  * (detector3d/pcdet/models/backbones_3d/spconv_backbone.py:9-27,73; torch.nn.BatchNorm1d semantics: biased batch variance for
  * normalisation, unbiased for running_var, running = (1-momentum)*running + momentum*batch).  C multiple of 4, C/4 divides 256.

@@ -129,6 +129,7 @@ SIGNATURES = {
     "sv_batchnorm_scratch_bytes": (c_sz, [c_i]),
     "sv_batchnorm_relu_forward": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_batchnorm_relu_backward": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sv_run_ops": (c_i, [c_p, c_i, c_p]),
     "sv_anchor_decode": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p]),
     "sv_assign_targets_axis_aligned": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
 }

@@ -1,0 +1,73 @@
+// Launch-list executor: one C-ABI call that enqueues a whole list of this library's operations on a stream.
+//
+// The trained side of a step (VoxelBackBone8x: 13 x [sparse conv -> BatchNorm -> ReLU], and the reverse chain of BatchNorm backward, weight
+// gradient and data gradient) is ~65 launches whose arguments are all known before the first one runs (the rulebooks and plans were built
+// ahead, the buffers are slices of one allocation).  Enqueued from Python one call at a time they cost the host 2.2 ms per step -- autograd
+// node, output allocations and a ctypes call per layer and direction -- next to 4.0 ms of GPU time; the reference pays the same per-layer
+// price inside spconv's Python autograd functions (spconv_backbone.py:128-180 is the caller).  Here the host writes the list as rows of 32
+// int64 (pointers, sizes, flags; floats as the bits of a double) and hands it over once: seevcn_amd/spconv/chain.py builds the forward and the
+// backward list of a conv -> norm -> ReLU chain and runs each with one sv_run_ops call inside ONE autograd node.
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+inline double as_double(int64_t bits) {
+  double d;
+  memcpy(&d, &bits, sizeof d);
+  return d;
+}
+template <typename T>
+inline T* ptr_of(int64_t v) { return reinterpret_cast<T*>(static_cast<uintptr_t>(v)); }
+}   // namespace
+
+extern "C" int sv_run_ops(const int64_t* ops, int n_ops, void* stream) {
+  SV_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "sv_run_ops: null list");
+  for (int k = 0; k < n_ops; ++k) {
+    const int64_t* o = ops + (size_t)k * SV_OP_WORDS;
+    const int64_t* i = o + 1;       // 8 small integers
+    const int64_t* n = o + 9;       // 4 sizes / strides
+    const int64_t* f = o + 13;      // 4 doubles (bit patterns)
+    const int64_t* p = o + 17;      // 15 pointers
+    int rc = SV_OK;
+    switch ((int)o[0]) {
+      case SV_OP_CONV_PLANNED:
+        rc = sv_sparse_conv_gather_gemm_planned(ptr_of<const float>(p[0]), n[0], ptr_of<const int32_t>(p[1]), ptr_of<const int32_t>(p[2]),
+                                                ptr_of<const int32_t>(p[3]), ptr_of<const int32_t>(p[4]), (int)i[0], ptr_of<const float>(p[5]),
+                                                ptr_of<float>(p[6]), n[1], (int)i[1], (int)i[2], (int)i[3], ptr_of<const float>(p[7]),
+                                                ptr_of<const float>(p[8]), ptr_of<const float>(p[9]), ptr_of<const float>(p[10]), (int)i[4], (int)i[5],
+                                                ptr_of<float>(p[11]), stream);
+        break;
+      case SV_OP_CONV_PLAIN:
+        rc = sv_sparse_conv_gather_gemm(ptr_of<const float>(p[0]), n[0], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[1],
+                                        (int)i[0], (int)i[1], (int)i[2], ptr_of<const float>(p[4]), ptr_of<const float>(p[5]), ptr_of<const float>(p[6]),
+                                        ptr_of<const float>(p[7]), (int)i[3], stream);
+        break;
+      case SV_OP_BN_FWD:
+        if (i[3] > 0)
+          rc = sv_batchnorm_relu_forward_partial(ptr_of<const float>(p[0]), n[0], (int)i[0], ptr_of<const float>(p[1]), ptr_of<const float>(p[2]),
+                                                 ptr_of<float>(p[3]), ptr_of<float>(p[4]), (float)as_double(f[0]), (float)as_double(f[1]), (int)i[2],
+                                                 ptr_of<void>(p[5]), (int)i[3], ptr_of<float>(p[6]), ptr_of<float>(p[7]), ptr_of<float>(p[8]),
+                                                 ptr_of<int64_t>(p[9]), stream);
+        else
+          rc = sv_batchnorm_relu_forward(ptr_of<const float>(p[0]), n[0], (int)i[0], ptr_of<const float>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]),
+                                         ptr_of<float>(p[4]), (float)as_double(f[0]), (float)as_double(f[1]), (int)i[1], (int)i[2], ptr_of<void>(p[5]),
+                                         ptr_of<float>(p[6]), ptr_of<float>(p[7]), ptr_of<float>(p[8]), ptr_of<int64_t>(p[9]), stream);
+        break;
+      case SV_OP_BN_BWD:
+        rc = sv_batchnorm_relu_backward(ptr_of<const float>(p[0]), ptr_of<const float>(p[1]), n[0], (int)i[0], ptr_of<const float>(p[2]),
+                                        ptr_of<const float>(p[3]), ptr_of<const float>(p[4]), ptr_of<const float>(p[5]), (int)i[1], ptr_of<void>(p[6]),
+                                        ptr_of<float>(p[7]), ptr_of<float>(p[8]), ptr_of<float>(p[9]), stream);
+        break;
+      case SV_OP_WGRAD:
+        rc = sv_sparse_conv_wgrad_strided(ptr_of<const float>(p[0]), ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
+                                          (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<void>(p[4]), stream);
+        break;
+      default:
+        sv_set_error("sv_run_ops: unknown operation %lld at position %d", (long long)o[0], k);
+        return SV_ERR_ARG;
+    }
+    if (rc != SV_OK) return rc;     // sv_last_error() names the failing entry point; `k` operations were enqueued
+  }
+  return SV_OK;
+}

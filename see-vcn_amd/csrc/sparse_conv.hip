@@ -438,7 +438,10 @@ extern "C" int sv_conv_table_rows(const int32_t* nbr, int64_t n_rows, int K, int
 // 1.65x (66 k rows) the mean and 16 % of the SIMDs with a wave less than the others.
 // Order inside a cost bucket is arbitrary: every output row is still produced by one wave with the same summation order, results do not
 // depend on the deal.  One workgroup per region, everything in LDS.
-constexpr int PL_WAVES_PER_SIMD = 4;
+#ifndef SEEVCN_PL_WAVES
+#define SEEVCN_PL_WAVES 4
+#endif
+constexpr int PL_WAVES_PER_SIMD = SEEVCN_PL_WAVES;
 constexpr int PL_BINS = 32;                                         // CUs per XCD
 constexpr int PL_QUAD = 4;                                          // tiles dealt together: one per wave of a workgroup
 constexpr int PL_REGION_WAVES = PL_BINS * PL_QUAD * PL_WAVES_PER_SIMD;   // 512 waves = 128 workgroups per region

@@ -3,7 +3,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from ....spconv import norm
+from ....spconv import chain, norm
 from ...utils.spconv_utils import replace_feature, spconv
 
 
@@ -64,6 +64,22 @@ class _BackBone8xBase(nn.Module):
         batch_dict.update({'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})
         return batch_dict
 
+    def _chain_blocks(self):
+        """The stages as one list of conv -> norm -> ReLU blocks (taps after conv1..conv4 and conv_out), or None; cached until a module is registered
+        anywhere (the registration epoch of seevcn_amd.spconv.conv)."""
+        from ....spconv import conv as sconv
+        epoch = sconv._registration_epoch[0]
+        hit = self.__dict__.get('_seevcn_chain')
+        if hit is None or hit[0] != epoch:
+            stages = [self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4, self.conv_out]
+            blocks = chain.flatten_blocks(stages)
+            if blocks is not None:
+                for b in blocks[:len(chain.flatten_blocks([self.conv_input]) or [])]:
+                    b.tap = False                                     # conv_input feeds conv1 only
+            hit = (epoch, blocks)
+            self.__dict__['_seevcn_chain'] = hit
+        return hit[1]
+
     def forward_stages(self, batch_dict):
         """forward() as a generator that yields between the backbone's stages (a caller with other work to enqueue in between, bench.py, steps
         through it); the value of the StopIteration is the batch_dict."""
@@ -75,6 +91,12 @@ class _BackBone8xBase(nn.Module):
         spconv.prebuild_rulebooks(self, input_sp_tensor, with_backward=self.training and torch.is_grad_enabled())
         # the MFMA fragment copies of all layer weights in one launch (they follow the weights every forward; spconv/functional.py)
         spconv.refresh_weight_fragments(self)
+        # training, every stage a plain run of conv -> BatchNorm1d -> ReLU blocks (VoxelBackBone8x): the whole chain and its backward as two launch
+        # lists inside one autograd node (seevcn_amd/spconv/chain.py) instead of ~100 calls from the module tree
+        blocks = self._chain_blocks()
+        if self.training and chain.applicable(blocks, input_sp_tensor):
+            x_conv1, x_conv2, x_conv3, x_conv4, out = chain.run_chain(blocks, input_sp_tensor)
+            return self._finish(batch_dict, x_conv1, x_conv2, x_conv3, x_conv4, out)
         x = self.conv_input(input_sp_tensor)
         x_conv1 = self.conv1(x)
         yield

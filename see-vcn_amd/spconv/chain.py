@@ -1,0 +1,216 @@
+"""A chain of [sparse conv -> BatchNorm1d -> ReLU] blocks as ONE autograd node over the launch-list executor (sv_run_ops, csrc/sequencer.hip).
+
+The reference's VoxelBackBone8x.forward (detector3d/pcdet/models/backbones_3d/spconv_backbone.py:128-180) is 13 such blocks; through the module
+tree each block costs the host an autograd node, three output allocations and two or three ctypes calls per direction (2.2 ms of Python per
+step for 4.0 ms of GPU time on the bench workload).  Here the forward of the whole chain is written as one list of operations -- every
+argument is known before the first kernel runs: the rulebooks and plans are built ahead, the activations are slices of one allocation -- and
+enqueued with one call; the backward (BatchNorm backward, weight gradient, data gradient per block, last to first) likewise.  Same kernels,
+same arithmetic, same parameters and running statistics as the per-module path (SparseSequential), which stays the fallback for anything
+this does not take (eval mode, hooks, a conv bias, a layer without a plan for its data gradient, residual blocks)."""
+import os
+import struct
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import functional as Fsp
+from . import norm
+
+CHAIN_OFF = os.environ.get("SEEVCN_CHAIN", "1") == "0"          # 0: every block through its own modules (A/B runs, tests)
+OP_CONV_PLANNED, OP_CONV_PLAIN, OP_BN_FWD, OP_BN_BWD, OP_WGRAD = 1, 2, 3, 5, 6
+WORDS = 32
+
+
+def _bits(x):
+    return struct.unpack('<q', struct.pack('<d', float(x)))[0]
+
+
+def _row(code, i=(), n=(), f=(), p=()):
+    r = [0] * WORDS
+    r[0] = code
+    r[1:1 + len(i)] = [int(v) for v in i]
+    r[9:9 + len(n)] = [int(v) for v in n]
+    r[13:13 + len(f)] = f
+    r[17:17 + len(p)] = [0 if v is None else int(v) for v in p]
+    return r
+
+
+def _run(rows, what):
+    arr = np.array(rows, dtype=np.int64)
+    _lib.check(_lib.load().sv_run_ops(arr.ctypes.data, len(rows), _lib.stream()), what)
+
+
+class Block:
+    """One conv -> norm (-> ReLU) block of a chain: the modules (parameters and running statistics stay theirs) and what is fixed about them."""
+
+    def __init__(self, conv, bn, relu, tap):
+        self.conv, self.bn, self.relu, self.tap = conv, bn, bool(relu), tap          # tap: this block's output is returned by the chain
+        self.K = conv.kernel_size[0] * conv.kernel_size[1] * conv.kernel_size[2]
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.mom_eps = (_bits(bn.momentum), _bits(bn.eps))
+
+
+def flatten_blocks(groups):
+    """groups: the backbone's stages in execution order (SparseSequential each).  -> list of Block, or None when a stage is not a plain sequence of
+    (SparseConvolution, BatchNorm1d, ReLU) triples.  The last block of every stage is a tap."""
+    from .conv import SparseConvolution
+    from .modules import SparseSequential
+    blocks = []
+
+    def walk(m, out):
+        for child in m._modules.values():
+            if isinstance(child, SparseSequential):
+                if not walk(child, out):
+                    return False
+            else:
+                out.append(child)
+        return True
+
+    for stage in groups:
+        mods = []
+        if not isinstance(stage, SparseSequential) or not walk(stage, mods) or len(mods) % 3 != 0 or not mods:
+            return None
+        for j in range(0, len(mods), 3):
+            conv, bn, relu = mods[j:j + 3]
+            if not (isinstance(conv, SparseConvolution) and type(bn) is torch.nn.BatchNorm1d and type(relu) is torch.nn.ReLU):
+                return None
+            blocks.append(Block(conv, bn, True, False))
+        blocks[-1].tap = True
+    return blocks
+
+
+def applicable(blocks, x):
+    """The chain takes these blocks on x now: training with gradients on, fp32 CUDA features, every block what fusable_with() accepts, no hooks,
+    every rulebook in x's indice_dict (prebuild_rulebooks ran) with at least two output rows, and a planned data-gradient kernel for every block
+    behind the first (the first one's is needed only when the input features want a gradient, which the backbone's never do)."""
+    if CHAIN_OFF or blocks is None or not torch.is_grad_enabled() or x.features.requires_grad or x.indices.shape[0] < 2:
+        return False
+    for k, b in enumerate(blocks):
+        if not b.conv.fusable_with(b.bn, x) or b.conv.indice_key is None:
+            return False
+        if any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in (b.conv, b.bn)):
+            return False
+        rb = x.indice_dict.get(b.conv.indice_key)
+        if rb is None or rb.n_out < 2 or rb.ksize != b.conv.kernel_size:
+            return False
+        if k > 0 and rb.plan("bwd", b.cout, b.cin) is None:
+            return False
+    return True
+
+
+class SparseChainFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, blocks, rulebooks, *params):
+        lib = _lib.load()
+        dev = features.device
+        ctx.set_materialize_grads(False)                                              # a tap nobody differentiates arrives as None, not as zeros
+        features = features.contiguous().float()
+        # one allocation for every activation: per block [conv output | block output | batch mean | batch invstd]
+        offs, total = [], 0
+        for b, rb in zip(blocks, rulebooks):
+            n = rb.n_out * b.cout
+            offs.append((total, total + n, total + 2 * n, total + 2 * n + b.cout))
+            total += 2 * n + 2 * b.cout
+        arena = torch.empty((total,), dtype=torch.float32, device=dev)
+        base = arena.data_ptr()
+        n_part = lib.sv_conv_planned_partials()
+        rows, x_ptr, n_src, keep = [], features.data_ptr(), features.shape[0], []
+        frags = []
+        for k, (b, rb) in enumerate(zip(blocks, rulebooks)):
+            w, gamma, beta = params[3 * k:3 * k + 3]
+            o_conv, o_y, o_mean, o_istd = (base + 4 * v for v in offs[k])
+            wk = b.conv.weight_kio()
+            plan = rb.plan("fwd", b.cin, b.cout)
+            scratch = norm._scratch(b.cout, dev)
+            partial = 0
+            if plan is not None:
+                tp, tile_of, g, rev = plan
+                ff, fb = Fsp.fragment_cache.get(wk)
+                frags.append(fb)
+                partial = scratch.data_ptr() + 16 * b.cout if norm.STATS_IN_CONV else 0
+                rows.append(_row(OP_CONV_PLANNED, i=(g, b.K, b.cin, b.cout, 0, int(bool(rev))), n=(n_src, rb.n_out),
+                                 p=(x_ptr, tp.rows.data_ptr(), tp.perm.data_ptr(), tp.masks_p.data_ptr(), tile_of.data_ptr(), ff.data_ptr(), o_conv, None, None, None,
+                                    None, partial or None)))
+            else:
+                frags.append(None)
+                wt = wk.detach().permute(0, 2, 1).contiguous()                       # (K, C_out, C_in): the 3-channel input layer only
+                keep.append(wt)
+                rows.append(_row(OP_CONV_PLAIN, i=(b.K, b.cin, b.cout, 0), n=(n_src, rb.n_out), p=(x_ptr, rb.nbr_out.data_ptr(), wt.data_ptr(), o_conv)))
+            rows.append(_row(OP_BN_FWD, i=(b.cout, 1, int(b.relu), n_part if partial else 0), n=(rb.n_out,), f=b.mom_eps,
+                             p=(o_conv, gamma.data_ptr(), beta.data_ptr(), b.bn.running_mean.data_ptr(), b.bn.running_var.data_ptr(), scratch.data_ptr(), o_y, o_mean,
+                                o_istd, b.bn.num_batches_tracked.data_ptr())))
+            x_ptr, n_src = o_y, rb.n_out
+        _run(rows, "sv_run_ops (chain forward)")
+        ctx.blocks, ctx.rulebooks, ctx.offs, ctx.frags = blocks, rulebooks, offs, frags
+        ctx.save_for_backward(features, arena, *params)
+        outs = tuple(arena[offs[k][1]:offs[k][2]].view(rulebooks[k].n_out, b.cout) for k, b in enumerate(blocks) if b.tap)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        features, arena, *params = ctx.saved_tensors
+        blocks, rulebooks, offs, frags = ctx.blocks, ctx.rulebooks, ctx.offs, ctx.frags
+        dev = arena.device
+        L = len(blocks)
+        ext, gi = [None] * L, 0                                                       # gradient that reaches a block's output from outside the chain
+        for k, b in enumerate(blocks):
+            if b.tap:
+                ext[k] = None if grads[gi] is None else grads[gi].contiguous().float()
+                gi += 1
+        if ext[L - 1] is None:
+            ext[L - 1] = torch.zeros((rulebooks[-1].n_out, blocks[-1].cout), dtype=torch.float32, device=dev)
+        # one allocation for the work buffers: per block [gradient of the conv output | gradient of the block's input (blocks >= 1) | dgamma | dbeta],
+        # one for the weight gradients (in the parameters' own layout)
+        boffs, total, woffs, wtotal, wbytes = [], 0, [], 0, 0
+        for k, (b, rb) in enumerate(zip(blocks, rulebooks)):
+            n, nin = rb.n_out * b.cout, (rb.n_in * b.cin if k > 0 else 0)
+            boffs.append((total, total + n, total + n + nin, total + n + nin + b.cout))
+            total += n + nin + 2 * b.cout
+            woffs.append(wtotal)
+            wtotal += b.K * b.cin * b.cout
+            wbytes = max(wbytes, lib.sv_sparse_conv_wgrad_scratch_bytes(rb.n_out, b.K, b.cin, b.cout))
+        work = torch.empty((total,), dtype=torch.float32, device=dev)
+        wgrads = torch.empty((wtotal,), dtype=torch.float32, device=dev)
+        wscratch = _lib.workspace.scratch("wgrad", wbytes, dev)
+        base, abase, wbase = work.data_ptr(), arena.data_ptr(), wgrads.data_ptr()
+        rows = []
+        dy_ptr = ext[L - 1].data_ptr()
+        for k in range(L - 1, -1, -1):
+            b, rb = blocks[k], rulebooks[k]
+            w, gamma, beta = params[3 * k:3 * k + 3]
+            o_dconv, o_dx, o_dg, o_db = (base + 4 * v for v in boffs[k])
+            a_conv, a_y, a_mean, a_istd = (abase + 4 * v for v in offs[k])
+            x_in = features.data_ptr() if k == 0 else abase + 4 * offs[k - 1][1]
+            scratch = norm._scratch(b.cout, dev)
+            rows.append(_row(OP_BN_BWD, i=(b.cout, int(b.relu)), n=(rb.n_out,),
+                             p=(a_conv, dy_ptr, gamma.data_ptr(), beta.data_ptr(), a_mean, a_istd, scratch.data_ptr(), o_dconv, o_dg, o_db)))
+            rows.append(_row(OP_WGRAD, i=(b.K, b.cin, b.cout), n=(rb.n_out, b.cin, 1, b.K * b.cin),
+                             p=(x_in, rb.nbr_out.data_ptr(), o_dconv, wbase + 4 * woffs[k], wscratch.data_ptr())))
+            if k > 0:
+                tp, tile_of, g, rev = rb.plan("bwd", b.cout, b.cin)
+                res = ext[k - 1]
+                rows.append(_row(OP_CONV_PLANNED, i=(g, b.K, b.cout, b.cin, 0, int(bool(rev))), n=(rb.n_out, rb.n_in),
+                                 p=(o_dconv, tp.rows.data_ptr(), tp.perm.data_ptr(), tp.masks_p.data_ptr(), tile_of.data_ptr(), frags[k].data_ptr(), o_dx, None, None,
+                                    None, None if res is None else res.data_ptr(), None)))
+                dy_ptr = o_dx
+        _run(rows, "sv_run_ops (chain backward)")
+        out = [None, None, None]
+        for k, b in enumerate(blocks):
+            w = params[3 * k]
+            o = boffs[k]
+            out += [wgrads[woffs[k]:woffs[k] + b.K * b.cin * b.cout].view(w.shape), work[o[2]:o[3]], work[o[3]:o[3] + b.cout]]
+        return tuple(out)
+
+
+def run_chain(blocks, x):
+    """x: SparseConvTensor at the chain's input with every rulebook prebuilt.  -> list of SparseConvTensor, one per tap, in order."""
+    from .core import SparseConvTensor
+    rulebooks = [x.indice_dict[b.conv.indice_key] for b in blocks]
+    params = []
+    for b in blocks:
+        params += [b.conv.weight, b.bn.weight, b.bn.bias]
+    outs = SparseChainFunction.apply(x.features, blocks, rulebooks, *params)
+    taps = [rb for b, rb in zip(blocks, rulebooks) if b.tap]
+    return [SparseConvTensor(f, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.indice_dict) for f, rb in zip(outs, taps)]

@@ -600,3 +600,42 @@ def test_hip_batchnorm_statistics_from_the_conv_epilogue(cuda, hip_lib, cin, cou
     np.testing.assert_allclose(a[2], b[2], rtol=1e-5, atol=1e-7)
     assert_close_per_channel(a[3], b[3], rtol=1e-3, atol_frac=1e-4, name="input gradient")
     assert_close_per_channel(a[4], b[4], rtol=1e-3, atol_frac=1e-4, name="weight gradient")
+
+
+@pytest.mark.gpu
+def test_hip_backbone_chain_equals_the_module_path(cuda, hip_lib):
+    """VoxelBackBone8x in training mode through the launch-list chain (one autograd node, sv_run_ops) against the per-module path
+    (SparseSequential: one node per block): the same kernels with the same arguments, so outputs, running statistics and every gradient are
+    bit-identical; a gradient that enters at a multi-scale tap (x_conv3, as PV-RCNN's set abstraction sends it) is carried as well.
+    (Run with the BatchNorm statistics made by their own reduction pass: made in the conv epilogue they are summed in the order of the plan's
+    tiles, which the plan builder's LDS atomics do not fix from one run to the next -- equal to 1e-6, not bit for bit.)"""
+    import copy
+    import seevcn_amd.synth as synth
+    from seevcn_amd.pcdet.models import backbones_3d
+    from seevcn_amd.pcdet.ops import voxel_ops
+    from seevcn_amd.spconv import chain, norm
+    pts, _ = synth.make_scene_batch(2, seed=2000, n_az=120)
+    g = dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.05, 0.05, 0.1], grid_size=[1408, 1600, 40])
+    f, c, _ = voxel_ops.voxelize_dynamic(torch.from_numpy(pts).to(cuda), g["point_cloud_range"], g["voxel_size"], g["grid_size"], 2)
+    torch.manual_seed(0)
+    net1 = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size']).to(cuda).train()
+    net2 = copy.deepcopy(net1)
+    res = []
+    for net, off in ((net1, False), (net2, True)):
+        saved, chain.CHAIN_OFF = chain.CHAIN_OFF, off
+        saved_stats, norm.STATS_IN_CONV = norm.STATS_IN_CONV, False
+        try:
+            assert (net._chain_blocks() is not None)
+            bd = net({'batch_size': 2, 'voxel_features': f.clone(), 'voxel_coords': c.clone()})
+            out, x3 = bd['encoded_spconv_tensor'].features, bd['multi_scale_3d_features']['x_conv3'].features
+            (out.square().sum() + (x3 * 0.5).sum()).backward()
+        finally:
+            chain.CHAIN_OFF = saved
+            norm.STATS_IN_CONV = saved_stats
+        res.append((out.detach(), x3.detach(), [p.grad.clone() for p in net.parameters()], [b.clone() for b in net.buffers()]))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for (n1, _), g1, g2 in zip(net1.named_parameters(), a[2], b[2]):
+        assert torch.equal(g1, g2), n1
+    for (n1, _), b1, b2 in zip(net1.named_buffers(), a[3], b[3]):
+        assert torch.equal(b1, b2), n1
