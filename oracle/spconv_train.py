@@ -62,3 +62,38 @@ def backbone8x_train_chain(sd, features, coords, batch_size, sparse_shape, dtype
     dense = dense.index_put((idx[0], idx[1], idx[2], idx[3]), x)                       # (B, D, H, W, C)
     dense = dense.permute(0, 4, 1, 2, 3).reshape(batch_size, x.shape[1] * oshape[0], oshape[1], oshape[2])
     return dense, leaves, (x, oc, oshape)
+
+
+def stage_train_chain(sd, layers, features, coords, shape, dtype=torch.float64, branch_hints=None, hint_band=0.0):
+    """One STAGE of the backbone (a run of conv -> BatchNorm(batch statistics) -> ReLU blocks, spconv_backbone.py:8-27) as a differentiable chain.
+    layers: [(conv key, bn prefix, 'subm' | 'sparse', ksize, stride, padding)], sd as in backbone8x_train_chain.  Returns (output tensor with grad_fn,
+    leaves incl. 'input', out_coords, out_shape, n_overridden) -- used by the 16-scene sampled-stage gradient test, where the inputs and the
+    upstream gradient of the stage are the GPU step's own tensors.
+
+    The ReLU's derivative jumps at zero: for a pre-activation within rounding distance of zero a float32 and a float64 evaluation may take
+    different branches, both valid, and the gradients of everything it feeds then differ by O(1).  branch_hints {conv key: bool (rows, C)} are
+    the branches the evaluation under test took (its ReLU output > 0); they are followed ONLY where |pre-activation| < hint_band, everywhere
+    else the oracle's own sign decides.  n_overridden counts the positions where the hint changed the oracle's branch."""
+    leaves = {}
+    x = torch.from_numpy(np.asarray(features)).to(dtype).requires_grad_(True)
+    leaves["input"] = x
+    c, shape = np.asarray(coords), tuple(int(s) for s in shape)
+    overridden = 0
+    for key, bn, kind, ksize, stride, pad in layers:
+        w = torch.from_numpy(osp.weight_to_kio(np.asarray(sd[key]))).to(dtype).requires_grad_(True)
+        g = torch.from_numpy(np.asarray(sd[bn + ".weight"])).to(dtype).requires_grad_(True)
+        b = torch.from_numpy(np.asarray(sd[bn + ".bias"])).to(dtype).requires_grad_(True)
+        leaves[key], leaves[bn + ".weight"], leaves[bn + ".bias"] = w, g, b
+        if kind == "subm":
+            nbr = osp.rulebook_subm(c, shape, ksize)
+        else:
+            c, nbr, _, shape = osp.rulebook_sparse(c, shape, ksize, stride, pad)
+        z = torch.nn.functional.batch_norm(_Conv.apply(x, w, nbr), None, None, g, b, True, 0.01, 1e-3)
+        on = z.detach() > 0
+        if branch_hints is not None and key in branch_hints:
+            hint = torch.from_numpy(np.asarray(branch_hints[key], bool))
+            use = (z.detach().abs() < hint_band) & (hint != on)
+            overridden += int(use.sum())
+            on = torch.where(use, hint, on)
+        x = torch.where(on, z, torch.zeros_like(z))
+    return x, leaves, c, shape, overridden

@@ -10,6 +10,12 @@
 
 #include "norm.h"
 
+// y = x * scale + shift, scale = invstd * gamma, shift = beta - mean * scale.  The backward pass recomputes the ReLU branch from x: it must
+// evaluate EXACTLY the forward's expression (same operations, same roundings), or an activation within an ulp of zero is "off" in the forward
+// and "on" in the backward.  Hence the explicit fused multiply-adds (no compiler contraction choices) in one place.
+__device__ __forceinline__ float bn_shift(float mean, float scale, float beta) { return __fmaf_rn(-mean, scale, beta); }
+__device__ __forceinline__ float bn_act(float x, float scale, float shift) { return __fmaf_rn(x, scale, shift); }
+
 // per-thread: channels c4*4..c4*4+3 of rows (row0 + tid / C4) + k * R
 template <bool BWD>
 __global__ __launch_bounds__(BN_THREADS) void k_bn_reduce(BnArgs a) {
@@ -27,6 +33,8 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_reduce(BnArgs a) {
     if (a.gamma) g = reinterpret_cast<const float4*>(a.gamma)[c4];
     if (a.beta) bt = reinterpret_cast<const float4*>(a.beta)[c4];
   }
+  const float4 sc = make_float4(istd.x * g.x, istd.y * g.y, istd.z * g.z, istd.w * g.w);
+  const float4 sh = make_float4(bn_shift(mean.x, sc.x, bt.x), bn_shift(mean.y, sc.y, bt.y), bn_shift(mean.z, sc.z, bt.z), bn_shift(mean.w, sc.w, bt.w));
   if (active) {
     for (int64_t r = r0 + rr; r < r1; r += R) {
       const float4 v = reinterpret_cast<const float4*>(a.x + r * a.C)[c4];
@@ -36,9 +44,9 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_reduce(BnArgs a) {
       } else {
         float4 d = reinterpret_cast<const float4*>(a.dy + r * a.C)[c4];
         const float4 xh = make_float4((v.x - mean.x) * istd.x, (v.y - mean.y) * istd.y, (v.z - mean.z) * istd.z, (v.w - mean.w) * istd.w);
-        if (a.relu) {   // ReLU mask recomputed from x: y > 0  <=>  xhat * gamma + beta > 0
-          d.x = (xh.x * g.x + bt.x > 0.f) ? d.x : 0.f, d.y = (xh.y * g.y + bt.y > 0.f) ? d.y : 0.f;
-          d.z = (xh.z * g.z + bt.z > 0.f) ? d.z : 0.f, d.w = (xh.w * g.w + bt.w > 0.f) ? d.w : 0.f;
+        if (a.relu) {   // ReLU branch recomputed from x with the forward's own expression
+          d.x = (bn_act(v.x, sc.x, sh.x) > 0.f) ? d.x : 0.f, d.y = (bn_act(v.y, sc.y, sh.y) > 0.f) ? d.y : 0.f;
+          d.z = (bn_act(v.z, sc.z, sh.z) > 0.f) ? d.z : 0.f, d.w = (bn_act(v.w, sc.w, sh.w) > 0.f) ? d.w : 0.f;
         }
         s0.x += d.x, s0.y += d.y, s0.z += d.z, s0.w += d.w;
         s1.x += d.x * xh.x, s1.y += d.y * xh.y, s1.z += d.z * xh.z, s1.w += d.w * xh.w;
@@ -92,8 +100,9 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_finalize(BnArgs a) {
       a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
       a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
     }
-    a.coef[c] = invstd * gm;                            // y = x * scale + shift
-    a.coef[a.C + c] = bb - (float)m * invstd * gm;
+    const float scale = invstd * gm;                    // y = x * scale + shift
+    a.coef[c] = scale;
+    a.coef[a.C + c] = bn_shift((float)m, scale, bb);
   } else {
     const float invstd = a.save_invstd[c], m = a.save_mean[c];
     a.dbeta[c] = (float)t0, a.dgamma[c] = (float)t1;
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply_fwd(BnArgs a) {
     const int c4 = (int)(i % C4);
     const float4 v = reinterpret_cast<const float4*>(a.x)[i];
     const float4 sc = reinterpret_cast<const float4*>(a.coef)[c4], sh = reinterpret_cast<const float4*>(a.coef + a.C)[c4];
-    float4 y = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    float4 y = make_float4(bn_act(v.x, sc.x, sh.x), bn_act(v.y, sc.y, sh.y), bn_act(v.z, sc.z, sh.z), bn_act(v.w, sc.w, sh.w));
     if (a.relu) y.x = fmaxf(y.x, 0.f), y.y = fmaxf(y.y, 0.f), y.z = fmaxf(y.z, 0.f), y.w = fmaxf(y.w, 0.f);
     reinterpret_cast<float4*>(a.out)[i] = y;
   }
@@ -132,8 +141,10 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply_bwd(BnArgs a) {
     if (a.relu) {
       const float4 g = a.gamma ? reinterpret_cast<const float4*>(a.gamma)[c4] : make_float4(1, 1, 1, 1);
       const float4 bt = a.beta ? reinterpret_cast<const float4*>(a.beta)[c4] : make_float4(0, 0, 0, 0);
-      d.x = (xh.x * g.x + bt.x > 0.f) ? d.x : 0.f, d.y = (xh.y * g.y + bt.y > 0.f) ? d.y : 0.f;
-      d.z = (xh.z * g.z + bt.z > 0.f) ? d.z : 0.f, d.w = (xh.w * g.w + bt.w > 0.f) ? d.w : 0.f;
+      const float4 sc = make_float4(istd.x * g.x, istd.y * g.y, istd.z * g.z, istd.w * g.w);       // the forward's scale / shift, bit for bit
+      const float4 sh = make_float4(bn_shift(m.x, sc.x, bt.x), bn_shift(m.y, sc.y, bt.y), bn_shift(m.z, sc.z, bt.z), bn_shift(m.w, sc.w, bt.w));
+      d.x = (bn_act(v.x, sc.x, sh.x) > 0.f) ? d.x : 0.f, d.y = (bn_act(v.y, sc.y, sh.y) > 0.f) ? d.y : 0.f;
+      d.z = (bn_act(v.z, sc.z, sh.z) > 0.f) ? d.z : 0.f, d.w = (bn_act(v.w, sc.w, sh.w) > 0.f) ? d.w : 0.f;
     }
     reinterpret_cast<float4*>(a.out)[i] = make_float4(k.x * (d.x - md.x - xh.x * mx.x), k.y * (d.y - md.y - xh.y * mx.y),
                                                       k.z * (d.z - md.z - xh.z * mx.z), k.w * (d.w - md.w - xh.w * mx.w));

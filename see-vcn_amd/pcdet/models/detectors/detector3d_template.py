@@ -141,9 +141,21 @@ class Detector3DTemplate(nn.Module):
     LOSS_HEADS = ('dense_head',)
 
     def run_modules(self, batch_dict):
-        if getattr(self, 'pfe', None) is not None and hasattr(self.pfe, 'prefetch_keypoints'):
-            self.pfe.prefetch_keypoints(batch_dict)                        # keypoint sampling on a side stream, beside the backbone
-        for module in self.module_list:
+        modules = list(self.module_list)
+        pfe = getattr(self, 'pfe', None)
+        if pfe is not None and hasattr(pfe, 'prefetch_keypoints'):
+            pfe.prefetch_keypoints(batch_dict)                             # keypoint sampling on a side stream, beside the backbones
+            if '_fps_prefetch' in batch_dict:
+                # The reference's topology (detector3d_template.py:34-37) puts the pfe in front of backbone_2d and dense_head, but neither reads a
+                # key the pfe writes (point_features, point_coords, point_features_before_fusion) nor writes one it reads (points, voxel_coords,
+                # multi_scale_3d_features, spatial_features): with the sampling in flight they run first, so that the pfe asks for the keypoints
+                # ~10 ms of GPU work after the sampling (7.9 ms) began instead of ~2 ms after.  Same batch_dict, same gradients.
+                i = j = modules.index(pfe)
+                independent = [m for m in (getattr(self, 'backbone_2d', None), getattr(self, 'dense_head', None)) if m is not None]
+                while j + 1 < len(modules) and any(modules[j + 1] is m for m in independent):
+                    j += 1
+                modules.insert(j, modules.pop(i))
+        for module in modules:
             batch_dict = module(batch_dict)
         return batch_dict
 
