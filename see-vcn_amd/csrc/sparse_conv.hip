@@ -864,7 +864,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int li = lane & 15, kk = lane >> 4;
   const int region = blockIdx.x % PL_REGIONS, lw = (blockIdx.x / PL_REGIONS) * 4 + wid;
-  const unsigned long long t_start = pv.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long t_start = (DBG && pv.trace) ? __builtin_amdgcn_s_memtime() : 0ull;    // per-wave stamps: debug instances only
   unsigned long long t_pro = 0ull, t_loop = 0ull;
   unsigned trace_work = 0;
   int32_t(*s_idx)[64] = s_idx_all[wid];
@@ -872,9 +872,10 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   const i32x4 srd_x = make_srd(a.X, x_bytes), srd_w = make_srd(wfrag, w_bytes);
   const int32_t* my_tiles = pv.tile_of + ((int64_t)region * PL_REGION_WAVES + lw) * (pv.d.n_pass * RS_G);
 
-  float bn0[NT], bn1[NT];                                  // this lane's column sums over all its rows (column 16 t + li)
-#pragma unroll
-  for (int t = 0; t < NT; ++t) bn0[t] = bn1[t] = 0.f;
+  // BatchNorm statistics: lane c < 16 NT sums column c of every tile the wave stores, read back from the staging tile row by row (fixed order).
+  // Two registers carried across the pass loop; the first version summed straight from the accumulators (column 16 t + li in lane (li, kk):
+  // 2 NT registers), which hipcc spilled around the main loop at four waves per SIMD.
+  float bn0 = 0.f, bn1 = 0.f;
 #pragma nounroll
   for (int pass = 0; pass < pv.d.n_pass; ++pass) {
   if (my_tiles[pass * RS_G] < 0) break;                    // slots are filled front to back: an empty first slot ends the wave's list
@@ -911,7 +912,9 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     maskreg = lane < a.K ? mk : 0u;
   }
   const unsigned long long active = __ballot(maskreg != 0);
-  if (pv.trace && pass == 0) t_pro = __builtin_amdgcn_s_memtime();
+  if constexpr (DBG) {
+    if (pv.trace && pass == 0) t_pro = __builtin_amdgcn_s_memtime();
+  }
 
   f32x4 acc[RS_G][NT];
 #pragma unroll
@@ -1051,12 +1054,18 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // retire the dummy loads before the registers are reused
   }
-  if (pv.trace) {
+  if (DBG && pv.trace) {
     t_loop = __builtin_amdgcn_s_memtime();
     for (int k = 0; k < a.K; ++k) trace_work += __popc((unsigned)__builtin_amdgcn_readlane((int)maskreg, k));
   }
   // D layout (16x16): col = lane&15, row = 4*(lane>>4) + reg
   const bool plain_out = !a.bias && !a.scale && !a.residual && !a.relu;       // the training layers: BatchNorm follows, nothing fused here
+  // An opaque copy of the lane id for the epilogue: its addresses (staging tile, output columns) are invariant over the pass loop, hipcc
+  // hoists them in front of it and then SPILLS them across the main loop (21 VGPRs, 43 MB of scratch traffic per launch by PMC) -- derived
+  // from a value defined here they are computed where they are used.
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int li_e = lane_e & 15, kk_e = lane_e >> 4;
   if (plain_out) {
     // Whole rows out: a tile goes through wave-private LDS (rows 0..16 of the neighbour-index block, free now; row RS3_KMAX = the output rows
     // stays) so that the 16 x NT lanes of a row store its 64 * NT bytes with one instruction.  Stored straight from the accumulators a row left
@@ -1071,15 +1080,20 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = acc[g][t][r];
-          T[(kk * 4 + r) * TP + t * 16 + li] = v;
-          bn0[t] += v, bn1[t] += v * v;                                // padding rows hold zeros
+          T[(kk_e * 4 + r) * TP + t * 16 + li_e] = acc[g][t][r];
         }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if (pv.bn_partial && (NT == 4 || lane_e < NT * 16)) {
+#pragma unroll
+        for (int rw = 0; rw < 16; ++rw) {
+          const float v = T[rw * TP + lane_e];                            // padding rows hold zeros
+          bn0 += v, bn1 += v * v;
+        }
+      }
       constexpr int C4N = NT * 4;                                     // 16-byte pieces per row
 #pragma unroll
       for (int i = 0; i < (16 * C4N + 63) / 64; ++i) {
-        const int f = lane + 64 * i, rw = f / C4N, c4 = f % C4N;
+        const int f = lane_e + 64 * i, rw = f / C4N, c4 = f % C4N;
         if (16 * C4N % 64 == 0 || f < 16 * C4N) {
           const int64_t row = s_idx[RS3_KMAX][g * 16 + rw];
           if (row >= 0) *reinterpret_cast<f32x4*>(a.Y + row * pv.nc_total + col_tile0 * 16 + c4 * 4) = *reinterpret_cast<const f32x4*>(T + rw * TP + c4 * 4);
@@ -1092,27 +1106,21 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     for (int g = 0; g < RS_G; ++g)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t row = s_idx[RS3_KMAX][g * 16 + kk * 4 + r];
+        const int64_t row = s_idx[RS3_KMAX][g * 16 + kk_e * 4 + r];
         if (row < 0) continue;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const int col = (col_tile0 + t) * 16 + li;
+          const int col = (col_tile0 + t) * 16 + li_e;
           a.Y[row * pv.nc_total + col] = conv_epilogue(acc[g][t][r], col, row, a);
         }
       }
   }
   }   // pass
   if (pv.bn_partial) {
-    // BatchNorm statistics of this launch's output: lane sums -> the wave (4 row groups) -> the workgroup (4 waves, fixed order) -> one partial
+    // BatchNorm statistics of this launch's output: lane c holds column c of its wave -> the workgroup (4 waves, fixed order) -> one partial
     // per workgroup and column, combined by k_bn_finalize in a fixed order
     __shared__ float s_bn[4][2][64];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float u = bn0[t], v = bn1[t];
-      u += __shfl_xor(u, 16), v += __shfl_xor(v, 16);
-      u += __shfl_xor(u, 32), v += __shfl_xor(v, 32);
-      if (kk == 0) s_bn[wid][0][t * 16 + li] = u, s_bn[wid][1][t * 16 + li] = v;
-    }
+    if (NT == 4 || lane < NT * 16) s_bn[wid][0][lane] = bn0, s_bn[wid][1][lane] = bn1;
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * NT * 16; e += 256) {
       const int which = e / (NT * 16), c = e % (NT * 16);
@@ -1120,7 +1128,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       pv.bn_partial[((size_t)blockIdx.x * 2 + which) * pv.nc_total + col_tile0 * 16 + c] = v;
     }
   }
-  if (pv.trace && lane == 0) {
+  if (DBG && pv.trace && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     unsigned hw = 0, xcc = 0;
@@ -1151,7 +1159,7 @@ template <int NT, int KQ>
 static void launch_rs3_g(const ConvArgs& a, const PlanView& pv, const float* wfrag, uint32_t xb, uint32_t wb, dim3 grid, hipStream_t st) {
   // tiles per pass: conv_tiles_per_wave (1 or 2 for the 64-column kernels, 4 for the narrow ones); the measurement switches of
   // SEEVCN_RS3_DEBUG live in instances of their own so that the production loop carries none of their tests
-  if (pv.debug) {
+  if (pv.debug || pv.trace) {
     if constexpr (NT == 4) {
       if (pv.d.G == 1) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 1, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
       else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
