@@ -1372,7 +1372,7 @@ __device__ __forceinline__ float wg_elem(const float& v, int) { return v; }
 // then MFMAs over the COMPACTED pairs only (4 pairs per 16x16x4 step) with the next step's operands requested first.
 // The four waves' accumulators are summed through LDS in a fixed order and one slab per (chunk, k) is stored.
 template <int CT, int NTL>  // register tile grid: CT x NTL tiles of 16x16 (rows = c_in, cols = c_out)
-__global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {
+__global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {      // tried: (256, 4) = 4 waves / SIMD at 122 VGPRs instead of 3 at 140 -- 4 % slower relative to the forward conv of the same run
   __shared__ int32_t pj[4][64 * WG_SUB], pr[4][64 * WG_SUB];
   __shared__ float red[CT * NTL * 256];
   // 1-D grid = (chunk fastest, offset, tile group).  SEEVCN_WGRAD_XCD=1 decodes it instead so that the chunks of one eighth of the rows run on
