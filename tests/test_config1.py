@@ -54,12 +54,19 @@ def test_hip_config1_vcn_on_the_demo_crops(golden_dir, cuda, hip_lib):
     # surface selection on the REFERENCE's coarse output: index sets must be identical -> bit-exact points
     surface, _ = sampling.get_partial_mesh_batch_device(x, torch.from_numpy(g["coarse"]).to(cuda), k=30)
     assert np.array_equal(surface.cpu().numpy(), g["surface"])
-    # and on this build's own coarse output (differs in the last bits): the selected sets may differ only where two distances nearly tie
-    # (one index more or less re-orders the whole CPython-set walk, so the comparison is between the point SETS of each object)
+    # and on this build's own coarse output (differs in the last bits): the selected sets may differ only where two distances nearly tie.
+    # One index more or less re-orders the whole CPython-set walk and the coordinates differ in their last bits, so the comparison is between
+    # the sets of selected ROWS of each object (a surface point is an exact copy of a row of the coarse cloud it was selected from).
     mine, _ = sampling.get_partial_mesh_batch_device(x, ret["coarse"], k=30)
+    my_coarse = ret["coarse"].cpu().numpy()
+
+    def rows_of(points, cloud):
+        where = {tuple(r): i for i, r in enumerate(cloud.tolist())}
+        return {where[tuple(r)] for r in points.tolist()}
+
     for b in range(len(g["surface"])):
-        want = {tuple(r) for r in g["surface"][b].tolist()}
-        got = {tuple(r) for r in mine[b].cpu().numpy().tolist()}
+        want = rows_of(g["surface"][b], g["coarse"][b])
+        got = rows_of(mine[b].cpu().numpy(), my_coarse[b])
         assert len(want & got) >= 0.98 * len(want | got), (b, len(want), len(got), len(want & got))
 
 

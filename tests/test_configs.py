@@ -220,7 +220,7 @@ def test_hip_train_step_gradients_of_sampled_stages_at_16_scenes(cuda, hip_lib):
     with torch.no_grad():                                                  # voxelised once (the mean's float atomics are not bit-reproducible)
         voxels = dyn_vfe({"batch_size": B, "points": torch.from_numpy(pts).to(cuda)})
     assert voxels["voxel_features"].shape[0] > 200_000
-    branches = {}
+    recorded = {}
 
     def step(chain_off, stats_in_conv=None):
         """one forward + backward; the stage boundaries (multi_scale_3d_features) with the gradient that reached them, and the parameter gradients"""
@@ -235,8 +235,8 @@ def test_hip_train_step_gradients_of_sampled_stages_at_16_scenes(cuda, hip_lib):
             if chain_off:                                                  # the ReLU branches every block of the sampled stages took
                 for name, blk in (("conv2", m.conv2), ("conv4", m.conv4)):
                     for i in range(3):
-                        hooks.append(blk[i].register_forward_hook(lambda _m, _i, out, k=f"{name}.{i}.0.weight": branches.__setitem__(k, out.features.detach() > 0)))
-                hooks.append(m.conv_out.register_forward_hook(lambda _m, _i, out: branches.__setitem__("conv_out.0.weight", out.features.detach() > 0)))
+                        hooks.append(blk[i].register_forward_hook(lambda _m, _i, out, k=f"{name}.{i}.0.weight": recorded.__setitem__(k, out.features.detach() > 0)))
+                hooks.append(m.conv_out.register_forward_hook(lambda _m, _i, out: recorded.__setitem__("conv_out.0.weight", out.features.detach() > 0)))
             bd = to_bev(m(bd))
             for h in hooks:
                 h.remove()
@@ -259,6 +259,7 @@ def test_hip_train_step_gradients_of_sampled_stages_at_16_scenes(cuda, hip_lib):
     # size when the statistics come from their own deterministic reduction pass, and (b) in its default configuration held to the oracle with the
     # absolute term of the tolerance widened from 2e-3 to 1e-2 of a channel's largest entry.
     taps, grads_modules = step(chain_off=True)
+    branches = dict(recorded)                                              # the branches of THIS run (the later module-path run records its own)
     taps_chain, grads_chain = step(chain_off=False)
     taps_b, grads_b = step(chain_off=True, stats_in_conv=False)
     taps_c, grads_c = step(chain_off=False, stats_in_conv=False)
