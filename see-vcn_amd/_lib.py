@@ -191,11 +191,36 @@ _sync_hooks = _threading.local()
 def host_int(t):
     """int(t.item()) -- a device -> host read that blocks the calling thread until the stream has produced t.  A caller that has other work to
     enqueue meanwhile (bench.py: the trained side of the previous batch) installs a hook with set_sync_hook(); it runs right before the read,
-    i.e. after the kernels that produce t were launched, so the wait is spent enqueueing instead of idling."""
+    i.e. after the kernels that produce t were launched, so the wait is spent enqueueing instead of idling.  Checks parked with defer_check()
+    ride on this read: their values come back in the same copy."""
     hook = getattr(_sync_hooks, "before", None)
     if hook is not None:
         hook()
-    return int(t.item())
+    pending = getattr(_sync_hooks, "checks", None)
+    if not pending:
+        return int(t.item())
+    _sync_hooks.checks = []
+    vals = torch.stack([t.reshape(()).to(torch.int64)] + [p.reshape(()).to(torch.int64) for p, _ in pending]).tolist()
+    for v, (_, fn) in zip(vals[1:], pending):
+        fn(int(v))
+    return int(vals[0])
+
+
+def defer_check(t, fn):
+    """Park a validity check on a 0-dim device integer: fn(value) runs (and may raise) at the calling thread's next host_int() or
+    flush_checks() -- on the SAME stream, whose order guarantees t is final by then -- instead of costing a blocking read of its own."""
+    if getattr(_sync_hooks, "checks", None) is None:
+        _sync_hooks.checks = []
+    _sync_hooks.checks.append((t, fn))
+
+
+def flush_checks():
+    """Run the parked checks now (one blocking read) -- for call sites that are not followed by a host_int()."""
+    pending = getattr(_sync_hooks, "checks", None)
+    if pending:
+        _sync_hooks.checks = []
+        for v, (_, fn) in zip(torch.stack([p.reshape(()).to(torch.int64) for p, _ in pending]).tolist(), pending):
+            fn(int(v))
 
 
 def set_sync_hook(fn):

@@ -1,5 +1,7 @@
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -138,6 +140,9 @@ def _sparse_convs(root):
     return hit[1]
 
 
+DEFER_INDEX_WORK = os.environ.get("SEEVCN_PREBUILD_DEFER", "1") != "0"     # 0: plans and submanifold rulebooks between the strided builders (A/B)
+
+
 def prebuild_rulebooks(root, x, with_backward=True):
     """Build every rulebook (and conv plan) a network will need on `x` BEFORE its layers run.  A strided rulebook needs the number of output
     sites on the host (to allocate the next level), i.e. a device -> host sync; done lazily inside the layer loop, each of those syncs waits
@@ -146,9 +151,16 @@ def prebuild_rulebooks(root, x, with_backward=True):
     by layer: spconv_backbone.py:141-157 is the caller).  `root` is walked in definition order, which is the execution order of the
     reference's backbones; convolutions without an indice_key end the walk (they are then handled lazily)."""
     idx, shape = x.indices, list(x.spatial_shape)
+    # Pass 1: only what the device -> host reads hang on -- the STRIDED rulebooks, each needing the output sites of the one before.  Everything
+    # else (submanifold rulebooks, all plans) is enqueued in pass 2, behind the last read: queued between the strided builders (round 2) it sat
+    # in front of every later read -- ~145 us of index kernels per level that the host waited for four times per step.
+    todo = []                                             # (module, its input indices, their shape) in execution order
     for m in _sparse_convs(root):
         if m.indice_key is None:
-            return
+            break
+        if m.subm and DEFER_INDEX_WORK:
+            todo.append((m, idx, list(shape)))
+            continue
         rb = x.indice_dict.get(m.indice_key)
         if rb is None:
             if m.subm:
@@ -158,12 +170,26 @@ def prebuild_rulebooks(root, x, with_backward=True):
             rb.in_indices, rb.in_shape = idx, list(shape)
             x.indice_dict[m.indice_key] = rb
         elif rb.in_indices is not idx:
-            return                                        # the key is bound to other indices: not the simple chain this walk assumes
+            break                                         # the key is bound to other indices: not the simple chain this walk assumes
+        if DEFER_INDEX_WORK:
+            todo.append((m, idx, list(shape)))
+        else:
+            rb.plan("fwd", m.in_channels, m.out_channels)
+            if with_backward:
+                rb.plan("bwd", m.out_channels, m.in_channels)
+        if not m.subm:
+            idx, shape = rb.out_indices, list(rb.out_shape)
+    for m, idx, shape in todo:                            # pass 2: no host reads from here on
+        rb = x.indice_dict.get(m.indice_key)
+        if rb is None:
+            rb = Fsp.build_subm_rulebook(idx, x.batch_size, shape, m.kernel_size, m.dilation)
+            rb.in_indices, rb.in_shape = idx, list(shape)
+            x.indice_dict[m.indice_key] = rb
+        elif rb.in_indices is not idx:
+            return
         rb.plan("fwd", m.in_channels, m.out_channels)
         if with_backward:
             rb.plan("bwd", m.out_channels, m.in_channels)
-        if not m.subm:
-            idx, shape = rb.out_indices, list(rb.out_shape)
 
 
 def refresh_weight_fragments(root):

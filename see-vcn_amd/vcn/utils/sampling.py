@@ -42,9 +42,15 @@ def get_partial_mesh_batch(batch_partial, batch_complete, k=20, surface_pts=1024
     return get_partial_mesh_batch_device(batch_partial, batch_complete, k, surface_pts)[0].cpu().numpy()
 
 
-def get_largest_cluster_batch_device(pc, eps=0.4, min_points=1, total_pts=1024):
+def _no_cluster(smallest):
+    if smallest == 0:
+        raise ValueError("attempt to get argmax of an empty sequence")
+
+
+def get_largest_cluster_batch_device(pc, eps=0.4, min_points=1, total_pts=1024, defer_check=False):
     """(B,n,3) CUDA tensor -> (B,total_pts,3) float32 tensor, cluster sizes (B) int32.  Raises ValueError (like the reference's
-    np.argmax over an empty bincount) if some object has no cluster at all."""
+    np.argmax over an empty bincount) if some object has no cluster at all -- at once, or with defer_check at the caller's next blocking
+    read on this stream (_lib.defer_check: the pipeline's voxel count follows within the same step)."""
     lib = _lib.load()
     _lib.require_cuda(pc)
     x = _as_device_f32(pc)
@@ -54,8 +60,11 @@ def get_largest_cluster_batch_device(pc, eps=0.4, min_points=1, total_pts=1024):
     cnt = torch.empty((B,), dtype=torch.int32, device=x.device)
     _lib.check(lib.sv_vcn_largest_cluster(_lib.ptr(x), B, x.shape[1], float(eps), int(min_points), int(total_pts), _lib.ptr(out), _lib.ptr(cnt),
                                           _lib.stream()), "sv_vcn_largest_cluster")
-    if B and _lib.host_int(cnt.min()) == 0:
-        raise ValueError("attempt to get argmax of an empty sequence")
+    if B:
+        if defer_check:
+            _lib.defer_check(cnt.min(), _no_cluster)
+        else:
+            _no_cluster(_lib.host_int(cnt.min()))
     return out, cnt
 
 
