@@ -319,6 +319,11 @@ int sv_group_points_grad_stack(int M, int C, int N, int nsample, const float* gr
  * ---------------------------------------------------------------------------------------------- */
 /* boxes_overlap_bev_gpu (iou=0) / boxes_iou_bev_gpu (iou=1): out (num_a, num_b) */
 int sv_boxes_overlap_bev(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* out, int iou, void* stream);
+/* boxes_iou3d_gpu (detector3d/pcdet/ops/iou3d_nms/iou3d_nms_utils.py:48-81: BEV overlap x height overlap / union volume, the elementwise chain
+ * around boxes_overlap_bev_gpu) in ONE launch, for `batch` independent box sets at once: boxes_a (batch, num_a, stride_a), boxes_b (batch, num_b,
+ * stride_b) rows whose first 7 floats are the box, out (batch, num_a, num_b). */
+int sv_boxes_iou3d_batch(const float* boxes_a, int num_a, int stride_a, const float* boxes_b, int num_b, int stride_b, int batch, float* out,
+                         void* stream);
 /* nms_gpu (normal=0, rotated BEV IoU) / nms_normal_gpu (normal=1, axis-aligned) over boxes ALREADY sorted by score:
  * keep (n) int64 device indices of the kept boxes in order, *num_out device int32.  Unlike the reference
  * (iou3d_nms.cpp:111-131: D2H copy of the mask + host sweep) the greedy sweep runs on the device. n <= 65536. */

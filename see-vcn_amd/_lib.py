@@ -85,6 +85,7 @@ SIGNATURES = {
     "sv_group_points_stack": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_group_points_grad_stack": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_boxes_overlap_bev": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p]),
+    "sv_boxes_iou3d_batch": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     "sv_nms_scratch_bytes": (c_sz, [c_i]),
     "sv_nms": (c_i, [c_p, c_i, c_f, c_i, c_p, c_p, c_p, c_p]),
     "sv_nms_prefix": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p, c_p]),

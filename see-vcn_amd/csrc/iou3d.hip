@@ -147,6 +147,44 @@ extern "C" int sv_boxes_overlap_bev(const float* boxes_a, int num_a, const float
   return SV_OK;
 }
 
+// 3-D IoU of every (a, b) pair of `batch` independent box sets: BEV overlap x height overlap / union volume, the arithmetic of the reference's
+// boxes_iou3d_gpu (iou3d_nms_utils.py:48-81) operation by operation -- there ~22 elementwise launches around the overlap kernel, per scene.
+// Boxes are rows of `stride` floats whose first 7 are [x,y,z,dx,dy,dz,heading] (ground-truth blocks carry a class column behind them).
+__global__ __launch_bounds__(256) void k_boxes_iou3d(int na, const float* __restrict__ A, int stride_a, int nb, const float* __restrict__ B, int stride_b,
+                                                     float* __restrict__ out) {
+  __shared__ RBox sb[64];
+  __shared__ float sbz[64][3];                                 // height max, height min, volume of the b boxes of the tile
+  const int scene = blockIdx.z;
+  A += (int64_t)scene * na * stride_a, B += (int64_t)scene * nb * stride_b, out += (int64_t)scene * na * nb;
+  const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 4;
+  if (threadIdx.x < 64 && col0 + threadIdx.x < nb) {
+    const float* b = B + (int64_t)(col0 + threadIdx.x) * stride_b;
+    sb[threadIdx.x] = make_rbox(b);
+    sbz[threadIdx.x][0] = b[2] + b[5] / 2.f, sbz[threadIdx.x][1] = b[2] - b[5] / 2.f, sbz[threadIdx.x][2] = b[3] * b[4] * b[5];
+  }
+  __syncthreads();
+  const int r = row0 + (threadIdx.x >> 6), c = col0 + (threadIdx.x & 63);
+  if (r >= na || c >= nb) return;
+  const float* a = A + (int64_t)r * stride_a;
+  const float a_hmax = a[2] + a[5] / 2.f, a_hmin = a[2] - a[5] / 2.f, vol_a = a[3] * a[4] * a[5];
+  const float* bz = sbz[threadIdx.x & 63];
+  const float overlap_bev = overlap_area(make_rbox(a), sb[threadIdx.x & 63]);
+  const float overlap_h = fmaxf(fminf(a_hmax, bz[0]) - fmaxf(a_hmin, bz[1]), 0.f);
+  const float overlap_3d = overlap_bev * overlap_h;
+  out[(int64_t)r * nb + c] = overlap_3d / fmaxf(vol_a + bz[2] - overlap_3d, 1e-6f);
+}
+
+extern "C" int sv_boxes_iou3d_batch(const float* boxes_a, int num_a, int stride_a, const float* boxes_b, int num_b, int stride_b, int batch, float* out,
+                                    void* stream) {
+  SV_CHECK_ARG(num_a >= 0 && num_b >= 0 && batch >= 0 && stride_a >= 7 && stride_b >= 7, "boxes_iou3d_batch: bad arguments");
+  if (num_a == 0 || num_b == 0 || batch == 0) return SV_OK;
+  SV_CHECK_ARG(boxes_a && boxes_b && out && batch <= 65535, "boxes_iou3d_batch: null pointer or more than 65535 box sets");
+  dim3 grid(sv_div_up(num_b, 64), sv_div_up(num_a, 4), batch);
+  hipLaunchKernelGGL(k_boxes_iou3d, grid, dim3(256), 0, sv_stream(stream), num_a, boxes_a, stride_a, num_b, boxes_b, stride_b, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 // ------------------------------------------------------------------ NMS: suppression masks (upper triangle)
 // one wave per 64x64 tile; lane = column box; each row contributes one ballot word
 // (row blocks rb0 + blockIdx.y of a chunked sweep; `done` non-null and set = an earlier chunk already kept max_keep boxes: nothing to do)

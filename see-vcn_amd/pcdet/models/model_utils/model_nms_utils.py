@@ -34,6 +34,7 @@ def class_agnostic_nms_padded(box_scores, box_preds, nms_config):
         z = torch.zeros((post,), dtype=torch.int64, device=box_scores.device)
         return z, z.bool()
     box_scores_nms, indices = torch.topk(box_scores, k=min(cfg_get(nms_config, 'NMS_PRE_MAXSIZE'), box_scores.shape[0]))
+    # torch.topk returns its values in descending order: the NMS need not sort them again
     keep, valid = iou3d_nms_utils.nms_gpu_padded(box_preds[indices][:, 0:7], box_scores_nms, cfg_get(nms_config, 'NMS_THRESH'), post,
-                                                 normal=cfg_get(nms_config, 'NMS_TYPE') == 'nms_normal_gpu')
+                                                 normal=cfg_get(nms_config, 'NMS_TYPE') == 'nms_normal_gpu', presorted=True)
     return indices[keep], valid

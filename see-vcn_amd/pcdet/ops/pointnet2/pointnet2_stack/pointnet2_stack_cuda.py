@@ -8,9 +8,29 @@ import torch
 from ..... import _lib
 
 
+def _version(t):
+    try:
+        return t._version
+    except RuntimeError:                                  # inference tensors keep no version counter: nothing is cached on them
+        return None
+
+
 def _starts(cnt):
-    cnt = cnt.to(torch.int32)
-    return (torch.cumsum(cnt, 0, dtype=torch.int32) - cnt).contiguous(), cnt.contiguous()
+    """(first row of every scene, rows per scene) as int32 device tensors.  A step asks for the same few count tensors again and again (every
+    scale of every source: 25 cumsum + 25 sub launches per PV-RCNN step), so the pair is kept on the count tensor OBJECT, keyed by its
+    version counter (an in-place change invalidates it)."""
+    ver = _version(cnt)
+    hit = getattr(cnt, "_sv_starts", None) if ver is not None else None
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    c32 = cnt.to(torch.int32).contiguous()
+    st = (torch.cumsum(c32, 0, dtype=torch.int32) - c32).contiguous()
+    if ver is not None:
+        try:
+            cnt._sv_starts = (ver, st, c32)
+        except Exception:                                 # a tensor subclass without instance attributes: no cache
+            pass
+    return st, c32
 
 
 BALL_HASH_MIN_POINTS = int(os.environ.get("SEEVCN_BALL_HASH_MIN", "2048"))   # support sets below this (or nsample > 64) are scanned like the reference does
@@ -38,8 +58,20 @@ def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, x
 
 def _row_start(idx_batch_cnt, features_batch_cnt, M):
     """first feature row of the scene each query belongs to (M,) int32"""
+    vf, vi = _version(features_batch_cnt), _version(idx_batch_cnt)
+    cacheable = vf is not None and vi is not None
+    cache = getattr(idx_batch_cnt, "_sv_row_start", None) if cacheable else None
+    key = (id(features_batch_cnt), vf, vi, int(M))
+    if cache is not None and cache[0] == key and cache[1] is features_batch_cnt:
+        return cache[2]
     fs, _ = _starts(features_batch_cnt)
-    return torch.repeat_interleave(fs, idx_batch_cnt.long(), output_size=int(M)).contiguous()
+    rs = torch.repeat_interleave(fs, idx_batch_cnt.long(), output_size=int(M)).contiguous()
+    if cacheable:
+        try:
+            idx_batch_cnt._sv_row_start = (key, features_batch_cnt, rs)  # the last support set asked for with these queries (scales come in a row)
+        except Exception:
+            pass
+    return rs
 
 
 def group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, out):

@@ -88,6 +88,17 @@ def test_hip_overlap_iou_iou3d(cuda, hip_lib):
     np.testing.assert_allclose(u.boxes_overlap_bev(ta, tb).cpu().numpy(), ob.boxes_overlap_bev(a, b), rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(u.boxes_iou_bev(ta, tb).cpu().numpy(), ob.boxes_iou_bev(a, b), rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(u.boxes_iou3d_gpu(ta, tb).cpu().numpy(), ob.boxes_iou3d(a, b), rtol=1e-3, atol=1e-4)
+    # the one-launch 3-D IoU == the reference's chain of torch ops around the overlap kernel, bit for bit; batched over scenes, rows of 8 floats
+    fused = u.boxes_iou3d_gpu(ta, tb)
+    saved, u.FUSED_IOU3D = u.FUSED_IOU3D, False
+    try:
+        assert torch.equal(fused, u.boxes_iou3d_gpu(ta, tb))
+    finally:
+        u.FUSED_IOU3D = saved
+    b8 = torch.cat([tb, torch.full((len(b), 1), 3.0, device=cuda)], dim=1)                  # ground-truth layout: a class column behind the box
+    both = u.boxes_iou3d_batch(torch.stack([ta, ta.flip(0)]), torch.stack([b8, b8.flip(0)]))
+    assert torch.equal(both[0], fused) and torch.equal(both[1], fused.flip(0).flip(1))
+    assert u.boxes_iou3d_gpu(ta[:0], tb).shape == (0, 77) and u.boxes_iou3d_batch(ta[None], b8[None, :0]).shape == (1, 300, 0)
     assert u.boxes_iou_bev(ta[:0], tb).shape == (0, 77)
     cpu = u.boxes_iou_bev_cpu(a, b)                                   # numpy in / numpy out, like the reference's CPU entry point
     assert isinstance(cpu, np.ndarray) and np.array_equal(cpu, u.boxes_iou_bev(ta, tb).cpu().numpy())
