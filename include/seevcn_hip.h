@@ -198,6 +198,14 @@ int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src, const int3
                                        const float* wfrag, float* Y, int64_t n_rows, int K, int Kd, int Nc, const float* bias,
                                        const float* scale, const float* shift, const float* residual, int relu, int table_k_reversed,
                                        float* bn_partial, void* stream);
+/* Data gradient on a plan whose output is the gradient of a BatchNorm1d(+ReLU) OUTPUT (the layer below in VoxelBackBone8x, spconv_backbone.py:8-27):
+ * the same kernel, and its epilogue also leaves the two per-channel sums of that BatchNorm's backward (sum of dy on the forward's ReLU branch,
+ * and of dy * xhat) as sv_conv_planned_partials() per-workgroup partials in bn_partial -- sv_batchnorm_relu_backward_partial starts at the
+ * combine.  bn_x = the BatchNorm's input (n_rows, Nc), bn_mean / bn_invstd its saved batch statistics, bn_gamma / bn_beta may be NULL. */
+int sv_sparse_conv_dgrad_planned_bn(const float* dZ, int64_t n_src, const int32_t* table_rows, const int32_t* perm, const int32_t* masks_p,
+                                    const int32_t* tile_of, int tiles_per_wave, const float* wfrag, float* dY, int64_t n_rows, int K, int Kd, int Nc,
+                                    int table_k_reversed, const float* bn_x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                    const float* bn_beta, int bn_relu, float* bn_partial, void* stream);
 /* bn_partial (null or sv_conv_planned_partials() x 2 x Nc floats; plain epilogue only: no bias / scale / residual / relu): per-workgroup column
  * sums and sums of squares of Y, the first pass of the training-mode BatchNorm behind the convolution (post_act_block, spconv_backbone.py:9-27)
  * made in the epilogue that holds the values in registers anyway; consumed by sv_batchnorm_relu_forward_partial. */
@@ -426,8 +434,11 @@ int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float*
  *   SV_OP_BN_FWD        sv_batchnorm_relu_forward (i3 = 0) / _forward_partial (i3 = number of partials): p = x, gamma, beta, running_mean,
  *                       running_var, scratch, y, save_mean, save_invstd, num_batches_tracked; n = rows; i = channels, training, relu, n_partials;
  *                       f = momentum, eps
- *   SV_OP_BN_BWD        sv_batchnorm_relu_backward: p = x, dy, gamma, beta, save_mean, save_invstd, scratch, dx, dgamma, dbeta; n = rows; i = channels, relu
+ *   SV_OP_BN_BWD        sv_batchnorm_relu_backward (i2 = 0) / _backward_partial (i2 = number of partials): p = x, dy, gamma, beta, save_mean,
+ *                       save_invstd, scratch, dx, dgamma, dbeta; n = rows; i = channels, relu, n_partials
  *   SV_OP_WGRAD         sv_sparse_conv_wgrad_strided: p = X, nbr, dY, dW, scratch; n = n_rows, stride_k, stride_cin, stride_cout; i = K, Cin, Cout
+ *   SV_OP_DGRAD_PLANNED_BN  sv_sparse_conv_dgrad_planned_bn: p = dZ, table_rows, perm, masks_p, tile_of, wfrag, dY, bn_x, bn_mean, bn_invstd, bn_gamma,
+ *                       bn_beta, bn_partial; n = n_src, n_rows; i = tiles_per_wave, K, Kd, Nc, table_k_reversed, bn_relu
  * Used by seevcn_amd/spconv/chain.py: the forward and the backward of a conv -> BatchNorm -> ReLU chain (VoxelBackBone8x, spconv_backbone.py:128-180)
  * as two calls inside one autograd node. */
 #define SV_OP_WORDS 32
@@ -436,6 +447,7 @@ int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float*
 #define SV_OP_BN_FWD 3
 #define SV_OP_BN_BWD 5
 #define SV_OP_WGRAD 6
+#define SV_OP_DGRAD_PLANNED_BN 7
 int sv_run_ops(const int64_t* ops, int n_ops, void* stream);
 
 /* ---- BatchNorm1d (+ReLU) on (N,C) voxel features: the norm_fn -> ReLU tail of post_act_block
@@ -456,6 +468,11 @@ int sv_batchnorm_relu_forward_partial(const float* x, int64_t n, int channels, c
 int sv_batchnorm_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, int relu, void* scratch, float* dx, float* dgamma,
                                float* dbeta, void* stream);
+/* sv_batchnorm_relu_backward with the first pass of its two sums already in `scratch` (n_partials workgroup partials behind the 4 * C coefficient
+ * floats, written by sv_sparse_conv_dgrad_planned_bn's epilogue): combine + elementwise pass only. */
+int sv_batchnorm_relu_backward_partial(const float* x, const float* dy, int64_t n, int channels, const float* gamma, const float* beta,
+                                       const float* save_mean, const float* save_invstd, int relu, void* scratch, int n_partials, float* dx,
+                                       float* dgamma, float* dbeta, void* stream);
 
 /* Ragged-group variant of sv_gemm_bias_act: row_group[M] (non-decreasing int32) names the group of every row; used after
  * sv_unique_rows, when each object keeps only its distinct points (ResamplePoints, vcn/datasets/data_transforms.py:254-262,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "sv_conv_plan_perm_bytes": (c_sz, [c_i64]),
     "sv_conv_plan_build": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     "sv_sparse_conv_gather_gemm_planned": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "sv_sparse_conv_dgrad_planned_bn": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     "sv_conv_planned_partials": (c_i, []),
     "sv_batchnorm_relu_forward_partial": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_debug_conv_trace": (c_i, [c_p]),
@@ -130,6 +131,7 @@ SIGNATURES = {
     "sv_batchnorm_scratch_bytes": (c_sz, [c_i]),
     "sv_batchnorm_relu_forward": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_batchnorm_relu_backward": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sv_batchnorm_relu_backward_partial": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
     "sv_run_ops": (c_i, [c_p, c_i, c_p]),
     "sv_anchor_decode": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p]),
     "sv_assign_targets_axis_aligned": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

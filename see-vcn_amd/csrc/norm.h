@@ -27,5 +27,11 @@ struct BnArgs {
   int64_t* num_batches_tracked;   // nn.BatchNorm1d's counter, incremented by the training forward (may be null)
 };
 
+// y = x * scale + shift, scale = invstd * gamma, shift = beta - mean * scale.  Every place that needs the ReLU branch of the forward (the backward
+// passes recompute it from x) must evaluate EXACTLY this expression -- same operations, same roundings -- or an activation within an ulp of zero
+// is "off" in the forward and "on" in the backward.  Hence explicit fused multiply-adds (no compiler contraction choices) in one place.
+__device__ __forceinline__ float bn_shift(float mean, float scale, float beta) { return __fmaf_rn(-mean, scale, beta); }
+__device__ __forceinline__ float bn_act(float x, float scale, float shift) { return __fmaf_rn(x, scale, shift); }
+
 void sv_bn_finalize_fwd(const BnArgs& a, hipStream_t st);   // partial (wgs,2,C) -> save_mean, save_invstd, running stats, coef = {scale, shift}
 void sv_bn_finalize_bwd(const BnArgs& a, hipStream_t st);   // partial -> dgamma, dbeta, coef = {gamma*invstd, mean(dy), mean(dy*xhat), mean}

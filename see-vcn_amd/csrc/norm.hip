@@ -10,12 +10,6 @@
 
 #include "norm.h"
 
-// y = x * scale + shift, scale = invstd * gamma, shift = beta - mean * scale.  The backward pass recomputes the ReLU branch from x: it must
-// evaluate EXACTLY the forward's expression (same operations, same roundings), or an activation within an ulp of zero is "off" in the forward
-// and "on" in the backward.  Hence the explicit fused multiply-adds (no compiler contraction choices) in one place.
-__device__ __forceinline__ float bn_shift(float mean, float scale, float beta) { return __fmaf_rn(-mean, scale, beta); }
-__device__ __forceinline__ float bn_act(float x, float scale, float shift) { return __fmaf_rn(x, scale, shift); }
-
 // per-thread: channels c4*4..c4*4+3 of rows (row0 + tid / C4) + k * R
 template <bool BWD>
 __global__ __launch_bounds__(BN_THREADS) void k_bn_reduce(BnArgs a) {
@@ -247,6 +241,28 @@ extern "C" int sv_batchnorm_relu_backward(const float* x, const float* dy, int64
   bn_scratch(a, scratch);
   hipStream_t st = sv_stream(stream);
   hipLaunchKernelGGL(k_bn_reduce<true>, dim3(a.wgs), dim3(BN_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_bn_finalize<true>, dim3(channels), dim3(BN_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_bn_apply_bwd, dim3(sv_grid_1d(n * (channels / 4), BN_THREADS)), dim3(BN_THREADS), 0, st, a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// The same backward with the two per-channel sums' first pass already done: `scratch` holds n_partials per-workgroup partial sums
+// (n_partials, 2, C) = {sum of masked dy, sum of masked dy * xhat} behind its 4 * C coefficient floats -- written there by the epilogue of the
+// data-gradient convolution that produced dy (sv_sparse_conv_dgrad_planned_bn).  Two launches instead of three, x and dy read once.
+extern "C" int sv_batchnorm_relu_backward_partial(const float* x, const float* dy, int64_t n, int channels, const float* gamma, const float* beta,
+                                                  const float* save_mean, const float* save_invstd, int relu, void* scratch, int n_partials, float* dx,
+                                                  float* dgamma, float* dbeta, void* stream) {
+  if (int rc = bn_common_check("sv_batchnorm_relu_backward_partial", n, channels)) return rc;
+  SV_CHECK_ARG(x && dy && dx && dgamma && dbeta && save_mean && save_invstd && scratch, "sv_batchnorm_relu_backward_partial: null pointer");
+  SV_CHECK_ARG(n_partials >= 1 && n_partials <= BN_MAX_WGS, "sv_batchnorm_relu_backward_partial: 1..%d partials (got %d)", BN_MAX_WGS, n_partials);
+  BnArgs a{};
+  a.x = x, a.dy = dy, a.out = dx, a.gamma = gamma, a.beta = beta, a.dgamma = dgamma, a.dbeta = dbeta;
+  a.save_mean = const_cast<float*>(save_mean), a.save_invstd = const_cast<float*>(save_invstd);
+  a.n = n, a.C = channels, a.relu = relu;
+  a.wgs = n_partials;
+  bn_scratch(a, scratch);
+  hipStream_t st = sv_stream(stream);
   hipLaunchKernelGGL(k_bn_finalize<true>, dim3(channels), dim3(BN_THREADS), 0, st, a);
   hipLaunchKernelGGL(k_bn_apply_bwd, dim3(sv_grid_1d(n * (channels / 4), BN_THREADS)), dim3(BN_THREADS), 0, st, a);
   SV_LAUNCH_CHECK();

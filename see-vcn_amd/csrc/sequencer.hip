@@ -54,7 +54,19 @@ extern "C" int sv_run_ops(const int64_t* ops, int n_ops, void* stream) {
                                          ptr_of<float>(p[4]), (float)as_double(f[0]), (float)as_double(f[1]), (int)i[1], (int)i[2], ptr_of<void>(p[5]),
                                          ptr_of<float>(p[6]), ptr_of<float>(p[7]), ptr_of<float>(p[8]), ptr_of<int64_t>(p[9]), stream);
         break;
+      case SV_OP_DGRAD_PLANNED_BN:
+        rc = sv_sparse_conv_dgrad_planned_bn(ptr_of<const float>(p[0]), n[0], ptr_of<const int32_t>(p[1]), ptr_of<const int32_t>(p[2]),
+                                             ptr_of<const int32_t>(p[3]), ptr_of<const int32_t>(p[4]), (int)i[0], ptr_of<const float>(p[5]),
+                                             ptr_of<float>(p[6]), n[1], (int)i[1], (int)i[2], (int)i[3], (int)i[4], ptr_of<const float>(p[7]),
+                                             ptr_of<const float>(p[8]), ptr_of<const float>(p[9]), ptr_of<const float>(p[10]), ptr_of<const float>(p[11]),
+                                             (int)i[5], ptr_of<float>(p[12]), stream);
+        break;
       case SV_OP_BN_BWD:
+        if (i[2] > 0)
+          rc = sv_batchnorm_relu_backward_partial(ptr_of<const float>(p[0]), ptr_of<const float>(p[1]), n[0], (int)i[0], ptr_of<const float>(p[2]),
+                                                  ptr_of<const float>(p[3]), ptr_of<const float>(p[4]), ptr_of<const float>(p[5]), (int)i[1],
+                                                  ptr_of<void>(p[6]), (int)i[2], ptr_of<float>(p[7]), ptr_of<float>(p[8]), ptr_of<float>(p[9]), stream);
+        else
         rc = sv_batchnorm_relu_backward(ptr_of<const float>(p[0]), ptr_of<const float>(p[1]), n[0], (int)i[0], ptr_of<const float>(p[2]),
                                         ptr_of<const float>(p[3]), ptr_of<const float>(p[4]), ptr_of<const float>(p[5]), (int)i[1], ptr_of<void>(p[6]),
                                         ptr_of<float>(p[7]), ptr_of<float>(p[8]), ptr_of<float>(p[9]), stream);

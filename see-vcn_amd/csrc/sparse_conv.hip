@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "norm.h"
 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -851,6 +852,15 @@ struct PlanView {
   int k_flip;               // read table entry K-1-k for offset k (a submanifold table serving its own data gradient)
   int nc_total;             // columns of Y and of the weight fragments (a.Nc is the block's share)
   float* bn_partial;        // (gridDim.x, 2, nc_total) per-workgroup column sums / sums of squares of Y, or null (BatchNorm statistics made here)
+  // BatchNorm BACKWARD sums instead (a data-gradient launch whose output Y is the gradient dy of a BatchNorm(+ReLU) output): bn_x = that
+  // BatchNorm's input (n_rows, nc_total), its saved batch statistics and affine parameters; the partials are {sum of masked dy, sum of masked
+  // dy * xhat} -- what k_bn_reduce<true> makes in a pass of its own.  bn_x null: forward statistics of Y.
+  const float* bn_x;
+  const float* bn_mean;
+  const float* bn_istd;
+  const float* bn_gamma;    // may be null (1)
+  const float* bn_beta;     // may be null (0)
+  int bn_relu;
   int debug;                // measurement only (SEEVCN_RS3_DEBUG; results are wrong): 1 no gathered-row loads, 2 no weight loads, 4 no MFMAs,
                             // 8 / 16 weight / row loads of a wave all at ONE address (one cache line per load instead of 16)
   unsigned long long* trace;   // measurement only (sv_debug_conv_trace): 8 words per wave, or null
@@ -1084,10 +1094,29 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
         }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       if (pv.bn_partial && (NT == 4 || lane_e < NT * 16)) {
+        if (pv.bn_x) {
+          // backward sums of the BatchNorm whose output gradient this tile is: x rows of the tile (whole 64 NT-byte runs, one per row)
+          const int col = col_tile0 * 16 + lane_e;
+          const float mean = pv.bn_mean[col], istd = pv.bn_istd[col];
+          const float sc = istd * (pv.bn_gamma ? pv.bn_gamma[col] : 1.f), sh = bn_shift(mean, sc, pv.bn_beta ? pv.bn_beta[col] : 0.f);
+          float xv[16];
 #pragma unroll
-        for (int rw = 0; rw < 16; ++rw) {
-          const float v = T[rw * TP + lane_e];                            // padding rows hold zeros
-          bn0 += v, bn1 += v * v;
+          for (int rw = 0; rw < 16; ++rw) {
+            const int row = __builtin_amdgcn_readfirstlane(s_idx[RS3_KMAX][g * 16 + rw]);
+            xv[rw] = row >= 0 ? pv.bn_x[(int64_t)row * pv.nc_total + col] : 0.f;
+          }
+#pragma unroll
+          for (int rw = 0; rw < 16; ++rw) {
+            float d = T[rw * TP + lane_e];                                // padding rows hold zeros
+            if (pv.bn_relu) d = bn_act(xv[rw], sc, sh) > 0.f ? d : 0.f;
+            bn0 += d, bn1 += d * ((xv[rw] - mean) * istd);
+          }
+        } else {
+#pragma unroll
+          for (int rw = 0; rw < 16; ++rw) {
+            const float v = T[rw * TP + lane_e];                          // padding rows hold zeros
+            bn0 += v, bn1 += v * v;
+          }
         }
       }
       constexpr int C4N = NT * 4;                                     // 16-byte pieces per row
@@ -1192,11 +1221,13 @@ extern "C" int sv_debug_conv_trace(void* buf) {
   return SV_OK;
 }
 
-extern "C" int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src, const int32_t* table_rows, const int32_t* perm, const int32_t* masks_p,
-                                                  const int32_t* tile_of, int tiles_per_wave,
-                                                  const float* wfrag, float* Y, int64_t n_rows, int K, int Kd, int Nc, const float* bias,
-                                                  const float* scale, const float* shift, const float* residual, int relu, int table_k_reversed,
-                                                  float* bn_partial, void* stream) {
+struct BnBwdView {            // the BatchNorm whose output gradient a data-gradient launch produces (PlanView's bn_* fields)
+  const float *x, *mean, *istd, *gamma, *beta;
+  int relu;
+};
+static int conv_planned(const float* X, int64_t n_src, const int32_t* table_rows, const int32_t* perm, const int32_t* masks_p, const int32_t* tile_of,
+                        int tiles_per_wave, const float* wfrag, float* Y, int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale,
+                        const float* shift, const float* residual, int relu, int table_k_reversed, float* bn_partial, const BnBwdView* bnb, void* stream) {
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Kd > 0 && Nc > 0, "sparse_conv (planned): bad sizes");
   SV_CHECK_ARG(!bn_partial || (!bias && !scale && !residual && !relu), "sparse_conv (planned): BatchNorm partial sums are made by the plain epilogue only");
   if (n_rows == 0) return SV_OK;
@@ -1209,6 +1240,8 @@ extern "C" int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src,
   ConvArgs a{X, nullptr, nullptr, Y, bias, scale, shift, residual, relu, n_rows, K, Kd, Nc};
   PlanView pv;
   pv.tab = table_rows, pv.perm = perm, pv.masks_p = masks_p, pv.tile_of = tile_of, pv.d = plan_dims(n_rows, tiles_per_wave), pv.k_flip = table_k_reversed ? 1 : 0, pv.nc_total = Nc, pv.bn_partial = bn_partial;
+  pv.bn_x = pv.bn_mean = pv.bn_istd = pv.bn_gamma = pv.bn_beta = nullptr, pv.bn_relu = 0;
+  if (bnb) pv.bn_x = bnb->x, pv.bn_mean = bnb->mean, pv.bn_istd = bnb->istd, pv.bn_gamma = bnb->gamma, pv.bn_beta = bnb->beta, pv.bn_relu = bnb->relu;
   static const int debug = getenv("SEEVCN_RS3_DEBUG") ? atoi(getenv("SEEVCN_RS3_DEBUG")) : 0;
   pv.debug = debug;
   pv.trace = g_conv_trace;
@@ -1223,6 +1256,29 @@ extern "C" int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src,
   }
   SV_LAUNCH_CHECK();
   return SV_OK;
+}
+
+extern "C" int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src, const int32_t* table_rows, const int32_t* perm, const int32_t* masks_p,
+                                                  const int32_t* tile_of, int tiles_per_wave,
+                                                  const float* wfrag, float* Y, int64_t n_rows, int K, int Kd, int Nc, const float* bias,
+                                                  const float* scale, const float* shift, const float* residual, int relu, int table_k_reversed,
+                                                  float* bn_partial, void* stream) {
+  return conv_planned(X, n_src, table_rows, perm, masks_p, tile_of, tiles_per_wave, wfrag, Y, n_rows, K, Kd, Nc, bias, scale, shift, residual, relu,
+                      table_k_reversed, bn_partial, nullptr, stream);
+}
+
+// The data gradient of a layer whose INPUT came out of a BatchNorm (+ReLU): Y (n_rows, Nc) is the gradient w.r.t. that BatchNorm's output, and
+// the launch's epilogue also leaves the two per-channel sums of the BatchNorm's backward -- sum(dy * branch) and sum(dy * branch * xhat), branch
+// = the forward's ReLU decision recomputed from bn_x with the forward's own expression -- as sv_conv_planned_partials() per-workgroup partials in
+// bn_partial, laid out like sv_batchnorm_relu_backward's scratch: sv_batchnorm_relu_backward_partial starts at the combine.
+extern "C" int sv_sparse_conv_dgrad_planned_bn(const float* dZ, int64_t n_src, const int32_t* table_rows, const int32_t* perm, const int32_t* masks_p,
+                                               const int32_t* tile_of, int tiles_per_wave, const float* wfrag, float* dY, int64_t n_rows, int K, int Kd,
+                                               int Nc, int table_k_reversed, const float* bn_x, const float* bn_mean, const float* bn_invstd,
+                                               const float* bn_gamma, const float* bn_beta, int bn_relu, float* bn_partial, void* stream) {
+  SV_CHECK_ARG(bn_x && bn_mean && bn_invstd && bn_partial, "sparse_conv_dgrad_planned_bn: null pointer");
+  const BnBwdView bnb{bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_relu ? 1 : 0};
+  return conv_planned(dZ, n_src, table_rows, perm, masks_p, tile_of, tiles_per_wave, wfrag, dY, n_rows, K, Kd, Nc, nullptr, nullptr, nullptr, nullptr, 0,
+                      table_k_reversed, bn_partial, &bnb, stream);
 }
 
 // Generic VALU path for channel counts the MFMA tiling does not cover (e.g. the C_in = 3 input layer):

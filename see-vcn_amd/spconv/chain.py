@@ -18,7 +18,11 @@ from . import functional as Fsp
 from . import norm
 
 CHAIN_OFF = os.environ.get("SEEVCN_CHAIN", "1") == "0"          # 0: every block through its own modules (A/B runs, tests)
-OP_CONV_PLANNED, OP_CONV_PLAIN, OP_BN_FWD, OP_BN_BWD, OP_WGRAD = 1, 2, 3, 5, 6
+# 1: a BatchNorm backward takes its two per-channel sums from the epilogue of the data-gradient launch above it (sv_sparse_conv_dgrad_planned_bn)
+# instead of reducing them in a pass of its own.  Built, tested, and OFF by default: same-box A/B 5.13-5.26 ms without, 5.26-5.56 ms with -- the
+# 11 saved reduce launches (12 us each) are paid back by the epilogues' 16 extra row reads per tile (conv launches +3.4 .. +8.6 us each).
+BWD_SUMS_IN_CONV = os.environ.get("SEEVCN_BN_BWD_IN_CONV", "0") == "1"
+OP_CONV_PLANNED, OP_CONV_PLAIN, OP_BN_FWD, OP_BN_BWD, OP_WGRAD, OP_DGRAD_PLANNED_BN = 1, 2, 3, 5, 6, 7
 WORDS = 32
 
 
@@ -176,6 +180,7 @@ class SparseChainFunction(torch.autograd.Function):
         wscratch = _lib.workspace.scratch("wgrad", wbytes, dev)
         base, abase, wbase = work.data_ptr(), arena.data_ptr(), wgrads.data_ptr()
         rows = []
+        n_part, n_part_bwd = lib.sv_conv_planned_partials(), 0          # n_part_bwd: partials the data-gradient launch above left for this BatchNorm
         dy_ptr = ext[L - 1].data_ptr()
         for k in range(L - 1, -1, -1):
             b, rb = blocks[k], rulebooks[k]
@@ -184,16 +189,29 @@ class SparseChainFunction(torch.autograd.Function):
             a_conv, a_y, a_mean, a_istd = (abase + 4 * v for v in offs[k])
             x_in = features.data_ptr() if k == 0 else abase + 4 * offs[k - 1][1]
             scratch = norm._scratch(b.cout, dev)
-            rows.append(_row(OP_BN_BWD, i=(b.cout, int(b.relu)), n=(rb.n_out,),
+            rows.append(_row(OP_BN_BWD, i=(b.cout, int(b.relu), n_part_bwd), n=(rb.n_out,),
                              p=(a_conv, dy_ptr, gamma.data_ptr(), beta.data_ptr(), a_mean, a_istd, scratch.data_ptr(), o_dconv, o_dg, o_db)))
+            n_part_bwd = 0
             rows.append(_row(OP_WGRAD, i=(b.K, b.cin, b.cout), n=(rb.n_out, b.cin, 1, b.K * b.cin),
                              p=(x_in, rb.nbr_out.data_ptr(), o_dconv, wbase + 4 * woffs[k], wscratch.data_ptr())))
             if k > 0:
                 tp, tile_of, g, rev = rb.plan("bwd", b.cout, b.cin)
                 res = ext[k - 1]
-                rows.append(_row(OP_CONV_PLANNED, i=(g, b.K, b.cout, b.cin, 0, int(bool(rev))), n=(rb.n_out, rb.n_in),
-                                 p=(o_dconv, tp.rows.data_ptr(), tp.perm.data_ptr(), tp.masks_p.data_ptr(), tile_of.data_ptr(), frags[k].data_ptr(), o_dx, None, None,
-                                    None, None if res is None else res.data_ptr(), None)))
+                if res is None and norm.STATS_IN_CONV and BWD_SUMS_IN_CONV:
+                    # the gradient this launch writes is the whole gradient of block k-1's output: its epilogue also makes the two sums of that
+                    # block's BatchNorm backward (the rows' x comes from the arena), and the BatchNorm op below starts at the combine
+                    lo = blocks[k - 1]
+                    p_conv, _, p_mean, p_istd = (abase + 4 * v for v in offs[k - 1])
+                    g_lo, b_lo = params[3 * (k - 1) + 1], params[3 * (k - 1) + 2]
+                    partial = norm._scratch(lo.cout, dev).data_ptr() + 16 * lo.cout
+                    rows.append(_row(OP_DGRAD_PLANNED_BN, i=(g, b.K, b.cout, b.cin, int(bool(rev)), int(lo.relu)), n=(rb.n_out, rb.n_in),
+                                     p=(o_dconv, tp.rows.data_ptr(), tp.perm.data_ptr(), tp.masks_p.data_ptr(), tile_of.data_ptr(), frags[k].data_ptr(), o_dx,
+                                        p_conv, p_mean, p_istd, g_lo.data_ptr(), b_lo.data_ptr(), partial)))
+                    n_part_bwd = n_part
+                else:
+                    rows.append(_row(OP_CONV_PLANNED, i=(g, b.K, b.cout, b.cin, 0, int(bool(rev))), n=(rb.n_out, rb.n_in),
+                                     p=(o_dconv, tp.rows.data_ptr(), tp.perm.data_ptr(), tp.masks_p.data_ptr(), tile_of.data_ptr(), frags[k].data_ptr(), o_dx, None,
+                                        None, None, None if res is None else res.data_ptr(), None)))
                 dy_ptr = o_dx
         _run(rows, "sv_run_ops (chain backward)")
         out = [None, None, None]

@@ -639,3 +639,51 @@ def test_hip_backbone_chain_equals_the_module_path(cuda, hip_lib):
         assert torch.equal(g1, g2), n1
     for (n1, _), b1, b2 in zip(net1.named_buffers(), a[3], b[3]):
         assert torch.equal(b1, b2), n1
+
+
+@pytest.mark.gpu
+def test_hip_chain_with_statistics_in_the_conv_epilogues_matches_the_separate_passes(cuda, hip_lib):
+    """Default chain: BatchNorm's forward statistics come out of the conv epilogue and its BACKWARD sums out of the epilogue of the data-gradient
+    launch above (sv_sparse_conv_dgrad_planned_bn + sv_batchnorm_relu_backward_partial).  Same numbers as the chain with every BatchNorm making
+    its sums in passes of its own, up to the summation order (plan order instead of row order): 1e-5 of each tensor's largest entry."""
+    import copy
+    import seevcn_amd.synth as synth
+    from seevcn_amd.pcdet.models import backbones_3d
+    from seevcn_amd.pcdet.ops import voxel_ops
+    from seevcn_amd.spconv import chain, norm
+    pts, _ = synth.make_scene_batch(2, seed=2001, n_az=120)
+    g = dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.05, 0.05, 0.1], grid_size=[1408, 1600, 40])
+    f, c, _ = voxel_ops.voxelize_dynamic(torch.from_numpy(pts).to(cuda), g["point_cloud_range"], g["voxel_size"], g["grid_size"], 2)
+    torch.manual_seed(1)
+    net1 = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size']).to(cuda).train()
+    with torch.no_grad():                                                  # negative and positive gammas, non-zero betas: both ReLU branches matter
+        for m in net1.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(-1.5, 1.5), m.bias.uniform_(-0.5, 0.5)
+    net2, net3 = copy.deepcopy(net1), copy.deepcopy(net1)
+    res, indice_dict = [], None
+    # run 1: default.  run 2: forward statistics in the conv epilogue, backward sums in passes of their own -- on the same plans the forward is
+    # bit-identical (same ReLU branches), so the gradients differ by the summation order only.  run 3: nothing in the conv epilogues.
+    for net, in_conv, bwd_in_conv in ((net1, True, True), (net2, True, False), (net3, False, False)):
+        saved, norm.STATS_IN_CONV = norm.STATS_IN_CONV, in_conv
+        saved_off, chain.CHAIN_OFF = chain.CHAIN_OFF, False
+        saved_bwd, chain.BWD_SUMS_IN_CONV = chain.BWD_SUMS_IN_CONV, bwd_in_conv
+        try:
+            bd = {'batch_size': 2, 'voxel_features': f.clone(), 'voxel_coords': c.clone()}
+            if indice_dict is not None:
+                bd['spconv_indice_dict'] = indice_dict                    # same rulebooks and plans for all runs
+            bd = net(bd)
+            indice_dict = bd['encoded_spconv_tensor'].indice_dict
+            out, x3 = bd['encoded_spconv_tensor'].features, bd['multi_scale_3d_features']['x_conv3'].features
+            (out.square().sum() + (x3 * 0.5).sum()).backward()           # the x_conv3 tap carries an outside gradient: that block keeps its own pass
+        finally:
+            norm.STATS_IN_CONV, chain.CHAIN_OFF, chain.BWD_SUMS_IN_CONV = saved, saved_off, saved_bwd
+        res.append((out.detach(), [p.grad.clone() for p in net.parameters()]))
+    (o1, g1), (o2, g2), (o3, g3) = res
+    assert torch.equal(o1, o2)
+    for (name, _), a, b in zip(net1.named_parameters(), g1, g2):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7, (name, float((a - b).abs().max()), float(b.abs().max()))
+    # against the fully separate passes a handful of the 10^6 activations may take the other ReLU branch (statistics equal to ~1e-7 only)
+    assert float((o1 - o3).abs().max()) <= 1e-5 * float(o3.abs().max())
+    for (name, _), a, b in zip(net1.named_parameters(), g1, g3):
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-7, (name, float((a - b).abs().max()), float(b.abs().max()))
