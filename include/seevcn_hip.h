@@ -391,6 +391,16 @@ size_t sv_bev_interpolate_grad_scratch_bytes(int batch, int C, int H, int W);
 int sv_bev_interpolate_grad(const float* keypoints, int64_t num_keypoints, const float* grad_out, int batch, int C, int H, int W,
                             float x_min, float y_min, float voxel_x, float voxel_y, float bev_stride, void* scratch, float* grad_bev, void* stream);
 
+/* SigmoidFocalClassificationLoss.forward (detector3d/pcdet/utils/loss_utils.py:9-72: alpha-balanced sigmoid focal loss, un-reduced) and its
+ * derivative w.r.t. the logits, one launch each instead of ~20 / ~30 elementwise ones.  input, target (n_rows, num_class), weights (n_rows) or
+ * NULL.  grad_out NULL: out = loss (n_rows, num_class); grad_out given: out = grad_out * d loss / d input. */
+int sv_sigmoid_focal_loss(const float* input, const float* target, const float* weights, int64_t n_rows, int num_class, float alpha, float gamma,
+                          const float* grad_out, float* out, void* stream);
+/* WeightedSmoothL1Loss.forward (loss_utils.py:75-136: code-wise weighted smooth-L1, nan targets ignored, un-reduced) and its derivative w.r.t.
+ * input.  input, target (n_rows, num_codes), code_weights (num_codes) or NULL, weights (n_rows) or NULL; grad_out as above. */
+int sv_weighted_smooth_l1_loss(const float* input, const float* target, const float* code_weights, const float* weights, int64_t n_rows,
+                               int num_codes, float beta, const float* grad_out, float* out, void* stream);
+
 /* CenterHead.assign_targets (detector3d/pcdet/models/dense_heads/center_head.py:103-213; gaussian_radius /
  * draw_gaussian_to_heatmap, models/model_utils/centernet_utils.py:9-69): all heads and scenes in one launch.
  * gt_boxes (B,G,box_dim) with the global 1-based class id in the last column (0 = padding); cls_to_local

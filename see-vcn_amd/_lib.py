@@ -96,6 +96,8 @@ SIGNATURES = {
     "sv_pillar_decorate": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "sv_bev_interpolate": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
     "sv_bev_interpolate_grad_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "sv_sigmoid_focal_loss": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_p, c_p, c_p]),
+    "sv_weighted_smooth_l1_loss": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_p, c_p, c_p]),
     "sv_bev_interpolate_grad": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     "sv_center_assign_targets": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_p, c_p, c_p,
                                        c_p, c_p]),

@@ -437,3 +437,88 @@ extern "C" int sv_center_assign_targets(const float* gt_boxes, int batch, int ma
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Loss functions of the heads as one launch per direction.  The reference evaluates them as chains of elementwise torch ops
+// (detector3d/pcdet/utils/loss_utils.py:9-136: 20 launches forward and ~30 in autograd's backward for the focal loss, 10 + 15 for the smooth-L1)
+// on tensors of a few hundred thousand elements: launch-bound on any GPU.  Same arithmetic here, operation by operation in the forward; the
+// backward is the analytic derivative w.r.t. the prediction (targets and weights are constants, as in the reference's use).
+// ------------------------------------------------------------------------------------------------------------------------------------------
+struct FocalTerm {
+  float alpha_w, pt, p, bce;
+};
+__device__ __forceinline__ FocalTerm focal_terms(float x, float t, float alpha) {
+  FocalTerm f;
+  f.p = 1.f / (1.f + expf(-x));                                        // torch.sigmoid
+  f.alpha_w = t * alpha + (1.f - t) * (1.f - alpha);
+  f.pt = t * (1.f - f.p) + (1.f - t) * f.p;
+  f.bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));             // max(x, 0) - x z + log(1 + exp(-|x|))
+  return f;
+}
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_sigmoid_focal(int64_t total, int C, const float* __restrict__ x, const float* __restrict__ t,
+                                                        const float* __restrict__ w, float alpha, float gamma, const float* __restrict__ gout,
+                                                        float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float xv = x[i], tv = t[i], wv = w ? w[i / C] : 1.f;
+    const FocalTerm f = focal_terms(xv, tv, alpha);
+    const float mod = gamma == 2.f ? f.pt * f.pt : powf(f.pt, gamma);  // torch.pow(pt, 2.0) is a square
+    if (!GRAD) {
+      out[i] = f.alpha_w * mod * f.bce * wv;
+    } else {
+      // d/dx [alpha_w pt^gamma bce] = alpha_w (gamma pt^(gamma-1) pt' bce + pt^gamma bce'),  pt' = (1 - 2 t) p (1 - p),  bce' = p - t -- written
+      // the way autograd differentiates max(x, 0) - x t + log1p(exp(-|x|)), so that a logit of exactly 0 gets the reference's sub-gradient
+      // (clamp passes the gradient at its bound, |x| has slope 0 at 0: 1 - t there, not 1/2 - t)
+      const float dmod = gamma == 2.f ? 2.f * f.pt : (f.pt > 0.f ? gamma * powf(f.pt, gamma - 1.f) : 0.f);
+      const float dpt = (1.f - 2.f * tv) * f.p * (1.f - f.p);
+      const float e = expf(-fabsf(xv));
+      const float dbce = (xv >= 0.f ? 1.f : 0.f) - tv - (xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f)) * (e / (1.f + e));
+      out[i] = gout[i] * wv * f.alpha_w * (dmod * dpt * f.bce + mod * dbce);
+    }
+  }
+}
+
+extern "C" int sv_sigmoid_focal_loss(const float* input, const float* target, const float* weights, int64_t n_rows, int num_class, float alpha, float gamma,
+                                     const float* grad_out, float* out, void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && num_class > 0, "sigmoid_focal_loss: bad sizes");
+  if (n_rows == 0) return SV_OK;
+  SV_CHECK_ARG(input && target && out, "sigmoid_focal_loss: null pointer");
+  const int64_t total = n_rows * num_class;
+  const dim3 grid(sv_grid_1d(total, 256, 256 * 16));
+  if (grad_out) hipLaunchKernelGGL(k_sigmoid_focal<true>, grid, dim3(256), 0, sv_stream(stream), total, num_class, input, target, weights, alpha, gamma, grad_out, out);
+  else hipLaunchKernelGGL(k_sigmoid_focal<false>, grid, dim3(256), 0, sv_stream(stream), total, num_class, input, target, weights, alpha, gamma, nullptr, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_weighted_smooth_l1(int64_t total, int C, const float* __restrict__ x, const float* __restrict__ t,
+                                                             const float* __restrict__ cw, const float* __restrict__ w, float beta,
+                                                             const float* __restrict__ gout, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float xv = x[i], tr = t[i];
+    const float tv = isnan(tr) ? xv : tr;                               // nan targets are ignored (loss_utils.py:117)
+    const float cwv = cw ? cw[i % C] : 1.f, wv = w ? w[i / C] : 1.f;
+    const float d = (xv - tv) * cwv, n = fabsf(d);
+    if (!GRAD) {
+      const float l = beta < 1e-5f ? n : (n < beta ? 0.5f * (n * n) / beta : n - 0.5f * beta);
+      out[i] = l * wv;
+    } else {
+      const float dl = isnan(tr) ? 0.f : (beta < 1e-5f || n >= beta ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : d / beta);
+      out[i] = gout[i] * wv * cwv * dl;
+    }
+  }
+}
+
+extern "C" int sv_weighted_smooth_l1_loss(const float* input, const float* target, const float* code_weights, const float* weights, int64_t n_rows,
+                                          int num_codes, float beta, const float* grad_out, float* out, void* stream) {
+  SV_CHECK_ARG(n_rows >= 0 && num_codes > 0, "weighted_smooth_l1_loss: bad sizes");
+  if (n_rows == 0) return SV_OK;
+  SV_CHECK_ARG(input && target && out, "weighted_smooth_l1_loss: null pointer");
+  const int64_t total = n_rows * num_codes;
+  const dim3 grid(sv_grid_1d(total, 256, 256 * 16));
+  if (grad_out) hipLaunchKernelGGL(k_weighted_smooth_l1<true>, grid, dim3(256), 0, sv_stream(stream), total, num_codes, input, target, code_weights, weights, beta, grad_out, out);
+  else hipLaunchKernelGGL(k_weighted_smooth_l1<false>, grid, dim3(256), 0, sv_stream(stream), total, num_codes, input, target, code_weights, weights, beta, nullptr, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -1,8 +1,72 @@
 """RPN losses with the reference's class names and call signatures (detector3d/pcdet/utils/loss_utils.py:9-206)."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from ... import _lib
+
+
+FUSED_LOSS = os.environ.get("SEEVCN_FUSED_LOSS", "1") != "0"     # 0: the reference's chains of torch ops also on the GPU (A/B, tests)
+
+
+class _FocalFunction(torch.autograd.Function):
+    """SigmoidFocalClassificationLoss.forward and its derivative w.r.t. the logits as one launch each (sv_sigmoid_focal_loss); targets and
+    weights are constants, as everywhere the reference calls it."""
+
+    @staticmethod
+    def forward(ctx, input, target, weights, alpha, gamma):
+        lib = _lib.load()
+        x, t = input.contiguous().float(), target.contiguous().float()
+        w = None if weights is None else weights.contiguous().float()
+        c = x.shape[-1]
+        out = torch.empty_like(x)
+        _lib.check(lib.sv_sigmoid_focal_loss(_lib.ptr(x), _lib.ptr(t), _lib.ptr(w), x.numel() // c, c, float(alpha), float(gamma), None, _lib.ptr(out),
+                                             _lib.stream()), "sv_sigmoid_focal_loss")
+        ctx.save_for_backward(x, t, w)
+        ctx.alpha, ctx.gamma = float(alpha), float(gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        x, t, w = ctx.saved_tensors
+        g = grad_out.contiguous().float()
+        c = x.shape[-1]
+        gin = torch.empty_like(x)
+        _lib.check(lib.sv_sigmoid_focal_loss(_lib.ptr(x), _lib.ptr(t), _lib.ptr(w), x.numel() // c, c, ctx.alpha, ctx.gamma, _lib.ptr(g), _lib.ptr(gin),
+                                             _lib.stream()), "sv_sigmoid_focal_loss (gradient)")
+        return gin, None, None, None, None
+
+
+class _SmoothL1Function(torch.autograd.Function):
+    """WeightedSmoothL1Loss.forward and its derivative w.r.t. the prediction as one launch each (sv_weighted_smooth_l1_loss)."""
+
+    @staticmethod
+    def forward(ctx, input, target, code_weights, weights, beta):
+        lib = _lib.load()
+        x, t = input.contiguous().float(), target.contiguous().float()
+        w = None if weights is None else weights.contiguous().float()
+        c = x.shape[-1]
+        out = torch.empty_like(x)
+        _lib.check(lib.sv_weighted_smooth_l1_loss(_lib.ptr(x), _lib.ptr(t), _lib.ptr(code_weights), _lib.ptr(w), x.numel() // c, c, float(beta), None,
+                                                  _lib.ptr(out), _lib.stream()), "sv_weighted_smooth_l1_loss")
+        ctx.save_for_backward(x, t, code_weights, w)
+        ctx.beta = float(beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        x, t, cw, w = ctx.saved_tensors
+        g = grad_out.contiguous().float()
+        c = x.shape[-1]
+        gin = torch.empty_like(x)
+        _lib.check(lib.sv_weighted_smooth_l1_loss(_lib.ptr(x), _lib.ptr(t), _lib.ptr(cw), _lib.ptr(w), x.numel() // c, c, ctx.beta, _lib.ptr(g), _lib.ptr(gin),
+                                                  _lib.stream()), "sv_weighted_smooth_l1_loss (gradient)")
+        return gin, None, None, None, None
 
 
 class SigmoidFocalClassificationLoss(nn.Module):
@@ -18,6 +82,9 @@ class SigmoidFocalClassificationLoss(nn.Module):
         return torch.clamp(input, min=0) - input * target + torch.log1p(torch.exp(-torch.abs(input)))
 
     def forward(self, input, target, weights):
+        if (FUSED_LOSS and input.is_cuda and input.dtype == torch.float32 and not target.requires_grad and not weights.requires_grad
+                and target.shape == input.shape and weights.numel() * input.shape[-1] == input.numel()):
+            return _FocalFunction.apply(input, target, weights, self.alpha, self.gamma)           # one launch per direction, same arithmetic
         p = torch.sigmoid(input)
         alpha_w = target * self.alpha + (1 - target) * (1 - self.alpha)
         pt = target * (1.0 - p) + (1.0 - target) * p
@@ -42,6 +109,12 @@ class WeightedSmoothL1Loss(nn.Module):
         return n if beta < 1e-5 else torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
 
     def forward(self, input, target, weights=None):
+        if (FUSED_LOSS and input.is_cuda and input.dtype == torch.float32 and not target.requires_grad and target.shape == input.shape
+                and (weights is None or (not weights.requires_grad and weights.numel() * input.shape[-1] == input.numel()))
+                and (self.code_weights is None or self.code_weights.numel() == input.shape[-1])):
+            if self.code_weights is not None and self.code_weights.device != input.device:
+                self.code_weights = self.code_weights.to(input.device)
+            return _SmoothL1Function.apply(input, target, self.code_weights, weights, self.beta)
         target = torch.where(torch.isnan(target), input, target)  # ignore nan targets
         diff = input - target
         if self.code_weights is not None:

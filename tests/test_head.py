@@ -132,3 +132,44 @@ def test_hip_second_net_train_and_eval(cuda, hip_lib):
         # identical selection unless two scores tie exactly (sort order of ties is implementation-defined)
         if len(np.unique(scores[m])) == len(m):
             np.testing.assert_allclose(got, boxes[keep], rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+def test_hip_fused_losses_match_the_reference_op_chains(cuda, hip_lib):
+    """SigmoidFocalClassificationLoss / WeightedSmoothL1Loss as one launch per direction (sv_sigmoid_focal_loss, sv_weighted_smooth_l1_loss)
+    against the reference's chains of torch ops with autograd (loss_utils.py:9-136): values and gradients w.r.t. the predictions."""
+    from seevcn_amd.pcdet.utils import loss_utils
+    g = torch.Generator().manual_seed(3)
+    B, A, C = 3, 5000, 3
+    x = (torch.randn(B, A, C, generator=g) * 4.0).to(cuda)
+    x[0, :10] = torch.tensor([0.0, 30.0, -30.0])                            # saturated and exactly-zero logits
+    t = torch.nn.functional.one_hot(torch.randint(0, C + 1, (B, A), generator=g), C + 1)[..., 1:].float().to(cuda)
+    w = torch.rand(B, A, generator=g).to(cuda)
+    go = torch.randn(B, A, C, generator=g).to(cuda)
+    focal = loss_utils.SigmoidFocalClassificationLoss(alpha=0.25, gamma=2.0)
+    codes = 8
+    reg = loss_utils.WeightedSmoothL1Loss(code_weights=[1.0, 1.0, 1.0, 2.0, 0.5, 1.0, 1.0, 3.0])
+    p = (torch.randn(B, A, codes, generator=g) * 0.3).to(cuda)
+    q = (torch.randn(B, A, codes, generator=g) * 0.3).to(cuda)
+    q[1, :50, 2] = float("nan")                                             # ignored targets
+    q[2, :50] = p[2, :50]                                                   # zero differences
+    go2 = torch.randn(B, A, codes, generator=g).to(cuda)
+    res = {}
+    for fused in (True, False):
+        saved, loss_utils.FUSED_LOSS = loss_utils.FUSED_LOSS, fused
+        try:
+            xi, pi = x.clone().requires_grad_(True), p.clone().requires_grad_(True)
+            lf = focal(xi, t, w)
+            lf.backward(go)
+            lr = reg(pi, q, w)
+            lr.backward(go2)
+            lr2 = reg(p, q)                                                 # no anchor weights
+            res[fused] = (lf.detach(), xi.grad, lr.detach(), pi.grad, lr2)
+        finally:
+            loss_utils.FUSED_LOSS = saved
+    for name, a, b in zip(("focal", "focal gradient", "smooth-L1", "smooth-L1 gradient", "smooth-L1 without weights"), res[True], res[False]):
+        assert a.shape == b.shape and torch.isfinite(a).all(), name
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-6 * float(b.abs().max()), err_msg=name)
+    # the point head's call shape: (N, C) logits, (N,) weights
+    xi = x[0].clone().requires_grad_(True)
+    assert focal(xi, t[0], w[0]).shape == (A, C)
