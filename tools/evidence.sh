@@ -2,7 +2,7 @@
 # usage (on the GPU box, from the repo root): tools/evidence.sh <tag>      e.g. r02_a
 # One call that leaves everything profiles/ holds for a round under gpurun_out/: the default bench line, the rocprofv3 kernel stats of the
 # same command (whole process + steady steps), the PMC traffic passes, the side-mode bench lines with their steady kernel tables, and the
-# micro-benchmarks (per-layer sparse conv, FPS).
+# micro-benchmarks (per-layer sparse conv, FPS), the host-time split, the blocking-read traces and the launch sites of the PV-RCNN step.
 TAG=$1
 cd $GRAFT_REPO_ROOT
 timeout 900 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
@@ -19,4 +19,7 @@ cut -c1-220 gpurun_out/${TAG}_side_modes.jsonl
 timeout 300 python3 tools/spconv_micro.py > gpurun_out/${TAG}_spconv_micro.txt 2>&1
 timeout 120 python3 tools/fps_micro.py > gpurun_out/${TAG}_fps_micro.txt 2>&1
 tail -3 gpurun_out/${TAG}_spconv_micro.txt
+timeout 300 python3 tools/host_time.py > gpurun_out/${TAG}_host_time.txt 2>&1
+for c in pvrcnn centerpoint second; do timeout 300 python3 tools/sync_trace.py $c > gpurun_out/${TAG}_sync_trace_$c.txt 2>&1; done
+timeout 300 python3 tools/launch_sites.py pvrcnn 40 > gpurun_out/${TAG}_launch_sites_pvrcnn.txt 2>&1
 rm -rf gpurun_out/${TAG}_pmc_FETCH_SIZE gpurun_out/${TAG}_pmc_WRITE_SIZE gpurun_out/prof_*.log
