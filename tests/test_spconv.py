@@ -687,3 +687,39 @@ def test_hip_chain_with_statistics_in_the_conv_epilogues_matches_the_separate_pa
     assert float((o1 - o3).abs().max()) <= 1e-5 * float(o3.abs().max())
     for (name, _), a, b in zip(net1.named_parameters(), g1, g3):
         assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-7, (name, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.gpu
+def test_hip_launch_list_executor_runs_in_order_and_reports_errors(cuda, hip_lib):
+    """sv_run_ops: a list of BatchNorm forward rows equals the same calls made one by one (same kernels, same arguments); an unknown code and a
+    failing operation stop the list with the library's error text; an empty list is fine."""
+    from seevcn_amd import _lib
+    from seevcn_amd.spconv import chain, norm
+    g = torch.Generator().manual_seed(0)
+    n, c = 5000, 32
+    x = torch.randn(n, c, generator=g).to(cuda)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(cuda), torch.randn(c, generator=g).to(cuda)
+
+    def stats():
+        return torch.zeros(c, device=cuda), torch.ones(c, device=cuda), torch.zeros((), dtype=torch.int64, device=cuda)
+
+    rm1, rv1, nb1 = stats()
+    y1, mean1, istd1 = norm.bn_forward_raw(x, gamma, beta, rm1, rv1, 0.01, 1e-3, True, True, nb1)
+    z1, _, _ = norm.bn_forward_raw(y1, gamma, beta, rm1, rv1, 0.01, 1e-3, True, False, nb1)
+    rm2, rv2, nb2 = stats()
+    y2, z2 = torch.empty_like(x), torch.empty_like(x)
+    m2, i2, m3, i3 = (torch.empty(c, device=cuda) for _ in range(4))
+    scratch = norm._scratch(c, cuda)
+    me = (chain._bits(0.01), chain._bits(1e-3))
+    rows = [chain._row(chain.OP_BN_FWD, i=(c, 1, 1, 0), n=(n,), f=me, p=(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm2.data_ptr(), rv2.data_ptr(),
+                                                                     scratch.data_ptr(), y2.data_ptr(), m2.data_ptr(), i2.data_ptr(), nb2.data_ptr())),
+            chain._row(chain.OP_BN_FWD, i=(c, 1, 0, 0), n=(n,), f=me, p=(y2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm2.data_ptr(), rv2.data_ptr(),
+                                                                     scratch.data_ptr(), z2.data_ptr(), m3.data_ptr(), i3.data_ptr(), nb2.data_ptr()))]
+    chain._run(rows, "two BatchNorm rows")
+    assert torch.equal(y1, y2) and torch.equal(z1, z2) and torch.equal(mean1, m2) and torch.equal(istd1, i2)
+    assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2) and int(nb2) == 2 == int(nb1)
+    chain._run([], "empty list")
+    with pytest.raises(_lib.SeevcnHipError, match="unknown operation 99 at position 1"):
+        chain._run([rows[0], chain._row(99)], "bad code")
+    with pytest.raises(_lib.SeevcnHipError, match="null pointer"):
+        chain._run([chain._row(chain.OP_BN_FWD, i=(c, 1, 1, 0), n=(n,), f=me)], "null pointers")
