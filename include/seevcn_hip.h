@@ -135,6 +135,17 @@ int sv_rulebook_sparse(const int32_t* coords, int64_t n_in, int batch, const int
                        const int32_t* ksize_host, const int32_t* stride_host, const int32_t* padding_host,
                        const int32_t* dilation_host, void* index_ws, void* scratch, int32_t* out_coords,
                        int32_t* nbr_in, int32_t* in_block, int64_t capacity, int32_t* num_out, void* stream);
+/* The two halves of sv_rulebook_sparse (K <= 27), for a CHAIN of strided layers (spconv_backbone.py:141-157: conv2, conv3, conv4, conv_out):
+ * count = mark the output cells + count + scan -> *num_out on the device; the inputs are either `coords` (n_in rows) or, with coords NULL,
+ * the occupancy bitmap of the level below (`below_index_ws`: that level's index after ITS count and before its fill) -- so every level of the
+ * chain can be counted before any output-site count is read, and ONE device -> host read serves the whole chain.
+ * fill = look-up (nbr_in, in_block, out_coords) + returning the index to all-zero, for an index that holds exactly these coords' marks. */
+int sv_rulebook_sparse_count(const int32_t* coords, int64_t n_in, const void* below_index_ws, int batch, const int32_t* in_shape,
+                             const int32_t* ksize, const int32_t* stride, const int32_t* padding, const int32_t* dilation, void* index_ws,
+                             void* scratch, int32_t* num_out, void* stream);
+int sv_rulebook_sparse_fill(const int32_t* coords, int64_t n_in, int batch, const int32_t* in_shape, const int32_t* ksize, const int32_t* stride,
+                            const int32_t* padding, const int32_t* dilation, void* index_ws, int32_t* out_coords, int32_t* nbr_in,
+                            int32_t* in_block, int64_t capacity, void* stream);
 /* phase 2 (after the caller knows n_out): nbr_out (K, n_out) output-major table from nbr_in */
 int sv_rulebook_invert(const int32_t* nbr_in, int64_t n_in, int K, int32_t* nbr_out, int64_t n_out, void* stream);
 /* The same inversion (K <= 27) from the row-major input table (sv_rulebook_sparse's in_block) that also writes the row-major twin and the

@@ -41,6 +41,8 @@ SIGNATURES = {
     "sv_cellmap_persistent_bytes": (c_sz, [c_i, c_p]),
     "sv_rulebook_subm_cellmap": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_rulebook_sparse": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
+    "sv_rulebook_sparse_count": (c_i, [c_p, c_i64, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sv_rulebook_sparse_fill": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "sv_rulebook_invert": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p]),
     "sv_rulebook_invert_rows": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p]),
     "sv_rulebook_pair_counts": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
@@ -209,6 +211,19 @@ def host_int(t):
     for v, (_, fn) in zip(vals[1:], pending):
         fn(int(v))
     return int(vals[0])
+
+
+def host_ints(tensors):
+    """[int(t) for t in tensors] with ONE blocking device -> host read (same hook and parked checks as host_int)."""
+    hook = getattr(_sync_hooks, "before", None)
+    if hook is not None:
+        hook()
+    pending = getattr(_sync_hooks, "checks", None) or []
+    _sync_hooks.checks = []
+    vals = torch.stack([t.reshape(()).to(torch.int64) for t in tensors] + [p.reshape(()).to(torch.int64) for p, _ in pending]).tolist()
+    for v, (_, fn) in zip(vals[len(tensors):], pending):
+        fn(int(v))
+    return [int(v) for v in vals[:len(tensors)]]
 
 
 def defer_check(t, fn):

@@ -388,12 +388,9 @@ __device__ __forceinline__ AxisCand axis_candidates(const int4 c, const ConvGeom
 }
 __device__ __forceinline__ bool small_kernel(const ConvGeom& g) { return g.ksize[0] <= 3 && g.ksize[1] <= 3 && g.ksize[2] <= 3; }
 
+// every output cell input coordinate c reaches: set its bit (no-return atomic) or, clear != 0, return its word and chunk count to zero
 template <bool FULL3>   // FULL3: 3x3x3 kernel, offsets decomposed at compile time
-__global__ __launch_bounds__(RB_THREADS) void k_sparse_mark_rows(const int4* __restrict__ coords, int64_t n, ConvGeom g, SvIndexView ix, int clear) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int4 c = coords[i];
-  if (!coord_ok(c, g.batch, g.in_shape)) return;
+__device__ __forceinline__ void sparse_mark_one(const int4 c, const ConvGeom& g, const SvIndexView& ix, int clear) {
   const int kyx = g.ksize[1] * g.ksize[2];
   const bool small = FULL3 || small_kernel(g);            // wave-uniform
   const AxisCand ac = small ? axis_candidates(c, g) : AxisCand{};
@@ -418,6 +415,41 @@ __global__ __launch_bounds__(RB_THREADS) void k_sparse_mark_rows(const int4* __r
           __hip_atomic_fetch_or(&ix.words[key >> 5].x, 1u << (key & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // result unused: no-return atomic
         }
       }
+    }
+  }
+}
+
+template <bool FULL3>
+__global__ __launch_bounds__(RB_THREADS) void k_sparse_mark_rows(const int4* __restrict__ coords, int64_t n, ConvGeom g, SvIndexView ix, int clear) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = coords[i];
+  if (!coord_ok(c, g.batch, g.in_shape)) return;
+  sparse_mark_one<FULL3>(c, g, ix, clear);
+}
+
+// The same marks with the inputs taken from the OCCUPANCY BITMAP of the level below (a strided rulebook's index that has been marked and
+// counted but not cleared yet) instead of from its list of coordinates: the list needs the number of sites on the host, the bitmap does not, so
+// a chain of strided levels can be counted end to end with ONE device -> host read (sv_rulebook_sparse_count).  32 lanes per chunk of the
+// lower bitmap; empty chunks are skipped by their count.
+template <bool FULL3>
+__global__ __launch_bounds__(RB_THREADS) void k_sparse_mark_from_index(SvIndexView below, ConvGeom g, SvIndexView ix) {
+  const int lane = threadIdx.x & 31;
+  const int64_t nchunks = (below.ncells + 1023) / 1024;
+  const int64_t sub = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5, nsub = ((int64_t)gridDim.x * blockDim.x) >> 5;
+  const int64_t yx = (int64_t)g.in_shape[1] * g.in_shape[2], zyx = yx * g.in_shape[0];
+  for (int64_t cc = sub; cc < nchunks; cc += nsub) {
+    if (below.chunk_cnt[cc] == 0) continue;
+    const int64_t w = cc * SV_CHUNK_WORDS + lane;
+    uint32_t bits = below.words[w].x;
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1u;
+      const int64_t key = w * 32 + b;                     // lin_key of the lower level: ((batch * Z + z) * Y + y) * X + x
+      if (key >= below.ncells) break;
+      const int64_t r = key % zyx;
+      const int4 c = make_int4((int)(key / zyx), (int)(r / yx), (int)((r % yx) / g.in_shape[2]), (int)(r % g.in_shape[2]));
+      sparse_mark_one<FULL3>(c, g, ix, 0);
     }
   }
 }
@@ -505,6 +537,71 @@ extern "C" int sv_conv_out_shape(const int32_t* in_shape_host, const int32_t* ks
   int rc = fill_geom(g, 1, in_shape_host, ksize_host, stride_host, padding_host, dilation_host, false);
   if (rc) return rc;
   for (int d = 0; d < 3; ++d) out_shape_host[d] = g.out_shape[d];
+  return SV_OK;
+}
+
+// ---- a strided rulebook in two halves (K <= 27): count = mark + count + scan (-> *num_out on the device), fill = look-up + clear.
+// sv_rulebook_sparse below is count followed by fill; a CHAIN of strided levels runs every level's count first -- level l + 1 marks from level
+// l's bitmap (below_index_ws) -- reads all the counts at once and then fills level by level with exactly sized tables.
+extern "C" int sv_rulebook_sparse_count(const int32_t* coords, int64_t n_in, const void* below_index_ws, int batch, const int32_t* in_shape_host,
+                                        const int32_t* ksize_host, const int32_t* stride_host, const int32_t* padding_host,
+                                        const int32_t* dilation_host, void* index_ws, void* scratch, int32_t* num_out, void* stream) {
+  SV_CHECK_ARG(batch > 0 && num_out && index_ws && scratch && (coords != nullptr) != (below_index_ws != nullptr),
+               "rulebook_sparse_count: needs the index, the scratch, num_out and EITHER the coordinates or the index of the level below");
+  ConvGeom g;
+  int rc = fill_geom(g, batch, in_shape_host, ksize_host, stride_host, padding_host, dilation_host, false);
+  if (rc) return rc;
+  SV_CHECK_ARG(g.K <= RB_KMAX, "rulebook_sparse_count: K <= %d", RB_KMAX);
+  hipStream_t st = sv_stream(stream);
+  const int64_t ncells = (int64_t)batch * g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+  SvIndexView ix = sv_index_view(index_ws, ncells);
+  const int64_t nchunks = sv_index_nchunks(ncells);
+  const bool full3 = g.ksize[0] == 3 && g.ksize[1] == 3 && g.ksize[2] == 3;
+  if (coords) {
+    SV_CHECK_ARG(n_in >= 0, "rulebook_sparse_count: bad n_in");
+    if (n_in > 0) {
+      const int rows_grid = sv_div_up(n_in, RB_THREADS);
+      const int4* c4 = reinterpret_cast<const int4*>(coords);
+      if (full3) hipLaunchKernelGGL(k_sparse_mark_rows<true>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 0);
+      else hipLaunchKernelGGL(k_sparse_mark_rows<false>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 0);
+    }
+  } else {
+    const int64_t below_cells = (int64_t)batch * g.in_shape[0] * g.in_shape[1] * g.in_shape[2];
+    SvIndexView below = sv_index_view(const_cast<void*>(below_index_ws), below_cells);
+    const dim3 grid(sv_grid_1d(sv_index_nchunks(below_cells) * 32, RB_THREADS, 256 * 16));
+    if (full3) hipLaunchKernelGGL(k_sparse_mark_from_index<true>, grid, dim3(RB_THREADS), 0, st, below, g, ix);
+    else hipLaunchKernelGGL(k_sparse_mark_from_index<false>, grid, dim3(RB_THREADS), 0, st, below, g, ix);
+  }
+  hipLaunchKernelGGL(k_index_count, dim3(sv_grid_1d(nchunks * 32, RB_THREADS, 256 * 16)), dim3(RB_THREADS), 0, st, ix, nchunks);
+  rc = sv_index_scan_launch(ix, num_out, scratch, st);
+  if (rc) return rc;
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_rulebook_sparse_fill(const int32_t* coords, int64_t n_in, int batch, const int32_t* in_shape_host, const int32_t* ksize_host,
+                                       const int32_t* stride_host, const int32_t* padding_host, const int32_t* dilation_host, void* index_ws,
+                                       int32_t* out_coords, int32_t* nbr_in, int32_t* in_block, int64_t capacity, void* stream) {
+  SV_CHECK_ARG(n_in >= 0 && batch > 0 && capacity >= 0 && index_ws, "rulebook_sparse_fill: bad arguments");
+  if (n_in == 0) return SV_OK;
+  SV_CHECK_ARG(coords && out_coords && nbr_in, "rulebook_sparse_fill: null pointer");
+  ConvGeom g;
+  int rc = fill_geom(g, batch, in_shape_host, ksize_host, stride_host, padding_host, dilation_host, false);
+  if (rc) return rc;
+  SV_CHECK_ARG(g.K <= RB_KMAX, "rulebook_sparse_fill: K <= %d", RB_KMAX);
+  hipStream_t st = sv_stream(stream);
+  const int64_t ncells = (int64_t)batch * g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+  SvIndexView ix = sv_index_view(index_ws, ncells);
+  const int4* c4 = reinterpret_cast<const int4*>(coords);
+  int4* oc4 = reinterpret_cast<int4*>(out_coords);
+  const int rows_grid = sv_div_up(n_in, RB_THREADS);
+  const bool full3 = g.ksize[0] == 3 && g.ksize[1] == 3 && g.ksize[2] == 3;
+  int32_t* masks_in = in_block ? in_block + (size_t)RB_ROW * n_in : nullptr;
+  if (full3) hipLaunchKernelGGL(k_sparse_lookup_rows<true>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, nbr_in, oc4, capacity, in_block, masks_in);
+  else hipLaunchKernelGGL(k_sparse_lookup_rows<false>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, nbr_in, oc4, capacity, in_block, masks_in);
+  if (full3) hipLaunchKernelGGL(k_sparse_mark_rows<true>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 1);
+  else hipLaunchKernelGGL(k_sparse_mark_rows<false>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 1);
+  SV_LAUNCH_CHECK();
   return SV_OK;
 }
 

@@ -140,6 +140,11 @@ def _sparse_convs(root):
     return hit[1]
 
 
+# 1: the strided rulebooks of a backbone counted end to end on the device, ONE blocking read for all their output-site counts
+# (Fsp.build_sparse_rulebook_chain).  Built, bit-exact, and OFF: same-box A/B headline 5.05-5.25 ms without, 5.18-5.36 with; PV-RCNN 43.0 -> 48.5 ms,
+# CenterPoint 23.9 -> 25.3 -- marking level l + 1 from level l's occupancy bitmap gives a lane 0..32 inputs (one word) where the list-driven
+# kernel gives every lane exactly one, and that costs more than the four saved round trips bring.
+CHAIN_READS = os.environ.get("SEEVCN_RULEBOOK_CHAIN", "0") == "1"
 DEFER_INDEX_WORK = os.environ.get("SEEVCN_PREBUILD_DEFER", "1") != "0"     # 0: plans and submanifold rulebooks between the strided builders (A/B)
 
 
@@ -155,6 +160,27 @@ def prebuild_rulebooks(root, x, with_backward=True):
     # else (submanifold rulebooks, all plans) is enqueued in pass 2, behind the last read: queued between the strided builders (round 2) it sat
     # in front of every later read -- ~145 us of index kernels per level that the host waited for four times per step.
     todo = []                                             # (module, its input indices, their shape) in execution order
+    if DEFER_INDEX_WORK and CHAIN_READS:
+        # the strided layers in front (conv2, conv3, conv4, conv_out of the reference's backbones) as ONE chain: counted end to end on the
+        # device, one read for all their output-site counts (Fsp.build_sparse_rulebook_chain) instead of one blocking read per layer
+        chain, shapes, sh = [], set(), list(shape)
+        for m in _sparse_convs(root):
+            if m.indice_key is None:
+                break
+            if m.subm:
+                continue
+            K = m.kernel_size[0] * m.kernel_size[1] * m.kernel_size[2]
+            sh = Fsp.conv_out_shape(sh, m.kernel_size, m.stride, m.padding, m.dilation)
+            if x.indice_dict.get(m.indice_key) is not None or K > 27 or tuple(sh) in shapes or any(v.indice_key == m.indice_key for v in chain):
+                break
+            chain.append(m), shapes.add(tuple(sh))
+        if len(chain) >= 2 and idx.shape[0] > 0:
+            built = Fsp.build_sparse_rulebook_chain(idx, x.batch_size, shape, [(m.kernel_size, m.stride, m.padding, m.dilation) for m in chain])
+            cur, cur_shape = idx, list(shape)
+            for m, rb in zip(chain, built):
+                rb.in_indices, rb.in_shape = cur, list(cur_shape)
+                x.indice_dict[m.indice_key] = rb
+                cur, cur_shape = rb.out_indices, list(rb.out_shape)
     for m in _sparse_convs(root):
         if m.indice_key is None:
             break

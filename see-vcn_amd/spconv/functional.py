@@ -206,6 +206,61 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
     return rb
 
 
+def build_sparse_rulebook_chain(indices, batch_size, spatial_shape, specs):
+    """The strided rulebooks of a chain of layers -- specs = [(ksize, stride, padding, dilation), ...], layer l + 1 fed by layer l's output
+    sites -- with ONE device -> host read instead of one per layer: every level is counted first (sv_rulebook_sparse_count; level l + 1 marks
+    its output cells from level l's occupancy bitmap, which needs no site count), the counts come back together, then every level is filled
+    with exactly sized tables (sv_rulebook_sparse_fill + sv_rulebook_invert_rows).  Same tables as build_sparse_rulebook layer by layer
+    (tests/test_spconv.py).  K <= 27 per layer; -> list of Rulebook."""
+    lib = _lib.load()
+    _lib.require_cuda(indices)
+    assert indices.dtype == torch.int32 and indices.dim() == 2 and indices.shape[1] == 4
+    indices = indices.contiguous()
+    dev = indices.device
+    B = int(batch_size)
+    shapes, works, nums = [list(spatial_shape)], [], []
+    for l, (ksize, stride, padding, dilation) in enumerate(specs):
+        assert int(ksize[0]) * int(ksize[1]) * int(ksize[2]) <= 27
+        oshape = conv_out_shape(shapes[-1], ksize, stride, padding, dilation)
+        ncells = B * oshape[0] * oshape[1] * oshape[2]
+        ws = _lib.workspace.persistent(f"rb_index_{tuple(oshape)}_{batch_size}", lib.sv_index_persistent_bytes(ncells), dev)
+        assert all(ws is not w for w in works), "two levels of a chain on one grid would share their index"
+        scratch = _lib.workspace.scratch("rb_scratch", lib.sv_rulebook_scratch_bytes(0, ncells), dev)
+        num = torch.empty((1,), dtype=torch.int32, device=dev)
+        rc = lib.sv_rulebook_sparse_count(_lib.ptr(indices) if l == 0 else None, indices.shape[0] if l == 0 else 0, None if l == 0 else _lib.ptr(works[-1]), B,
+                                          _i3(shapes[-1]), _i3(ksize), _i3(stride), _i3(padding), _i3(dilation), _lib.ptr(ws), _lib.ptr(scratch), _lib.ptr(num),
+                                          _lib.stream())
+        _lib.check(rc, "sv_rulebook_sparse_count")
+        shapes.append(oshape), works.append(ws), nums.append(num)
+    counts = _lib.host_ints(nums)                                   # the one read of the chain
+    out, idx = [], indices
+    for l, (ksize, stride, padding, dilation) in enumerate(specs):
+        K = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
+        n_in, n_out = idx.shape[0], counts[l]
+        out_coords = torch.empty((max(n_out, 1), 4), dtype=torch.int32, device=dev)
+        nbr_in = torch.empty((K, n_in), dtype=torch.int32, device=dev)
+        in_block = torch.empty((33 * n_in,), dtype=torch.int32, device=dev) if n_in > 0 else None
+        rc = lib.sv_rulebook_sparse_fill(_lib.ptr(idx) if n_in else None, n_in, B, _i3(shapes[l]), _i3(ksize), _i3(stride), _i3(padding), _i3(dilation),
+                                         _lib.ptr(works[l]), _lib.ptr(out_coords), _lib.ptr(nbr_in) if n_in else None, _lib.ptr(in_block), max(n_out, 1),
+                                         _lib.stream())
+        _lib.check(rc, "sv_rulebook_sparse_fill")
+        out_coords = out_coords[:n_out]
+        if n_in == 0 or n_out == 0:
+            nbr_out = torch.empty((K, n_out), dtype=torch.int32, device=dev)
+            _lib.check(lib.sv_rulebook_invert(_lib.ptr(nbr_in) if n_in else None, n_in, K, _lib.ptr(nbr_out) if n_out else None, n_out, _lib.stream()),
+                       "sv_rulebook_invert")
+            rb = Rulebook(nbr_out, nbr_in, out_coords, shapes[l + 1], n_in, n_out, False, list(ksize))
+        else:
+            out_block = torch.empty(((32 + K + 1) * n_out,), dtype=torch.int32, device=dev)
+            _lib.check(lib.sv_rulebook_invert_rows(_lib.ptr(in_block), n_in, K, _lib.ptr(out_block), n_out, _lib.stream()), "sv_rulebook_invert_rows")
+            rb = Rulebook(out_block[32 * n_out:(32 + K) * n_out].view(K, n_out), nbr_in, out_coords, shapes[l + 1], n_in, n_out, False, list(ksize))
+            rb.rows_out, rb.masks_out = out_block[:32 * n_out].view(n_out, 32), out_block[(32 + K) * n_out:]
+            rb.rows_in, rb.masks_in = in_block[:32 * n_in].view(n_in, 32), in_block[32 * n_in:]
+        out.append(rb)
+        idx = out_coords
+    return out
+
+
 class _FragmentCache:
     """Weights in MFMA fragment order (sv_conv_weight_fragments), both directions in one launch, into buffers owned by the weight tensor's
     cache entry (tied to the base tensor by a weak reference: a data pointer alone can be handed to a new tensor after the old one is

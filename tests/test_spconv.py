@@ -723,3 +723,33 @@ def test_hip_launch_list_executor_runs_in_order_and_reports_errors(cuda, hip_lib
         chain._run([rows[0], chain._row(99)], "bad code")
     with pytest.raises(_lib.SeevcnHipError, match="null pointer"):
         chain._run([chain._row(chain.OP_BN_FWD, i=(c, 1, 1, 0), n=(n,), f=me)], "null pointers")
+
+
+@pytest.mark.gpu
+def test_hip_strided_rulebook_chain_equals_the_layer_by_layer_build(cuda, hip_lib):
+    """build_sparse_rulebook_chain (every level counted on the device first -- level l + 1 marks from level l's occupancy bitmap -- one read for all
+    output-site counts) == build_sparse_rulebook level after level: coordinates, both tables, row-major twins and masks, bit for bit; and the
+    persistent indices are left all-zero (a second chain on them gives the same tables)."""
+    from seevcn_amd.spconv import functional as Fsp
+    rng = np.random.default_rng(11)
+    batch, shape = 3, (21, 96, 80)
+    coords = torch.from_numpy(_rand_coords(rng, 20000, batch, shape)).to(cuda)
+    specs = [((3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1), (1, 1, 1)),
+             ((3, 1, 1), (2, 1, 1), (0, 0, 0), (1, 1, 1))]
+    want, idx, sh = [], coords, list(shape)
+    for ks, st, pd, dl in specs:
+        rb = Fsp.build_sparse_rulebook(idx, batch, sh, ks, st, pd, dl)
+        want.append(rb)
+        idx, sh = rb.out_indices, list(rb.out_shape)
+    for _ in range(2):
+        got = Fsp.build_sparse_rulebook_chain(coords, batch, shape, specs)
+        assert len(got) == len(want)
+        for l, (a, b) in enumerate(zip(got, want)):
+            assert a.n_in == b.n_in and a.n_out == b.n_out and list(a.out_shape) == list(b.out_shape), l
+            for name in ("out_indices", "nbr_in", "nbr_out", "rows_in", "rows_out", "masks_in", "masks_out"):
+                assert torch.equal(getattr(a, name), getattr(b, name)), (l, name)
+    # oracle for the first two levels
+    oc, nbr_out, nbr_in, _ = osp.rulebook_sparse(coords.cpu().numpy(), shape, 3, 2, 1)
+    assert np.array_equal(got[0].out_indices.cpu().numpy(), oc) and np.array_equal(got[0].nbr_out.cpu().numpy(), nbr_out)
+    oc2, nbr_out2, _, _ = osp.rulebook_sparse(oc, got[0].out_shape, 3, 2, 1)
+    assert np.array_equal(got[1].out_indices.cpu().numpy(), oc2) and np.array_equal(got[1].nbr_out.cpu().numpy(), nbr_out2)
