@@ -1419,6 +1419,10 @@ template <> struct WgVec<1> { using type = float; };
 __device__ __forceinline__ void wg_gload(f32x4& v, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
 __device__ __forceinline__ void wg_gload(f32x2& v, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
 __device__ __forceinline__ void wg_gload(float& v, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
+// the same loads addressed as (uniform 64-bit base in SGPRs) + (32-bit byte offset per lane): no 64-bit vector arithmetic per load
+__device__ __forceinline__ void wg_gload_s(f32x4& v, uint32_t off, const float* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void wg_gload_s(f32x2& v, uint32_t off, const float* base) { asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void wg_gload_s(float& v, uint32_t off, const float* base) { asm volatile("global_load_dword %0, %1, %2" : "=&v"(v) : "v"(off), "s"(base) : "memory"); }
 __device__ __forceinline__ float wg_elem(const f32x4& v, int i) { return v[i]; }
 __device__ __forceinline__ float wg_elem(const f32x2& v, int i) { return v[i]; }
 __device__ __forceinline__ float wg_elem(const float& v, int) { return v; }
@@ -1427,9 +1431,13 @@ __device__ __forceinline__ float wg_elem(const float& v, int) { return v; }
 // neighbour table, ballot + prefix popcount compaction of the valid (row, source) pairs into a wave-private LDS list,
 // then MFMAs over the COMPACTED pairs only (4 pairs per 16x16x4 step) with the next step's operands requested first.
 // The four waves' accumulators are summed through LDS in a fixed order and one slab per (chunk, k) is stored.
-template <int CT, int NTL>  // register tile grid: CT x NTL tiles of 16x16 (rows = c_in, cols = c_out)
+// OFF32: operand addresses as 32-bit byte offsets from uniform bases (the launcher checks that every offset fits) and the tail mask only in a
+// list's last step -- 35 -> ~15 non-MFMA instructions per 16-MFMA step
+template <int CT, int NTL, bool OFF32>  // register tile grid: CT x NTL tiles of 16x16 (rows = c_in, cols = c_out)
 __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {      // tried: (256, 4) = 4 waves / SIMD at 122 VGPRs instead of 3 at 140 -- 4 % slower relative to the forward conv of the same run
-  __shared__ int32_t pj[4][64 * WG_SUB], pr[4][64 * WG_SUB];
+  // the wave's compacted pairs: (source, row) -- OFF32: as byte offsets of the two operand rows, and 32 copies of the last pair behind the list so that
+  // the ring's dummy tail loads need no clamp
+  __shared__ int2 pjr[4][64 * WG_SUB + 32];
   __shared__ float red[CT * NTL * 256];
   // 1-D grid = (chunk fastest, offset, tile group).  SEEVCN_WGRAD_XCD=1 decodes it instead so that the chunks of one eighth of the rows run on
   // ONE XCD (workgroup b runs on XCD b % 8; a scene's rows then go through one L2 for all 27 offsets, offset-major inside the XCD).  Measured
@@ -1473,27 +1481,47 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {      // tri
   using XV = typename WgVec<CT>::type;
   using YV = typename WgVec<NTL>::type;
   const bool x_in = CT > 1 || c_base + li < a.Cin;           // the 3-channel input layer runs with zero-padded rows
+  const float* dYc = a.dY + r_begin * a.Cout;                // this chunk's rows (uniform)
+  const uint32_t xconst = (uint32_t)(x_in ? c_base + CT * li : 0) * 4u, yconst = (uint32_t)(n_base + NTL * li) * 4u;
+  const uint32_t xrow = (uint32_t)a.Cin * 4u, yrow = (uint32_t)a.Cout * 4u;
   auto issue = [&](int p, int cnt, XV& xs, YV& ys) {
-    const int pc = p < cnt ? p : cnt - 1;
-    const int32_t j = pj[wid][pc];
-    const int32_t r = pr[wid][pc];
-    wg_gload(xs, a.X + (int64_t)j * a.Cin + (x_in ? c_base + CT * li : 0));
-    wg_gload(ys, a.dY + ((int64_t)r_begin + r) * a.Cout + n_base + NTL * li);
+    if constexpr (OFF32) {
+      const int2 jr = pjr[wid][p];                             // byte offsets; entries past the list repeat its last pair
+      wg_gload_s(xs, (uint32_t)jr.x + xconst, a.X);
+      wg_gload_s(ys, (uint32_t)jr.y + yconst, dYc);
+    } else {
+      const int2 jr = pjr[wid][p < cnt ? p : cnt - 1];
+      wg_gload(xs, a.X + (int64_t)jr.x * a.Cin + (x_in ? c_base + CT * li : 0));
+      wg_gload(ys, a.dY + ((int64_t)r_begin + jr.y) * a.Cout + n_base + NTL * li);
+    }
   };
   // waits for the two loads of this step (the 3 younger steps stay in flight), then 16 x CT x NTL MFMAs
   auto consume = [&](int p0, int cnt, XV& xs, YV& ys) {
     asm volatile("s_waitcnt vmcnt(6)" : "+v"(xs), "+v"(ys));
     if (p0 >= cnt) return;                                   // wave-uniform: a dummy step of the ring's tail
-    const bool ok = p0 + kk < cnt;
-    float xa[CT], yb[NTL];
+    if constexpr (OFF32) {
+      // ONE block of MFMAs (two would get two sets of accumulators); the tail mask is applied in place, and only in a list's last step
+      if (p0 + 4 > cnt || !(CT > 1 || c_base + 16 <= a.Cin)) {                       // wave-uniform
+        const bool ok = p0 + kk < cnt;
+        if (!(ok && x_in)) xs = XV{};
+        if (!ok) ys = YV{};
+      }
 #pragma unroll
-    for (int c = 0; c < CT; ++c) xa[c] = (ok && x_in) ? wg_elem(xs, c) : 0.f;
+      for (int c = 0; c < CT; ++c)
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) yb[t] = ok ? wg_elem(ys, t) : 0.f;
+        for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg_elem(xs, c), wg_elem(ys, t), acc[c][t], 0, 0, 0);
+    } else {
+      const bool ok = p0 + kk < cnt;
+      float xa[CT], yb[NTL];
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
+      for (int c = 0; c < CT; ++c) xa[c] = (ok && x_in) ? wg_elem(xs, c) : 0.f;
 #pragma unroll
-      for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[c], yb[t], acc[c][t], 0, 0, 0);
+      for (int t = 0; t < NTL; ++t) yb[t] = ok ? wg_elem(ys, t) : 0.f;
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[c], yb[t], acc[c][t], 0, 0, 0);
+    }
   };
 
   for (int64_t base = r_begin + wid * (64 * WG_SUB); base < r_end; base += 256 * WG_SUB) {
@@ -1511,13 +1539,17 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {      // tri
       const unsigned long long m = __ballot(jv[s] >= 0);
       if (jv[s] >= 0) {
         const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        pj[wid][pos] = jv[s];
-        pr[wid][pos] = (int32_t)(base + s * 64 + lane - r_begin);
+        const int32_t r = (int32_t)(base + s * 64 + lane - r_begin);
+        pjr[wid][pos] = OFF32 ? make_int2((int)((uint32_t)jv[s] * xrow), (int)((uint32_t)r * yrow)) : make_int2(jv[s], r);   // one multiply per PAIR, here
       }
       cnt += __popcll(m);
     }
     if (cnt == 0) continue;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private list: LDS ops of one wave complete in order
+    if constexpr (OFF32) {
+      if (lane < 32) pjr[wid][cnt + lane] = pjr[wid][cnt - 1];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
     // operand ring, 4 steps deep: step s uses stage s % 4 while the loads of steps s+1 .. s+3 are in flight (a gathered row
     // takes ~2 us under load, a step's MFMAs 0.2 us).  EVERY ring slot issues exactly two loads and every consume waits for
     // vmcnt(6): no conditional issue, so each stage register has one definition per slot and hipcc never copies a stage whose
@@ -1640,7 +1672,12 @@ static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
   const int groups = (((a.Cin + 15) / 16) / CT) * ((a.Cout / 16) / NTL);
   const int cpr = (a.nchunks + 7) / 8;
   const unsigned blocks = a.xcd_order ? (unsigned)(8 * cpr * a.K * groups) : (unsigned)(a.nchunks * a.K * groups);
-  hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL>), dim3(blocks), dim3(256), 0, st, a);
+  // 32-bit operand offsets: a source row index is below 32 x n_rows for any rulebook (an output row has at most K <= 27 sources; the input-major
+  // direction has fewer rows than sources), so 32 x n_rows x row bytes < 2^32 bounds every X offset; dY offsets are chunk-relative
+  static const int off32_env = getenv("SEEVCN_WGRAD_OFF32") ? atoi(getenv("SEEVCN_WGRAD_OFF32")) : 1;
+  const bool off32 = off32_env && (uint64_t)a.n_rows * 32u * (uint64_t)a.Cin * 4u < 0xffffffffull && (uint64_t)a.chunk_rows * a.Cout * 4u < 0xffffffffull;
+  if (off32) hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true>), dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, false>), dim3(blocks), dim3(256), 0, st, a);
 }
 
 static int wgrad_run(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
