@@ -1505,6 +1505,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {      // tri
         const bool ok = p0 + kk < cnt;
         if (!(ok && x_in)) xs = XV{};
         if (!ok) ys = YV{};
+        asm volatile("" : "+v"(xs), "+v"(ys));               // keeps this a BRANCH: if-converted, its selects ran in every step
       }
 #pragma unroll
       for (int c = 0; c < CT; ++c)
