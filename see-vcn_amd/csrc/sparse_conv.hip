@@ -1525,6 +1525,9 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {      // tri
     }
   };
 
+  // (Tried: the table entries of pass n + 1 requested with asm loads right after the compaction of pass n, waited for at the top of the next
+  // iteration -- memory fault: with the destination registers live across the whole MFMA loop hipcc moves them while the loads are in flight.
+  // And the pair-list entry of step s + 1 read from LDS one step ahead: no change, 134.3 vs 133.8 us.)
   for (int64_t base = r_begin + wid * (64 * WG_SUB); base < r_end; base += 256 * WG_SUB) {
     // WG_SUB x 64 rows per wave and pass: the neighbour reads are in flight together and the start-up latency of a pass
     // (table read -> compaction -> first operand loads) is paid once per ~80 pairs instead of once per ~20
