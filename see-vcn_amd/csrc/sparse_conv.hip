@@ -1434,7 +1434,9 @@ __device__ __forceinline__ float wg_elem(const float& v, int) { return v; }
 // OFF32: operand addresses as 32-bit byte offsets from uniform bases (the launcher checks that every offset fits) and the tail mask only in a
 // list's last step -- 35 -> ~15 non-MFMA instructions per 16-MFMA step
 template <int CT, int NTL, bool OFF32>  // register tile grid: CT x NTL tiles of 16x16 (rows = c_in, cols = c_out)
-__global__ __launch_bounds__(256) void k_spconv_wgrad(WgradArgs a) {      // tried: (256, 4) = 4 waves / SIMD at 122 VGPRs instead of 3 at 140 -- 4 % slower relative to the forward conv of the same run
+// four waves per SIMD (<4,4>: 122 VGPRs; 140 and three waves unbounded): 4 % slower before the loop was trimmed, 3 % faster on the 139 k-row layer
+// and equal elsewhere after it
+__global__ __launch_bounds__(256, 4) void k_spconv_wgrad(WgradArgs a) {
   // the wave's compacted pairs: (source, row) -- OFF32: as byte offsets of the two operand rows, and 32 copies of the last pair behind the list so that
   // the ring's dummy tail loads need no clamp
   __shared__ int2 pjr[4][64 * WG_SUB + 32];
