@@ -1450,7 +1450,12 @@ __global__ __launch_bounds__(256, 4) void k_spconv_wgrad(WgradArgs a) {
   {
     const int cpr = (a.nchunks + 7) / 8;                       // chunks per region
     const int b = blockIdx.x;
-    if (a.xcd_order) {
+    if (a.xcd_order == 2) {                                    // offsets fastest: the 27 offsets of a chunk back to back on its XCD
+      const int xcd = b % 8, j = b / 8;
+      k = j % a.K;
+      chunk = xcd * cpr + (j / a.K) % cpr;
+      zgroup = j / (cpr * a.K);
+    } else if (a.xcd_order) {
       const int xcd = b % 8, j = b / 8;
       chunk = xcd * cpr + j % cpr;
       k = (j / cpr) % a.K;
@@ -1711,9 +1716,10 @@ static int wgrad_run(const float* X, const int32_t* nbr, const float* dY, float*
   // workgroup order: the narrow layers (C_in <= 32: little matrix work per gathered byte) run the chunks of an eighth of the rows on ONE XCD, so that
   // a scene's rows go through one L2 for all 27 offsets -- measured after the loop's instruction stream was trimmed: 16->16 32.7 -> 26.5 us,
   // 16->32 35.1 -> 29.7, 32->32 87.7 -> 74.7, 32->64 56.2 -> 54.0; the 64-channel layers lose with it (135 -> 144 us: they are bound by their
-  // busiest workgroups, and the plain order spreads the heavy centre offsets over all XCDs).  SEEVCN_WGRAD_XCD=0/1 forces one order for all.
+  // busiest workgroups, and the plain order spreads the heavy centre offsets over all XCDs; with the 27 offsets of a chunk back to back on its XCD,
+  // order 2, 135 -> 158 us).  SEEVCN_WGRAD_XCD=0/1/2 forces one order for all layers (measurement).
   static const int xcd_env = getenv("SEEVCN_WGRAD_XCD") ? atoi(getenv("SEEVCN_WGRAD_XCD")) : -1;
-  const int xcd_order = xcd_env >= 0 ? (xcd_env == 1) : (Cin <= 32 ? 1 : 0);
+  const int xcd_order = xcd_env >= 0 ? xcd_env : (Cin <= 32 ? 1 : 0);
   WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, (int)((n_rows + chunk_rows - 1) / chunk_rows), chunk_rows, xcd_order};
   int nslabs = a.nchunks;
   if (mfma) {
