@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   if (active) {
     // ring depth 3 = two steps of loads in flight.  Tried: 5 stages for the one-tile-per-wave instance (its registers allow it) -- slower,
     // 64->64 at 66 k rows 78 -> 85 us, 64->128 28 -> 39 us: the extra dummy loads of the tail and the longer prologue cost more than the
-    // lookahead buys (round 1 found the same on the narrow kernels)
+    // lookahead buys (round 1 found the same on the narrow kernels); 4 stages for it in round 3 (128 VGPRs, no spill): 65.5 -> 67-68 us
     constexpr int RING = 3;
     f32x4 A[RING][RS_G], B[RING][NT];
     // defined here so that their live ranges start inside the pass (the asm waits below read-modify them: left undefined, hipcc keeps all
