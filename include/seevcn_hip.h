@@ -225,15 +225,16 @@ int sv_conv_planned_partials(void);
  * (s_memtime at start / after the prologue / after the main loop / at the end, HW_ID, XCC_ID, tile-offset steps, block << 8 | wave);
  * buf holds grid.x * grid.y * 4 slots of 64 bytes (size it as 8 * (n_tiles + 64) * columns / 64 slots).  Not for production use. */
 int sv_debug_conv_trace(void* buf);
-/* dW (K, C_in, C_out) = sum_o X[nbr[k][o]]^T dY[o]; deterministic two-stage reduction */
+/* dW (K, C_in, C_out) = sum_o X[nbr[k][o]]^T dY[o]; deterministic two-stage reduction.  n_src = rows of X (every table entry is < n_src): when
+ * n_src * C_in * 4 < 2^32 the operand rows are addressed with 32-bit byte offsets from uniform bases; n_src <= 0 = unknown (64-bit addresses). */
 size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout);
-int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
+int sv_sparse_conv_wgrad(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
                          int Cin, int Cout, void* scratch, void* stream);
 /* The same with element (k, c_in, c_out) written at dW[k * stride_k + c_in * stride_cin + c_out * stride_cout] -- the layout of the
  * caller's parameter (spconv's (C_out, kz, ky, kx, C_in)), so that no transposing copy of the gradient is needed.  The strides must
  * address a permutation of the K * C_in * C_out slab. */
-int sv_sparse_conv_wgrad_strided(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin, int Cout,
-                                 int64_t stride_k, int64_t stride_cin, int64_t stride_cout, void* scratch, void* stream);
+int sv_sparse_conv_wgrad_strided(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin,
+                                 int Cout, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, void* scratch, void* stream);
 
 /* SparseConvTensor.dense(): (N,C) + coords -> (B, C, D, H, W), every element written once */
 size_t sv_sparse_to_dense_scratch_bytes(int batch, int D, int H, int W);
@@ -457,7 +458,7 @@ int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float*
  *                       f = momentum, eps
  *   SV_OP_BN_BWD        sv_batchnorm_relu_backward (i2 = 0) / _backward_partial (i2 = number of partials): p = x, dy, gamma, beta, save_mean,
  *                       save_invstd, scratch, dx, dgamma, dbeta; n = rows; i = channels, relu, n_partials
- *   SV_OP_WGRAD         sv_sparse_conv_wgrad_strided: p = X, nbr, dY, dW, scratch; n = n_rows, stride_k, stride_cin, stride_cout; i = K, Cin, Cout
+ *   SV_OP_WGRAD         sv_sparse_conv_wgrad_strided: p = X, nbr, dY, dW, scratch; n = n_rows, stride_k, stride_cin, stride_cout; i = K, Cin, Cout, n_src
  *   SV_OP_DGRAD_PLANNED_BN  sv_sparse_conv_dgrad_planned_bn: p = dZ, table_rows, perm, masks_p, tile_of, wfrag, dY, bn_x, bn_mean, bn_invstd, bn_gamma,
  *                       bn_beta, bn_partial; n = n_src, n_rows; i = tiles_per_wave, K, Kd, Nc, table_k_reversed, bn_relu
  * Used by seevcn_amd/spconv/chain.py: the forward and the backward of a conv -> BatchNorm -> ReLU chain (VoxelBackBone8x, spconv_backbone.py:128-180)

@@ -1410,6 +1410,7 @@ struct WgradArgs {
   int64_t n_rows;
   int K, Cin, Cout, nchunks, chunk_rows;
   int xcd_order;         // workgroup -> (chunk, offset, tile group) decoded per XCD (k_spconv_wgrad)
+  int64_t n_src;         // rows of X, or <= 0 when the caller does not know (then no 32-bit offsets)
 };
 
 template <int N> struct WgVec;
@@ -1683,15 +1684,14 @@ static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
   const int groups = (((a.Cin + 15) / 16) / CT) * ((a.Cout / 16) / NTL);
   const int cpr = (a.nchunks + 7) / 8;
   const unsigned blocks = a.xcd_order ? (unsigned)(8 * cpr * a.K * groups) : (unsigned)(a.nchunks * a.K * groups);
-  // 32-bit operand offsets: a source row index is below 32 x n_rows for any rulebook (an output row has at most K <= 27 sources; the input-major
-  // direction has fewer rows than sources), so 32 x n_rows x row bytes < 2^32 bounds every X offset; dY offsets are chunk-relative
+  // 32-bit operand offsets: every source row starts below 2^32 bytes (n_src from the caller); dY offsets are chunk-relative
   static const int off32_env = getenv("SEEVCN_WGRAD_OFF32") ? atoi(getenv("SEEVCN_WGRAD_OFF32")) : 1;
-  const bool off32 = off32_env && (uint64_t)a.n_rows * 32u * (uint64_t)a.Cin * 4u < 0xffffffffull && (uint64_t)a.chunk_rows * a.Cout * 4u < 0xffffffffull;
+  const bool off32 = off32_env && a.n_src > 0 && (uint64_t)a.n_src * (uint64_t)a.Cin * 4u < 0xffffffffull && (uint64_t)a.chunk_rows * a.Cout * 4u < 0xffffffffull;
   if (off32) hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true>), dim3(blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, false>), dim3(blocks), dim3(256), 0, st, a);
 }
 
-static int wgrad_run(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
+static int wgrad_run(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
                                     int Cin, int Cout, void* scratch, void* stream, WgradOut out) {
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Cin > 0 && Cout > 0 && dW, "sparse_conv_wgrad: bad arguments");
   hipStream_t st = sv_stream(stream);
@@ -1720,7 +1720,7 @@ static int wgrad_run(const float* X, const int32_t* nbr, const float* dY, float*
   // order 2, 135 -> 158 us).  SEEVCN_WGRAD_XCD=0/1/2 forces one order for all layers (measurement).
   static const int xcd_env = getenv("SEEVCN_WGRAD_XCD") ? atoi(getenv("SEEVCN_WGRAD_XCD")) : -1;
   const int xcd_order = xcd_env >= 0 ? xcd_env : (Cin <= 32 ? 1 : 0);
-  WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, (int)((n_rows + chunk_rows - 1) / chunk_rows), chunk_rows, xcd_order};
+  WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, (int)((n_rows + chunk_rows - 1) / chunk_rows), chunk_rows, xcd_order, n_src};
   int nslabs = a.nchunks;
   if (mfma) {
     if (tiles_c == 4) launch_wgrad<4, 4>(a, st);
@@ -1740,14 +1740,14 @@ static int wgrad_run(const float* X, const int32_t* nbr, const float* dY, float*
   return SV_OK;
 }
 
-extern "C" int sv_sparse_conv_wgrad(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
+extern "C" int sv_sparse_conv_wgrad(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
                                     int Cin, int Cout, void* scratch, void* stream) {
-  return wgrad_run(X, nbr, dY, dW, n_rows, K, Cin, Cout, scratch, stream, WgradOut{0, 0, 0, Cin, Cout, 1});
+  return wgrad_run(X, n_src, nbr, dY, dW, n_rows, K, Cin, Cout, scratch, stream, WgradOut{0, 0, 0, Cin, Cout, 1});
 }
 
 // the same with the gradient written at element strides (stride_k, stride_cin, stride_cout) of dW -- a permutation of the K * C_in * C_out slab
-extern "C" int sv_sparse_conv_wgrad_strided(const float* X, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
+extern "C" int sv_sparse_conv_wgrad_strided(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
                                     int Cin, int Cout, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, void* scratch, void* stream) {
   SV_CHECK_ARG(stride_k > 0 && stride_cin > 0 && stride_cout > 0, "sparse_conv_wgrad_strided: strides must be positive");
-  return wgrad_run(X, nbr, dY, dW, n_rows, K, Cin, Cout, scratch, stream, WgradOut{stride_k, stride_cin, stride_cout, Cin, Cout, 0});
+  return wgrad_run(X, n_src, nbr, dY, dW, n_rows, K, Cin, Cout, scratch, stream, WgradOut{stride_k, stride_cin, stride_cout, Cin, Cout, 0});
 }

@@ -192,7 +192,7 @@ class SparseChainFunction(torch.autograd.Function):
             rows.append(_row(OP_BN_BWD, i=(b.cout, int(b.relu), n_part_bwd), n=(rb.n_out,),
                              p=(a_conv, dy_ptr, gamma.data_ptr(), beta.data_ptr(), a_mean, a_istd, scratch.data_ptr(), o_dconv, o_dg, o_db)))
             n_part_bwd = 0
-            rows.append(_row(OP_WGRAD, i=(b.K, b.cin, b.cout), n=(rb.n_out, b.cin, 1, b.K * b.cin),
+            rows.append(_row(OP_WGRAD, i=(b.K, b.cin, b.cout, rb.n_in), n=(rb.n_out, b.cin, 1, b.K * b.cin),
                              p=(x_in, rb.nbr_out.data_ptr(), o_dconv, wbase + 4 * woffs[k], wscratch.data_ptr())))
             if k > 0:
                 tp, tile_of, g, rev = rb.plan("bwd", b.cout, b.cin)

@@ -378,11 +378,11 @@ def wgrad(x, nbr, dy, K, cin, cout, like=None):
     st = None if like is None else tuple(int(v) for v in like.stride())
     if st is not None and not like.is_contiguous() and min(st) > 0 and sorted(st)[0] == 1 and _dense_permutation(tuple(like.shape), st):
         dw = torch.empty_strided((K, cin, cout), st, dtype=torch.float32, device=dy.device)
-        rc = lib.sv_sparse_conv_wgrad_strided(xs, ns, ds, dw.data_ptr(), n_rows, K, cin, cout, st[0], st[1], st[2], _lib.ptr(scratch), _lib.stream())
+        rc = lib.sv_sparse_conv_wgrad_strided(xs, int(x.shape[0]), ns, ds, dw.data_ptr(), n_rows, K, cin, cout, st[0], st[1], st[2], _lib.ptr(scratch), _lib.stream())
         _lib.check(rc, "sv_sparse_conv_wgrad_strided")
         return dw
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dy.device)
-    rc = lib.sv_sparse_conv_wgrad(xs, ns, ds, _lib.ptr(dw), n_rows, K, cin, cout, _lib.ptr(scratch), _lib.stream())
+    rc = lib.sv_sparse_conv_wgrad(xs, int(x.shape[0]), ns, ds, _lib.ptr(dw), n_rows, K, cin, cout, _lib.ptr(scratch), _lib.stream())
     _lib.check(rc, "sv_sparse_conv_wgrad")
     return dw
 
