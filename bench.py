@@ -296,7 +296,7 @@ def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
     return f"k_spconv_rs3<{nt}, {kq}, ", ms / n, flop / n, byt / n, n // reps, ms / reps
 
 
-def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1, warmup=3, timed=5):
+def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1, warmup=3, timed=10):
     """Oracle (CPU port) on a bounded sample of the same workload: VCN + post-processing on n_objects objects and one scene's
     merge -> voxelise -> VoxelBackBone8x forward/backward (numpy sparse conv inside torch-CPU autograd for BN/ReLU).
     SURVEY 8(d): warm-up passes, then the median of the timed passes (each pass = the whole sample)."""
@@ -347,6 +347,27 @@ def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1, warmup=3, t
             "sample": f"oracle (numpy/torch-CPU, {threads} threads), {warmup} warm-up + {timed} timed passes, medians: VCN_VC fwd + surface select + "
                       f"DBSCAN on {n_objects} objects ({t_vcn:.3f} s/object) + {n_scenes} scene merge+voxelise+VoxelBackBone8x fwd+bwd "
                       f"({t_scene:.2f} s/scene); scaled to {per_scene_objs} objects/scene"}
+
+
+def rank_identity(device):
+    """What this rank runs on, for the record of an N > 1 run: (hostname, visible device index, device UUID, PCI bus id)."""
+    if device is None or device.type != "cuda":
+        return (socket.gethostname(), -1, f"cpu-{os.getpid()}", "")
+    pr = torch.cuda.get_device_properties(device)
+    return (socket.gethostname(), int(device.index or 0), str(getattr(pr, "uuid", "")), f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}")
+
+
+def gather_rank_identities(device, world):
+    """All-gathered over the process group: {'world_size_seen': ranks that answered, 'devices': sorted per-rank identities, 'distinct_devices': n}.
+    A SCALE record can then PROVE that N ranks ran on N different GPUs (or, in the shared-GPU test mode, that they did not)."""
+    me = rank_identity(device)
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, me)
+    else:
+        got = [me]
+    devs = sorted(f"{h}/{i}/{u}/{b}" for h, i, u, b in got)
+    return {"world_size_seen": len(got), "devices": devs, "distinct_devices": len(set(devs))}
 
 
 def _free_port():
@@ -401,9 +422,10 @@ def dry_run_rank(args, rank, world):
         elapsed = float(t.item())
     want = sum(range(1, world + 1)) / world
     ok = all(torch.allclose(p.grad, torch.full_like(p, want * (i + 1))) for i, p in enumerate(params))
+    ident = gather_rank_identities(None, world)
     if rank == 0:
         print(json.dumps({"metric": "dry-run", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "exchange_ok": bool(ok),
-                          "elapsed_s": round(elapsed, 4)}), flush=True)
+                          "elapsed_s": round(elapsed, 4), "ranks": ident}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -500,6 +522,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    ident = gather_rank_identities(device, world)            # collective: every rank, before rank 0 goes off measuring alone
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         scenes = SCENES_PER_GPU * world * args.steps
@@ -516,6 +539,7 @@ def main():
                        "geometry": "KITTI [0,-40,-3,70.4,40,1] @ [0.05,0.05,0.1] -> sparse [41,1600,1408]", "parallelism": f"dp{world}",
                        "input_side": "in line" if pre is None else "side stream, one batch ahead (every step = 1 front + 1 compute)"},
             "completed_objects_per_sec": round(OBJECTS_PER_GPU * world * args.steps / elapsed, 1), "device_spinup_s": args.spinup,
+            "ranks": ident, "backend": (backend if world > 1 else None),
         }
         if not args.no_kernel_rooflines:
             # rank 0 only, so NO collective inside: the measured steps run with world = 1 (the exchange step is skipped)
@@ -583,8 +607,10 @@ def side_mode(args, rank, world, device):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ident = gather_rank_identities(device, world)
     if rank == 0:
         config["parallelism"] = f"dp{world}"
+        config["ranks"] = ident
         print(json.dumps({"metric": metric, "value": round(units * world * args.steps / elapsed, 3), "unit": unit, "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "side_mode": args.config}), flush=True)

@@ -195,22 +195,26 @@ import threading as _threading
 _sync_hooks = _threading.local()
 
 
+def _take_checks():
+    """The parked checks whose value the CURRENT stream orders (parked on it); checks parked on another stream stay parked -- read here they
+    would race with the stream that still computes them (bench.py runs a piece of the trained side, main stream, inside a read of the
+    input side, side stream: a lazily built rulebook there must not pick up the input side's pending empty-cluster check)."""
+    pending = getattr(_sync_hooks, "checks", None)
+    if not pending:
+        return []
+    cur = stream()
+    mine = [c for c in pending if c[0] == cur]
+    if mine:
+        _sync_hooks.checks = [c for c in pending if c[0] != cur]
+    return mine
+
+
 def host_int(t):
     """int(t.item()) -- a device -> host read that blocks the calling thread until the stream has produced t.  A caller that has other work to
     enqueue meanwhile (bench.py: the trained side of the previous batch) installs a hook with set_sync_hook(); it runs right before the read,
     i.e. after the kernels that produce t were launched, so the wait is spent enqueueing instead of idling.  Checks parked with defer_check()
-    ride on this read: their values come back in the same copy."""
-    hook = getattr(_sync_hooks, "before", None)
-    if hook is not None:
-        hook()
-    pending = getattr(_sync_hooks, "checks", None)
-    if not pending:
-        return int(t.item())
-    _sync_hooks.checks = []
-    vals = torch.stack([t.reshape(()).to(torch.int64)] + [p.reshape(()).to(torch.int64) for p, _ in pending]).tolist()
-    for v, (_, fn) in zip(vals[1:], pending):
-        fn(int(v))
-    return int(vals[0])
+    on the same stream ride on this read: their values come back in the same copy."""
+    return host_ints([t])[0]
 
 
 def host_ints(tensors):
@@ -218,28 +222,28 @@ def host_ints(tensors):
     hook = getattr(_sync_hooks, "before", None)
     if hook is not None:
         hook()
-    pending = getattr(_sync_hooks, "checks", None) or []
-    _sync_hooks.checks = []
-    vals = torch.stack([t.reshape(()).to(torch.int64) for t in tensors] + [p.reshape(()).to(torch.int64) for p, _ in pending]).tolist()
-    for v, (_, fn) in zip(vals[len(tensors):], pending):
+    pending = _take_checks()
+    if not pending and len(tensors) == 1:
+        return [int(tensors[0].item())]
+    vals = torch.stack([t.reshape(()).to(torch.int64) for t in tensors] + [p.reshape(()).to(torch.int64) for _, p, _ in pending]).tolist()
+    for v, (_, _, fn) in zip(vals[len(tensors):], pending):
         fn(int(v))
     return [int(v) for v in vals[:len(tensors)]]
 
 
 def defer_check(t, fn):
     """Park a validity check on a 0-dim device integer: fn(value) runs (and may raise) at the calling thread's next host_int() or
-    flush_checks() -- on the SAME stream, whose order guarantees t is final by then -- instead of costing a blocking read of its own."""
+    flush_checks() ON THE SAME STREAM -- whose order guarantees t is final by then -- instead of costing a blocking read of its own."""
     if getattr(_sync_hooks, "checks", None) is None:
         _sync_hooks.checks = []
-    _sync_hooks.checks.append((t, fn))
+    _sync_hooks.checks.append((stream(), t, fn))
 
 
 def flush_checks():
-    """Run the parked checks now (one blocking read) -- for call sites that are not followed by a host_int()."""
-    pending = getattr(_sync_hooks, "checks", None)
+    """Run the checks parked on the current stream now (one blocking read) -- for call sites that are not followed by a host_int()."""
+    pending = _take_checks()
     if pending:
-        _sync_hooks.checks = []
-        for v, (_, fn) in zip(torch.stack([p.reshape(()).to(torch.int64) for p, _ in pending]).tolist(), pending):
+        for v, (_, _, fn) in zip(torch.stack([p.reshape(()).to(torch.int64) for _, p, _ in pending]).tolist(), pending):
             fn(int(v))
 
 

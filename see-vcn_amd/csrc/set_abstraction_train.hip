@@ -706,8 +706,9 @@ __global__ void k_sa_coef(const float* gamma, const float* beta, const float* me
   const int c = threadIdx.x;
   if (c >= C) return;
   const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-  o[c] = istd[c] * g;
-  o[C + c] = bt - mean[c] * istd[c] * g;
+  const float sc = istd[c] * g;                 // exactly k_bn_finalize's forward expressions (norm.h): the ReLU-1 mask of the backward is recomputed from them
+  o[c] = sc;
+  o[C + c] = bn_shift(mean[c], sc, bt);
 }
 
 // ------------------------------------------------------------------------------------------------ host side

@@ -64,10 +64,14 @@ class RoIHeadTemplate(nn.Module):
             box_preds, cls_preds = box_preds_all[mask], cls_preds_all[mask]
             cur_scores, cur_labels = torch.max(cls_preds, dim=1)
             # the survivors of the NMS in a fixed-size block, the rest zeros: no read of the survivor count on the host
+            if box_preds.shape[0] == 0:
+                continue                                   # a scene without predictions keeps its zero rows (the reference writes an empty slice)
             selected, valid = class_agnostic_nms_padded(box_scores=cur_scores, box_preds=box_preds, nms_config=nms_config)
-            rois[i] = box_preds[selected] * valid.view(-1, 1)
-            roi_scores[i] = cur_scores[selected] * valid
-            roi_labels[i] = cur_labels[selected] * valid
+            valid = valid.bool()
+            # selects, not products: a NaN / inf in the row the padding points at (row 0) must not reach the padded rows
+            rois[i] = torch.where(valid.view(-1, 1), box_preds[selected], 0)
+            roi_scores[i] = torch.where(valid, cur_scores[selected], 0)
+            roi_labels[i] = torch.where(valid, cur_labels[selected], 0)
         batch_dict['rois'], batch_dict['roi_scores'], batch_dict['roi_labels'] = rois, roi_scores, roi_labels + 1
         batch_dict['has_class_labels'] = True if cls_preds_all.shape[-1] > 1 else False
         batch_dict.pop('batch_index', None)
@@ -120,11 +124,14 @@ class RoIHeadTemplate(nn.Module):
             batch_anchors = all_rois.clone().detach()
             roi_ry, roi_xyz = all_rois[:, :, 6].view(-1), all_rois[:, :, 0:3].view(-1, 3)
             batch_anchors[:, :, 0:3] = 0
-            boxes = self.box_coder.decode_torch(rcnn_reg.view(1, -1, code), batch_anchors).view(-1, code)
+            # mask the INPUTS of the decode, not the product behind it: a background RoI's unsupervised residuals may overflow exp() in
+            # decode_torch, and inf * 0 = NaN would poison the loss and every gradient (the reference never decodes a background RoI)
+            reg_fg = torch.where(fg_mask.view(1, -1, 1), rcnn_reg.view(1, -1, code), 0)
+            boxes = self.box_coder.decode_torch(reg_fg, batch_anchors).view(-1, code)
             boxes = common_utils.rotate_points_along_z(boxes.unsqueeze(1), roi_ry).squeeze(1)
             boxes = torch.cat([boxes[:, 0:3] + roi_xyz, boxes[:, 3:]], dim=1)
             per_roi = loss_utils.get_corner_loss_lidar(boxes[:, 0:7], gt_src[:, 0:7])
-            corner = (per_roi * fg_mask.float()).sum() / fg_norm * lw['rcnn_corner_weight']
+            corner = torch.where(fg_mask, per_roi, 0).sum() / fg_norm * lw['rcnn_corner_weight']
             loss = loss + corner
             tb['rcnn_loss_corner'] = common_utils.tb_value(corner)
         return loss, tb

@@ -75,14 +75,18 @@ def init_dist_pytorch(tcp_port, local_rank, backend='nccl'):
     import os
     import torch.distributed as dist
     import torch.multiprocessing as mp
+    # Environment FIRST, before anything below touches the GPU: ROCr reads HSA_ENABLE_IPC_MODE_LEGACY once, at hsa_init (the first HIP call of
+    # the process -- torch.cuda.set_device below).  This pool's driver only supports dmabuf IPC and RCCL needs it.  If the caller has already
+    # initialised the GPU the setting comes too late for this process: the LAUNCHER must export it then (bench.py launch_ranks does); never
+    # re-exec a GPU-initialised process to apply it.  The nccl path of this helper is exercised on a node only (tests use gloo): unverified here.
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(tcp_port))
     if mp.get_start_method(allow_none=True) is None:
         mp.set_start_method('spawn')
     num_gpus = torch.cuda.device_count()
     if num_gpus > 0:
         torch.cuda.set_device(local_rank % num_gpus)
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', str(tcp_port))
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # this pool's driver only supports dmabuf IPC (RCCL needs it)
     dist.init_process_group(backend=backend)
     return num_gpus, dist.get_rank()
 

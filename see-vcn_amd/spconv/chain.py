@@ -52,7 +52,21 @@ class Block:
         self.conv, self.bn, self.relu, self.tap = conv, bn, bool(relu), tap          # tap: this block's output is returned by the chain
         self.K = conv.kernel_size[0] * conv.kernel_size[1] * conv.kernel_size[2]
         self.cin, self.cout = conv.in_channels, conv.out_channels
-        self.mom_eps = (_bits(bn.momentum), _bits(bn.eps))
+
+    @property
+    def mom_eps(self):
+        # read when the launch list is made, i.e. after applicable() -> fusable_with() has rejected momentum=None (cumulative average)
+        return (_bits(self.bn.momentum), _bits(self.bn.eps))
+
+
+class BlockList(list):
+    """The blocks of a chain + every module the flattening walked over (stage containers, nested SparseSequentials, convs, norms, ReLUs): the chain
+    bypasses __call__ of ALL of them, so a hook on any of them must send the forward back to the module tree."""
+    walked = ()
+
+
+def _has_hooks(m):
+    return bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, '_backward_pre_hooks', None))
 
 
 def flatten_blocks(groups):
@@ -60,14 +74,17 @@ def flatten_blocks(groups):
     (SparseConvolution, BatchNorm1d, ReLU) triples.  The last block of every stage is a tap."""
     from .conv import SparseConvolution
     from .modules import SparseSequential
-    blocks = []
+    blocks = BlockList()
+    walked = []
 
     def walk(m, out):
+        walked.append(m)
         for child in m._modules.values():
             if isinstance(child, SparseSequential):
                 if not walk(child, out):
                     return False
             else:
+                walked.append(child)
                 out.append(child)
         return True
 
@@ -81,6 +98,7 @@ def flatten_blocks(groups):
                 return None
             blocks.append(Block(conv, bn, True, False))
         blocks[-1].tap = True
+    blocks.walked = tuple(walked)
     return blocks
 
 
@@ -90,10 +108,10 @@ def applicable(blocks, x):
     behind the first (the first one's is needed only when the input features want a gradient, which the backbone's never do)."""
     if CHAIN_OFF or blocks is None or not torch.is_grad_enabled() or x.features.requires_grad or x.indices.shape[0] < 2:
         return False
+    if any(_has_hooks(m) for m in getattr(blocks, 'walked', ())):
+        return False               # a forward / pre-forward / backward hook on a stage, a nested sequential, a conv, a norm or a ReLU: module path
     for k, b in enumerate(blocks):
         if not b.conv.fusable_with(b.bn, x) or b.conv.indice_key is None:
-            return False
-        if any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in (b.conv, b.bn)):
             return False
         rb = x.indice_dict.get(b.conv.indice_key)
         if rb is None or rb.n_out < 2 or rb.ksize != b.conv.kernel_size:

@@ -101,6 +101,8 @@ def test_bench_self_launches_its_ranks_world2_gloo():
     """`python bench.py --gpus 2` with no launcher: the parent starts the two ranks itself (dry run = the N > 1 control flow on gloo)."""
     out = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"])
     assert out["n_gpus"] == 2 and out["exchange_ok"] is True
+    # the record proves how many ranks answered and what each ran on (all-gathered identities; on a node: one device UUID per rank)
+    assert out["ranks"]["world_size_seen"] == 2 and len(out["ranks"]["devices"]) == 2 and out["ranks"]["distinct_devices"] == 2
 
 
 def test_bench_rank_under_an_external_launcher_world2_gloo():
@@ -125,6 +127,8 @@ def test_bench_main_two_ranks_end_to_end_on_one_gpu():
                      {"SEEVCN_BENCH_SHARE_GPU": "1", "SEEVCN_BENCH_BACKEND": "gloo"}, timeout=900)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["achieved"] > 0
     assert out["config"]["scenes_per_gpu"] == 2
+    # two ranks answered, and the record shows that they SHARED one device (this test mode) -- on a node it would list two UUIDs
+    assert out["ranks"]["world_size_seen"] == 2 and out["ranks"]["distinct_devices"] == 1 and out["backend"] == "gloo"
 
 
 def _dist_helper_worker(rank, world, port, out):
@@ -204,3 +208,28 @@ def test_ddp_wrapped_second_net_two_ranks_on_one_gpu(sync_bn):
     out = mgr.dict()
     mp.spawn(_ddp_worker, args=(world, _free_port(), sync_bn, out), nprocs=world, join=True)
     assert dict(out) == {0: (True, True, True, True, True), 1: (True, True, True, True, True)}
+
+
+def _nccl_helper_worker(rank, port, out):
+    sys.path.insert(0, ROOT)
+    import seevcn_amd  # noqa: F401
+    from seevcn_amd.pcdet.utils import common_utils
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1")
+    os.environ.pop("MASTER_PORT", None)
+    os.environ.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)          # the helper itself must export it before the first HIP call
+    n_gpus, r = common_utils.init_dist_pytorch(port, rank, backend="nccl")
+    t = torch.full((4,), 3.0, device="cuda")
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    out[0] = (r, n_gpus >= 1, t.cpu().tolist(), os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), os.environ.get("MASTER_PORT") == str(port))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_init_dist_pytorch_nccl_one_rank():
+    """The reference-compatible RCCL path of the helper (torchrun -> init_dist_pytorch(backend='nccl')): a fresh process whose FIRST GPU
+    call happens inside the helper -- the dmabuf-IPC switch must be in the environment by then -- then one all-reduce on the device."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_nccl_helper_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert dict(out) == {0: (0, True, [3.0] * 4, "0", True)}

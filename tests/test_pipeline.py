@@ -57,3 +57,29 @@ def test_hip_front_then_compute_equals_forward(cuda, hip_lib):
         torch.testing.assert_close(b, a, rtol=1e-4, atol=1e-5)
     finally:
         bench.SCENES_PER_GPU, bench.OBJECTS_PER_GPU = saved
+
+
+@pytest.mark.gpu
+def test_hip_parked_checks_stay_with_their_stream(cuda, hip_lib):
+    """A check parked on the side stream (the input side's empty-cluster word) is NOT consumed by a read on another stream (a piece of the
+    trained side run from the read hook); it is consumed -- and may raise -- at the next read on its own stream."""
+    from seevcn_amd import _lib
+    side = torch.cuda.Stream()
+    seen = []
+    one = torch.ones((), dtype=torch.int32, device=cuda)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        _lib.defer_check(one * 7, seen.append)
+    assert _lib.host_int(one * 3) == 3 and seen == []          # main stream: the side stream's check stays parked
+    _lib.flush_checks()
+    assert seen == []
+    with torch.cuda.stream(side):
+        assert _lib.host_ints([one * 4, one * 5]) == [4, 5]
+    assert seen == [7]
+    with torch.cuda.stream(side):
+        def boom(v):
+            raise RuntimeError(f"value {v}")
+        _lib.defer_check(one * 9, boom)
+        with pytest.raises(RuntimeError, match="value 9"):
+            _lib.flush_checks()
+        _lib.flush_checks()                                      # consumed: nothing left to raise

@@ -753,3 +753,39 @@ def test_hip_strided_rulebook_chain_equals_the_layer_by_layer_build(cuda, hip_li
     assert np.array_equal(got[0].out_indices.cpu().numpy(), oc) and np.array_equal(got[0].nbr_out.cpu().numpy(), nbr_out)
     oc2, nbr_out2, _, _ = osp.rulebook_sparse(oc, got[0].out_shape, 3, 2, 1)
     assert np.array_equal(got[1].out_indices.cpu().numpy(), oc2) and np.array_equal(got[1].nbr_out.cpu().numpy(), nbr_out2)
+
+
+@pytest.mark.gpu
+def test_hip_chain_stands_down_for_hooks_on_any_walked_module(cuda, hip_lib):
+    """A forward hook on a STAGE (backbone_3d.conv2 -- the usual way to tap features), on a nested post_act_block or on a ReLU fires in training
+    mode exactly as in eval mode: the launch-list chain bypasses __call__ of all of them, so it must stand down.  A BatchNorm with momentum=None
+    (cumulative average) falls back too instead of raising when the chain is flattened."""
+    import seevcn_amd.synth as synth
+    from seevcn_amd.pcdet.models import backbones_3d
+    from seevcn_amd.pcdet.ops import voxel_ops
+    from seevcn_amd.spconv import chain
+    pts, _ = synth.make_scene_batch(2, seed=2002, n_az=96)
+    g = dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.05, 0.05, 0.1], grid_size=[1408, 1600, 40])
+    f, c, _ = voxel_ops.voxelize_dynamic(torch.from_numpy(pts).to(cuda), g["point_cloud_range"], g["voxel_size"], g["grid_size"], 2)
+    torch.manual_seed(0)
+    net = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size']).to(cuda).train()
+
+    def run():
+        return net({'batch_size': 2, 'voxel_features': f.clone(), 'voxel_coords': c.clone()})
+
+    blocks = net._chain_blocks()
+    assert blocks is not None and net.conv2 in blocks.walked and net.conv2[0] in blocks.walked and net.conv2[0][2] in blocks.walked
+    for target in (net.conv2, net.conv3[1], net.conv1[0][2]):
+        fired = []
+        h = target.register_forward_hook(lambda m, i, o: fired.append(type(m).__name__))
+        try:
+            run()
+        finally:
+            h.remove()
+        assert len(fired) == 1, (target, fired)
+    # no hook left: the chain takes the forward again (one autograd node for the whole backbone)
+    out = run()['encoded_spconv_tensor'].features
+    assert type(out.grad_fn).__name__ == "SparseChainFunctionBackward"
+    net.conv3[1][1].momentum = None
+    out = run()['encoded_spconv_tensor'].features                  # no TypeError: module path, torch's cumulative moving average
+    assert type(out.grad_fn).__name__ != "SparseChainFunctionBackward" and torch.isfinite(out).all()
