@@ -90,6 +90,9 @@ int sv_gemm_bias_act(const float* A, int lda, const float* W, int ldw, const flo
 /* out[m][c] = act(weight[c][0..2] . xyz[m] + bias[c])   (the Conv1d(3, C, 1) first layers; C % 4 == 0) */
 int sv_pointwise_conv3(const float* xyz, const float* weight, const float* bias, float* out, int64_t M,
                        int C, int act, float slope, void* stream);
+/* The same layer on gathered rows: out[m] = f(xyz[sel[m]]) for m < *m_dev (<= M_cap), sel int64 row indices (sv_unique_rows_compact). */
+int sv_pointwise_conv3_gather(const float* xyz, const int64_t* sel, int64_t M_cap, const int32_t* m_dev, const float* weight, const float* bias,
+                              float* out, int C, int act, float slope, void* stream);
 
 /* VCN_VC.py:185-190: frustum angle, rotation to the frustum view, mean-centering.
  * input (B,n,3) -> fview (B,n,3), centred (B,n,3), state (B,32) [angle, mean xyz, centre xyz, rot 3x3]. */
@@ -135,17 +138,29 @@ int sv_rulebook_sparse(const int32_t* coords, int64_t n_in, int batch, const int
                        const int32_t* ksize_host, const int32_t* stride_host, const int32_t* padding_host,
                        const int32_t* dilation_host, void* index_ws, void* scratch, int32_t* out_coords,
                        int32_t* nbr_in, int32_t* in_block, int64_t capacity, int32_t* num_out, void* stream);
-/* The two halves of sv_rulebook_sparse (K <= 27), for a CHAIN of strided layers (spconv_backbone.py:141-157: conv2, conv3, conv4, conv_out):
- * count = mark the output cells + count + scan -> *num_out on the device; the inputs are either `coords` (n_in rows) or, with coords NULL,
- * the occupancy bitmap of the level below (`below_index_ws`: that level's index after ITS count and before its fill) -- so every level of the
- * chain can be counted before any output-site count is read, and ONE device -> host read serves the whole chain.
- * fill = look-up (nbr_in, in_block, out_coords) + returning the index to all-zero, for an index that holds exactly these coords' marks. */
-int sv_rulebook_sparse_count(const int32_t* coords, int64_t n_in, const void* below_index_ws, int batch, const int32_t* in_shape,
-                             const int32_t* ksize, const int32_t* stride, const int32_t* padding, const int32_t* dilation, void* index_ws,
-                             void* scratch, int32_t* num_out, void* stream);
-int sv_rulebook_sparse_fill(const int32_t* coords, int64_t n_in, int batch, const int32_t* in_shape, const int32_t* ksize, const int32_t* stride,
-                            const int32_t* padding, const int32_t* dilation, void* index_ws, int32_t* out_coords, int32_t* nbr_in,
-                            int32_t* in_block, int64_t capacity, void* stream);
+/* A CHAIN of strided layers (spconv_backbone.py:141-157: conv2, conv3, conv4, conv_out; spconv reads every level's indice-pair count back
+ * to the host) counted end to end on the device -- ONE device -> host read for all output-site counts, or none when the caller defers it:
+ * level l marks its output cells from level l-1's site list (one lane per site; level 0 from `coords0`, whose length may live on the device:
+ * n0_dev non-NULL overrides n0, which then only bounds the grid), counts its occupancy bitmap and writes its sites in canonical (ascending
+ * key) order into sites[l] (capacity caps[l] rows of int4 [b,z,y,x]) and their number into num_out[l] (device).  Kernels up to 3 per axis.
+ * geoms_host: n_levels x 15 int32 = {in_shape[3], ksize[3], stride[3], padding[3], dilation[3]}; index_ws[l]: sv_index_persistent_bytes(batch *
+ * prod(out_shape_l)), all zero on entry and left MARKED (the SET jobs of sv_rulebook_batch return the touched words to zero);
+ * scratch: sv_rulebook_chain_scratch_bytes(largest batch * prod(out_shape)). */
+size_t sv_rulebook_chain_scratch_bytes(int64_t max_ncells);
+int sv_rulebook_chain_count(const int32_t* coords0, int64_t n0, const int32_t* n0_dev, int batch, int n_levels, const int32_t* geoms_host,
+                            void* const* index_ws, int32_t* const* sites, const int64_t* caps, int32_t* num_out, void* scratch, void* stream);
+/* Every rulebook table of a network in three launches, through dense cell -> row maps (sv_cellmap_persistent_bytes per level, all zero between
+ * calls).  jobs_host: n_jobs rows of 32 int64, row[0] = kind:
+ *   1 SET    [1] sites (n, 4) of a level, [2] exact-size copy of them or 0, [3] the level's cell map or 0, [4] index workspace the sites were
+ *            marked in (sv_rulebook_chain_count) to return to zero, or 0, [5] n, [6..8] level shape (Z, Y, X), [9] batch
+ *   2 QUERY  one table: row r (coordinate c) and offset k = (kz, ky, kx) address cell (c * mul + add + k * step) / div of the TARGET level (exact
+ *            division, inside its shape), whose map gives the source row.  [1] row sites, [2] target map, [3] nbr (K, n) k-major table, [4] (n, 32)
+ *            row-major twin, [5] masks (n), [6] n, [7..9] row-level shape, [10..12] target shape, [13..15] ksize, [16..18] mul, [19..21] add,
+ *            [22..24] step, [25..27] div, [28] batch.  Submanifold: mul 1, add -(ks/2)*dil, step dil, div 1; strided output-major: mul stride,
+ *            add -pad, step dil, div 1 (target = input level); strided input-major: mul 1, add pad, step -dil, div stride (target = output level).
+ * Runs every SET, then every QUERY, then zeroes the maps of the SET jobs.  Same tables as sv_rulebook_subm_cellmap / sv_rulebook_sparse +
+ * sv_rulebook_invert_rows, bit for bit. */
+int sv_rulebook_batch(const int64_t* jobs_host, int n_jobs, void* stream);
 /* phase 2 (after the caller knows n_out): nbr_out (K, n_out) output-major table from nbr_in */
 int sv_rulebook_invert(const int32_t* nbr_in, int64_t n_in, int K, int32_t* nbr_out, int64_t n_out, void* stream);
 /* The same inversion (K <= 27) from the row-major input table (sv_rulebook_sparse's in_block) that also writes the row-major twin and the
@@ -190,6 +205,9 @@ int sv_conv_plan_tiles(const int32_t* masks_p, int64_t n_rows, int tiles_per_wav
  * on it). */
 int sv_conv_plan_build_dealt(const int32_t* masks, int64_t n_rows, int tiles_per_wave, int32_t* perm, int32_t* masks_p, int32_t* tile_of,
                              void* stream);
+/* sv_conv_plan_build_dealt for several tables in ONE launch (one workgroup per region and table); jobs_host: n_jobs rows of 8 int64 =
+ * {masks, n_rows, tiles_per_wave, perm, masks_p, tile_of, 0, 0} (device addresses). */
+int sv_conv_plan_build_dealt_batch(const int64_t* jobs_host, int n_jobs, void* stream);
 /* 1 iff the plan kernel is built for this layer shape (K <= 27 offsets, C_in in {16,32,64,128}, C_out in {16,32} or a multiple of 64 up to
  * 512) and X (n_src rows) is addressable through a 32-bit buffer descriptor; other shapes take sv_sparse_conv_gather_gemm. */
 int sv_conv_mfma_kernel_applies(int K, int Kd, int Nc, int64_t n_src);
@@ -502,6 +520,11 @@ int sv_batchnorm_relu_backward_partial(const float* x, const float* dy, int64_t 
 int sv_gemm_bias_act_ragged(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias,
                             const int32_t* row_group, float* C, int ldc, float* group_max, int M, int N, int K, int act, float slope,
                             void* stream);
+/* The ragged form with the number of rows ON THE DEVICE: M_cap rows of A / C / row_group are addressable and size the launch, the first *m_dev
+ * (<= M_cap) are computed -- sv_unique_rows_compact's total feeds it directly, so that VCN's forward needs no device -> host read. */
+int sv_gemm_bias_act_ragged_dev(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias,
+                                const int32_t* row_group, float* C, int ldc, float* group_max, int M_cap, const int32_t* m_dev, int N, int K,
+                                int act, float slope, void* stream);
 /* x (B,n,3), n <= 1024 -> uniq_idx (B,n): the first counts[b] entries of row b index one copy of each distinct point of object b
  * (exact float equality, -0.0 == 0.0), lexicographic order. */
 int sv_unique_rows(const float* x, int batch, int n, int32_t* uniq_idx, int32_t* counts, void* stream);

@@ -31,6 +31,7 @@ SIGNATURES = {
     "sv_fill_f32": (c_i, [c_p, c_i64, c_f, c_p]),
     "sv_gemm_bias_act": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "sv_pointwise_conv3": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p]),
+    "sv_pointwise_conv3_gather": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
     "sv_vcn_vc_prep": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_vcn_vc_pose": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_vcn_vc_finish": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
@@ -41,8 +42,9 @@ SIGNATURES = {
     "sv_cellmap_persistent_bytes": (c_sz, [c_i, c_p]),
     "sv_rulebook_subm_cellmap": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_rulebook_sparse": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
-    "sv_rulebook_sparse_count": (c_i, [c_p, c_i64, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "sv_rulebook_sparse_fill": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "sv_rulebook_chain_scratch_bytes": (c_sz, [c_i64]),
+    "sv_rulebook_chain_count": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sv_rulebook_batch": (c_i, [c_p, c_i, c_p]),
     "sv_rulebook_invert": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p]),
     "sv_rulebook_invert_rows": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p]),
     "sv_rulebook_pair_counts": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
@@ -61,6 +63,7 @@ SIGNATURES = {
     "sv_conv_weight_fragments_batch": (c_i, [c_p, c_i, c_i64, c_p]),
     "sv_conv_plan_build_dealt": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p]),
     "sv_conv_plan_tiles": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
+    "sv_conv_plan_build_dealt_batch": (c_i, [c_p, c_i, c_p]),
     "sv_conv_mfma_kernel_applies": (c_i, [c_i, c_i, c_i, c_i64]),
     "sv_conv_weight_fragments": (c_i, [c_p, c_i64, c_i64, c_i64, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_sparse_conv_wgrad_scratch_bytes": (c_sz, [c_i64, c_i, c_i, c_i]),
@@ -120,6 +123,7 @@ SIGNATURES = {
     "sv_isolate_cluster_scratch_bytes": (c_i64, [c_i, c_i64]),
     "sv_isolate_largest_cluster": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i64, c_d, c_d, c_d, c_d, c_d, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_gemm_bias_act_ragged": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "sv_gemm_bias_act_ragged_dev": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
     "sv_unique_rows": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "sv_unique_rows_compact": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_ball_query_batch": (c_i, [c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p]),

@@ -428,32 +428,6 @@ __global__ __launch_bounds__(RB_THREADS) void k_sparse_mark_rows(const int4* __r
   sparse_mark_one<FULL3>(c, g, ix, clear);
 }
 
-// The same marks with the inputs taken from the OCCUPANCY BITMAP of the level below (a strided rulebook's index that has been marked and
-// counted but not cleared yet) instead of from its list of coordinates: the list needs the number of sites on the host, the bitmap does not, so
-// a chain of strided levels can be counted end to end with ONE device -> host read (sv_rulebook_sparse_count).  32 lanes per chunk of the
-// lower bitmap; empty chunks are skipped by their count.
-template <bool FULL3>
-__global__ __launch_bounds__(RB_THREADS) void k_sparse_mark_from_index(SvIndexView below, ConvGeom g, SvIndexView ix) {
-  const int lane = threadIdx.x & 31;
-  const int64_t nchunks = (below.ncells + 1023) / 1024;
-  const int64_t sub = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5, nsub = ((int64_t)gridDim.x * blockDim.x) >> 5;
-  const int64_t yx = (int64_t)g.in_shape[1] * g.in_shape[2], zyx = yx * g.in_shape[0];
-  for (int64_t cc = sub; cc < nchunks; cc += nsub) {
-    if (below.chunk_cnt[cc] == 0) continue;
-    const int64_t w = cc * SV_CHUNK_WORDS + lane;
-    uint32_t bits = below.words[w].x;
-    while (bits) {
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1u;
-      const int64_t key = w * 32 + b;                     // lin_key of the lower level: ((batch * Z + z) * Y + y) * X + x
-      if (key >= below.ncells) break;
-      const int64_t r = key % zyx;
-      const int4 c = make_int4((int)(key / zyx), (int)(r / yx), (int)((r % yx) / g.in_shape[2]), (int)(r % g.in_shape[2]));
-      sparse_mark_one<FULL3>(c, g, ix, 0);
-    }
-  }
-}
-
 // chunk_cnt[c] = occupied cells of chunk c; words[w].y = occupied cells of the chunk before word w (only written where the word is
 // non-empty, so untouched words stay all-zero).  32 lanes per chunk.
 __global__ __launch_bounds__(RB_THREADS) void k_index_count(SvIndexView ix, int64_t nchunks) {
@@ -537,71 +511,6 @@ extern "C" int sv_conv_out_shape(const int32_t* in_shape_host, const int32_t* ks
   int rc = fill_geom(g, 1, in_shape_host, ksize_host, stride_host, padding_host, dilation_host, false);
   if (rc) return rc;
   for (int d = 0; d < 3; ++d) out_shape_host[d] = g.out_shape[d];
-  return SV_OK;
-}
-
-// ---- a strided rulebook in two halves (K <= 27): count = mark + count + scan (-> *num_out on the device), fill = look-up + clear.
-// sv_rulebook_sparse below is count followed by fill; a CHAIN of strided levels runs every level's count first -- level l + 1 marks from level
-// l's bitmap (below_index_ws) -- reads all the counts at once and then fills level by level with exactly sized tables.
-extern "C" int sv_rulebook_sparse_count(const int32_t* coords, int64_t n_in, const void* below_index_ws, int batch, const int32_t* in_shape_host,
-                                        const int32_t* ksize_host, const int32_t* stride_host, const int32_t* padding_host,
-                                        const int32_t* dilation_host, void* index_ws, void* scratch, int32_t* num_out, void* stream) {
-  SV_CHECK_ARG(batch > 0 && num_out && index_ws && scratch && (coords != nullptr) != (below_index_ws != nullptr),
-               "rulebook_sparse_count: needs the index, the scratch, num_out and EITHER the coordinates or the index of the level below");
-  ConvGeom g;
-  int rc = fill_geom(g, batch, in_shape_host, ksize_host, stride_host, padding_host, dilation_host, false);
-  if (rc) return rc;
-  SV_CHECK_ARG(g.K <= RB_KMAX, "rulebook_sparse_count: K <= %d", RB_KMAX);
-  hipStream_t st = sv_stream(stream);
-  const int64_t ncells = (int64_t)batch * g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
-  SvIndexView ix = sv_index_view(index_ws, ncells);
-  const int64_t nchunks = sv_index_nchunks(ncells);
-  const bool full3 = g.ksize[0] == 3 && g.ksize[1] == 3 && g.ksize[2] == 3;
-  if (coords) {
-    SV_CHECK_ARG(n_in >= 0, "rulebook_sparse_count: bad n_in");
-    if (n_in > 0) {
-      const int rows_grid = sv_div_up(n_in, RB_THREADS);
-      const int4* c4 = reinterpret_cast<const int4*>(coords);
-      if (full3) hipLaunchKernelGGL(k_sparse_mark_rows<true>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 0);
-      else hipLaunchKernelGGL(k_sparse_mark_rows<false>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 0);
-    }
-  } else {
-    const int64_t below_cells = (int64_t)batch * g.in_shape[0] * g.in_shape[1] * g.in_shape[2];
-    SvIndexView below = sv_index_view(const_cast<void*>(below_index_ws), below_cells);
-    const dim3 grid(sv_grid_1d(sv_index_nchunks(below_cells) * 32, RB_THREADS, 256 * 16));
-    if (full3) hipLaunchKernelGGL(k_sparse_mark_from_index<true>, grid, dim3(RB_THREADS), 0, st, below, g, ix);
-    else hipLaunchKernelGGL(k_sparse_mark_from_index<false>, grid, dim3(RB_THREADS), 0, st, below, g, ix);
-  }
-  hipLaunchKernelGGL(k_index_count, dim3(sv_grid_1d(nchunks * 32, RB_THREADS, 256 * 16)), dim3(RB_THREADS), 0, st, ix, nchunks);
-  rc = sv_index_scan_launch(ix, num_out, scratch, st);
-  if (rc) return rc;
-  SV_LAUNCH_CHECK();
-  return SV_OK;
-}
-
-extern "C" int sv_rulebook_sparse_fill(const int32_t* coords, int64_t n_in, int batch, const int32_t* in_shape_host, const int32_t* ksize_host,
-                                       const int32_t* stride_host, const int32_t* padding_host, const int32_t* dilation_host, void* index_ws,
-                                       int32_t* out_coords, int32_t* nbr_in, int32_t* in_block, int64_t capacity, void* stream) {
-  SV_CHECK_ARG(n_in >= 0 && batch > 0 && capacity >= 0 && index_ws, "rulebook_sparse_fill: bad arguments");
-  if (n_in == 0) return SV_OK;
-  SV_CHECK_ARG(coords && out_coords && nbr_in, "rulebook_sparse_fill: null pointer");
-  ConvGeom g;
-  int rc = fill_geom(g, batch, in_shape_host, ksize_host, stride_host, padding_host, dilation_host, false);
-  if (rc) return rc;
-  SV_CHECK_ARG(g.K <= RB_KMAX, "rulebook_sparse_fill: K <= %d", RB_KMAX);
-  hipStream_t st = sv_stream(stream);
-  const int64_t ncells = (int64_t)batch * g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
-  SvIndexView ix = sv_index_view(index_ws, ncells);
-  const int4* c4 = reinterpret_cast<const int4*>(coords);
-  int4* oc4 = reinterpret_cast<int4*>(out_coords);
-  const int rows_grid = sv_div_up(n_in, RB_THREADS);
-  const bool full3 = g.ksize[0] == 3 && g.ksize[1] == 3 && g.ksize[2] == 3;
-  int32_t* masks_in = in_block ? in_block + (size_t)RB_ROW * n_in : nullptr;
-  if (full3) hipLaunchKernelGGL(k_sparse_lookup_rows<true>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, nbr_in, oc4, capacity, in_block, masks_in);
-  else hipLaunchKernelGGL(k_sparse_lookup_rows<false>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, nbr_in, oc4, capacity, in_block, masks_in);
-  if (full3) hipLaunchKernelGGL(k_sparse_mark_rows<true>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 1);
-  else hipLaunchKernelGGL(k_sparse_mark_rows<false>, dim3(rows_grid), dim3(RB_THREADS), 0, st, c4, n_in, g, ix, 1);
-  SV_LAUNCH_CHECK();
   return SV_OK;
 }
 
@@ -747,6 +656,422 @@ extern "C" int sv_rulebook_pair_counts(const int32_t* nbr, int64_t n_out, int K,
   SV_CHECK_ARG(nbr, "rulebook_pair_counts: null pointer");
   dim3 grid(sv_grid_1d(n_out, RB_THREADS, 64), K);
   hipLaunchKernelGGL(k_pair_count, grid, dim3(RB_THREADS), 0, st, nbr, n_out, K, counts);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ===========================================================================================================================================
+// A CHAIN of strided levels without a host read per level, and all tables of a network in three launches.
+//
+// The reference's backbones (spconv_backbone.py:141-157) run conv2 -> conv3 -> conv4 -> conv_out; spconv builds the indice pairs of each
+// lazily and reads the number of output sites back to the host every time (four blocking reads per step here in round 3, each waiting for
+// everything queued in front of it).  Two phases instead:
+//
+//  phase 1  sv_rulebook_chain_count: the OUTPUT SITE SETS of every level, end to end on the device.  Level l marks its output cells in its
+//           occupancy bitmap from level l-1's site list (k_chain_mark_list: one lane per site, the list's length read from the device --
+//           driving the marks from the bitmap below was built in round 3 and lost to divergence), counts the bitmap (k_chain_count: per-chunk
+//           counts, in-chunk prefixes, per-block sums) and turns it into the ascending-key site list in a capacity buffer (k_chain_emit).
+//           3 L launches, then ONE read for all L counts (+ the voxel count, whose device word feeds level 0's marks).
+//  phase 2  sv_rulebook_batch: with the counts known every table has its exact size.  Three multi-job launches for the whole network:
+//           SET   every level's sites into its dense cell -> row map (and: copy the sites into their exact-size tensor, return the
+//                 bitmap words they set to zero),
+//           QUERY every table -- submanifold (K, n), strided output-major (K, n_out) and input-major (K, n_in) -- as "row r, offset k ->
+//                 one cell of a map": no atomics, no scattered stores, no -1 pre-fill, no inversion pass; each job also writes the
+//                 row-major twin and the neighbour masks the conv plans consume,
+//           CLEAR the maps.
+// Same tables as sv_rulebook_sparse + sv_rulebook_invert_rows / sv_rulebook_subm_cellmap, bit for bit (tests/test_spconv.py).
+// ===========================================================================================================================================
+constexpr int CH_BLOCK = 256;          // chunks per workgroup of the count / emit passes (256 KiB of cells, 64 KiB of bitmap)
+constexpr int CH_MAX_LEVELS = 8;
+static_assert(CH_BLOCK == RB_THREADS, "k_chain_emit scans one chunk count per thread");
+static bool small_kernel_host(const ConvGeom& g) { return g.ksize[0] <= 3 && g.ksize[1] <= 3 && g.ksize[2] <= 3; }
+
+template <bool FULL3>
+__global__ __launch_bounds__(RB_THREADS) void k_chain_mark_list(const int4* __restrict__ coords, const int32_t* __restrict__ n_dev, int64_t n_host,
+                                                                ConvGeom g, SvIndexView ix) {
+  int64_t n = n_dev ? (int64_t)*n_dev : n_host;
+  if (n > n_host) n = n_host;                          // with the count on the device n_host is the buffer's capacity
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = coords[i];
+    if (coord_ok(c, g.batch, g.in_shape)) sparse_mark_one<FULL3>(c, g, ix, 0);
+  }
+}
+
+// chunk_cnt[c], words[w].y (in-chunk prefix, only where the word is non-empty) and block_sums[b] = occupied cells of the block's CH_BLOCK chunks.
+// 32 lanes per chunk; a thread requests the words of all its 32 chunks before it looks at the first (one load at a time the pass is a chain of
+// 32 memory latencies: 22 us for a 47 MB bitmap).  Empty chunks (most of them) take no scan and no store: their count is zero already.
+__global__ __launch_bounds__(RB_THREADS) void k_chain_count(SvIndexView ix, int64_t nchunks, int32_t* __restrict__ block_sums) {
+  __shared__ int s_sum[RB_THREADS / 32];
+  constexpr int PER = CH_BLOCK / (RB_THREADS / 32);        // chunks per 32-lane group
+  const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int64_t c0 = (int64_t)blockIdx.x * CH_BLOCK;
+  uint32_t bits[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int64_t c = c0 + sub + (RB_THREADS / 32) * i;
+    bits[i] = c < nchunks ? ix.words[c * SV_CHUNK_WORDS + lane].x : 0u;
+  }
+  int mine = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const unsigned long long any = __ballot(bits[i] != 0u);
+    if (!((any >> (32 * (sub & 1))) & 0xffffffffull)) continue;         // uniform over the 32-lane group
+    const int64_t c = c0 + sub + (RB_THREADS / 32) * i;
+    const int p = __popc(bits[i]);
+    int incl = p;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const int t = __shfl_up(incl, d, 32);
+      if (lane >= d) incl += t;
+    }
+    if (bits[i]) ix.words[c * SV_CHUNK_WORDS + lane].y = (uint32_t)(incl - p);
+    if (lane == 31) ix.chunk_cnt[c] = incl, mine += incl;
+  }
+  if (lane == 31) s_sum[sub] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < RB_THREADS / 32; ++i) t += s_sum[i];
+    block_sums[blockIdx.x] = t;
+  }
+}
+
+// block b: rank base = sum of the blocks before it; the sites of its non-empty chunks -> sites[rank] (ascending key).  The next level's marks are a
+// launch of their own (k_chain_mark_list with the count on the device): fused in here they were bound by the few blocks that hold most of a
+// LiDAR scene's sites (186 us for level 1 of the bench batch).
+__global__ __launch_bounds__(RB_THREADS) void k_chain_emit(SvIndexView ix, int64_t nchunks, const int32_t* __restrict__ block_sums, int4* __restrict__ sites,
+                                                           int64_t capacity, int32_t* __restrict__ num_out, ConvGeom gout /* shape of THIS level in out_shape */) {
+  __shared__ int s_red[RB_THREADS / SV_WAVE], s_wtot[RB_THREADS / SV_WAVE], s_wne[RB_THREADS / SV_WAVE];
+  __shared__ int s_cbase[CH_BLOCK];
+  __shared__ uint16_t s_list[CH_BLOCK];
+  const int tid = threadIdx.x, lane32 = tid & 31, sub = tid >> 5, b = blockIdx.x, lane = tid & 63, wid = tid >> 6;
+  int before = 0;
+  for (int j = tid; j < b; j += RB_THREADS) before += block_sums[j];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, SV_WAVE);
+  // exclusive scan of the block's chunk counts (one chunk per thread: CH_BLOCK == RB_THREADS) and the list of its non-empty chunks
+  const int64_t c_mine = (int64_t)b * CH_BLOCK + tid;
+  const int cnt = c_mine < nchunks ? ix.chunk_cnt[c_mine] : 0;
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < SV_WAVE; d <<= 1) {
+    const int t = __shfl_up(incl, d, SV_WAVE);
+    if (lane >= d) incl += t;
+  }
+  const unsigned long long ne = __ballot(cnt > 0);
+  if (lane == 0) s_red[wid] = before, s_wne[wid] = __popcll(ne);
+  if (lane == 63) s_wtot[wid] = incl;
+  __syncthreads();
+  int base = 0, wbase = 0, total = 0, nebase = 0, n_ne = 0;
+#pragma unroll
+  for (int i = 0; i < RB_THREADS / SV_WAVE; ++i) {
+    base += s_red[i];
+    if (i < wid) wbase += s_wtot[i], nebase += s_wne[i];
+    total += s_wtot[i], n_ne += s_wne[i];
+  }
+  s_cbase[tid] = base + wbase + incl - cnt;
+  if (cnt > 0) s_list[nebase + __popcll(ne & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+  if (b == (int)gridDim.x - 1 && tid == 0) *num_out = base + total;
+  __syncthreads();
+  // emit: 32 lanes per non-empty chunk, a lane walks the set bits of its word.  The word's first key is decoded with divisions once; its 32
+  // cells follow by carries (x-fastest key).  EM_B words are requested before the first is used.
+  const int X = gout.out_shape[2], Y = gout.out_shape[1], Z = gout.out_shape[0];
+  const bool narrow = ix.ncells < ((int64_t)1 << 31);
+  constexpr int EM_B = 4, GROUPS = RB_THREADS / 32;
+  for (int q0 = sub; q0 < n_ne; q0 += GROUPS * EM_B) {
+    uint2 wd[EM_B];
+    int jj[EM_B];
+#pragma unroll
+    for (int u = 0; u < EM_B; ++u) {
+      const int q = q0 + GROUPS * u;
+      jj[u] = q < n_ne ? (int)s_list[q] : -1;
+      wd[u] = jj[u] >= 0 ? ix.words[((int64_t)b * CH_BLOCK + jj[u]) * SV_CHUNK_WORDS + lane32] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < EM_B; ++u) {
+      uint32_t bits = wd[u].x;
+      if (!bits) continue;
+      const int64_t w = ((int64_t)b * CH_BLOCK + jj[u]) * SV_CHUNK_WORDS + lane32;
+      int64_t r = (int64_t)s_cbase[jj[u]] + wd[u].y;
+      int bb, z0, y0, x0;
+      if (narrow) {
+        const uint32_t key = (uint32_t)w * 32u;
+        const uint32_t q1 = key / (uint32_t)X;
+        x0 = (int)(key - q1 * (uint32_t)X);
+        const uint32_t q2 = q1 / (uint32_t)Y;
+        y0 = (int)(q1 - q2 * (uint32_t)Y);
+        bb = (int)(q2 / (uint32_t)Z);
+        z0 = (int)(q2 - (uint32_t)bb * (uint32_t)Z);
+      } else {
+        const int64_t key = w * 32;
+        const int64_t q1 = key / X, q2 = q1 / Y;
+        x0 = (int)(key - q1 * X), y0 = (int)(q1 - q2 * Y), bb = (int)(q2 / Z), z0 = (int)(q2 - (int64_t)bb * Z);
+      }
+      while (bits) {
+        const int bit = __ffs(bits) - 1;
+        bits &= bits - 1u;
+        int x = x0 + bit, y = y0, z = z0, bq = bb;
+        while (x >= X) {
+          x -= X;
+          if (++y == Y) {
+            y = 0;
+            if (++z == Z) z = 0, ++bq;
+          }
+        }
+        if (r < capacity) sites[r] = make_int4(bq, z, y, x);
+        ++r;
+      }
+    }
+  }
+}
+
+extern "C" size_t sv_rulebook_chain_scratch_bytes(int64_t max_ncells) {
+  return align256((size_t)(sv_index_nchunks(max_ncells) / CH_BLOCK + 2) * sizeof(int32_t));
+}
+
+// geoms_host: n_levels x 15 int32 = {in_shape[3], ksize[3], stride[3], padding[3], dilation[3]} (level l's in_shape must be level l-1's output
+// shape).  index_ws[l]: the persistent index of level l's OUTPUT grid (all zero on entry; left MARKED -- sv_rulebook_batch's SET jobs return the
+// touched words to zero, or memset the workspace).  sites[l]: capacity caps[l] x int4; num_out: n_levels int32 on the device.
+extern "C" int sv_rulebook_chain_count(const int32_t* coords0, int64_t n0, const int32_t* n0_dev, int batch, int n_levels, const int32_t* geoms_host,
+                                       void* const* index_ws, int32_t* const* sites, const int64_t* caps, int32_t* num_out, void* scratch, void* stream) {
+  SV_CHECK_ARG(batch > 0 && n_levels >= 1 && n_levels <= CH_MAX_LEVELS && n0 >= 0 && geoms_host && index_ws && sites && caps && num_out && scratch,
+               "rulebook_chain_count: bad arguments (1 <= levels <= %d)", CH_MAX_LEVELS);
+  SV_CHECK_ARG(coords0 || n0 == 0, "rulebook_chain_count: null coordinates");
+  hipStream_t st = sv_stream(stream);
+  ConvGeom g[CH_MAX_LEVELS];
+  SvIndexView ix[CH_MAX_LEVELS];
+  bool full3[CH_MAX_LEVELS];
+  for (int l = 0; l < n_levels; ++l) {
+    const int32_t* q = geoms_host + 15 * l;
+    int rc = fill_geom(g[l], batch, q, q + 3, q + 6, q + 9, q + 12, false);
+    if (rc) return rc;
+    SV_CHECK_ARG(g[l].K <= RB_KMAX && small_kernel_host(g[l]), "rulebook_chain_count: kernels up to 3 per axis");
+    if (l > 0)
+      for (int d = 0; d < 3; ++d) SV_CHECK_ARG(g[l].in_shape[d] == g[l - 1].out_shape[d], "rulebook_chain_count: level %d does not take level %d's output shape", l, l - 1);
+    SV_CHECK_ARG(index_ws[l] && sites[l] && caps[l] > 0, "rulebook_chain_count: null pointer at level %d", l);
+    const int64_t ncells = (int64_t)batch * g[l].out_shape[0] * g[l].out_shape[1] * g[l].out_shape[2];
+    ix[l] = sv_index_view(index_ws[l], ncells);
+    full3[l] = g[l].ksize[0] == 3 && g[l].ksize[1] == 3 && g[l].ksize[2] == 3;
+  }
+  const int4* c4 = reinterpret_cast<const int4*>(coords0);
+  if (n0 > 0) {
+    const dim3 grid(sv_grid_1d(n0, RB_THREADS, 2048));
+    if (full3[0]) hipLaunchKernelGGL(k_chain_mark_list<true>, grid, dim3(RB_THREADS), 0, st, c4, n0_dev, n0, g[0], ix[0]);
+    else hipLaunchKernelGGL(k_chain_mark_list<false>, grid, dim3(RB_THREADS), 0, st, c4, n0_dev, n0, g[0], ix[0]);
+  }
+  int32_t* sums = reinterpret_cast<int32_t*>(scratch);
+  for (int l = 0; l < n_levels; ++l) {
+    const int64_t nchunks = sv_index_nchunks(ix[l].ncells);
+    const int blocks = (int)((nchunks + CH_BLOCK - 1) / CH_BLOCK);
+    int4* s4 = reinterpret_cast<int4*>(sites[l]);
+    hipLaunchKernelGGL(k_chain_count, dim3(blocks), dim3(RB_THREADS), 0, st, ix[l], nchunks, sums);
+    hipLaunchKernelGGL(k_chain_emit, dim3(blocks), dim3(RB_THREADS), 0, st, ix[l], nchunks, sums, s4, caps[l], num_out + l, g[l]);
+    if (l + 1 < n_levels) {
+      // the next level's marks from the sites just written; their number is num_out[l] on the device, the grid is sized for the capacity
+      const dim3 grid(sv_grid_1d(caps[l], RB_THREADS, 2048));
+      if (full3[l + 1]) hipLaunchKernelGGL(k_chain_mark_list<true>, grid, dim3(RB_THREADS), 0, st, s4, num_out + l, caps[l], g[l + 1], ix[l + 1]);
+      else hipLaunchKernelGGL(k_chain_mark_list<false>, grid, dim3(RB_THREADS), 0, st, s4, num_out + l, caps[l], g[l + 1], ix[l + 1]);
+    }
+  }
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------- phase 2: batch
+constexpr int RBJ_MAX = 16;            // jobs per launch (kernel-argument block: 16 x 152 B)
+
+struct SetJob {                        // every site of a level into the level's cell -> row map
+  const int4* src;                     // the level's sites (n rows)
+  int4* dst;                           // optional exact-size copy (the rulebook's out_indices)
+  int32_t* map;                        // tiled cell -> row + 1 map of the level (nullable: copy / bitmap clean-up only)
+  uint2* words;                        // optional: occupancy bitmap the sites were marked in (phase 1) -- their words and chunk counts return to zero
+  int32_t* chunk_cnt;
+  int64_t n;
+  int shape[3];
+  int batch;
+  CellTiling t;
+  int wg0;                             // first workgroup of the job in the launch
+};
+struct SetBatch { SetJob j[RBJ_MAX]; int n; };
+
+template <typename B>
+__device__ __forceinline__ int job_of_block(const B& b, int blk) {
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < RBJ_MAX; ++q) j += (q < b.n && blk >= b.j[q].wg0) ? 1 : 0;
+  return j;
+}
+
+__global__ __launch_bounds__(RB_THREADS) void k_batch_set(SetBatch b, int clear_only) {
+  const int ji = job_of_block(b, blockIdx.x);
+  const SetJob& J = b.j[ji];
+  const int64_t i = (int64_t)(blockIdx.x - J.wg0) * RB_THREADS + threadIdx.x;
+  if (i >= J.n) return;
+  const int4 c = J.src[i];
+  if (clear_only) {
+    if (J.map && coord_ok(c, J.batch, J.shape)) J.map[tiled_cell(c.x, c.y, c.z, c.w, J.t)] = 0;
+    return;
+  }
+  if (J.dst) J.dst[i] = c;
+  if (!coord_ok(c, J.batch, J.shape)) return;
+  if (J.map) J.map[tiled_cell(c.x, c.y, c.z, c.w, J.t)] = (int32_t)i + 1;
+  if (J.words) {
+    const int64_t key = lin_key(c.x, c.y, c.z, c.w, J.shape);
+    J.words[key >> 5] = make_uint2(0u, 0u);
+    J.chunk_cnt[key >> SV_CHUNK_SHIFT] = 0;
+  }
+}
+
+// One table: row r (coordinate c) and kernel offset k = (kz, ky, kx) address the cell  t = (c * mul + add + k * step) / div  of the TARGET level
+// (exact division, inside the target shape), whose map gives the source row.
+//   submanifold:                 mul 1,      add -(ks/2)*dil, step +dil, div 1       (target = the level itself)
+//   strided, output-major table: mul stride, add -pad,        step +dil, div 1       (rows = output sites, target = input level)
+//   strided, input-major table:  mul 1,      add +pad,        step -dil, div stride  (rows = input sites,  target = output level)
+struct QueryJob {
+  const int4* rows;                    // (n) coordinates of the table's rows
+  const int32_t* map;                  // target level's cell map
+  int32_t* nbr;                        // (K, n) k-major table
+  int32_t* tab;                        // (n, 32) row-major twin
+  int32_t* masks;                      // (n)
+  int64_t n;
+  int rshape[3], tshape[3];            // shapes of the row level / target level
+  int ksize[3], mul[3], add[3], step[3], div[3];
+  int batch, K;
+  CellTiling t;                        // tiling of the target map
+  int wg0;
+};
+struct QueryBatch { QueryJob j[RBJ_MAX]; int n; };
+static_assert(sizeof(QueryBatch) <= 3900 && sizeof(SetBatch) <= 3900, "kernel argument block");
+
+template <bool FULL3>
+__device__ __forceinline__ void query_row(const QueryJob& J, int64_t i) {
+  const int4 c = J.rows[i];
+  const bool ok = coord_ok(c, J.batch, J.rshape);
+  const int cc[3] = {c.y, c.z, c.w};
+  int cand[3][3];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const int dv = J.div[ax];
+#pragma unroll
+    for (int ka = 0; ka < 3; ++ka) {
+      int o = -1;
+      if (ka < J.ksize[ax]) {
+        const int t = cc[ax] * J.mul[ax] + J.add[ax] + ka * J.step[ax];
+        if (t >= 0) {
+          if (dv == 1) o = t;
+          else if (dv == 2) o = (t & 1) ? -1 : (t >> 1);
+          else o = (t % dv) ? -1 : t / dv;
+          if (o >= J.tshape[ax]) o = -1;
+        }
+      }
+      cand[ax][ka] = o;
+    }
+  }
+  const int kyx = J.ksize[1] * J.ksize[2];
+  int32_t e[RB_ROW];
+#pragma unroll
+  for (int k = 0; k < RB_ROW; ++k) e[k] = -1;
+#pragma unroll
+  for (int k = 0; k < RB_KMAX; ++k) {
+    if (k < J.K) {
+      const int kz = FULL3 ? k / 9 : k / kyx, ky = FULL3 ? (k / 3) % 3 : (k - kz * kyx) / J.ksize[2], kx = FULL3 ? k % 3 : k - kz * kyx - ky * J.ksize[2];
+      const int z = cand[0][kz % 3], y = cand[1][ky % 3], x = cand[2][kx % 3];
+      if (ok && (z | y | x) >= 0) e[k] = J.map[tiled_cell(c.x, z, y, x, J.t)] - 1;
+    }
+  }
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < RB_KMAX; ++k) {
+    if (k < J.K) {
+      J.nbr[(int64_t)k * J.n + i] = e[k];
+      m |= e[k] >= 0 ? (1u << k) : 0u;
+    }
+  }
+  J.masks[i] = (int32_t)m;
+  rb_i32x4* dst = reinterpret_cast<rb_i32x4*>(J.tab + i * RB_ROW);
+#pragma unroll
+  for (int q = 0; q < RB_ROW / 4; ++q) dst[q] = (rb_i32x4){e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]};
+}
+
+__global__ __launch_bounds__(RB_THREADS) void k_batch_query(QueryBatch b) {
+  const int ji = job_of_block(b, blockIdx.x);
+  const QueryJob& J = b.j[ji];
+  const int64_t i = (int64_t)(blockIdx.x - J.wg0) * RB_THREADS + threadIdx.x;
+  if (i >= J.n) return;
+  if (J.ksize[0] == 3 && J.ksize[1] == 3 && J.ksize[2] == 3) query_row<true>(J, i);      // job-uniform, hence workgroup-uniform
+  else query_row<false>(J, i);
+}
+
+// jobs_host: n_jobs rows of 32 int64.  row[0] = kind:
+//   1 SET:    [1] src sites, [2] dst sites or 0, [3] cell map or 0, [4] index workspace to clean or 0, [5] n, [6..8] shape (Z, Y, X), [9] batch
+//   2 QUERY:  [1] row sites, [2] target cell map, [3] nbr (K, n), [4] tab (n, 32), [5] masks (n), [6] n, [7..9] row-level shape, [10..12] target shape,
+//             [13..15] ksize, [16..18] mul, [19..21] add, [22..24] step, [25..27] div, [28] batch
+// Order of execution: every SET, then every QUERY, then the maps of every SET with a map are returned to zero (three launches; more than RBJ_MAX
+// jobs of a kind are run in groups).  A SET that cleans an index takes the index's level shape from [6..8].
+extern "C" int sv_rulebook_batch(const int64_t* jobs_host, int n_jobs, void* stream) {
+  SV_CHECK_ARG(n_jobs >= 0 && (jobs_host || n_jobs == 0), "rulebook_batch: bad arguments");
+  hipStream_t st = sv_stream(stream);
+  SetBatch sb;
+  QueryBatch qb;
+  auto flush_set = [&](int clear_only, int wgs) {
+    if (sb.n > 0 && wgs > 0) hipLaunchKernelGGL(k_batch_set, dim3(wgs), dim3(RB_THREADS), 0, st, sb, clear_only);
+  };
+  for (int pass = 0; pass < 3; ++pass) {              // 0: SET, 1: QUERY, 2: CLEAR
+    sb.n = 0, qb.n = 0;
+    int wgs = 0;
+    for (int q = 0; q < n_jobs; ++q) {
+      const int64_t* r = jobs_host + 32 * q;
+      if (r[0] == 1 && pass != 1) {
+        const int64_t n = r[5];
+        SV_CHECK_ARG(n >= 0 && r[9] > 0, "rulebook_batch: SET job %d: bad sizes", q);
+        if (n == 0 || (pass == 2 && !r[3])) continue;
+        SV_CHECK_ARG(r[1], "rulebook_batch: SET job %d: null sites", q);
+        SetJob& J = sb.j[sb.n];
+        J.src = reinterpret_cast<const int4*>(r[1]), J.dst = reinterpret_cast<int4*>(r[2]), J.map = reinterpret_cast<int32_t*>(r[3]);
+        J.n = n, J.batch = (int)r[9];
+        for (int d = 0; d < 3; ++d) J.shape[d] = (int)r[6 + d];
+        J.t = cell_tiling(J.shape);
+        J.words = nullptr, J.chunk_cnt = nullptr;
+        if (r[4]) {
+          SvIndexView ix = sv_index_view(reinterpret_cast<void*>(r[4]), (int64_t)J.batch * J.shape[0] * J.shape[1] * J.shape[2]);
+          J.words = ix.words, J.chunk_cnt = ix.chunk_cnt;
+        }
+        J.wg0 = wgs;
+        wgs += sv_div_up(n, RB_THREADS);
+        if (++sb.n == RBJ_MAX) flush_set(pass == 2, wgs), sb.n = 0, wgs = 0;
+      } else if (r[0] == 2 && pass == 1) {
+        const int64_t n = r[6];
+        SV_CHECK_ARG(n >= 0 && r[28] > 0, "rulebook_batch: QUERY job %d: bad sizes", q);
+        if (n == 0) continue;
+        SV_CHECK_ARG(r[1] && r[2] && r[3] && r[4] && r[5], "rulebook_batch: QUERY job %d: null pointer", q);
+        QueryJob& J = qb.j[qb.n];
+        J.rows = reinterpret_cast<const int4*>(r[1]), J.map = reinterpret_cast<const int32_t*>(r[2]), J.nbr = reinterpret_cast<int32_t*>(r[3]);
+        J.tab = reinterpret_cast<int32_t*>(r[4]), J.masks = reinterpret_cast<int32_t*>(r[5]), J.n = n, J.batch = (int)r[28];
+        J.K = 1;
+        for (int d = 0; d < 3; ++d) {
+          J.rshape[d] = (int)r[7 + d], J.tshape[d] = (int)r[10 + d], J.ksize[d] = (int)r[13 + d], J.mul[d] = (int)r[16 + d], J.add[d] = (int)r[19 + d];
+          J.step[d] = (int)r[22 + d], J.div[d] = (int)r[25 + d];
+          SV_CHECK_ARG(J.ksize[d] >= 1 && J.ksize[d] <= 3 && J.div[d] >= 1 && J.rshape[d] > 0 && J.tshape[d] > 0, "rulebook_batch: QUERY job %d: bad geometry", q);
+          J.K *= J.ksize[d];
+        }
+        J.t = cell_tiling(J.tshape);
+        J.wg0 = wgs;
+        wgs += sv_div_up(n, RB_THREADS);
+        if (++qb.n == RBJ_MAX) {
+          hipLaunchKernelGGL(k_batch_query, dim3(wgs), dim3(RB_THREADS), 0, st, qb);
+          qb.n = 0, wgs = 0;
+        }
+      } else if (r[0] != 1 && r[0] != 2) {
+        SV_CHECK_ARG(false, "rulebook_batch: unknown job kind %lld at position %d", (long long)r[0], q);
+      }
+    }
+    if (pass == 1) {
+      if (qb.n > 0) hipLaunchKernelGGL(k_batch_query, dim3(wgs), dim3(RB_THREADS), 0, st, qb);
+    } else {
+      flush_set(pass == 2, wgs);
+    }
+  }
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -537,16 +537,29 @@ struct PlanFusedArgs {
   PlanDims d;
   int max_tiles;          // tiles of the largest region (LDS layout)
   int debug;              // measurement only (SEEVCN_PLAN_DEBUG): 1 no histogram pass, 2 no perm / masks_p stores, 4 no deal
+  int stable;             // every region has <= 65535 rows: the deterministic body (plan_region_body_stable)
 };
 
-__global__ __launch_bounds__(1024) void k_plan_region(PlanFusedArgs a) {
+// LDS of one plan workgroup and whether the deterministic body takes the table (sets a.stable)
+static size_t plan_lds_bytes(PlanFusedArgs& a) {
+  static const int force_atomic = getenv("SEEVCN_PLAN_ATOMIC") ? atoi(getenv("SEEVCN_PLAN_ATOMIC")) : 0;   // 1: the LDS-atomic placement (A/B runs, tests)
+  int64_t big = 0;
+  for (int r = 0; r < PL_REGIONS; ++r) {
+    const int64_t s0 = plan_region_start(a.n_rows, r), s1 = r + 1 < PL_REGIONS ? plan_region_start(a.n_rows, r + 1) : a.n_rows;
+    if (s1 - s0 > big) big = s1 - s0;
+  }
+  a.stable = (big <= 65535 && !force_atomic) ? 1 : 0;
+  return (size_t)(a.stable ? 8 : 2) * PL_CLASSES * 4 + (size_t)a.max_tiles * 6;
+}
+
+__device__ __forceinline__ void plan_region_body(const PlanFusedArgs& a, const int r) {
   extern __shared__ int32_t s_dyn[];
   int32_t* s_start = s_dyn;                                   // [PL_CLASSES] counts, then class starts
   int32_t* s_cur = s_dyn + PL_CLASSES;                        // [PL_CLASSES] rows of the class placed so far
   uint32_t* s_tmask = reinterpret_cast<uint32_t*>(s_dyn + 2 * PL_CLASSES);            // [max_tiles] OR of the tile's 16 masks
   uint16_t* s_sorted = reinterpret_cast<uint16_t*>(s_tmask + a.max_tiles);            // [max_tiles] tiles in descending cost order
   __shared__ int s_wsum[16], s_cnt[32], s_cstart[32];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int64_t row0 = plan_region_start(a.n_rows, r);
   const int64_t row1 = r + 1 < PL_REGIONS ? plan_region_start(a.n_rows, r + 1) : a.n_rows;
   const int64_t n_pad = (a.n_rows + 15) / 16 * 16;
@@ -665,6 +678,183 @@ __global__ __launch_bounds__(1024) void k_plan_region(PlanFusedArgs a) {
   }
 }
 
+// The same plan with a DETERMINISTIC order: inside a class the rows keep their table order, inside a cost bucket the tiles theirs, so a table has
+// exactly one plan.  (With the LDS-atomic placement above the rows of a class land in arrival order; every output row is still computed by one wave
+// in a fixed summation order, but the BatchNorm column sums the conv epilogue leaves per workgroup -- and with them the batch statistics, to ~1e-7
+// -- depended on which rows shared a tile: two builds of the same table could flip the ReLU branch of an activation within an ulp of zero.)
+// Every wave owns a contiguous run of the region's rows and counts / places them into ITS OWN 16-bit counter per class (16 waves x 4096 classes x
+// 2 B = 128 KB of LDS, two waves per 32-bit word, updated with packed atomic adds that cannot carry while the region has <= 65535 rows); the
+// counters turn into positions relative to the region start by one scan over (class, wave).  Regions of more than 65535 rows take the body above.
+__device__ __forceinline__ void plan_region_body_stable(const PlanFusedArgs& a, const int r) {
+  extern __shared__ int32_t s_dyn[];
+  uint32_t* s_wc = reinterpret_cast<uint32_t*>(s_dyn);                                // [8][PL_CLASSES]: wave w -> half w & 1 of word [w >> 1][class]
+  uint32_t* s_tmask = reinterpret_cast<uint32_t*>(s_dyn + 8 * PL_CLASSES);            // [max_tiles] OR of the tile's 16 masks
+  uint16_t* s_sorted = reinterpret_cast<uint16_t*>(s_tmask + a.max_tiles);            // [max_tiles] tiles in descending cost order
+  __shared__ int s_wsum[16], s_cstart[32];
+  __shared__ int s_wcnt[16][32];                                                      // tiles of cost c owned by wave w (then: placed so far)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t row0 = plan_region_start(a.n_rows, r);
+  const int64_t row1 = r + 1 < PL_REGIONS ? plan_region_start(a.n_rows, r + 1) : a.n_rows;
+  const int64_t n_pad = (a.n_rows + 15) / 16 * 16;
+  const int nt = a.d.tiles[r], slots = a.d.n_pass * a.d.G;
+  int32_t* out = a.tile_of + (int64_t)r * PL_REGION_WAVES * slots;
+  for (int i = tid; i < 8 * PL_CLASSES; i += 1024) s_wc[i] = 0u;
+  for (int i = tid; i < nt; i += 1024) s_tmask[i] = 0u;
+  for (int i = tid; i < PL_REGION_WAVES * slots; i += 1024) out[i] = -1;
+  if (tid < 512) (&s_wcnt[0][0])[tid] = 0;
+  __syncthreads();
+  // this wave's rows: a contiguous run, a multiple of 64 long
+  const int64_t per_wave = (((row1 - row0) + 15) / 16 + 63) / 64 * 64;
+  const int64_t w0 = row0 + (int64_t)wid * per_wave, w1 = min(w0 + per_wave, row1);
+  uint32_t* my_wc = s_wc + (size_t)(wid >> 1) * PL_CLASSES;
+  const int sh = 16 * (wid & 1);
+  constexpr int PLR_B = 8;
+  // pass 1: per-(wave, class) counts
+  for (int64_t base = w0; base < w1; base += 64 * PLR_B) {
+    unsigned m[PLR_B];
+#pragma unroll
+    for (int u = 0; u < PLR_B; ++u) {
+      const int64_t row = base + u * 64 + lane;
+      m[u] = row < w1 ? (unsigned)a.masks[row] : 0xFFFFFFFFu;              // bit 31 is never set in a mask: marks "no row"
+    }
+#pragma unroll
+    for (int u = 0; u < PLR_B; ++u)
+      if (m[u] != 0xFFFFFFFFu) atomicAdd(&my_wc[class_key(m[u])], 1u << sh);
+  }
+  __syncthreads();
+  // pass 2: counts -> positions relative to the region start, class-major then wave-major (4 consecutive classes per thread)
+  {
+    uint32_t wd[4][8];
+    int tot[4], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      tot[u] = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        wd[u][q] = s_wc[q * PL_CLASSES + tid * 4 + u];
+        tot[u] += (int)(wd[u][q] & 0xffffu) + (int)(wd[u][q] >> 16);
+      }
+      sum += tot[u];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wsum[wid] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wid; ++w) run += s_wsum[w];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int lo = (int)(wd[u][q] & 0xffffu), hi = (int)(wd[u][q] >> 16);
+        s_wc[q * PL_CLASSES + tid * 4 + u] = (uint32_t)run | ((uint32_t)(run + lo) << 16);
+        run += lo + hi;
+      }
+    }
+  }
+  __syncthreads();
+  // pass 3: placement in table order + the OR of every tile's masks
+  for (int64_t base = w0; base < w1; base += 64 * PLR_B) {
+    unsigned m[PLR_B];
+#pragma unroll
+    for (int u = 0; u < PLR_B; ++u) {
+      const int64_t row = base + u * 64 + lane;
+      m[u] = row < w1 ? (unsigned)a.masks[row] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < PLR_B; ++u) {
+      const int64_t row = base + u * 64 + lane;
+      const bool live = m[u] != 0xFFFFFFFFu;
+      const int key = live ? class_key(m[u]) : 0;
+      int rank, size, first_lane;
+      wave_key_groups(key, live, rank, size, first_lane);
+      uint32_t old = 0;
+      if (live && rank == 0) old = atomicAdd(&my_wc[key], (uint32_t)size << sh);
+      old = (uint32_t)__shfl((int)old, first_lane);
+      if (live) {
+        const int64_t pos = row0 + (int64_t)((old >> sh) & 0xffffu) + rank;
+        a.perm[pos] = (int32_t)row;
+        a.masks_p[pos] = (int32_t)m[u];
+        if (m[u]) atomicOr(&s_tmask[(pos - row0) >> 4], m[u]);
+      }
+    }
+  }
+  if (r + 1 == PL_REGIONS && a.n_rows + tid < n_pad) a.perm[a.n_rows + tid] = -1, a.masks_p[a.n_rows + tid] = 0;    // padding of the last tile
+  __syncthreads();
+  // pass 4: tiles by descending cost (stable: ascending tile inside a cost), quads dealt to the 32 CU bins in snake order (k_plan_deal)
+  const int tiles_per_wave = ((nt + 15) / 16 + 63) / 64 * 64;
+  const int t0 = wid * tiles_per_wave, t1 = min(t0 + tiles_per_wave, nt);
+  for (int base = t0; base < t1; base += 64) {
+    const int t = base + lane;
+    const bool live = t < t1;
+    const int c = live ? min(__popc(s_tmask[t]), 31) : 0;
+    int rank, size, first_lane;
+    wave_key_groups(c, live, rank, size, first_lane);
+    if (live && rank == 0) s_wcnt[wid][c] += size;                     // the wave's own row of counters: no other wave touches it
+  }
+  __syncthreads();
+  if (tid < 32) {                                                       // cost tid: exclusive prefix over the waves; then the bucket starts, most expensive first
+    int run = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int c = s_wcnt[w][tid];
+      s_wcnt[w][tid] = run;
+      run += c;
+    }
+    s_cstart[tid] = run;                                                // total of the cost, turned into its start below
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int c = 31; c >= 0; --c) {
+      const int n = s_cstart[c];
+      s_cstart[c] = acc, acc += n;
+    }
+  }
+  __syncthreads();
+  for (int base = t0; base < t1; base += 64) {
+    const int t = base + lane;
+    const bool live = t < t1;
+    const int c = live ? min(__popc(s_tmask[t]), 31) : 0;
+    int rank, size, first_lane;
+    wave_key_groups(c, live, rank, size, first_lane);
+    int off = 0;
+    if (live && rank == 0) off = s_wcnt[wid][c], s_wcnt[wid][c] = off + size;
+    off = __shfl(off, first_lane);
+    if (live) s_sorted[s_cstart[c] + off + rank] = (uint16_t)t;
+  }
+  __syncthreads();
+  const int nq = (nt + PL_QUAD - 1) / PL_QUAD;
+  for (int qd = tid; qd < nq; qd += 1024) {
+    const int j = qd / PL_BINS, pos = qd % PL_BINS;
+    const int bin = (j & 1) ? PL_BINS - 1 - pos : pos;
+    const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;
+#pragma unroll
+    for (int part = 0; part < PL_QUAD; ++part) {
+      const int p = qd * PL_QUAD + part;
+      if (p < nt) out[(int64_t)((bin + PL_BINS * wg) * 4 + part) * slots + j / PL_WAVES_PER_SIMD] = a.d.tile0[r] + s_sorted[p];
+    }
+  }
+}
+
+__device__ __forceinline__ void plan_region_dispatch(const PlanFusedArgs& a, const int r) {
+  if (a.stable) plan_region_body_stable(a, r);
+  else plan_region_body(a, r);
+}
+__global__ __launch_bounds__(1024) void k_plan_region(PlanFusedArgs a) { plan_region_dispatch(a, blockIdx.x); }
+
+// The plans of SEVERAL tables in one launch: workgroup b builds region b % 8 of table b / 8.  A step of the bench needs 12 plans; one
+// workgroup per region and table is 96 workgroups side by side instead of 12 launches of 8 (29 us each, 8 of 256 CUs busy).
+constexpr int PL_BATCH_MAX = 16;
+struct PlanBatchArgs {
+  PlanFusedArgs j[PL_BATCH_MAX];
+};
+static_assert(sizeof(PlanBatchArgs) <= 3900, "kernel argument block");
+__global__ __launch_bounds__(1024) void k_plan_region_batch(PlanBatchArgs b) { plan_region_dispatch(b.j[blockIdx.x / PL_REGIONS], blockIdx.x % PL_REGIONS); }
+
 // Tiles a wave holds in registers at a time: 2 for the 64-column kernels (113 VGPRs: four waves per SIMD), 4 for the narrow ones (their
 // MFMA work per weight load is small).  The weight loads are shared by the G tiles of a pass.
 static int conv_tiles_per_wave(int64_t n_rows, int Kd, int Nc) {
@@ -711,13 +901,63 @@ extern "C" int sv_conv_plan_build_dealt(const int32_t* masks, int64_t n_rows, in
     if (a.d.tiles[r] > a.max_tiles) a.max_tiles = a.d.tiles[r];
   }
   a.max_tiles = (a.max_tiles + 1) & ~1;                                  // keeps the uint16 array 4-byte aligned
-  const size_t lds = (size_t)2 * PL_CLASSES * 4 + (size_t)a.max_tiles * 6;
+  const size_t lds = plan_lds_bytes(a);
   static bool raised = false;
   if (lds > 48 * 1024 && !raised) {
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_region), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_region), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     raised = true;
   }
   hipLaunchKernelGGL(k_plan_region, dim3(PL_REGIONS), dim3(1024), lds, sv_stream(stream), a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// jobs_host: n_jobs rows of 8 int64 = {masks, n_rows, tiles_per_wave, perm, masks_p, tile_of, 0, 0}: sv_conv_plan_build_dealt for every row, all
+// in one launch (groups of PL_BATCH_MAX tables)
+extern "C" int sv_conv_plan_build_dealt_batch(const int64_t* jobs_host, int n_jobs, void* stream) {
+  SV_CHECK_ARG(n_jobs >= 0 && (jobs_host || n_jobs == 0), "sv_conv_plan_build_dealt_batch: bad arguments");
+  static bool raised = false;
+  hipStream_t st = sv_stream(stream);
+  PlanBatchArgs b;
+  int nb = 0;
+  size_t lds = 0;
+  auto flush = [&]() -> int {
+    if (nb == 0) return SV_OK;
+    if (lds > 48 * 1024 && !raised) {
+      SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_region_batch), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+      raised = true;
+    }
+    hipLaunchKernelGGL(k_plan_region_batch, dim3(PL_REGIONS * nb), dim3(1024), lds, st, b);
+    nb = 0, lds = 0;
+    return SV_OK;
+  };
+  for (int q = 0; q < n_jobs; ++q) {
+    const int64_t* r = jobs_host + 8 * q;
+    const int64_t n_rows = r[1];
+    const int g = (int)r[2];
+    SV_CHECK_ARG(n_rows >= 0 && n_rows < (int64_t)1 << 30 && g >= 1 && g <= 4, "sv_conv_plan_build_dealt_batch: job %d: bad sizes", q);
+    if (n_rows == 0) continue;
+    SV_CHECK_ARG(r[0] && r[3] && r[4] && r[5], "sv_conv_plan_build_dealt_batch: job %d: null pointer", q);
+    PlanFusedArgs& a = b.j[nb];
+    a.masks = reinterpret_cast<const int32_t*>(r[0]), a.n_rows = n_rows, a.perm = reinterpret_cast<int32_t*>(r[3]);
+    a.masks_p = reinterpret_cast<int32_t*>(r[4]), a.tile_of = reinterpret_cast<int32_t*>(r[5]);
+    a.d = plan_dims(n_rows, g);
+    a.debug = 0;
+    a.max_tiles = 1;
+    for (int rg = 0; rg < PL_REGIONS; ++rg) {
+      SV_CHECK_ARG(a.d.tiles[rg] <= PL_MAX_REGION_TILES, "sv_conv_plan_build_dealt_batch: at most %d tiles per region", PL_MAX_REGION_TILES);
+      if (a.d.tiles[rg] > a.max_tiles) a.max_tiles = a.d.tiles[rg];
+    }
+    a.max_tiles = (a.max_tiles + 1) & ~1;
+    const size_t need = plan_lds_bytes(a);
+    if (need > lds) lds = need;
+    if (++nb == PL_BATCH_MAX) {
+      int rc = flush();
+      if (rc) return rc;
+    }
+  }
+  int rc = flush();
+  if (rc) return rc;
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -51,6 +51,7 @@ struct GemmArgs {
   float* gmax;              // EPI_MAX: [M / rows_per_group][N], pre-filled with -inf
   int M, N, K;
   int act; float slope;
+  const int32_t* m_dev;     // optional: the true number of rows lives on the device (<= M, which then sizes the grid and the buffers)
 };
 
 template <int EPI>
@@ -62,7 +63,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmArgs g) {
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of the
   // (row-block major) tile list: the N-tiles that share an A row-block then hit the same L2 instead of 8 different ones.
   int lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int total = gridDim.x * gridDim.y;
+  int total = gridDim.x * gridDim.y;
+  if (g.m_dev) {
+    // rows counted on the device (VCN's distinct rows: no host read): the launch is sized for the capacity, the tiles past the count leave at
+    // once, and the XCD-aware order is made over the real tiles -- the first `total` workgroup ids, dealt to the XCDs round-robin like any launch
+    const int m_real = min(*g.m_dev, g.M);
+    g.M = m_real;
+    total = (int)gridDim.x * ((m_real + BM - 1) / BM);
+    if (lin >= total) return;
+  }
   if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
   const int m0 = (lin / (int)gridDim.x) * BM, n0 = (lin % (int)gridDim.x) * BN;
   const int lr = tid >> 3, lc = (tid & 7) * 4;  // staging: row lr (+32*i), k offset lc
@@ -245,17 +254,17 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs g) {
 
 static int gemm_launch(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias, int rows_per_group,
                        const int32_t* row_group, float* C, int ldc, float* group_max, int M, int N, int K, int act, float slope,
-                       void* stream) {
+                       void* stream, const int32_t* m_dev = nullptr) {
   SV_CHECK_ARG(A && W && (C || group_max), "gemm_bias_act: null pointer");
   SV_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0, "gemm_bias_act: K=%d must be a positive multiple of %d", K, BK);
   SV_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= K, "gemm_bias_act: lda/ldw must be >= K and multiples of 4");
   SV_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "gemm_bias_act: A/W must be 16-byte aligned");
   SV_CHECK_ARG(rows_per_group >= 1, "gemm_bias_act: rows_per_group must be >= 1");
   SV_CHECK_ARG(act >= 0 && act <= 2, "gemm_bias_act: unknown activation %d", act);
-  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, row_group, C, ldc, group_max, M, N, K, act, slope};
+  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, row_group, C, ldc, group_max, M, N, K, act, slope, m_dev};
   dim3 grid(sv_div_up(N, BN), sv_div_up(M, BM));
   hipStream_t st = sv_stream(stream);
-  if (M <= 64 && C && !group_max && !group_bias && !row_group) {
+  if (M <= 64 && C && !group_max && !group_bias && !row_group && !m_dev) {
     hipLaunchKernelGGL(k_gemm_small_m, dim3(sv_div_up(N, 16)), dim3(256), 0, st, g);
     SV_LAUNCH_CHECK();
     return SV_OK;
@@ -283,18 +292,29 @@ extern "C" int sv_gemm_bias_act_ragged(const float* A, int lda, const float* W, 
   return gemm_launch(A, lda, W, ldw, bias, group_bias, 1, row_group, C, ldc, group_max, M, N, K, act, slope, stream);
 }
 
+// The ragged GEMM with the number of rows on the device: M_cap rows of A / C / row_group are addressable, the first *m_dev are computed (the
+// distinct rows of VCN's input clouds, sv_unique_rows_compact's total -- which the host then never has to read).
+extern "C" int sv_gemm_bias_act_ragged_dev(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias,
+                                           const int32_t* row_group, float* C, int ldc, float* group_max, int M_cap, const int32_t* m_dev, int N, int K,
+                                           int act, float slope, void* stream) {
+  SV_CHECK_ARG(row_group && m_dev, "gemm_bias_act_ragged_dev: row_group and m_dev are required");
+  return gemm_launch(A, lda, W, ldw, bias, group_bias, 1, row_group, C, ldc, group_max, M_cap, N, K, act, slope, stream, m_dev);
+}
+
 // ------------------------------------------------------------------------------------------------
 // out[m][c] = act(w[c][0]*x + w[c][1]*y + w[c][2]*z + b[c]) : the K=3 first layers (VALU, HBM-write-bound)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pointwise3(const float* __restrict__ xyz, const float* __restrict__ w,
                                                     const float* __restrict__ b, float* __restrict__ out, int64_t M,
-                                                    int C, int act, float slope) {
+                                                    int C, int act, float slope, const int64_t* __restrict__ sel, const int32_t* __restrict__ m_dev) {
   const int cq = C / 4;
+  if (m_dev) M = min((int64_t)*m_dev, M);
   const int64_t total = M * cq;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / cq;
     const int c = (int)(i - m * cq) * 4;
-    const float x = xyz[m * 3], y = xyz[m * 3 + 1], z = xyz[m * 3 + 2];
+    const int64_t src = sel ? sel[m] : m;                       // optional row gather (the distinct rows of the clouds)
+    const float x = xyz[src * 3], y = xyz[src * 3 + 1], z = xyz[src * 3 + 2];
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -312,7 +332,17 @@ extern "C" int sv_pointwise_conv3(const float* xyz, const float* weight, const f
                                   int C, int act, float slope, void* stream) {
   SV_CHECK_ARG(xyz && weight && out && M > 0 && C > 0 && C % 4 == 0, "pointwise_conv3: bad arguments (C must be a multiple of 4)");
   hipLaunchKernelGGL(k_pointwise3, dim3(sv_grid_1d(M * (C / 4), 256)), dim3(256), 0, sv_stream(stream), xyz, weight, bias,
-                     out, M, C, act, slope);
+                     out, M, C, act, slope, nullptr, nullptr);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// The same layer on GATHERED rows out[m] = f(xyz[sel[m]]) for m < *m_dev (<= M_cap): the gather and the count stay on the device.
+extern "C" int sv_pointwise_conv3_gather(const float* xyz, const int64_t* sel, int64_t M_cap, const int32_t* m_dev, const float* weight, const float* bias,
+                                         float* out, int C, int act, float slope, void* stream) {
+  SV_CHECK_ARG(xyz && sel && m_dev && weight && out && M_cap > 0 && C > 0 && C % 4 == 0, "pointwise_conv3_gather: bad arguments (C must be a multiple of 4)");
+  hipLaunchKernelGGL(k_pointwise3, dim3(sv_grid_1d(M_cap * (C / 4), 256, 2048)), dim3(256), 0, sv_stream(stream), xyz, weight, bias, out, M_cap, C, act, slope,
+                     sel, m_dev);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

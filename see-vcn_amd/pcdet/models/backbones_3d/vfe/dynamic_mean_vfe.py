@@ -23,8 +23,15 @@ class DynamicMeanVFE(VFETemplate):
         return self.num_point_features
 
     @torch.no_grad()
-    def forward(self, batch_dict, **kwargs):
+    def forward(self, batch_dict, lazy_count=False, **kwargs):
+        """lazy_count (seevcn extension, default off = the reference's contract): no device -> host read here -- voxel_features / voxel_coords keep
+        their CAPACITY rows (one per point) and batch_dict['voxel_count_device'] holds the true count on the device; the consumer
+        (spconv.prebuild_rulebooks(..., n0_dev=)) reads it together with its own counts and narrows the tensors."""
         points = batch_dict['points']  # (batch_idx, x, y, z, i, e)
+        if lazy_count:
+            feats, coords, _, nvox = voxel_ops.voxelize_dynamic(points, self.point_cloud_range, self.voxel_size, self.grid_size, batch_dict['batch_size'], sync=False)
+            batch_dict['voxel_features'], batch_dict['voxel_coords'], batch_dict['voxel_count_device'] = feats, coords, nvox
+            return batch_dict
         feats, coords, _ = voxel_ops.voxelize_dynamic(
             points, self.point_cloud_range, self.voxel_size, self.grid_size, batch_dict['batch_size'])
         batch_dict['voxel_features'] = feats.contiguous()

@@ -61,11 +61,14 @@ class SceneStep(nn.Module):
         from . import spconv
         with torch.no_grad():
             pts = self.complete_and_paste(points, objects, object_scene)
-            bd = self.vfe({'batch_size': batch_size, 'points': pts})
-            sp = spconv.SparseConvTensor(features=bd['voxel_features'], indices=bd['voxel_coords'].int(), spatial_shape=self.backbone_3d.sparse_shape,
+            # ONE device -> host read for the whole input side: the voxel count stays on the device until the strided levels of the backbone
+            # have been counted there too (spconv.prebuild_rulebooks -> Fsp.build_network_index); the empty-cluster check rides on the same read
+            bd = self.vfe({'batch_size': batch_size, 'points': pts}, lazy_count=True)
+            sp = spconv.SparseConvTensor(features=bd['voxel_features'], indices=bd['voxel_coords'], spatial_shape=self.backbone_3d.sparse_shape,
                                          batch_size=batch_size)
-            spconv.prebuild_rulebooks(self.backbone_3d, sp, with_backward=self.training)
-            _lib.flush_checks()                                   # nothing parked survives the front (normally taken by the voxel-count read)
+            spconv.prebuild_rulebooks(self.backbone_3d, sp, with_backward=self.training, n0_dev=bd.pop('voxel_count_device'))
+            _lib.flush_checks()                                   # nothing parked survives the front (normally taken by the one read above)
+            bd['voxel_features'] = sp.features
             bd['voxel_coords'] = sp.indices                       # the very tensor the rulebooks are bound to
             bd['spconv_indice_dict'] = sp.indice_dict
         return bd

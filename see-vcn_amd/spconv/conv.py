@@ -140,47 +140,67 @@ def _sparse_convs(root):
     return hit[1]
 
 
-# 1: the strided rulebooks of a backbone counted end to end on the device, ONE blocking read for all their output-site counts
-# (Fsp.build_sparse_rulebook_chain).  Built, bit-exact, and OFF: same-box A/B headline 5.05-5.25 ms without, 5.18-5.36 with; PV-RCNN 43.0 -> 48.5 ms,
-# CenterPoint 23.9 -> 25.3 -- marking level l + 1 from level l's occupancy bitmap gives a lane 0..32 inputs (one word) where the list-driven
-# kernel gives every lane exactly one, and that costs more than the four saved round trips bring.
-CHAIN_READS = os.environ.get("SEEVCN_RULEBOOK_CHAIN", "0") == "1"
-DEFER_INDEX_WORK = os.environ.get("SEEVCN_PREBUILD_DEFER", "1") != "0"     # 0: plans and submanifold rulebooks between the strided builders (A/B)
+# 0: rulebooks and plans built layer by layer (one device -> host read per strided level, ~57 launches per VoxelBackBone8x) instead of by
+# Fsp.build_network_index (one read, 13 launches) -- A/B runs and tests; the tables are bit-identical either way
+BATCH_INDEX = os.environ.get("SEEVCN_INDEX_BATCH", "1") != "0"
+DEFER_INDEX_WORK = os.environ.get("SEEVCN_PREBUILD_DEFER", "1") != "0"     # layer-by-layer path only. 0: plans and submanifold rulebooks between the strided builders (A/B)
 
 
-def prebuild_rulebooks(root, x, with_backward=True):
+def _index_specs(root, x):
+    """ConvSpec list of the keyed convolutions in front of `root`'s walk, or None when the batch form does not apply to them."""
+    specs, seen, level = [], {}, 0
+    for m in _sparse_convs(root):
+        if m.indice_key is None:
+            break
+        if x.indice_dict.get(m.indice_key) is not None:
+            return None                                   # something was built already: the layer-by-layer walk knows how to continue from it
+        prev = seen.get(m.indice_key)
+        if prev is not None and not (m.subm and prev[0].subm and prev[0].kernel_size == m.kernel_size and prev[0].dilation == m.dilation and prev[1] == level):
+            return None                                   # a key shared by different kernels, by strided layers or across levels
+        seen.setdefault(m.indice_key, (m, level))
+        specs.append(Fsp.ConvSpec(m.indice_key, m.subm, m.kernel_size, m.stride, m.padding, m.dilation, m.in_channels, m.out_channels))
+        if not m.subm:
+            level += 1
+    return specs or None
+
+
+def prebuild_rulebooks(root, x, with_backward=True, n0_dev=None):
     """Build every rulebook (and conv plan) a network will need on `x` BEFORE its layers run.  A strided rulebook needs the number of output
     sites on the host (to allocate the next level), i.e. a device -> host sync; done lazily inside the layer loop, each of those syncs waits
-    for all the convolution work queued so far and then leaves the GPU idle until the host has enqueued the next layers.  Done here, the
-    syncs wait for small index kernels only and the whole layer loop is enqueued without one (spconv builds its indice pairs lazily, layer
-    by layer: spconv_backbone.py:141-157 is the caller).  `root` is walked in definition order, which is the execution order of the
-    reference's backbones; convolutions without an indice_key end the walk (they are then handled lazily)."""
+    for all the convolution work queued so far and then leaves the GPU idle until the host has enqueued the next layers (spconv builds its
+    indice pairs lazily, layer by layer: spconv_backbone.py:141-157 is the caller).  Default: Fsp.build_network_index -- the whole chain
+    counted on the device, ONE read, all tables and plans in a handful of launches.  `root` is walked in definition order, which is the
+    execution order of the reference's backbones; convolutions without an indice_key end the walk (they are then handled lazily).
+    n0_dev: x.indices / x.features still have CAPACITY rows and the true count is this device word (a voxeliser called with sync=False): the
+    count comes back with the same read and x is narrowed in place.  -> x"""
+    if BATCH_INDEX or n0_dev is not None:
+        specs = _index_specs(root, x) if BATCH_INDEX else None
+        built = Fsp.build_network_index(x.indices, x.batch_size, x.spatial_shape, specs, n0_dev=n0_dev, with_backward=with_backward) if specs else None
+        if built is not None:
+            n0, rulebooks = built
+            if n0_dev is not None:
+                x.indices, x.features = x.indices[:n0], x.features[:n0]
+            for key, rb in rulebooks.items():
+                if rb.in_indices.data_ptr() == x.indices.data_ptr() and rb.in_indices.shape == x.indices.shape:
+                    rb.in_indices = x.indices         # level 0: the very tensor the layers will present (get_rulebook compares identities)
+                if rb.subm and rb.out_indices.data_ptr() == x.indices.data_ptr():
+                    rb.out_indices = x.indices
+                x.indice_dict[key] = rb
+            return x
+        if n0_dev is not None:
+            from .. import _lib
+            n0 = _lib.host_int(n0_dev)
+            x.indices, x.features = x.indices[:n0], x.features[:n0]
+    _prebuild_layer_by_layer(root, x, with_backward)
+    return x
+
+
+def _prebuild_layer_by_layer(root, x, with_backward):
     idx, shape = x.indices, list(x.spatial_shape)
     # Pass 1: only what the device -> host reads hang on -- the STRIDED rulebooks, each needing the output sites of the one before.  Everything
     # else (submanifold rulebooks, all plans) is enqueued in pass 2, behind the last read: queued between the strided builders (round 2) it sat
     # in front of every later read -- ~145 us of index kernels per level that the host waited for four times per step.
     todo = []                                             # (module, its input indices, their shape) in execution order
-    if DEFER_INDEX_WORK and CHAIN_READS:
-        # the strided layers in front (conv2, conv3, conv4, conv_out of the reference's backbones) as ONE chain: counted end to end on the
-        # device, one read for all their output-site counts (Fsp.build_sparse_rulebook_chain) instead of one blocking read per layer
-        chain, shapes, sh = [], set(), list(shape)
-        for m in _sparse_convs(root):
-            if m.indice_key is None:
-                break
-            if m.subm:
-                continue
-            K = m.kernel_size[0] * m.kernel_size[1] * m.kernel_size[2]
-            sh = Fsp.conv_out_shape(sh, m.kernel_size, m.stride, m.padding, m.dilation)
-            if x.indice_dict.get(m.indice_key) is not None or K > 27 or tuple(sh) in shapes or any(v.indice_key == m.indice_key for v in chain):
-                break
-            chain.append(m), shapes.add(tuple(sh))
-        if len(chain) >= 2 and idx.shape[0] > 0:
-            built = Fsp.build_sparse_rulebook_chain(idx, x.batch_size, shape, [(m.kernel_size, m.stride, m.padding, m.dilation) for m in chain])
-            cur, cur_shape = idx, list(shape)
-            for m, rb in zip(chain, built):
-                rb.in_indices, rb.in_shape = cur, list(cur_shape)
-                x.indice_dict[m.indice_key] = rb
-                cur, cur_shape = rb.out_indices, list(rb.out_shape)
     for m in _sparse_convs(root):
         if m.indice_key is None:
             break

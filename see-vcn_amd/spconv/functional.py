@@ -51,6 +51,15 @@ class TablePlan:
         _lib.check(lib.sv_conv_plan_build(_lib.ptr(masks), self.n_rows, _lib.ptr(hist), _lib.ptr(self.perm), _lib.ptr(self.masks_p), _lib.stream()),
                    "sv_conv_plan_build")
 
+    @classmethod
+    def from_parts(cls, table, n_rows, K, rows, masks, perm, masks_p, g, tile_of):
+        """A plan whose pieces were made elsewhere (build_network_index: all plans of a network in one launch)."""
+        self = cls.__new__(cls)
+        self.n_rows, self.K, self.source = int(n_rows), int(K), table
+        self.rows, self.masks, self.perm, self.masks_p = rows, masks, perm, masks_p
+        self._tiles = {int(g): tile_of}
+        return self
+
     def tiles(self, g):
         g = int(g)
         if g not in self._tiles:
@@ -206,59 +215,192 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
     return rb
 
 
-def build_sparse_rulebook_chain(indices, batch_size, spatial_shape, specs):
-    """The strided rulebooks of a chain of layers -- specs = [(ksize, stride, padding, dilation), ...], layer l + 1 fed by layer l's output
-    sites -- with ONE device -> host read instead of one per layer: every level is counted first (sv_rulebook_sparse_count; level l + 1 marks
-    its output cells from level l's occupancy bitmap, which needs no site count), the counts come back together, then every level is filled
-    with exactly sized tables (sv_rulebook_sparse_fill + sv_rulebook_invert_rows).  Same tables as build_sparse_rulebook layer by layer
-    (tests/test_spconv.py).  K <= 27 per layer; -> list of Rulebook."""
+class ConvSpec:
+    """What build_network_index needs to know about one sparse convolution, in execution order."""
+    __slots__ = ("key", "subm", "ksize", "stride", "padding", "dilation", "cin", "cout")
+
+    def __init__(self, key, subm, ksize, stride, padding, dilation, cin, cout):
+        self.key, self.subm = key, bool(subm)
+        self.ksize, self.stride, self.padding, self.dilation = ([int(v) for v in t] for t in (ksize, stride, padding, dilation))
+        self.cin, self.cout = int(cin), int(cout)
+
+
+def _al(n, q=64):
+    return (int(n) + q - 1) // q * q
+
+
+def build_network_index(coords, batch_size, spatial_shape, specs, n0_dev=None, with_backward=True):
+    """Every rulebook AND conv plan of a network in 12 + 4 launches and ONE device -> host read (round 3: ~57 launches, one read per strided
+    level): sv_rulebook_chain_count walks the strided levels end to end on the device (level l + 1 marks from level l's freshly written site
+    list), the site counts -- and, with n0_dev, the voxel count the caller has not read yet -- come back together, then sv_rulebook_batch fills
+    every table through the levels' dense cell maps (SET / QUERY / CLEAR, one launch each) and sv_conv_plan_build_dealt_batch makes all plans in
+    one launch.  specs: ConvSpec per convolution in execution order; a strided spec moves to the next level, submanifold specs of one key
+    share a table.  coords (cap0, 4) int32 [b,z,y,x]: the first n0 rows count (n0 = *n0_dev or cap0).
+    -> (n0, {key: Rulebook}) with tables bit-identical to build_subm_rulebook / build_sparse_rulebook, or None (nothing launched) when the
+    network does not fit the batch form: a kernel wider than 3, a cell map beyond CELLMAP_MAX_BYTES, more than 8 levels, no rows."""
+    import numpy as np
     lib = _lib.load()
-    _lib.require_cuda(indices)
-    assert indices.dtype == torch.int32 and indices.dim() == 2 and indices.shape[1] == 4
-    indices = indices.contiguous()
-    dev = indices.device
-    B = int(batch_size)
-    shapes, works, nums = [list(spatial_shape)], [], []
-    for l, (ksize, stride, padding, dilation) in enumerate(specs):
-        assert int(ksize[0]) * int(ksize[1]) * int(ksize[2]) <= 27
-        oshape = conv_out_shape(shapes[-1], ksize, stride, padding, dilation)
-        ncells = B * oshape[0] * oshape[1] * oshape[2]
-        ws = _lib.workspace.persistent(f"rb_index_{tuple(oshape)}_{batch_size}", lib.sv_index_persistent_bytes(ncells), dev)
-        assert all(ws is not w for w in works), "two levels of a chain on one grid would share their index"
-        scratch = _lib.workspace.scratch("rb_scratch", lib.sv_rulebook_scratch_bytes(0, ncells), dev)
-        num = torch.empty((1,), dtype=torch.int32, device=dev)
-        rc = lib.sv_rulebook_sparse_count(_lib.ptr(indices) if l == 0 else None, indices.shape[0] if l == 0 else 0, None if l == 0 else _lib.ptr(works[-1]), B,
-                                          _i3(shapes[-1]), _i3(ksize), _i3(stride), _i3(padding), _i3(dilation), _lib.ptr(ws), _lib.ptr(scratch), _lib.ptr(num),
-                                          _lib.stream())
-        _lib.check(rc, "sv_rulebook_sparse_count")
-        shapes.append(oshape), works.append(ws), nums.append(num)
-    counts = _lib.host_ints(nums)                                   # the one read of the chain
-    out, idx = [], indices
-    for l, (ksize, stride, padding, dilation) in enumerate(specs):
-        K = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
-        n_in, n_out = idx.shape[0], counts[l]
-        out_coords = torch.empty((max(n_out, 1), 4), dtype=torch.int32, device=dev)
-        nbr_in = torch.empty((K, n_in), dtype=torch.int32, device=dev)
-        in_block = torch.empty((33 * n_in,), dtype=torch.int32, device=dev) if n_in > 0 else None
-        rc = lib.sv_rulebook_sparse_fill(_lib.ptr(idx) if n_in else None, n_in, B, _i3(shapes[l]), _i3(ksize), _i3(stride), _i3(padding), _i3(dilation),
-                                         _lib.ptr(works[l]), _lib.ptr(out_coords), _lib.ptr(nbr_in) if n_in else None, _lib.ptr(in_block), max(n_out, 1),
-                                         _lib.stream())
-        _lib.check(rc, "sv_rulebook_sparse_fill")
-        out_coords = out_coords[:n_out]
-        if n_in == 0 or n_out == 0:
-            nbr_out = torch.empty((K, n_out), dtype=torch.int32, device=dev)
-            _lib.check(lib.sv_rulebook_invert(_lib.ptr(nbr_in) if n_in else None, n_in, K, _lib.ptr(nbr_out) if n_out else None, n_out, _lib.stream()),
-                       "sv_rulebook_invert")
-            rb = Rulebook(nbr_out, nbr_in, out_coords, shapes[l + 1], n_in, n_out, False, list(ksize))
+    _lib.require_cuda(coords)
+    assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+    coords = coords.contiguous()
+    dev, B, cap0 = coords.device, int(batch_size), int(coords.shape[0])
+    strided = [sp for sp in specs if not sp.subm]
+    if cap0 == 0 or not specs or len(strided) > 8 or any(max(sp.ksize) > 3 for sp in specs) or any(not (k & 1) for sp in specs if sp.subm for k in sp.ksize):
+        return None
+    shapes = [[int(v) for v in spatial_shape]]
+    for sp in strided:
+        shapes.append(conv_out_shape(shapes[-1], sp.ksize, sp.stride, sp.padding, sp.dilation))
+    L = len(strided)
+    map_bytes = [lib.sv_cellmap_persistent_bytes(B, _i3(sh)) for sh in shapes]
+    if max(map_bytes) > CELLMAP_MAX_BYTES:
+        return None
+    ncells = [B * sh[0] * sh[1] * sh[2] for sh in shapes]
+    # ---- phase 1: the site sets of all strided levels, counted on the device
+    counts = None
+    if L:
+        caps, cap = [], cap0
+        for l, sp in enumerate(strided):
+            per_in = 1
+            for k, st in zip(sp.ksize, sp.stride):
+                per_in *= -(-k // st)
+            cap = max(min(cap * per_in, ncells[l + 1]), 1)           # an input reaches at most prod(ceil(k/s)) outputs; never more than the cells
+            caps.append(cap)
+        works = [_lib.workspace.persistent(f"rb_index_{tuple(shapes[l + 1])}_{B}", lib.sv_index_persistent_bytes(ncells[l + 1]), dev) for l in range(L)]
+        assert len({w.data_ptr() for w in works}) == L, "two levels of a chain on one grid would share their index"
+        sites = [_lib.workspace.scratch(f"rb_chain_sites_{l}", caps[l] * 16, dev) for l in range(L)]
+        scratch = _lib.workspace.scratch("rb_chain_scratch", lib.sv_rulebook_chain_scratch_bytes(max(ncells[1:])), dev)
+        num_out = torch.empty((L,), dtype=torch.int32, device=dev)
+        geoms = []
+        for l, sp in enumerate(strided):
+            geoms += shapes[l] + sp.ksize + sp.stride + sp.padding + sp.dilation
+        rc = lib.sv_rulebook_chain_count(_lib.ptr(coords), cap0, _lib.ptr(n0_dev), B, L, _lib.host_array(ctypes.c_int32, geoms),
+                                         _lib.host_array(ctypes.c_void_p, [w.data_ptr() for w in works]),
+                                         _lib.host_array(ctypes.c_void_p, [t.data_ptr() for t in sites]), _lib.host_array(ctypes.c_int64, caps),
+                                         _lib.ptr(num_out), _lib.ptr(scratch), _lib.stream())
+        _lib.check(rc, "sv_rulebook_chain_count")
+    try:
+        if L:
+            vals = _lib.host_ints(([n0_dev] if n0_dev is not None else []) + list(num_out.unbind(0)))        # THE read
         else:
-            out_block = torch.empty(((32 + K + 1) * n_out,), dtype=torch.int32, device=dev)
-            _lib.check(lib.sv_rulebook_invert_rows(_lib.ptr(in_block), n_in, K, _lib.ptr(out_block), n_out, _lib.stream()), "sv_rulebook_invert_rows")
-            rb = Rulebook(out_block[32 * n_out:(32 + K) * n_out].view(K, n_out), nbr_in, out_coords, shapes[l + 1], n_in, n_out, False, list(ksize))
-            rb.rows_out, rb.masks_out = out_block[:32 * n_out].view(n_out, 32), out_block[(32 + K) * n_out:]
-            rb.rows_in, rb.masks_in = in_block[:32 * n_in].view(n_in, 32), in_block[32 * n_in:]
-        out.append(rb)
-        idx = out_coords
-    return out
+            vals = _lib.host_ints([n0_dev]) if n0_dev is not None else []
+        n = [vals.pop(0) if n0_dev is not None else cap0] + vals
+        assert all(n[l + 1] <= caps[l] for l in range(L)), "site capacity exceeded: the bound prod(ceil(k/s)) per input does not hold?"
+    except BaseException:
+        if L:
+            for w in works:                                            # phase 1 left its marks: a failed read must not leak them into the next call
+                w.zero_()
+        raise
+    if n[0] != cap0:
+        coords = coords[:n[0]]
+    # ---- layout of ONE int32 arena for every table and plan
+    total = [0]
+
+    def take(count):
+        off = total[0]
+        total[0] += _al(max(int(count), 0))
+        return off, int(count)
+
+    level_of, lv, tables, plans = {}, 0, {}, []                         # tables: key -> dict of arena slices
+    for sp in specs:
+        K = sp.ksize[0] * sp.ksize[1] * sp.ksize[2]
+        if sp.subm:
+            if sp.key not in tables:
+                tables[sp.key] = dict(spec=sp, level=lv, K=K, nbr=take(K * n[lv]), rows=take(32 * n[lv]), masks=take(n[lv]), plans={})
+            t = tables[sp.key]
+            assert t["spec"].subm and t["spec"].ksize == sp.ksize and t["level"] == lv, f"indice_key {sp.key} reused with a different kernel or level"
+        else:
+            assert sp.key not in tables, f"indice_key {sp.key} used by two strided convolutions"
+            tables[sp.key] = dict(spec=sp, level=lv, K=K, out_idx=take(4 * n[lv + 1]), nbr_in=take(K * n[lv]), in_block=take(33 * n[lv]),
+                                  out_block=take((32 + K + 1) * n[lv + 1]), plans={})
+            t = tables[sp.key]
+        # plans this convolution will ask for (Rulebook.plan): forward on the output-major table, data gradient on the input-major one (a
+        # submanifold table serves both)
+        n_in_rows, n_out_rows = n[t["level"]], n[t["level"] + (0 if sp.subm else 1)]
+        wants = [("fwd", n_out_rows, n_in_rows, sp.cin, sp.cout)]
+        if with_backward:
+            wants.append(("fwd" if sp.subm else "bwd", n_in_rows, n_out_rows, sp.cout, sp.cin))
+        for pkey, n_rows, n_src, kd, nc in wants:
+            if USE_PLAN and FUSED_PLAN and n_rows > 0 and pkey not in t["plans"] and lib.sv_conv_mfma_kernel_applies(K, kd, nc, n_src):
+                g = lib.sv_conv_tiles_per_wave(n_rows, kd, nc)
+                n_perm = lib.sv_conv_plan_perm_bytes(n_rows) // 4
+                t["plans"][pkey] = dict(n_rows=n_rows, g=g, perm=take(n_perm), masks_p=take(n_perm), tiles=take(lib.sv_conv_plan_tiles_bytes(n_rows, g) // 4))
+        if not sp.subm:
+            lv += 1
+    arena = torch.empty((max(total[0], 1),), dtype=torch.int32, device=dev)
+    base = arena.data_ptr()
+
+    def view(sl, *shape):
+        return arena[sl[0]:sl[0] + sl[1]].view(*shape) if shape else arena[sl[0]:sl[0] + sl[1]]
+
+    def addr(sl, extra=0):
+        return base + 4 * (sl[0] + extra)
+
+    # ---- phase 2: SET every level, QUERY every table, CLEAR the maps
+    maps = [_lib.workspace.persistent(f"rb_cellmap_{tuple(sh)}", mb, dev) for sh, mb in zip(shapes, map_bytes)]
+    strided_tabs = [tables[sp.key] for sp in strided]
+    jobs = []
+
+    def row(*vals):
+        r = [0] * 32
+        r[:len(vals)] = [int(v) for v in vals]
+        jobs.append(r)
+
+    level_sites = [coords.data_ptr() if n[0] else 0] + [addr(t["out_idx"]) for t in strided_tabs]
+    row(1, level_sites[0], 0, maps[0].data_ptr(), 0, n[0], *shapes[0], B)
+    for l, t in enumerate(strided_tabs):
+        row(1, sites[l].data_ptr(), level_sites[l + 1], maps[l + 1].data_ptr(), works[l].data_ptr(), n[l + 1], *shapes[l + 1], B)
+    for t in tables.values():
+        sp, l, K = t["spec"], t["level"], t["K"]
+        if sp.subm:
+            row(2, level_sites[l], maps[l].data_ptr(), addr(t["nbr"]), addr(t["rows"]), addr(t["masks"]), n[l], *shapes[l], *shapes[l], *sp.ksize,
+                1, 1, 1, *[-(k // 2) * d for k, d in zip(sp.ksize, sp.dilation)], *sp.dilation, 1, 1, 1, B)
+        else:
+            no, ni = n[l + 1], n[l]
+            # output-major: [rows_out (n_out, 32) | nbr_out (K, n_out) | masks_out (n_out)], rows = the output sites, target = the input level
+            row(2, level_sites[l + 1], maps[l].data_ptr(), addr(t["out_block"], 32 * no), addr(t["out_block"]), addr(t["out_block"], (32 + K) * no), no,
+                *shapes[l + 1], *shapes[l], *sp.ksize, *sp.stride, *[-p for p in sp.padding], *sp.dilation, 1, 1, 1, B)
+            # input-major: nbr_in (K, n_in) + [rows_in (n_in, 32) | masks_in (n_in)], rows = the input sites, target = the output level
+            row(2, level_sites[l], maps[l + 1].data_ptr(), addr(t["nbr_in"]), addr(t["in_block"]), addr(t["in_block"], 32 * ni), ni,
+                *shapes[l], *shapes[l + 1], *sp.ksize, 1, 1, 1, *sp.padding, *[-d for d in sp.dilation], *sp.stride, B)
+    arr = np.array(jobs, dtype=np.int64)
+    _lib.check(lib.sv_rulebook_batch(arr.ctypes.data, len(jobs), _lib.stream()), "sv_rulebook_batch")
+    # ---- all plans in one launch
+    pj = []
+    for t in tables.values():
+        sp, l, K = t["spec"], t["level"], t["K"]
+        for pkey, pl in t["plans"].items():
+            if sp.subm:
+                masks = addr(t["masks"])
+            elif pkey == "fwd":
+                masks = addr(t["out_block"], (32 + K) * n[l + 1])
+            else:
+                masks = addr(t["in_block"], 32 * n[l])
+            pj.append([masks, pl["n_rows"], pl["g"], addr(pl["perm"]), addr(pl["masks_p"]), addr(pl["tiles"]), 0, 0])
+    if pj:
+        parr = np.array(pj, dtype=np.int64)
+        _lib.check(lib.sv_conv_plan_build_dealt_batch(parr.ctypes.data, len(pj), _lib.stream()), "sv_conv_plan_build_dealt_batch")
+    # ---- the Rulebook objects
+    out, idx = {}, coords
+    level_idx = [coords]
+    for t in strided_tabs:
+        level_idx.append(view(t["out_idx"], n[t["level"] + 1], 4))
+    for key, t in tables.items():
+        sp, l, K = t["spec"], t["level"], t["K"]
+        if sp.subm:
+            rb = Rulebook(view(t["nbr"], K, n[l]), None, level_idx[l], list(shapes[l]), n[l], n[l], True, list(sp.ksize))
+            rb.rows_out, rb.masks_out = view(t["rows"], n[l], 32), view(t["masks"])
+        else:
+            no, ni = n[l + 1], n[l]
+            ob, ib = view(t["out_block"]), view(t["in_block"])
+            rb = Rulebook(ob[32 * no:(32 + K) * no].view(K, no), view(t["nbr_in"], K, ni), level_idx[l + 1], list(shapes[l + 1]), ni, no, False, list(sp.ksize))
+            rb.rows_out, rb.masks_out = ob[:32 * no].view(no, 32), ob[(32 + K) * no:]
+            rb.rows_in, rb.masks_in = ib[:32 * ni].view(ni, 32), ib[32 * ni:]
+        rb.in_indices, rb.in_shape = level_idx[l], list(shapes[l])
+        for pkey, pl in t["plans"].items():
+            table, rows, masks = (rb.nbr_out, rb.rows_out, rb.masks_out) if pkey == "fwd" else (rb.nbr_in, rb.rows_in, rb.masks_in)
+            rb._plans[pkey] = TablePlan.from_parts(table, pl["n_rows"], K, rows, masks, view(pl["perm"]), view(pl["masks_p"]), pl["g"], view(pl["tiles"]))
+        out[key] = rb
+    return n[0], out
 
 
 class _FragmentCache:

@@ -79,11 +79,10 @@ class VCN_CN(nn.Module):
         st = _lib.stream()
         pc = torch.empty_like(x)
         _lib.check(lib.sv_vcn_cn_transform(_lib.ptr(x), bs, n, _lib.ptr(boxes), 0, _lib.ptr(pc), st), "sv_vcn_cn_transform")
-        pts, rg = pc.view(bs * n, 3), None
+        pts, rg, sel, u_dev = pc.view(bs * n, 3), None, None, None
         if self.dedup_points and n > 1:
-            sel, rg = L.distinct_rows(x)
-            pts = pts[sel]
-        feat = L.encode(p["enc"], pts, bs, n, row_group=rg)
+            sel, rg, u_dev = L.distinct_rows(x, sync=False)       # the number of distinct rows stays on the device (see VCN_VC._forward_eval)
+        feat = L.encode(p["enc"], pts, bs, n, row_group=rg, sel=sel, m_dev=u_dev)
         coarse_cn = L.run_fc(p["shape_fc"], feat, L.ACT_RELU)
         nc = self.number_coarse
         coarse = torch.empty((bs, nc, 3), dtype=torch.float32, device=x.device)

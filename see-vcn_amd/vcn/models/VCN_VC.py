@@ -12,6 +12,11 @@ from . import layers as L
 from .build import MODELS
 
 
+import os
+
+LAZY_ROWS = os.environ.get("SEEVCN_VCN_LAZY_ROWS", "1") != "0"     # 0: the distinct-row count is read on the host and the layers get exact sizes (A/B, tests)
+
+
 def normalize_vector(v):
     v_mag = torch.sqrt(v.pow(2).sum(1)).clamp_min(1e-8)          # VCN_VC.py:12-21 (max with 1e-8)
     return v / v_mag.view(-1, 1)
@@ -136,19 +141,21 @@ class VCN_VC(nn.Module):
         _lib.check(lib.sv_vcn_vc_prep(_lib.ptr(x), bs, n, _lib.ptr(fview), _lib.ptr(centred), _lib.ptr(state), st), "sv_vcn_vc_prep")
         # pose encoder: 3->64 LReLU, 64->128 LReLU, 128->1024, max over n   (VCN_VC.py:116-123,193)
         (w0, b0), (w1, b1), (w2, b2) = p["pose"]
-        sel = rg = None
+        sel = rg = u_dev = None
         if self.dedup_points and n > 1:
-            sel, rg = L.distinct_rows(x)
+            # the number of distinct rows stays on the device (no host read in the forward): the row-wise layers are launched for the capacity and
+            # compute the first *u_dev rows (sv_gemm_bias_act_ragged_dev, sv_pointwise_conv3_gather)
+            sel, rg, u_dev = L.distinct_rows(x, sync=False) if LAZY_ROWS else L.distinct_rows(x) + (None,)
         pts = centred.view(bs * n, 3)
-        h = L.pointwise3(pts if sel is None else pts[sel], w0, b0, L.ACT_LRELU)
-        h = L.gemm(h, w1, b1, L.ACT_LRELU)
+        h = L.pointwise3(pts, w0, b0, L.ACT_LRELU, sel=sel, m_dev=u_dev)
+        h = L.gemm(h, w1, b1, L.ACT_LRELU, row_group=rg if u_dev is not None else None, m_dev=u_dev)
         pose_feat = L.neg_inf((bs, w2.shape[0]), dev)
-        L.gemm(h, w2, b2, L.ACT_NONE, rows_per_group=n, store=False, group_max=pose_feat, row_group=rg)
+        L.gemm(h, w2, b2, L.ACT_NONE, rows_per_group=n, store=False, group_max=pose_feat, row_group=rg, m_dev=u_dev)
         rel_pose = L.run_fc(p["pose_fc"], pose_feat, L.ACT_LRELU)                     # (B, 9)   :194
         pc_cn = torch.empty_like(x)
         _lib.check(lib.sv_vcn_vc_pose(_lib.ptr(fview), bs, n, _lib.ptr(rel_pose), _lib.ptr(state), _lib.ptr(pc_cn), st), "sv_vcn_vc_pose")
         pts = pc_cn.view(bs * n, 3)
-        feat = L.encode(p["enc"], pts if sel is None else pts[sel], bs, n, row_group=rg)   # (B, 1024) :203
+        feat = L.encode(p["enc"], pts, bs, n, row_group=rg, sel=sel, m_dev=u_dev)      # (B, 1024) :203
         coarse_cn = L.run_fc(p["shape_fc"], feat, L.ACT_RELU)                         # (B, 3072) :204
         nc = self.number_coarse
         coarse = torch.empty((bs, nc, 3), dtype=torch.float32, device=dev)

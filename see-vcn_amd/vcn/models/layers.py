@@ -69,9 +69,10 @@ class PreparedCache:
         return self.value
 
 
-def gemm(a, w, bias=None, act=ACT_NONE, group_bias=None, rows_per_group=1, store=True, group_max=None, slope=LRELU_SLOPE, row_group=None):
+def gemm(a, w, bias=None, act=ACT_NONE, group_bias=None, rows_per_group=1, store=True, group_max=None, slope=LRELU_SLOPE, row_group=None, m_dev=None):
     """act(a @ w.T + bias + group_bias[group(row)]) via sv_gemm_bias_act (fp32 MFMA); group(row) = row // rows_per_group, or
-    row_group[row] (int32, non-decreasing) for ragged groups.
+    row_group[row] (int32, non-decreasing) for ragged groups.  m_dev (with row_group): the number of valid rows of `a` lives on the device
+    (int32 tensor); a.shape[0] is then the capacity, the output keeps capacity rows and only the first *m_dev are computed.
 
     Returns the (M,N) output (or None when store=False); `group_max` (groups, N) must be pre-filled with -inf."""
     lib = _lib.load()
@@ -80,22 +81,28 @@ def gemm(a, w, bias=None, act=ACT_NONE, group_bias=None, rows_per_group=1, store
     assert w.shape[1] == K and a.is_contiguous() and w.is_contiguous()
     out = torch.empty((M, N), dtype=torch.float32, device=a.device) if store else None
     if row_group is None:
+        assert m_dev is None
         rc = lib.sv_gemm_bias_act(_lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(bias), _lib.ptr(group_bias), int(rows_per_group),
                                   _lib.ptr(out), N, _lib.ptr(group_max), M, N, K, int(act), float(slope), _lib.stream())
-    else:
+    elif m_dev is None:
         assert row_group.dtype == torch.int32 and row_group.shape[0] == M
         rc = lib.sv_gemm_bias_act_ragged(_lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(bias), _lib.ptr(group_bias), _lib.ptr(row_group),
                                          _lib.ptr(out), N, _lib.ptr(group_max), M, N, K, int(act), float(slope), _lib.stream())
+    else:
+        assert row_group.dtype == torch.int32 and row_group.shape[0] == M and m_dev.dtype == torch.int32
+        rc = lib.sv_gemm_bias_act_ragged_dev(_lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(bias), _lib.ptr(group_bias), _lib.ptr(row_group),
+                                             _lib.ptr(out), N, _lib.ptr(group_max), M, _lib.ptr(m_dev), N, K, int(act), float(slope), _lib.stream())
     _lib.check(rc, "sv_gemm_bias_act")
     return out
 
 
-def distinct_rows(x):
+def distinct_rows(x, sync=True):
     """x (B,n,3) -> (sel (U,) int64 flat row indices into x.view(B*n,3), row_group (U,) int32 object of each kept row).
 
     ResamplePoints (vcn/datasets/data_transforms.py:254-262) tiles an object's Ni points to n = 1024, so a cloud holds only
     Ni distinct rows; the per-point layers (Conv1d k=1, eval-mode BatchNorm folded) and the max-pools over points give
-    bit-identical results on the distinct rows alone.  One host sync (the number of kept rows)."""
+    bit-identical results on the distinct rows alone.  sync=True: one host sync (the number of kept rows).  sync=False: no read --
+    (sel, row_group) keep their B*n capacity rows and the third value is U as a device int32 tensor for the *_dev / *_gather layer entries."""
     lib = _lib.load()
     B, n, _ = x.shape
     idx = torch.empty((B, n), dtype=torch.int32, device=x.device)
@@ -106,15 +113,28 @@ def distinct_rows(x):
     total = torch.empty((1,), dtype=torch.int32, device=x.device)
     _lib.check(lib.sv_unique_rows_compact(_lib.ptr(idx), _lib.ptr(cnt), B, n, _lib.ptr(sel), _lib.ptr(row_group), _lib.ptr(total), _lib.stream()),
                "sv_unique_rows_compact")
+    if not sync:
+        return sel, row_group, total
     u = _lib.host_int(total)                                                                                     # sync: U rows
     sel, row_group = sel[:u], row_group[:u]
     return sel, row_group
 
 
-def pointwise3(xyz, w, b, act, slope=LRELU_SLOPE):
+def pointwise3(xyz, w, b, act, slope=LRELU_SLOPE, sel=None, m_dev=None):
+    """K = 3 first layer on the rows of xyz (M, 3) -- or, with sel (capacity,) int64 and m_dev, on xyz[sel[m]] for m < *m_dev (the output keeps
+    the capacity's rows; gather and count stay on the device)."""
     lib = _lib.load()
-    M = xyz.shape[0]
     C = w.shape[0]
+    if sel is not None and m_dev is not None:
+        M = sel.shape[0]
+        out = torch.empty((M, C), dtype=torch.float32, device=xyz.device)
+        rc = lib.sv_pointwise_conv3_gather(_lib.ptr(xyz), _lib.ptr(sel), M, _lib.ptr(m_dev), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), C, int(act), float(slope),
+                                           _lib.stream())
+        _lib.check(rc, "sv_pointwise_conv3_gather")
+        return out
+    if sel is not None:
+        xyz = xyz[sel]
+    M = xyz.shape[0]
     out = torch.empty((M, C), dtype=torch.float32, device=xyz.device)
     rc = lib.sv_pointwise_conv3(_lib.ptr(xyz), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, C, int(act), float(slope), _lib.stream())
     _lib.check(rc, "sv_pointwise_conv3")
@@ -140,17 +160,17 @@ def prepare_encoder(enc):
                 b2a=b2a, w2b=w2b, b2b=b2b)
 
 
-def encode(p, pts, batch, n, row_group=None):
-    """FeatureEncoder.forward (VCN_VC.py:97-106) on channel-last activations. pts: (B*n, 3) or, with row_group, the (U, 3)
-    distinct rows -> (B, 1024)."""
+def encode(p, pts, batch, n, row_group=None, sel=None, m_dev=None):
+    """FeatureEncoder.forward (VCN_VC.py:97-106) on channel-last activations. pts: (B*n, 3); with row_group only the distinct rows
+    pts[sel] are run (row_group = their objects; m_dev: their number on the device, sel / row_group at capacity) -> (B, 1024)."""
     dev = pts.device
-    f1 = pointwise3(pts, p["w1a"], p["b1a"], ACT_RELU)                               # conv 3->128 + BN + ReLU
+    f1 = pointwise3(pts, p["w1a"], p["b1a"], ACT_RELU, sel=sel, m_dev=m_dev)         # conv 3->128 + BN + ReLU
     g1 = neg_inf((batch, p["w1b"].shape[0]), dev)
-    local = gemm(f1, p["w1b"], p["b1b"], ACT_NONE, rows_per_group=n, group_max=g1, row_group=row_group)  # conv 128->256, max over n
+    local = gemm(f1, p["w1b"], p["b1b"], ACT_NONE, rows_per_group=n, group_max=g1, row_group=row_group, m_dev=m_dev)  # conv 128->256, max over n
     gb = gemm(g1, p["w2a_g"], None, ACT_NONE)                                        # global half of conv 512->512
-    f2 = gemm(local, p["w2a_l"], p["b2a"], ACT_RELU, group_bias=gb, rows_per_group=n, row_group=row_group)  # + BN + ReLU
+    f2 = gemm(local, p["w2a_l"], p["b2a"], ACT_RELU, group_bias=gb, rows_per_group=n, row_group=row_group, m_dev=m_dev)  # + BN + ReLU
     g2 = neg_inf((batch, p["w2b"].shape[0]), dev)
-    gemm(f2, p["w2b"], p["b2b"], ACT_NONE, rows_per_group=n, store=False, group_max=g2, row_group=row_group)  # conv 512->1024, max over n
+    gemm(f2, p["w2b"], p["b2b"], ACT_NONE, rows_per_group=n, store=False, group_max=g2, row_group=row_group, m_dev=m_dev)  # conv 512->1024, max over n
     return g2
 
 

@@ -303,6 +303,21 @@ def test_hip_table_plan_is_a_permutation_into_regions_with_balanced_waves(cuda, 
     assert (cu_work <= 1.5 * per_region + 27).all(), (cu_work.max(1) / per_region[:, 0])
     useful = sum(bin(int(m)).count("1") for m in tab[:, 27])
     assert useful / (16.0 * cost.sum()) >= 0.75                                           # useful / executed MFMA steps (consecutive rows: ~0.55)
+    if fused:
+        # a table has exactly ONE plan: rows keep their table order inside a class, tiles theirs inside a cost bucket (plan_region_body_stable) --
+        # so the BatchNorm column sums the conv epilogue makes per workgroup, and everything behind them, are the same in every run
+        classes = np.array([(((m >> 9) & 0x1ff) | (((1 if m & 0x1ff else 0) | (2 if (m >> 18) & 0x1ff else 0)) << 9)) if (m >> 9) & 0x1ff
+                            else (2048 | (((1 if m & 0x1ff else 0) | (2 if (m >> 18) & 0x1ff else 0)) << 9) | ((m & 0x1ff) or ((m >> 18) & 0x1ff))) for m in masks])
+        for r in range(8):
+            seg = rows[starts[r]:starts[r + 1]]
+            seg = seg[seg >= 0]
+            key = classes[seg]
+            assert (np.diff(key) >= 0).all(), r                                            # class-major
+            same = np.diff(key) == 0
+            assert (np.diff(seg)[same] > 0).all(), r                                       # table order inside a class
+        for _ in range(2):
+            tp2 = Fsp.TablePlan(rb.nbr_out, n, rb.K, rb.rows_out, rb.masks_out, g=g)
+            assert torch.equal(tp2.perm, tp.perm) and torch.equal(tp2.masks_p, tp.masks_p) and torch.equal(tp2.tiles(g), tile_of)
 
 
 @pytest.mark.gpu
@@ -607,8 +622,8 @@ def test_hip_backbone_chain_equals_the_module_path(cuda, hip_lib):
     """VoxelBackBone8x in training mode through the launch-list chain (one autograd node, sv_run_ops) against the per-module path
     (SparseSequential: one node per block): the same kernels with the same arguments, so outputs, running statistics and every gradient are
     bit-identical; a gradient that enters at a multi-scale tap (x_conv3, as PV-RCNN's set abstraction sends it) is carried as well.
-    (Run with the BatchNorm statistics made by their own reduction pass: made in the conv epilogue they are summed in the order of the plan's
-    tiles, which the plan builder's LDS atomics do not fix from one run to the next -- equal to 1e-6, not bit for bit.)"""
+    Both in the DEFAULT configuration (BatchNorm statistics summed in the conv epilogues, in the order of the plan's tiles -- the two networks
+    build their own rulebooks and plans, and a table has exactly one plan) and with the statistics made by their own reduction pass."""
     import copy
     import seevcn_amd.synth as synth
     from seevcn_amd.pcdet.models import backbones_3d
@@ -619,26 +634,29 @@ def test_hip_backbone_chain_equals_the_module_path(cuda, hip_lib):
     f, c, _ = voxel_ops.voxelize_dynamic(torch.from_numpy(pts).to(cuda), g["point_cloud_range"], g["voxel_size"], g["grid_size"], 2)
     torch.manual_seed(0)
     net1 = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size']).to(cuda).train()
-    net2 = copy.deepcopy(net1)
-    res = []
-    for net, off in ((net1, False), (net2, True)):
-        saved, chain.CHAIN_OFF = chain.CHAIN_OFF, off
-        saved_stats, norm.STATS_IN_CONV = norm.STATS_IN_CONV, False
-        try:
-            assert (net._chain_blocks() is not None)
-            bd = net({'batch_size': 2, 'voxel_features': f.clone(), 'voxel_coords': c.clone()})
-            out, x3 = bd['encoded_spconv_tensor'].features, bd['multi_scale_3d_features']['x_conv3'].features
-            (out.square().sum() + (x3 * 0.5).sum()).backward()
-        finally:
-            chain.CHAIN_OFF = saved
-            norm.STATS_IN_CONV = saved_stats
-        res.append((out.detach(), x3.detach(), [p.grad.clone() for p in net.parameters()], [b.clone() for b in net.buffers()]))
-    a, b = res
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    for (n1, _), g1, g2 in zip(net1.named_parameters(), a[2], b[2]):
-        assert torch.equal(g1, g2), n1
-    for (n1, _), b1, b2 in zip(net1.named_buffers(), a[3], b[3]):
-        assert torch.equal(b1, b2), n1
+    for stats_in_conv in (True, False):
+        net2 = copy.deepcopy(net1)
+        net3 = copy.deepcopy(net1)
+        res = []
+        for net, off in ((net2, False), (net3, True)):
+            saved, chain.CHAIN_OFF = chain.CHAIN_OFF, off
+            saved_stats, norm.STATS_IN_CONV = norm.STATS_IN_CONV, stats_in_conv
+            try:
+                assert (net._chain_blocks() is not None)
+                bd = net({'batch_size': 2, 'voxel_features': f.clone(), 'voxel_coords': c.clone()})
+                out, x3 = bd['encoded_spconv_tensor'].features, bd['multi_scale_3d_features']['x_conv3'].features
+                assert (type(out.grad_fn).__name__ == "SparseChainFunctionBackward") == (not off)
+                (out.square().sum() + (x3 * 0.5).sum()).backward()
+            finally:
+                chain.CHAIN_OFF = saved
+                norm.STATS_IN_CONV = saved_stats
+            res.append((out.detach(), x3.detach(), [p.grad.clone() for p in net.parameters()], [b.clone() for b in net.buffers()]))
+        a, b = res
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), stats_in_conv
+        for (n1, _), g1, g2 in zip(net1.named_parameters(), a[2], b[2]):
+            assert torch.equal(g1, g2), (n1, stats_in_conv)
+        for (n1, _), b1, b2 in zip(net1.named_buffers(), a[3], b[3]):
+            assert torch.equal(b1, b2), (n1, stats_in_conv)
 
 
 @pytest.mark.gpu
@@ -725,34 +743,133 @@ def test_hip_launch_list_executor_runs_in_order_and_reports_errors(cuda, hip_lib
         chain._run([chain._row(chain.OP_BN_FWD, i=(c, 1, 1, 0), n=(n,), f=me)], "null pointers")
 
 
+def _same_rulebook(a, b, tag):
+    assert a.subm == b.subm and a.n_in == b.n_in and a.n_out == b.n_out and list(a.out_shape) == list(b.out_shape) and a.ksize == b.ksize, tag
+    for name in ("out_indices", "nbr_in", "nbr_out", "rows_in", "rows_out", "masks_in", "masks_out"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert (x is None) == (y is None), (tag, name)
+        if x is not None:
+            assert x.shape == y.shape and torch.equal(x, y), (tag, name)
+
+
 @pytest.mark.gpu
-def test_hip_strided_rulebook_chain_equals_the_layer_by_layer_build(cuda, hip_lib):
-    """build_sparse_rulebook_chain (every level counted on the device first -- level l + 1 marks from level l's occupancy bitmap -- one read for all
-    output-site counts) == build_sparse_rulebook level after level: coordinates, both tables, row-major twins and masks, bit for bit; and the
-    persistent indices are left all-zero (a second chain on them gives the same tables)."""
+@pytest.mark.parametrize("lazy_count", [False, True])
+def test_hip_network_index_equals_the_layer_by_layer_build(cuda, hip_lib, lazy_count):
+    """build_network_index (strided levels counted end to end on the device -- level l + 1 marks from level l's freshly written site list --
+    ONE read for every count, then all tables through the levels' cell maps in three launches and all plans in one) == build_subm_rulebook /
+    build_sparse_rulebook layer after layer: coordinates, both tables, row-major twins and masks, bit for bit; the plans are valid plans of the
+    same tables; the persistent indices and cell maps are left all-zero (a second build on them gives the same tables).  lazy_count: the
+    coordinate tensor has capacity rows (garbage behind the first n0) and n0 lives on the device."""
+    from seevcn_amd import _lib
     from seevcn_amd.spconv import functional as Fsp
     rng = np.random.default_rng(11)
     batch, shape = 3, (21, 96, 80)
     coords = torch.from_numpy(_rand_coords(rng, 20000, batch, shape)).to(cuda)
-    specs = [((3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1), (1, 1, 1)),
-             ((3, 1, 1), (2, 1, 1), (0, 0, 0), (1, 1, 1))]
-    want, idx, sh = [], coords, list(shape)
-    for ks, st, pd, dl in specs:
-        rb = Fsp.build_sparse_rulebook(idx, batch, sh, ks, st, pd, dl)
-        want.append(rb)
-        idx, sh = rb.out_indices, list(rb.out_shape)
-    for _ in range(2):
-        got = Fsp.build_sparse_rulebook_chain(coords, batch, shape, specs)
-        assert len(got) == len(want)
-        for l, (a, b) in enumerate(zip(got, want)):
-            assert a.n_in == b.n_in and a.n_out == b.n_out and list(a.out_shape) == list(b.out_shape), l
-            for name in ("out_indices", "nbr_in", "nbr_out", "rows_in", "rows_out", "masks_in", "masks_out"):
-                assert torch.equal(getattr(a, name), getattr(b, name)), (l, name)
-    # oracle for the first two levels
+    n0 = coords.shape[0]
+    S = Fsp.ConvSpec
+    specs = [S("subm1", True, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 16, 16), S("subm1", True, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 16, 16),
+             S("sp2", False, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), 16, 32), S("subm2", True, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 32, 32),
+             S("sp3", False, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), 32, 64), S("subm3", True, (3, 1, 3), (1, 1, 1), (1, 0, 1), (1, 1, 1), 64, 64),
+             S("sp4", False, (3, 3, 3), (2, 2, 2), (0, 1, 1), (1, 1, 1), 64, 64), S("subm4", True, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 64, 64),
+             S("down", False, (3, 1, 1), (2, 1, 1), (0, 0, 0), (1, 1, 1), 64, 128)]
+    want, idx, sh = {}, coords, list(shape)
+    for sp in specs:
+        if sp.key in want:
+            continue
+        if sp.subm:
+            want[sp.key] = Fsp.build_subm_rulebook(idx, batch, sh, sp.ksize, sp.dilation)
+        else:
+            want[sp.key] = rb = Fsp.build_sparse_rulebook(idx, batch, sh, sp.ksize, sp.stride, sp.padding, sp.dilation)
+            idx, sh = rb.out_indices, list(rb.out_shape)
+    torch.cuda.synchronize()
+    _lib.workspace.reset()            # fresh (zeroed) workspaces: the layer-by-layer builders leave their scan output (chunk bases) behind
+    if lazy_count:
+        given = torch.cat([coords, torch.full((777, 4), 1 << 20, dtype=torch.int32, device=cuda)])      # capacity rows behind n0: never read
+        n0_dev = torch.tensor([n0], dtype=torch.int32, device=cuda)
+    else:
+        given, n0_dev = coords, None
+    for rep in range(2):
+        got_n0, got = Fsp.build_network_index(given, batch, shape, specs, n0_dev=n0_dev)
+        assert got_n0 == n0 and sorted(got) == sorted(want)
+        for key in want:
+            _same_rulebook(got[key], want[key], (rep, key))
+        # level identities: a strided table's output sites ARE the next level's input sites (get_rulebook compares identities)
+        assert got["sp3"].in_indices is got["sp2"].out_indices and got["subm2"].out_indices is got["sp2"].out_indices
+        # plans: a permutation of the rows into regions, masks carried along, every tile dealt exactly once
+        for key, rb in got.items():
+            for pkey, tp in rb._plans.items():
+                perm, n_rows = tp.perm.cpu().numpy(), tp.n_rows
+                assert np.array_equal(np.sort(perm[perm >= 0]), np.arange(n_rows)), (key, pkey)
+                assert np.array_equal(tp.masks_p.cpu().numpy()[perm >= 0], tp.masks.cpu().numpy()[perm[perm >= 0]]), (key, pkey)
+                (g, tiles), = tp._tiles.items()
+                t = tiles.cpu().numpy()
+                assert np.array_equal(np.sort(t[t >= 0]), np.arange((n_rows + 15) // 16)), (key, pkey)
+    # nothing left behind in the persistent workspaces this build touched (bitmaps of the strided levels, cell maps of all levels)
+    for (kind, name, *_), buf in _lib.workspace._bufs.items():
+        if kind == "p" and (name.startswith("rb_index_") or name.startswith("rb_cellmap_")):
+            assert int(buf.count_nonzero()) == 0, name
+    # oracle for the first two strided levels
     oc, nbr_out, nbr_in, _ = osp.rulebook_sparse(coords.cpu().numpy(), shape, 3, 2, 1)
-    assert np.array_equal(got[0].out_indices.cpu().numpy(), oc) and np.array_equal(got[0].nbr_out.cpu().numpy(), nbr_out)
-    oc2, nbr_out2, _, _ = osp.rulebook_sparse(oc, got[0].out_shape, 3, 2, 1)
-    assert np.array_equal(got[1].out_indices.cpu().numpy(), oc2) and np.array_equal(got[1].nbr_out.cpu().numpy(), nbr_out2)
+    assert np.array_equal(got["sp2"].out_indices.cpu().numpy(), oc) and np.array_equal(got["sp2"].nbr_out.cpu().numpy(), nbr_out)
+    oc2, nbr_out2, _, _ = osp.rulebook_sparse(oc, got["sp2"].out_shape, 3, 2, 1)
+    assert np.array_equal(got["sp3"].out_indices.cpu().numpy(), oc2) and np.array_equal(got["sp3"].nbr_out.cpu().numpy(), nbr_out2)
+
+
+@pytest.mark.gpu
+def test_hip_network_index_declines_what_it_does_not_take(cuda, hip_lib):
+    """Wider kernels, an empty input or a cell map beyond the budget: None before anything is launched -- the caller builds layer by layer."""
+    from seevcn_amd.spconv import functional as Fsp
+    S = Fsp.ConvSpec
+    coords = torch.from_numpy(_rand_coords(np.random.default_rng(3), 500, 2, (11, 40, 40))).to(cuda)
+    assert Fsp.build_network_index(coords, 2, (11, 40, 40), [S("a", False, (5, 5, 5), (2, 2, 2), (2, 2, 2), (1, 1, 1), 16, 16)]) is None
+    assert Fsp.build_network_index(coords[:0], 2, (11, 40, 40), [S("a", True, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 16, 16)]) is None
+    saved, Fsp.CELLMAP_MAX_BYTES = Fsp.CELLMAP_MAX_BYTES, 1024
+    try:
+        assert Fsp.build_network_index(coords, 2, (11, 40, 40), [S("a", True, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 16, 16)]) is None
+    finally:
+        Fsp.CELLMAP_MAX_BYTES = saved
+
+
+@pytest.mark.gpu
+def test_hip_backbone_on_the_batched_index_equals_the_layer_by_layer_index(cuda, hip_lib):
+    """VoxelBackBone8x forward + backward with its rulebooks and plans from build_network_index against the same network on rulebooks built
+    layer by layer (SEEVCN_INDEX_BATCH=0): identical tables, so -- with the BatchNorm statistics in passes of their own, which takes the plan's
+    row order out of the sums -- outputs and gradients are bit-identical.  The voxel count is read lazily in the first run (pipeline.front's way)."""
+    import copy
+    import seevcn_amd.synth as synth
+    from seevcn_amd import spconv
+    from seevcn_amd.pcdet.models import backbones_3d
+    from seevcn_amd.pcdet.ops import voxel_ops
+    from seevcn_amd.spconv import conv as sconv, norm
+    pts, _ = synth.make_scene_batch(2, seed=2003, n_az=120)
+    g = dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.05, 0.05, 0.1], grid_size=[1408, 1600, 40])
+    fcap, ccap, _, nvox = voxel_ops.voxelize_dynamic(torch.from_numpy(pts).to(cuda), g["point_cloud_range"], g["voxel_size"], g["grid_size"], 2, sync=False)
+    torch.manual_seed(0)
+    net1 = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size']).to(cuda).train()
+    net2 = copy.deepcopy(net1)
+    res = []
+    saved_stats, norm.STATS_IN_CONV = norm.STATS_IN_CONV, False
+    try:
+        for net, batched in ((net1, True), (net2, False)):
+            saved, sconv.BATCH_INDEX = sconv.BATCH_INDEX, batched
+            try:
+                sp = spconv.SparseConvTensor(fcap.clone(), ccap.clone(), net.sparse_shape, 2)
+                spconv.prebuild_rulebooks(net, sp, with_backward=True, n0_dev=nvox)
+                assert sp.indices.shape[0] == int(nvox) == sp.features.shape[0]
+                bd = net({'batch_size': 2, 'voxel_features': sp.features, 'voxel_coords': sp.indices, 'spconv_indice_dict': sp.indice_dict})
+                out, x3 = bd['encoded_spconv_tensor'].features, bd['multi_scale_3d_features']['x_conv3'].features
+                (out.square().sum() + (x3 * 0.5).sum()).backward()
+            finally:
+                sconv.BATCH_INDEX = saved
+            res.append((out.detach(), x3.detach(), [p.grad.clone() for p in net.parameters()], bd['encoded_spconv_tensor'].indices.clone(), sp.indice_dict))
+    finally:
+        norm.STATS_IN_CONV = saved_stats
+    a, b = res
+    assert torch.equal(a[3], b[3]) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for key in b[4]:
+        _same_rulebook(a[4][key], b[4][key], key)
+    for (n1, _), g1, g2 in zip(net1.named_parameters(), a[2], b[2]):
+        assert torch.equal(g1, g2), n1
 
 
 @pytest.mark.gpu

@@ -222,13 +222,26 @@ def test_hip_vcn_distinct_row_path_is_bit_identical(cuda, hip_lib):
         m.load_state_dict(seeded_state_dict(m, seed=0))
         m = m.to(cuda).eval()
         m.dedup_points = True
-        a = m({"input": x, **extra})
+        a = m({"input": x, **extra})                      # default: the distinct-row count never leaves the device (capacity-sized launches)
         m.dedup_points = False
         b = m({"input": x, **extra})
         for k in a:
             assert torch.equal(a[k], b[k]), (name, k)
+        if name == "VCN_VC":
+            import seevcn_amd.vcn.models.VCN_VC as vc_mod
+            m.dedup_points = True
+            saved, vc_mod.LAZY_ROWS = vc_mod.LAZY_ROWS, False
+            try:
+                c = m({"input": x, **extra})                  # the count read on the host, exact-size layers
+            finally:
+                vc_mod.LAZY_ROWS = saved
+            for k in a:
+                assert torch.equal(a[k], c[k]), (name, k, "host-read row count")
     from seevcn_amd.vcn.models import layers as L
     sel, rg = L.distinct_rows(x)
+    sel_cap, rg_cap, u_dev = L.distinct_rows(x, sync=False)
+    assert int(u_dev) == sel.shape[0] and sel_cap.shape[0] == x.shape[0] * x.shape[1]
+    assert torch.equal(sel_cap[:sel.shape[0]], sel) and torch.equal(rg_cap[:sel.shape[0]], rg)
     counts = torch.bincount(rg.long(), minlength=6).cpu().numpy()
     want = [len(np.unique(clouds[i], axis=0)) for i in range(6)]
     assert counts.tolist() == want and counts[4] == 1 and counts[5] == 1024
