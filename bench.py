@@ -193,33 +193,39 @@ def _compute_gen(model, opt, params, bd, world, out):
 
 
 def run_step_prefetched(model, opt, params, pre, world, interleave=True):
-    """One step = compute(N) on the main stream + front(N + 1) on the side stream, enqueued by ONE host thread.  The step is bound by that
-    thread (measured: 2.6 ms to enqueue the trained side, 2.4 ms in the input side, most of the latter spent WAITING in its seven device ->
-    host reads): so the pieces of compute(N) are enqueued exactly there -- each read of the front first runs the next piece (sync hook of
-    seevcn_amd._lib.host_int), after the kernels that produce the value it is about to read were launched."""
+    """One step = compute(N) on the main stream + front(N + 1) on the side stream, enqueued by ONE host thread, whose time is what the step is
+    made of (round 4: ~1.6 ms to enqueue the trained side, ~1.9 ms for the input side, against 3.8 ms of main-stream GPU time).  The input side has
+    ONE blocking device -> host read (voxel count + the strided levels' site counts).  Order: forward + loss of batch N right away (the main
+    stream has work from the start), then the input side of batch N + 1 up to its read; right BEFORE the read blocks -- sync hook of
+    seevcn_amd._lib.host_int -- everything that is left of batch N (backward, exchange, optimiser) is enqueued, so the host never waits while the
+    main stream could run dry; then the read, then the tables and plans of batch N + 1.  interleave False (A/B): the whole trained side first,
+    then the input side."""
     from seevcn_amd import _lib
     bd = pre.take()
     out = []
     gen = _compute_gen(model, opt, params, bd, world, out)
     main = torch.cuda.current_stream()
 
-    def piece():
-        # the hook is off while a piece runs: a device -> host read inside the trained side (a rulebook built lazily, distinct_rows) must not
-        # re-enter the generator that is executing it
+    def rest():
+        # the hook is off while the pieces run: a device -> host read inside the trained side (a rulebook built lazily) must not re-enter
         mine = _lib.set_sync_hook(None)
         try:
             with torch.cuda.stream(main), torch.enable_grad():    # the hook runs inside the front's side-stream / no_grad context
-                next(gen, None)
+                for _ in gen:
+                    pass
         finally:
             _lib.set_sync_hook(mine)
 
-    next(gen, None)                                           # first piece right away: the main stream has work from the start
-    prev = _lib.set_sync_hook(piece if interleave else None)
+    next(gen, None)                                           # forward + loss right away
+    if not interleave:
+        for _ in gen:
+            pass
+    prev = _lib.set_sync_hook(rest if interleave else None)
     try:
         pre.issue()
     finally:
         _lib.set_sync_hook(prev)
-    for _ in gen:                                             # whatever the front's reads did not take
+    for _ in gen:                                             # a front without a read (nothing to do) leaves the pieces here
         pass
     return out[0]
 
@@ -444,7 +450,7 @@ def main():
     ap.add_argument("--no-kernel-rooflines", action="store_true", help="skip the per-kernel event timing after the timed region (tests)")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only control flow of the multi-rank path (gloo), no kernels")
     ap.add_argument("--no-prefetch", action="store_true", help="run the input side (stage A, voxelise, rulebooks) in line on the main stream")
-    ap.add_argument("--no-interleave", action="store_true", help="enqueue the trained side before the input side instead of inside its reads (A/B)")
+    ap.add_argument("--no-interleave", action="store_true", help="enqueue the WHOLE trained side before the input side instead of its backward half inside the input side's read (A/B)")
     ap.add_argument("--prefetch-thread", action="store_true", help="input side issued by a host thread of its own (A/B: measured slower, "
                     "two launch-bound Python threads take turns on the GIL)")
     ap.add_argument("--spinup", type=float, default=0.0, help="seconds of untimed device spin-up (dense GEMMs) before the warm-up steps (A/B switch: a GPU "

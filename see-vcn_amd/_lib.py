@@ -222,17 +222,22 @@ def host_int(t):
 
 
 def host_ints(tensors):
-    """[int(t) for t in tensors] with ONE blocking device -> host read (same hook and parked checks as host_int)."""
+    """The integers of `tensors` (0-dim / one-element tensors, or longer ones: their elements in order) as one flat Python list with ONE blocking
+    device -> host read: one concatenation kernel + one copy (same hook and parked checks as host_int)."""
     hook = getattr(_sync_hooks, "before", None)
     if hook is not None:
         hook()
     pending = _take_checks()
-    if not pending and len(tensors) == 1:
+    if not pending and len(tensors) == 1 and tensors[0].numel() == 1:
         return [int(tensors[0].item())]
-    vals = torch.stack([t.reshape(()).to(torch.int64) for t in tensors] + [p.reshape(()).to(torch.int64) for _, p, _ in pending]).tolist()
-    for v, (_, _, fn) in zip(vals[len(tensors):], pending):
+    flat = [t.reshape(-1) for t in tensors] + [p.reshape(-1) for _, p, _ in pending]
+    if len({t.dtype for t in flat}) > 1:
+        flat = [t.to(torch.int64) for t in flat]
+    vals = torch.cat(flat).tolist()
+    n = len(vals) - len(pending)
+    for v, (_, _, fn) in zip(vals[n:], pending):
         fn(int(v))
-    return [int(v) for v in vals[:len(tensors)]]
+    return [int(v) for v in vals[:n]]
 
 
 def defer_check(t, fn):
@@ -247,7 +252,10 @@ def flush_checks():
     """Run the checks parked on the current stream now (one blocking read) -- for call sites that are not followed by a host_int()."""
     pending = _take_checks()
     if pending:
-        for v, (_, _, fn) in zip(torch.stack([p.reshape(()).to(torch.int64) for _, p, _ in pending]).tolist(), pending):
+        flat = [p.reshape(-1) for _, p, _ in pending]
+        if len({t.dtype for t in flat}) > 1:
+            flat = [t.to(torch.int64) for t in flat]
+        for v, (_, _, fn) in zip(torch.cat(flat).tolist(), pending):
             fn(int(v))
 
 

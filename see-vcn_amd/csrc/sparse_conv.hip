@@ -1674,10 +1674,13 @@ __device__ __forceinline__ float wg_elem(const float& v, int) { return v; }
 // The four waves' accumulators are summed through LDS in a fixed order and one slab per (chunk, k) is stored.
 // OFF32: operand addresses as 32-bit byte offsets from uniform bases (the launcher checks that every offset fits) and the tail mask only in a
 // list's last step -- 35 -> ~15 non-MFMA instructions per 16-MFMA step
-template <int CT, int NTL, bool OFF32>  // register tile grid: CT x NTL tiles of 16x16 (rows = c_in, cols = c_out)
+template <int CT, int NTL, bool OFF32, int DBG = 0>  // register tile grid: CT x NTL tiles of 16x16 (rows = c_in, cols = c_out); DBG (measurement): 1 no operand loads, 2 no MFMAs
 // four waves per SIMD (<4,4>: 122 VGPRs; 140 and three waves unbounded): 4 % slower before the loop was trimmed, 3 % faster on the 139 k-row layer
 // and equal elsewhere after it
-__global__ __launch_bounds__(256, 4) void k_spconv_wgrad(WgradArgs a) {
+#ifndef SEEVCN_WGRAD_WAVES
+#define SEEVCN_WGRAD_WAVES 4
+#endif
+__global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad(WgradArgs a) {
   // the wave's compacted pairs: (source, row) -- OFF32: as byte offsets of the two operand rows, and 32 copies of the last pair behind the list so that
   // the ring's dummy tail loads need no clamp
   __shared__ int2 pjr[4][64 * WG_SUB + 32];
@@ -1733,7 +1736,10 @@ __global__ __launch_bounds__(256, 4) void k_spconv_wgrad(WgradArgs a) {
   const uint32_t xconst = (uint32_t)(x_in ? c_base + CT * li : 0) * 4u, yconst = (uint32_t)(n_base + NTL * li) * 4u;
   const uint32_t xrow = (uint32_t)a.Cin * 4u, yrow = (uint32_t)a.Cout * 4u;
   auto issue = [&](int p, int cnt, XV& xs, YV& ys) {
-    if constexpr (OFF32) {
+    if constexpr (DBG & 1) {
+      xs = XV{} + 1.f, ys = YV{} + 1.f;                        // measurement: what the kernel costs without its operand loads
+      asm volatile("" : "+v"(xs), "+v"(ys));
+    } else if constexpr (OFF32) {
       const int2 jr = pjr[wid][p];                             // byte offsets; entries past the list repeat its last pair
       wg_gload_s(xs, (uint32_t)jr.x + xconst, a.X);
       wg_gload_s(ys, (uint32_t)jr.y + yconst, dYc);
@@ -1755,10 +1761,14 @@ __global__ __launch_bounds__(256, 4) void k_spconv_wgrad(WgradArgs a) {
         if (!ok) ys = YV{};
         asm volatile("" : "+v"(xs), "+v"(ys));               // keeps this a BRANCH: if-converted, its selects ran in every step
       }
+      if constexpr (DBG & 2) {
+        asm volatile("" :: "v"(xs), "v"(ys));                  // measurement: loads and waits only
+      } else {
 #pragma unroll
-      for (int c = 0; c < CT; ++c)
+        for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg_elem(xs, c), wg_elem(ys, t), acc[c][t], 0, 0, 0);
+          for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg_elem(xs, c), wg_elem(ys, t), acc[c][t], 0, 0, 0);
+      }
     } else {
       const bool ok = p0 + kk < cnt;
       float xa[CT], yb[NTL];
@@ -1797,6 +1807,7 @@ __global__ __launch_bounds__(256, 4) void k_spconv_wgrad(WgradArgs a) {
       cnt += __popcll(m);
     }
     if (cnt == 0) continue;
+    if constexpr (DBG & 8) continue;                         // measurement: table reads and compaction only
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private list: LDS ops of one wave complete in order
     if constexpr (OFF32) {
       if (lane < 32) pjr[wid][cnt + lane] = pjr[wid][cnt - 1];
@@ -1823,6 +1834,15 @@ __global__ __launch_bounds__(256, 4) void k_spconv_wgrad(WgradArgs a) {
       consume(p0 + 12, cnt, x3, y3);
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2));   // retire the tail's dummy loads
+  }
+  if constexpr (DBG & 4) {                                   // measurement: no reduction, no slab store (one value keeps the accumulators alive)
+    float sacc = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) sacc += acc[c][t][0] + acc[c][t][1] + acc[c][t][2] + acc[c][t][3];
+    if (sacc == 12345.678f) a.partial[0] = sacc;
+    return;
   }
   // fixed-order reduction over the 4 waves (wave 0 stores, waves 1..3 add in turn), then one slab per (chunk, k)
   for (int w = 0; w < 4; ++w) {
@@ -1927,6 +1947,15 @@ static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
   // 32-bit operand offsets: every source row starts below 2^32 bytes (n_src from the caller); dY offsets are chunk-relative
   static const int off32_env = getenv("SEEVCN_WGRAD_OFF32") ? atoi(getenv("SEEVCN_WGRAD_OFF32")) : 1;
   const bool off32 = off32_env && a.n_src > 0 && (uint64_t)a.n_src * (uint64_t)a.Cin * 4u < 0xffffffffull && (uint64_t)a.chunk_rows * a.Cout * 4u < 0xffffffffull;
+  static const int wg_debug = getenv("SEEVCN_WGRAD_DEBUG") ? atoi(getenv("SEEVCN_WGRAD_DEBUG")) : 0;
+  if constexpr (CT == 4 && NTL == 4) {
+    if (off32 && wg_debug == 1) { hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true, 1>), dim3(blocks), dim3(256), 0, st, a); return; }
+    if (off32 && wg_debug == 2) { hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true, 2>), dim3(blocks), dim3(256), 0, st, a); return; }
+    if (off32 && wg_debug == 4) { hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true, 4>), dim3(blocks), dim3(256), 0, st, a); return; }
+    if (off32 && wg_debug == 5) { hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true, 5>), dim3(blocks), dim3(256), 0, st, a); return; }
+    if (off32 && wg_debug == 12) { hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true, 12>), dim3(blocks), dim3(256), 0, st, a); return; }
+    if (off32 && wg_debug == 8) { hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true, 8>), dim3(blocks), dim3(256), 0, st, a); return; }
+  }
   if (off32) hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true>), dim3(blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, false>), dim3(blocks), dim3(256), 0, st, a);
 }

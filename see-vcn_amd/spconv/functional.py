@@ -280,7 +280,7 @@ def build_network_index(coords, batch_size, spatial_shape, specs, n0_dev=None, w
         _lib.check(rc, "sv_rulebook_chain_count")
     try:
         if L:
-            vals = _lib.host_ints(([n0_dev] if n0_dev is not None else []) + list(num_out.unbind(0)))        # THE read
+            vals = _lib.host_ints(([n0_dev] if n0_dev is not None else []) + [num_out])        # THE read
         else:
             vals = _lib.host_ints([n0_dev]) if n0_dev is not None else []
         n = [vals.pop(0) if n0_dev is not None else cap0] + vals
