@@ -116,7 +116,7 @@ def applicable(blocks, x):
         rb = x.indice_dict.get(b.conv.indice_key)
         if rb is None or rb.n_out < 2 or rb.ksize != b.conv.kernel_size:
             return False
-        if k > 0 and rb.plan("bwd", b.cout, b.cin) is None:
+        if k > 0 and rb.plan_addrs("bwd", b.cout, b.cin) is None:
             return False
     return True
 
@@ -142,25 +142,24 @@ class SparseChainFunction(torch.autograd.Function):
         for k, (b, rb) in enumerate(zip(blocks, rulebooks)):
             w, gamma, beta = params[3 * k:3 * k + 3]
             o_conv, o_y, o_mean, o_istd = (base + 4 * v for v in offs[k])
-            wk = b.conv.weight_kio()
-            plan = rb.plan("fwd", b.cin, b.cout)
-            scratch = norm._scratch(b.cout, dev)
+            wk = b.conv.weight_kio_nograd()
+            plan = rb.plan_addrs("fwd", b.cin, b.cout)
+            scratch = norm._scratch(b.cout, dev).data_ptr()
             partial = 0
             if plan is not None:
-                tp, tile_of, g, rev = plan
+                a_rows, a_perm, a_masks_p, a_tiles, g, rev = plan
                 ff, fb = Fsp.fragment_cache.get(wk)
                 frags.append(fb)
-                partial = scratch.data_ptr() + 16 * b.cout if norm.STATS_IN_CONV else 0
+                partial = scratch + 16 * b.cout if norm.STATS_IN_CONV else 0
                 rows.append(_row(OP_CONV_PLANNED, i=(g, b.K, b.cin, b.cout, 0, int(bool(rev))), n=(n_src, rb.n_out),
-                                 p=(x_ptr, tp.rows.data_ptr(), tp.perm.data_ptr(), tp.masks_p.data_ptr(), tile_of.data_ptr(), ff.data_ptr(), o_conv, None, None, None,
-                                    None, partial or None)))
+                                 p=(x_ptr, a_rows, a_perm, a_masks_p, a_tiles, ff.data_ptr(), o_conv, None, None, None, None, partial or None)))
             else:
                 frags.append(None)
                 wt = wk.detach().permute(0, 2, 1).contiguous()                       # (K, C_out, C_in): the 3-channel input layer only
                 keep.append(wt)
-                rows.append(_row(OP_CONV_PLAIN, i=(b.K, b.cin, b.cout, 0), n=(n_src, rb.n_out), p=(x_ptr, rb.nbr_out.data_ptr(), wt.data_ptr(), o_conv)))
+                rows.append(_row(OP_CONV_PLAIN, i=(b.K, b.cin, b.cout, 0), n=(n_src, rb.n_out), p=(x_ptr, rb.addr("nbr_out"), wt.data_ptr(), o_conv)))
             rows.append(_row(OP_BN_FWD, i=(b.cout, 1, int(b.relu), n_part if partial else 0), n=(rb.n_out,), f=b.mom_eps,
-                             p=(o_conv, gamma.data_ptr(), beta.data_ptr(), b.bn.running_mean.data_ptr(), b.bn.running_var.data_ptr(), scratch.data_ptr(), o_y, o_mean,
+                             p=(o_conv, gamma.data_ptr(), beta.data_ptr(), b.bn.running_mean.data_ptr(), b.bn.running_var.data_ptr(), scratch, o_y, o_mean,
                                 o_istd, b.bn.num_batches_tracked.data_ptr())))
             x_ptr, n_src = o_y, rb.n_out
         _run(rows, "sv_run_ops (chain forward)")
@@ -211,9 +210,9 @@ class SparseChainFunction(torch.autograd.Function):
                              p=(a_conv, dy_ptr, gamma.data_ptr(), beta.data_ptr(), a_mean, a_istd, scratch.data_ptr(), o_dconv, o_dg, o_db)))
             n_part_bwd = 0
             rows.append(_row(OP_WGRAD, i=(b.K, b.cin, b.cout, rb.n_in), n=(rb.n_out, b.cin, 1, b.K * b.cin),
-                             p=(x_in, rb.nbr_out.data_ptr(), o_dconv, wbase + 4 * woffs[k], wscratch.data_ptr())))
+                             p=(x_in, rb.addr("nbr_out"), o_dconv, wbase + 4 * woffs[k], wscratch.data_ptr())))
             if k > 0:
-                tp, tile_of, g, rev = rb.plan("bwd", b.cout, b.cin)
+                a_rows, a_perm, a_masks_p, a_tiles, g, rev = rb.plan_addrs("bwd", b.cout, b.cin)
                 res = ext[k - 1]
                 if res is None and norm.STATS_IN_CONV and BWD_SUMS_IN_CONV:
                     # the gradient this launch writes is the whole gradient of block k-1's output: its epilogue also makes the two sums of that
@@ -223,12 +222,12 @@ class SparseChainFunction(torch.autograd.Function):
                     g_lo, b_lo = params[3 * (k - 1) + 1], params[3 * (k - 1) + 2]
                     partial = norm._scratch(lo.cout, dev).data_ptr() + 16 * lo.cout
                     rows.append(_row(OP_DGRAD_PLANNED_BN, i=(g, b.K, b.cout, b.cin, int(bool(rev)), int(lo.relu)), n=(rb.n_out, rb.n_in),
-                                     p=(o_dconv, tp.rows.data_ptr(), tp.perm.data_ptr(), tp.masks_p.data_ptr(), tile_of.data_ptr(), frags[k].data_ptr(), o_dx,
+                                     p=(o_dconv, a_rows, a_perm, a_masks_p, a_tiles, frags[k].data_ptr(), o_dx,
                                         p_conv, p_mean, p_istd, g_lo.data_ptr(), b_lo.data_ptr(), partial)))
                     n_part_bwd = n_part
                 else:
                     rows.append(_row(OP_CONV_PLANNED, i=(g, b.K, b.cout, b.cin, 0, int(bool(rev))), n=(rb.n_out, rb.n_in),
-                                     p=(o_dconv, tp.rows.data_ptr(), tp.perm.data_ptr(), tp.masks_p.data_ptr(), tile_of.data_ptr(), frags[k].data_ptr(), o_dx, None,
+                                     p=(o_dconv, a_rows, a_perm, a_masks_p, a_tiles, frags[k].data_ptr(), o_dx, None,
                                         None, None, None if res is None else res.data_ptr(), None)))
                 dy_ptr = o_dx
         _run(rows, "sv_run_ops (chain backward)")

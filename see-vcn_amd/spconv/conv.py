@@ -50,6 +50,17 @@ class SparseConvolution(SparseModule):
         co = self.out_channels
         return self.weight.reshape(co, -1, self.in_channels).permute(1, 2, 0)
 
+    def weight_kio_nograd(self):
+        """The same view for consumers that only need its memory (fragment copies, launch lists): cached on the module while the parameter keeps
+        its storage (two torch view ops per layer and call otherwise: 24 per chained step)."""
+        w = self.weight
+        hit = self.__dict__.get('_seevcn_kio')
+        if hit is None or hit[0] is not w or hit[1] != w.data_ptr():
+            with torch.no_grad():
+                hit = (w, w.data_ptr(), w.reshape(self.out_channels, -1, self.in_channels).permute(1, 2, 0))     # ._base stays the Parameter: same fragment-cache key as weight_kio()
+            self.__dict__['_seevcn_kio'] = hit
+        return hit[2]
+
     def get_rulebook(self, x):
         rb = x.find_indice_pair(self.indice_key)
         if rb is not None and self.subm:
@@ -242,6 +253,6 @@ def refresh_weight_fragments(root):
     """One launch that re-lays the MFMA fragment copies of every planned-kernel convolution under `root` (Fsp.fragment_cache.refresh_all)."""
     if not Fsp.USE_PLAN:
         return
-    ws = [m.weight_kio() for m in _sparse_convs(root) if m.weight.is_cuda]
+    ws = [m.weight_kio_nograd() for m in _sparse_convs(root) if m.weight.is_cuda]
     with torch.no_grad():
         Fsp.fragment_cache.refresh_all(ws)

@@ -21,7 +21,36 @@ def conv_out_shape(in_shape, ksize, stride, padding, dilation):
     return [int(x) for x in out]
 
 
-class TablePlan:
+class _ArenaViews:
+    """Tensors that are slices of one int32 arena, materialised on first access (a torch view costs ~3 us; build_network_index hands out ~80 per
+    step and the launch-list chain only ever needs their ADDRESSES).  _lazy: name -> (offset in int32, count, shape or None); addr(name) is the
+    device address without making the view, whether the attribute is lazy or a plain tensor."""
+    _arena = None
+    _lazy = None
+
+    def __getattr__(self, name):
+        lazy = self.__dict__.get("_lazy")
+        if lazy is not None and name in lazy:
+            off, count, shape = lazy[name]
+            t = self._arena[off:off + count]
+            if shape is not None:
+                t = t.view(*shape)
+            setattr(self, name, t)
+            return t
+        raise AttributeError(name)
+
+    def addr(self, name):
+        lazy = self.__dict__.get("_lazy")
+        if lazy is not None and name in lazy and name not in self.__dict__:
+            return self._arena_ptr + 4 * lazy[name][0]
+        t = getattr(self, name)
+        return 0 if t is None else t.data_ptr()
+
+    def _set_lazy(self, arena, arena_ptr, specs):
+        self._arena, self._arena_ptr, self._lazy = arena, arena_ptr, specs
+
+
+class TablePlan(_ArenaViews):
     """Plan of one rulebook table for the MFMA kernel: the row-major table + masks (from the rulebook builder, or made here from a
     k-major table), the regrouping of the rows (sv_conv_plan_build) and the tile -> wave assignment per tiles-per-wave value
     (sv_conv_plan_tiles).  Built once per table, reused by every launch on it."""
@@ -30,7 +59,7 @@ class TablePlan:
         lib = _lib.load()
         dev = table.device
         self.n_rows, self.K = int(n_rows), int(K)
-        self.source = table                      # keep the k-major table alive with its plan
+        self._source = table                     # keep the k-major table alive with its plan
         if rows is None or masks is None:
             rows = torch.empty((max(self.n_rows, 1), 32), dtype=torch.int32, device=dev)
             masks = torch.empty((max(self.n_rows, 1),), dtype=torch.int32, device=dev)
@@ -55,13 +84,39 @@ class TablePlan:
     def from_parts(cls, table, n_rows, K, rows, masks, perm, masks_p, g, tile_of):
         """A plan whose pieces were made elsewhere (build_network_index: all plans of a network in one launch)."""
         self = cls.__new__(cls)
-        self.n_rows, self.K, self.source = int(n_rows), int(K), table
+        self.n_rows, self.K, self._source = int(n_rows), int(K), table
         self.rows, self.masks, self.perm, self.masks_p = rows, masks, perm, masks_p
         self._tiles = {int(g): tile_of}
         return self
 
+    @classmethod
+    def from_arena(cls, arena, arena_ptr, n_rows, K, table_name, owner, rows, masks, perm, masks_p, g, tile_of):
+        """from_parts with every piece given as an (offset, count, shape) slice of `arena`; `owner`.`table_name` is the k-major table."""
+        self = cls.__new__(cls)
+        self.n_rows, self.K = int(n_rows), int(K)
+        self._owner, self._table_name = owner, table_name
+        self._tiles = {}
+        self._tiles_lazy = {int(g): tile_of}
+        self._set_lazy(arena, arena_ptr, {"rows": rows, "masks": masks, "perm": perm, "masks_p": masks_p})
+        return self
+
+    @property
+    def source(self):
+        src = self.__dict__.get("_source")
+        return src if src is not None else getattr(self._owner, self._table_name)
+
+    def tiles_addr(self, g):
+        lz = self.__dict__.get("_tiles_lazy")
+        if lz is not None and int(g) in lz and int(g) not in self._tiles:
+            return self._arena_ptr + 4 * lz[int(g)][0]
+        return self.tiles(g).data_ptr()
+
     def tiles(self, g):
         g = int(g)
+        lz = self.__dict__.get("_tiles_lazy")
+        if g not in self._tiles and lz is not None and g in lz:
+            off, count, _ = lz[g]
+            self._tiles[g] = self._arena[off:off + count]
         if g not in self._tiles:
             lib = _lib.load()
             t = torch.empty((lib.sv_conv_plan_tiles_bytes(self.n_rows, g) // 4,), dtype=torch.int32, device=self.perm.device)
@@ -70,7 +125,7 @@ class TablePlan:
         return self._tiles[g]
 
 
-class Rulebook:
+class Rulebook(_ArenaViews):
     """Output-major table nbr_out (K, N_out) plus, for strided convs, the input-major nbr_in (K, N_in)."""
 
     def __init__(self, nbr_out, nbr_in, out_indices, out_shape, n_in, n_out, subm, ksize):
@@ -85,7 +140,8 @@ class Rulebook:
 
     @property
     def K(self):
-        return self.nbr_out.shape[0]
+        k = self.__dict__.get("_K")
+        return k if k is not None else self.nbr_out.shape[0]
 
     def table_for_backward_data(self):
         """Input-major k-major table (the plain kernels). For SubM it is the output-major table with the offsets reversed
@@ -125,6 +181,32 @@ class Rulebook:
                 self._plans[key] = TablePlan(self.nbr_in, n_rows, self.K, self.rows_in, self.masks_in, g=g)
         tp = self._plans[key]
         return tp, tp.tiles(g), g, (direction == "bwd" and self.subm)
+
+    def plan_addrs(self, direction, kd, nc):
+        """plan() as device addresses for a launch list: (rows, perm, masks_p, tile_of, tiles_per_wave, table_k_reversed) or None -- no tensor view
+        is made for pieces that live in an arena (build_network_index)."""
+        key = ("addr", direction, kd, nc, USE_PLAN)
+        hit = self._plan_results.get(key)
+        if hit is not None:
+            return hit[0]
+        out = None
+        if USE_PLAN:
+            pk = "fwd" if (direction == "fwd" or self.subm) else "bwd"
+            tp = self._plans.get(pk)
+            n_rows = self.n_out if direction == "fwd" else self.n_in
+            if tp is not None and n_rows > 0:
+                lib = _lib.load()
+                n_src = self.n_in if direction == "fwd" else self.n_out
+                if lib.sv_conv_mfma_kernel_applies(int(self.K), int(kd), int(nc), int(n_src)):
+                    g = lib.sv_conv_tiles_per_wave(n_rows, int(kd), int(nc))
+                    out = (tp.addr("rows"), tp.addr("perm"), tp.addr("masks_p"), tp.tiles_addr(g), g, (direction == "bwd" and self.subm))
+            else:
+                p = self.plan(direction, kd, nc)
+                if p is not None:
+                    tp, tile_of, g, rev = p
+                    out = (tp.addr("rows"), tp.addr("perm"), tp.addr("masks_p"), tile_of.data_ptr(), g, rev)
+        self._plan_results[key] = (out,)
+        return out
 
     def pair_counts(self):
         lib = _lib.load()
@@ -379,26 +461,34 @@ def build_network_index(coords, batch_size, spatial_shape, specs, n0_dev=None, w
     if pj:
         parr = np.array(pj, dtype=np.int64)
         _lib.check(lib.sv_conv_plan_build_dealt_batch(parr.ctypes.data, len(pj), _lib.stream()), "sv_conv_plan_build_dealt_batch")
-    # ---- the Rulebook objects
-    out, idx = {}, coords
+    # ---- the Rulebook objects: every table a lazy slice of the arena (views are made when something asks for the tensor)
+    out = {}
     level_idx = [coords]
     for t in strided_tabs:
         level_idx.append(view(t["out_idx"], n[t["level"] + 1], 4))
     for key, t in tables.items():
         sp, l, K = t["spec"], t["level"], t["K"]
         if sp.subm:
-            rb = Rulebook(view(t["nbr"], K, n[l]), None, level_idx[l], list(shapes[l]), n[l], n[l], True, list(sp.ksize))
-            rb.rows_out, rb.masks_out = view(t["rows"], n[l], 32), view(t["masks"])
+            rb = Rulebook(None, None, level_idx[l], list(shapes[l]), n[l], n[l], True, list(sp.ksize))
+            lazy = {"nbr_out": (t["nbr"][0], K * n[l], (K, n[l])), "rows_out": (t["rows"][0], 32 * n[l], (n[l], 32)), "masks_out": (t["masks"][0], n[l], None)}
         else:
             no, ni = n[l + 1], n[l]
-            ob, ib = view(t["out_block"]), view(t["in_block"])
-            rb = Rulebook(ob[32 * no:(32 + K) * no].view(K, no), view(t["nbr_in"], K, ni), level_idx[l + 1], list(shapes[l + 1]), ni, no, False, list(sp.ksize))
-            rb.rows_out, rb.masks_out = ob[:32 * no].view(no, 32), ob[(32 + K) * no:]
-            rb.rows_in, rb.masks_in = ib[:32 * ni].view(ni, 32), ib[32 * ni:]
+            ob, ib = t["out_block"][0], t["in_block"][0]
+            rb = Rulebook(None, None, level_idx[l + 1], list(shapes[l + 1]), ni, no, False, list(sp.ksize))
+            lazy = {"nbr_out": (ob + 32 * no, K * no, (K, no)), "rows_out": (ob, 32 * no, (no, 32)), "masks_out": (ob + (32 + K) * no, no, None),
+                    "nbr_in": (t["nbr_in"][0], K * ni, (K, ni)), "rows_in": (ib, 32 * ni, (ni, 32)), "masks_in": (ib + 32 * ni, ni, None)}
+        for name in ("nbr_out", "nbr_in", "rows_out", "masks_out", "rows_in", "masks_in"):
+            rb.__dict__.pop(name, None)                    # the constructor's None placeholders: the lazy table takes over
+        if sp.subm:
+            rb.nbr_in = rb.rows_in = rb.masks_in = None
+        rb._K = K
+        rb._set_lazy(arena, base, lazy)
         rb.in_indices, rb.in_shape = level_idx[l], list(shapes[l])
         for pkey, pl in t["plans"].items():
-            table, rows, masks = (rb.nbr_out, rb.rows_out, rb.masks_out) if pkey == "fwd" else (rb.nbr_in, rb.rows_in, rb.masks_in)
-            rb._plans[pkey] = TablePlan.from_parts(table, pl["n_rows"], K, rows, masks, view(pl["perm"]), view(pl["masks_p"]), pl["g"], view(pl["tiles"]))
+            side = "out" if pkey == "fwd" else "in"
+            rb._plans[pkey] = TablePlan.from_arena(arena, base, pl["n_rows"], K, "nbr_" + side, rb, lazy["rows_" + side], lazy["masks_" + side],
+                                                   (pl["perm"][0], pl["perm"][1], None), (pl["masks_p"][0], pl["masks_p"][1], None), pl["g"],
+                                                   (pl["tiles"][0], pl["tiles"][1], None))
         out[key] = rb
     return n[0], out
 

@@ -801,8 +801,8 @@ def test_hip_network_index_equals_the_layer_by_layer_build(cuda, hip_lib, lazy_c
                 perm, n_rows = tp.perm.cpu().numpy(), tp.n_rows
                 assert np.array_equal(np.sort(perm[perm >= 0]), np.arange(n_rows)), (key, pkey)
                 assert np.array_equal(tp.masks_p.cpu().numpy()[perm >= 0], tp.masks.cpu().numpy()[perm[perm >= 0]]), (key, pkey)
-                (g, tiles), = tp._tiles.items()
-                t = tiles.cpu().numpy()
+                (g,) = tp._tiles_lazy                                   # the tiles-per-wave value the plan was dealt for
+                t = tp.tiles(g).cpu().numpy()
                 assert np.array_equal(np.sort(t[t >= 0]), np.arange((n_rows + 15) // 16)), (key, pkey)
     # nothing left behind in the persistent workspaces this build touched (bitmaps of the strided levels, cell maps of all levels)
     for (kind, name, *_), buf in _lib.workspace._bufs.items():
