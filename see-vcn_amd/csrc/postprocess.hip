@@ -4,6 +4,8 @@
 //   k_largest_cluster  : open3d cluster_dbscan(eps, min_points<=2) -> bincount argmax -> tile to total_pts
 //   k_points_near_set  : compute_point_cloud_distance(...) < thresh (replace_with_completed_pts)
 // One workgroup per object; everything lives in LDS / registers, HBM traffic is the clouds in and the surface out.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define PP_MAXN 1024     // points per object (resample_num and the network's coarse size)
@@ -569,8 +571,12 @@ extern "C" int sv_vcn_surface_select(const float* partial, const float* complete
   a.nq = a.first + (size_t)batch * PP_MAXN;
   a.query = reinterpret_cast<unsigned short*>(a.nq + batch + (batch & 1));
   // enough query slices per object to give every CU a workgroup
-  int nsplit = 1024 / batch;
-  nsplit = nsplit < 1 ? 1 : (nsplit > 16 ? 16 : nsplit);
+  static const int nsplit_env = getenv("SEEVCN_KNN_SPLIT") ? atoi(getenv("SEEVCN_KNN_SPLIT")) : 0;     // measurement switch
+  // (64 objects: 16 slices 0.295 ms for the three launches, 32 slices 0.228, 64 slices 0.208 -- a slice's fixed cost, the 12 KB coarse cloud into LDS, is small
+  // beside a query's 16 float64 distances per lane, 80 compare-exchanges and k wave-min rounds)
+  int nsplit = 4096 / batch;
+  nsplit = nsplit < 1 ? 1 : (nsplit > 64 ? 64 : nsplit);
+  if (nsplit_env > 0) nsplit = nsplit_env;
   hipLaunchKernelGGL(k_surface_prep, dim3(batch), dim3(PP_THREADS), 0, sv_stream(stream), a);
   hipLaunchKernelGGL(k_surface_knn, dim3(nsplit, batch), dim3(KNN_THREADS), 0, sv_stream(stream), a, nsplit);
   hipLaunchKernelGGL(k_surface_finish, dim3(batch), dim3(PP_THREADS), 0, sv_stream(stream), a);

@@ -224,7 +224,26 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs g) {
     const int m = t * 16 + li;
     arow[t] = g.A + (int64_t)(m < g.M ? m : g.M - 1) * g.lda + 4 * kk;
   }
-  for (int k0 = wid * 16; k0 < g.K; k0 += 64) {             // lane (li, kk) holds k = k0 + 4*kk + s in MFMA s, for A and W alike
+  // lane (li, kk) holds k = k0 + 4*kk + s in MFMA s, for A and W alike.  SM_U k-steps of a wave are requested together: one step at a time the
+  // kernel was a chain of load latencies (13-16 us for a 4 MB weight matrix = 0.3 TB/s on 64 workgroups)
+  constexpr int SM_U = 4;
+  int k0 = wid * 16;
+  for (; k0 + 64 * (SM_U - 1) < g.K; k0 += 64 * SM_U) {
+    f32x4v b[SM_U], a[SM_U][4];
+#pragma unroll
+    for (int u = 0; u < SM_U; ++u) {
+      b[u] = *reinterpret_cast<const f32x4v*>(wrow + k0 + 64 * u);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[u][t] = *reinterpret_cast<const f32x4v*>(arow[t] + k0 + 64 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < SM_U; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t][s], b[u][s], acc[t], 0, 0, 0);
+  }
+  for (; k0 < g.K; k0 += 64) {
     const f32x4v b = *reinterpret_cast<const f32x4v*>(wrow + k0);
     f32x4v a[4];
 #pragma unroll

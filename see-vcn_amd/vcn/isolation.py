@@ -4,6 +4,7 @@ datasets/kitti/kitti_utils.py:15-114, datasets/kitti/kitti_objects.py:153-176).
 
   Calibration                     KITTI calibration with the reference's method names, projections on sv_project_lidar_to_image_kitti
   map_pointcloud_to_image         -> imgfov dict (pc_lidar, pc_cam, pts_img, fov_inds, img_shape)
+  map_pointcloud_to_image_precomputed / waymo_map_pointcloud_to_image   Waymo: projection made offline, loaded from its .npy pair
   get_pts_in_mask                 -> {"img_uv", "cam_xyz", "lidar_xyz", "img_labels"} lists, binary masks given directly
   isolate_det_pts                 range-adaptive DBSCAN(min_points 3) + largest cluster per instance
   populate_gtboxes / isolate_gt_pts   oriented-box crops of the ground-truth boxes
@@ -112,6 +113,44 @@ def map_pointcloud_to_image_custom(points, calib, img_shape, camera_model="pinho
             "fov_inds": fov_np, "img_shape": (img_h, img_w), "_device": (pts, uvd_int[:, :2].contiguous(), fovb)}
 
 
+def map_pointcloud_to_image_precomputed(points, pts_img, fov_inds, img_shape=None, device='cuda'):
+    """WaymoObjects.map_pointcloud_to_image (datasets/waymo/waymo_objects.py:170-186) on arrays: the lidar -> image projection was made offline
+    (image_lidar_projections/image_pc and /fov_inds, one .npy pair per frame and camera): pts_img (M, 2+) are the pixel coordinates of the M points
+    inside the camera's field of view, fov_inds says which points of the frame's cloud they are -- a boolean mask (N) or an index array (M), both
+    index `points` the way the reference's `get_pointcloud(idx)[fov_inds, :]` does.  Returns the reference's imgfov dict (pc_cam is None: Waymo
+    keeps no camera-frame coordinates) + the device arrays get_pts_in_mask works on; img_shape (H, W) is only needed for use_bbox lookups."""
+    pts = _dev_points(points, device)
+    n = pts.shape[0]
+    src = points if isinstance(points, np.ndarray) else points.cpu().numpy()
+    fi = np.asarray(fov_inds)
+    pix = np.asarray(pts_img)
+    rows = np.nonzero(fi)[0] if fi.dtype == np.bool_ else fi.astype(np.int64).reshape(-1)
+    assert pix.ndim == 2 and pix.shape[0] == rows.shape[0], "pts_img and fov_inds describe different numbers of points"
+    assert rows.size == 0 or (rows.min() >= 0 and rows.max() < n), "fov_inds points outside the cloud"
+    pos = np.full((n,), -1, dtype=np.int64)                      # point index -> row of the FOV-filtered arrays
+    pos[rows] = np.arange(rows.shape[0])
+    uv_all = np.full((n, 2), -1, dtype=np.int32)
+    uv_all[rows] = pix[:, :2].astype(np.int64).astype(np.int32)   # the reference indexes mask[v, u] with these values as they are
+    mask = pos >= 0
+    out = {"pc_lidar": src[fi, :], "pts_img": pix, "pc_cam": None, "fov_inds": fov_inds, "_fov_pos": pos,
+           "_device": (pts, torch.from_numpy(uv_all).to(pts.device), torch.from_numpy(mask).to(pts.device))}
+    if img_shape is not None:
+        out["img_shape"] = (int(img_shape[0]), int(img_shape[1]))
+    return out
+
+
+def waymo_map_pointcloud_to_image(root_dir, sequence_name, sample_idx, camera_channel, points, img_shape=None, device='cuda'):
+    """The file side of WaymoObjects.map_pointcloud_to_image (waymo_objects.py:170-186): loads
+    <root>/image_lidar_projections/image_pc/<camera>/<sequence>_<sample:04>.npy and .../fov_inds/<camera>/... and hands them to
+    map_pointcloud_to_image_precomputed together with the frame's cloud (`points` = WaymoObjects.get_pointcloud(idx), waymo_objects.py:140-152)."""
+    import os
+    name = f'{sequence_name}_{int(sample_idx):04}.npy'
+    base = os.path.join(str(root_dir), 'image_lidar_projections')
+    pts_img = np.load(os.path.join(base, 'image_pc', camera_channel, name))
+    fov_inds = np.load(os.path.join(base, 'fov_inds', camera_channel, name))
+    return map_pointcloud_to_image_precomputed(points, pts_img, fov_inds, img_shape=img_shape, device=device)
+
+
 def _quat_to_matrix(q):
     """Rotation matrix of a (w, x, y, z) quaternion, normalised first (what pyquaternion's Quaternion(q).rotation_matrix returns)."""
     w, x, y, z = (np.asarray(q, np.float64) / np.linalg.norm(np.asarray(q, np.float64)))
@@ -175,12 +214,12 @@ def get_pts_in_mask(dataset, instances, imgfov, shrink_percentage=0, use_bbox=Fa
     needs shapely and is not supported (shrink_percentage must be 0)."""
     assert shrink_percentage == 0, "mask shrinking (shapely) is outside this build's scope"
     pts, uv, fov = imgfov["_device"]
-    img_h, img_w = imgfov["img_shape"]
     kept = [dict(inst) for inst in instances if inst['segmentation']]
     out = {"img_uv": [], "cam_xyz": [], "lidar_xyz": [], "img_labels": []}
     if not kept:
         return out
     if use_bbox:
+        img_h, img_w = imgfov["img_shape"]                       # the reference builds its box mask with this shape (a Waymo imgfov has none)
         rects = []
         for inst in kept:
             bbox = np.array(inst['bbox'])
@@ -196,11 +235,13 @@ def get_pts_in_mask(dataset, instances, imgfov, shrink_percentage=0, use_bbox=Fa
         index, count = points_in_masks_device(uv, fov, masks=masks)
     count_h = count.cpu().numpy()
     index_h = index.cpu().numpy()
-    fov_pos = np.cumsum(imgfov["fov_inds"]) - 1               # point index -> row of the FOV-filtered arrays
+    fov_pos = imgfov.get("_fov_pos")
+    if fov_pos is None:
+        fov_pos = np.cumsum(imgfov["fov_inds"]) - 1           # point index -> row of the FOV-filtered arrays
     for g, inst in enumerate(kept):
         if count_h[g] == 0:
             continue
-        rows = fov_pos[index_h[g, :count_h[g]]]
+        rows = np.sort(fov_pos[index_h[g, :count_h[g]]])      # the reference walks the FOV-filtered arrays in THEIR order (an index-array fov_inds need not ascend)
         lidar = imgfov["pc_lidar"][rows, :]
         if imgfov["pc_cam"] is not None:
             out["cam_xyz"].append(imgfov["pc_cam"][rows, :])

@@ -130,6 +130,41 @@ def test_hip_projection_and_masks_bitexact_vs_reference_golden(inputs, golden, c
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("index_form", ["mask", "ascending", "shuffled"])
+def test_hip_waymo_precomputed_projection_feeds_the_same_mask_lookup(inputs, golden, cuda, hip_lib, tmp_path, index_form):
+    """The Waymo branch (waymo_objects.py:170-186): the projection is LOADED (image_pc + fov_inds .npy per frame and camera), then the same
+    get_pts_in_mask as every other dataset runs on it.  Fed with the reference's own projection of the golden frame -- as a boolean mask, as an
+    ascending index array and as a shuffled one, through the directory layout the reference reads -- the per-instance point lists must equal the
+    reference's (the shuffled form in its own FOV-row order)."""
+    from seevcn_amd.vcn import isolation as I
+    pts, fov, pix = inputs['points'], golden["fov_inds"], golden["pts_img"]
+    if index_form == "mask":
+        fi, px = fov, pix
+    else:
+        fi = np.nonzero(fov)[0]
+        px = pix
+        if index_form == "shuffled":
+            perm = np.random.default_rng(0).permutation(len(fi))
+            fi, px = fi[perm], pix[perm]
+    for sub, arr in (("image_pc", px), ("fov_inds", fi)):
+        d = tmp_path / "image_lidar_projections" / sub / "FRONT"
+        d.mkdir(parents=True)
+        np.save(d / "segment-1_0007.npy", arr)
+    imgfov = I.waymo_map_pointcloud_to_image(tmp_path, "segment-1", 7, "FRONT", pts, img_shape=IMG_SHAPE)
+    assert imgfov["pc_cam"] is None and np.array_equal(imgfov["pc_lidar"], pts[fi]) and np.array_equal(imgfov["pts_img"], px)
+    for mode, use_bbox in (("mask", False), ("bbox", True)):
+        proj = I.get_pts_in_mask(None, inputs['instances'], imgfov, shrink_percentage=0, use_bbox=use_bbox)
+        want_l, want_uv = _split(golden, f"inmask_{mode}_lidar"), _split(golden, f"inmask_{mode}_uv")
+        assert [l['box_id'] for l in proj["img_labels"]] == list(golden[f"inmask_{mode}_box_id"]) and proj["cam_xyz"] == []
+        for l, uv, wl, wuv in zip(proj["lidar_xyz"], proj["img_uv"], want_l, want_uv):
+            if index_form == "shuffled":                           # same point set per instance, in the shuffled arrays' row order
+                key = lambda a: a[np.lexsort(a.T[::-1])]
+                assert np.array_equal(key(l), key(wl)) and np.array_equal(key(np.asarray(uv)), key(np.asarray(wuv)))
+            else:
+                assert np.array_equal(l, wl) and np.array_equal(uv, wuv)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model", ["pinhole", "equidistant"])
 def test_hip_custom_camera_projection_vs_reference_golden(inputs, golden, cuda, hip_lib, model):
     from seevcn_amd.vcn import isolation as I
