@@ -94,6 +94,30 @@ int sv_pointwise_conv3(const float* xyz, const float* weight, const float* bias,
 int sv_pointwise_conv3_gather(const float* xyz, const int64_t* sel, int64_t M_cap, const int32_t* m_dev, const float* weight, const float* bias,
                               float* out, int C, int act, float slope, void* stream);
 
+/* ---- training side of the dense per-point / per-RoI layer stacks (see-vcn_amd/csrc/dense_train.hip).  The reference runs these through cuDNN / cuBLAS
+ * under autograd: VCN_VC.forward in training mode (see/surface_completion/models/vcn/models/VCN_VC.py:97-106,116-131,178-214) and PV-RCNN's
+ * point head / feature fusion / RoI head FC stacks (dense_heads/point_head_simple.py, pfe/voxel_set_abstraction.py:168-172, roi_heads/pvrcnn_head.py:171-176).
+ * sv_gemm_tn: C (N, K) = A^T B with A (M, N), B (M, K) row-major as they lie -- the weight gradient dW = dY^T X; fp32 MFMA, M split over workgroups,
+ * partial tiles summed in a fixed order (bitwise reproducible).  scratch: sv_gemm_tn_scratch_bytes(M, N, K). */
+size_t sv_gemm_tn_scratch_bytes(int64_t M, int N, int K);
+int sv_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, void* scratch, void* stream);
+/* C[i][j] = sum_c A[i * stride_a_row + c * stride_a_c] * B[c * stride_b_c + j * stride_b_col] for small / odd-shaped products (element strides);
+ * contraction split over workgroups, fixed-order sum.  scratch: sv_gemm_strided_scratch_bytes(rows, cols, contraction). */
+size_t sv_gemm_strided_scratch_bytes(int rows, int cols, int64_t contraction);
+int sv_gemm_strided(const float* A, int64_t stride_a_row, int64_t stride_a_c, const float* B, int64_t stride_b_c, int64_t stride_b_col, float* C, int64_t ldc,
+                    int rows, int cols, int64_t contraction, void* scratch, void* stream);
+/* out[n] = sum_m A[m][n] (bias gradient), fixed order.  scratch: sv_column_sums_scratch_bytes(M, N). */
+size_t sv_column_sums_scratch_bytes(int64_t M, int N);
+int sv_column_sums(const float* A, int64_t lda, int64_t M, int N, float* out, void* scratch, void* stream);
+/* Rows g * rows_per_group .. form group g (an object's points): column max with the first arg-max row (torch.max(dim) / AdaptiveMaxPool1d), its
+ * backward (dx written everywhere: the gradient at the arg-max row, zero elsewhere) and the column sum of a group's rows (gradient of a feature
+ * broadcast to the group's rows). */
+int sv_segment_max(const float* x, int64_t ldx, int groups, int rows_per_group, int channels, float* out, int32_t* arg, void* stream);
+int sv_segment_max_backward(const float* dout, const int32_t* arg, int groups, int rows_per_group, int channels, float* dx, int64_t ldx, void* stream);
+int sv_segment_sum(const float* x, int64_t ldx, int groups, int rows_per_group, int channels, float* out, void* stream);
+/* dz = dy * act'(y) for act = SV_ACT_RELU / SV_ACT_LRELU taken from the layer's output y (0: copy) */
+int sv_act_backward(const float* dy, const float* y, int64_t n, int act, float slope, float* dz, void* stream);
+
 /* VCN_VC.py:185-190: frustum angle, rotation to the frustum view, mean-centering.
  * input (B,n,3) -> fview (B,n,3), centred (B,n,3), state (B,32) [angle, mean xyz, centre xyz, rot 3x3]. */
 int sv_vcn_vc_prep(const float* input, int batch, int n, float* fview, float* centred, float* state, void* stream);

@@ -32,6 +32,16 @@ SIGNATURES = {
     "sv_gemm_bias_act": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "sv_pointwise_conv3": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p]),
     "sv_pointwise_conv3_gather": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
+    "sv_gemm_tn_scratch_bytes": (c_sz, [c_i64, c_i, c_i]),
+    "sv_gemm_tn": (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p]),
+    "sv_gemm_strided_scratch_bytes": (c_sz, [c_i, c_i, c_i64]),
+    "sv_gemm_strided": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i, c_i, c_i64, c_p, c_p]),
+    "sv_column_sums_scratch_bytes": (c_sz, [c_i64, c_i]),
+    "sv_column_sums": (c_i, [c_p, c_i64, c_i64, c_i, c_p, c_p, c_p]),
+    "sv_segment_max": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "sv_segment_max_backward": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_i64, c_p]),
+    "sv_segment_sum": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
+    "sv_act_backward": (c_i, [c_p, c_p, c_i64, c_i, c_f, c_p, c_p]),
     "sv_vcn_vc_prep": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_vcn_vc_pose": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_vcn_vc_finish": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

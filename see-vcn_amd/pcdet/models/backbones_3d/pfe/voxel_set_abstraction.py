@@ -176,6 +176,7 @@ class VoxelSetAbstraction(nn.Module):
                                                                           t.indices[:, 0], new_xyz, new_xyz_batch_cnt))
         point_features = torch.cat(feats, dim=-1)
         batch_dict['point_features_before_fusion'] = point_features.view(-1, point_features.shape[-1])
-        batch_dict['point_features'] = self.vsa_point_feature_fusion(point_features.view(-1, point_features.shape[-1]))
+        from .....dense_ops import run_sequential                       # Linear + BatchNorm1d + ReLU on the library's own GEMM / BatchNorm kernels
+        batch_dict['point_features'] = run_sequential(self.vsa_point_feature_fusion, point_features.view(-1, point_features.shape[-1]))
         batch_dict['point_coords'] = keypoints
         return batch_dict

@@ -29,7 +29,8 @@ class PointHeadSimple(PointHeadTemplate):
 
     def forward(self, batch_dict):
         key = 'point_features_before_fusion' if cfg_get(self.model_cfg, 'USE_POINT_FEATURES_BEFORE_FUSION', False) else 'point_features'
-        point_cls_preds = self.cls_layers(batch_dict[key])
+        from .... import dense_ops
+        point_cls_preds = dense_ops.run_sequential(self.cls_layers, batch_dict[key])       # own GEMM / BatchNorm kernels (module tree for CPU tensors)
         ret = {'point_cls_preds': point_cls_preds}
         batch_dict['point_cls_scores'], _ = torch.sigmoid(point_cls_preds).max(dim=-1)
         if self.training:

@@ -37,9 +37,12 @@ class RoIHeadTemplate(nn.Module):
 
     @staticmethod
     def run_fc(layers, x):
-        """The per-RoI FC stacks (Conv1d kernel 1 / BatchNorm1d / ReLU / Dropout over (N, C, 1), pvrcnn_head.py:171-176) on (N, C) rows: each
-        Conv1d is one GEMM with its own weight.  Handing MIOpen the (N, C, 1) tensor selects its naive non-packed kernels (40-80 ms per layer
-        at 512 RoIs x 27 648 channels)."""
+        """The per-RoI FC stacks (Conv1d kernel 1 / BatchNorm1d / ReLU / Dropout over (N, C, 1), pvrcnn_head.py:171-176) on (N, C) rows through the
+        library's own dense-layer kernels (seevcn_amd.dense_ops.run_sequential: fp32 MFMA GEMMs with hand-written backward, fused BatchNorm + ReLU).
+        Handing MIOpen the (N, C, 1) tensor selects its naive non-packed kernels (40-80 ms per layer at 512 RoIs x 27 648 channels)."""
+        from .... import dense_ops
+        if x.is_cuda and x.dtype == torch.float32:
+            return dense_ops.run_sequential(layers, x)
         for m in layers:
             if isinstance(m, nn.Conv1d):
                 assert m.kernel_size == (1,) and m.stride == (1,) and m.padding == (0,) and m.groups == 1

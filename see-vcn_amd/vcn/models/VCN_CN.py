@@ -45,16 +45,24 @@ class VCN_CN(nn.Module):
         return loss_dict
 
     def _forward_train(self, in_dict):
-        """The reference forward (VCN_CN.py:142-156) on torch ops, differentiable (batch-statistics BatchNorm)."""
+        """The reference forward (VCN_CN.py:142-156) in training mode, differentiable, on the library's own kernels (layers.encode_train /
+        run_fc_train: fp32 MFMA GEMMs with hand-written backward, fused batch-statistics BatchNorm + ReLU, segment max); the box
+        canonicalisation stays on torch ops.  SEEVCN_VCN_TRAIN_TORCH=1: the same graph on torch modules."""
+        from .VCN_VC import TRAIN_ON_TORCH
         x, boxes = in_dict['input'], in_dict['gt_boxes']
-        n = x.shape[1]
+        bs, n = x.shape[0], x.shape[1]
         pc = normalize_scale(vc_to_cn(x, boxes), boxes)
-        enc = self.encoder
-        feature = enc.mlp_conv1(pc.permute(0, 2, 1))
-        feature_global = torch.max(feature, dim=2, keepdim=True)[0]
-        feature = enc.mlp_conv2(torch.cat([feature_global.expand(-1, -1, n), feature], dim=1))
-        feature_global = torch.max(feature, dim=2)[0]
-        coarse = self.shape_fc(feature_global).reshape(-1, self.number_coarse, 3)
+        if TRAIN_ON_TORCH:
+            enc = self.encoder
+            feature = enc.mlp_conv1(pc.permute(0, 2, 1))
+            feature_global = torch.max(feature, dim=2, keepdim=True)[0]
+            feature = enc.mlp_conv2(torch.cat([feature_global.expand(-1, -1, n), feature], dim=1))
+            feature_global = torch.max(feature, dim=2)[0]
+            coarse = self.shape_fc(feature_global).reshape(-1, self.number_coarse, 3)
+        else:
+            _lib.require_cuda(x)
+            g2 = L.encode_train(self.encoder, pc.float().reshape(bs * n, 3), bs, n)
+            coarse = L.run_fc_train(self.shape_fc, g2).reshape(-1, self.number_coarse, 3)
         return {'coarse': cn_to_vc(restore_scale(coarse.contiguous(), boxes), boxes)}
 
     def train(self, mode=True):

@@ -14,6 +14,7 @@ from .build import MODELS
 
 import os
 
+TRAIN_ON_TORCH = os.environ.get("SEEVCN_VCN_TRAIN_TORCH", "0") == "1"   # 1: the training-mode forward on torch modules (cuBLAS-role library GEMMs) instead of dense_ops
 LAZY_ROWS = os.environ.get("SEEVCN_VCN_LAZY_ROWS", "1") != "0"     # 0: the distinct-row count is read on the host and the layers get exact sizes (A/B, tests)
 
 
@@ -94,7 +95,43 @@ class VCN_VC(nn.Module):
         return loss_dict
 
     def _forward_train(self, in_dict):
-        """The reference forward line by line (VCN_VC.py:178-214) on torch ops, differentiable."""
+        """The reference forward (VCN_VC.py:178-214) in training mode, differentiable, on the library's own kernels: every Conv1d(k=1) / Linear is
+        seevcn_amd.dense_ops.linear on channel-last rows (forward GEMM on the matrix cores, hand-written data / weight / bias gradients), the
+        training-mode BatchNorm1d + ReLU pairs are the fused kernels of the sparse backbone (spconv.norm.batch_norm_relu: batch statistics, running
+        statistics updated like torch's), the max-pools over the points are dense_ops.segment_max; only the 3x3 geometry of a few values per object
+        (rotations, Gram-Schmidt) stays on torch ops.  SEEVCN_VCN_TRAIN_TORCH=1: the same graph on torch modules (A/B, tests)."""
+        if TRAIN_ON_TORCH:
+            return self._forward_train_torch(in_dict)
+        from ... import dense_ops as D
+        x = in_dict['input']
+        _lib.require_cuda(x)
+        x = x.float()
+        bs, n, _ = x.shape
+        frustum_angle = torch.atan2(x[:, :, 1].mean(dim=1), x[:, :, 0].mean(dim=1))
+        pc_fview = rotate_points_along_z(x, -frustum_angle)
+        pts_mean = pc_fview.mean(dim=1).unsqueeze(1)
+        pe = self.pose_encoder
+
+        def conv(m, rows, act=D.ACT_NONE, **kw):
+            return D.linear(rows, m.weight.squeeze(-1), m.bias, act, L.LRELU_SLOPE, **kw)
+
+        h = conv(pe[0], (pc_fview - pts_mean).reshape(bs * n, 3), D.ACT_LRELU)
+        h = conv(pe[2], h, D.ACT_LRELU)
+        pose_feat = D.segment_max(conv(pe[4], h), n)                                     # AdaptiveMaxPool1d(1)
+        rel_pose = L.run_fc_train(self.pose_fc, pose_feat)
+        centre = pts_mean + rel_pose[:, :3].unsqueeze(1)
+        rot_mat = compute_rotation_matrix_from_ortho6d(rel_pose[:, 3:9])
+        pc_cn = torch.matmul(pc_fview - centre, rot_mat.permute(0, 2, 1))
+        g2 = L.encode_train(self.encoder, pc_cn.reshape(bs * n, 3), bs, n)                # (B, 1024)
+        t = L.run_fc_train(self.shape_fc, g2)
+        coarse = t.reshape(-1, self.number_coarse, 3)
+        coarse_vc = torch.matmul(coarse, rot_mat) + centre
+        return {'coarse': rotate_points_along_z(coarse_vc.contiguous(), frustum_angle),
+                'reg_rot': torch.matmul(rot_mat, rot_from_heading(frustum_angle)),
+                'reg_centre': rotate_points_along_z(centre, frustum_angle).squeeze(1)}
+
+    def _forward_train_torch(self, in_dict):
+        """The reference forward line by line (VCN_VC.py:178-214) on torch modules, differentiable (the cross-check of _forward_train)."""
         x = in_dict['input']
         bs, n, _ = x.shape
         frustum_angle = torch.atan2(x[:, :, 1].mean(dim=1), x[:, :, 0].mean(dim=1))
@@ -147,8 +184,8 @@ class VCN_VC(nn.Module):
             # compute the first *u_dev rows (sv_gemm_bias_act_ragged_dev, sv_pointwise_conv3_gather)
             sel, rg, u_dev = L.distinct_rows(x, sync=False) if LAZY_ROWS else L.distinct_rows(x) + (None,)
         pts = centred.view(bs * n, 3)
-        h = L.pointwise3(pts, w0, b0, L.ACT_LRELU, sel=sel, m_dev=u_dev)
-        h = L.gemm(h, w1, b1, L.ACT_LRELU, row_group=rg if u_dev is not None else None, m_dev=u_dev)
+        h = L.pointwise3(pts, w0, b0, L.ACT_LRELU, sel=sel, m_dev=u_dev, tag="pose_h0")
+        h = L.gemm(h, w1, b1, L.ACT_LRELU, row_group=rg if u_dev is not None else None, m_dev=u_dev, tag="pose_h1")
         pose_feat = L.neg_inf((bs, w2.shape[0]), dev)
         L.gemm(h, w2, b2, L.ACT_NONE, rows_per_group=n, store=False, group_max=pose_feat, row_group=rg, m_dev=u_dev)
         rel_pose = L.run_fc(p["pose_fc"], pose_feat, L.ACT_LRELU)                     # (B, 9)   :194

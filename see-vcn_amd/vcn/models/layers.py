@@ -69,7 +69,7 @@ class PreparedCache:
         return self.value
 
 
-def gemm(a, w, bias=None, act=ACT_NONE, group_bias=None, rows_per_group=1, store=True, group_max=None, slope=LRELU_SLOPE, row_group=None, m_dev=None):
+def gemm(a, w, bias=None, act=ACT_NONE, group_bias=None, rows_per_group=1, store=True, group_max=None, slope=LRELU_SLOPE, row_group=None, m_dev=None, tag=None):
     """act(a @ w.T + bias + group_bias[group(row)]) via sv_gemm_bias_act (fp32 MFMA); group(row) = row // rows_per_group, or
     row_group[row] (int32, non-decreasing) for ragged groups.  m_dev (with row_group): the number of valid rows of `a` lives on the device
     (int32 tensor); a.shape[0] is then the capacity, the output keeps capacity rows and only the first *m_dev are computed.
@@ -79,7 +79,12 @@ def gemm(a, w, bias=None, act=ACT_NONE, group_bias=None, rows_per_group=1, store
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and a.is_contiguous() and w.is_contiguous()
-    out = torch.empty((M, N), dtype=torch.float32, device=a.device) if store else None
+    if store and m_dev is not None and tag is not None:
+        # capacity-sized intermediate of the lazy-row forward (M = B n rows addressable, ~U computed): a grow-only per-stream buffer instead of a
+        # fresh 16-134 MB allocation per layer and call (the caching allocator went back to hipMalloc for them after every empty_cache())
+        out = _lib.workspace.scratch(f"vcn_{tag}", M * N * 4, a.device)[:M * N * 4].view(torch.float32).view(M, N)
+    else:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device) if store else None
     if row_group is None:
         assert m_dev is None
         rc = lib.sv_gemm_bias_act(_lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(bias), _lib.ptr(group_bias), int(rows_per_group),
@@ -120,14 +125,15 @@ def distinct_rows(x, sync=True):
     return sel, row_group
 
 
-def pointwise3(xyz, w, b, act, slope=LRELU_SLOPE, sel=None, m_dev=None):
+def pointwise3(xyz, w, b, act, slope=LRELU_SLOPE, sel=None, m_dev=None, tag=None):
     """K = 3 first layer on the rows of xyz (M, 3) -- or, with sel (capacity,) int64 and m_dev, on xyz[sel[m]] for m < *m_dev (the output keeps
     the capacity's rows; gather and count stay on the device)."""
     lib = _lib.load()
     C = w.shape[0]
     if sel is not None and m_dev is not None:
         M = sel.shape[0]
-        out = torch.empty((M, C), dtype=torch.float32, device=xyz.device)
+        out = (_lib.workspace.scratch(f"vcn_{tag}", M * C * 4, xyz.device)[:M * C * 4].view(torch.float32).view(M, C) if tag is not None
+               else torch.empty((M, C), dtype=torch.float32, device=xyz.device))
         rc = lib.sv_pointwise_conv3_gather(_lib.ptr(xyz), _lib.ptr(sel), M, _lib.ptr(m_dev), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), C, int(act), float(slope),
                                            _lib.stream())
         _lib.check(rc, "sv_pointwise_conv3_gather")
@@ -164,11 +170,11 @@ def encode(p, pts, batch, n, row_group=None, sel=None, m_dev=None):
     """FeatureEncoder.forward (VCN_VC.py:97-106) on channel-last activations. pts: (B*n, 3); with row_group only the distinct rows
     pts[sel] are run (row_group = their objects; m_dev: their number on the device, sel / row_group at capacity) -> (B, 1024)."""
     dev = pts.device
-    f1 = pointwise3(pts, p["w1a"], p["b1a"], ACT_RELU, sel=sel, m_dev=m_dev)         # conv 3->128 + BN + ReLU
+    f1 = pointwise3(pts, p["w1a"], p["b1a"], ACT_RELU, sel=sel, m_dev=m_dev, tag="enc_f1")         # conv 3->128 + BN + ReLU
     g1 = neg_inf((batch, p["w1b"].shape[0]), dev)
-    local = gemm(f1, p["w1b"], p["b1b"], ACT_NONE, rows_per_group=n, group_max=g1, row_group=row_group, m_dev=m_dev)  # conv 128->256, max over n
+    local = gemm(f1, p["w1b"], p["b1b"], ACT_NONE, rows_per_group=n, group_max=g1, row_group=row_group, m_dev=m_dev, tag="enc_local")  # conv 128->256, max over n
     gb = gemm(g1, p["w2a_g"], None, ACT_NONE)                                        # global half of conv 512->512
-    f2 = gemm(local, p["w2a_l"], p["b2a"], ACT_RELU, group_bias=gb, rows_per_group=n, row_group=row_group, m_dev=m_dev)  # + BN + ReLU
+    f2 = gemm(local, p["w2a_l"], p["b2a"], ACT_RELU, group_bias=gb, rows_per_group=n, row_group=row_group, m_dev=m_dev, tag="enc_f2")  # + BN + ReLU
     g2 = neg_inf((batch, p["w2b"].shape[0]), dev)
     gemm(f2, p["w2b"], p["b2b"], ACT_NONE, rows_per_group=n, store=False, group_max=g2, row_group=row_group, m_dev=m_dev)  # conv 512->1024, max over n
     return g2
@@ -181,4 +187,35 @@ def prepare_fc(seq):
 def run_fc(layers, x, hidden_act):
     for i, (w, b) in enumerate(layers):
         x = gemm(x, w, b, hidden_act if i + 1 < len(layers) else ACT_NONE)
+    return x
+
+
+# ---------------------------------------------------------------------------------------------------------------- training mode, own kernels
+def encode_train(enc, pts_rows, batch, n):
+    """FeatureEncoder.forward (VCN_VC.py:97-106) in TRAINING mode on channel-last rows (B n, 3) -> (B, 1024), differentiable: Conv1d(k=1) =
+    dense_ops.linear (fp32 MFMA forward, hand-written backward), BatchNorm1d(batch statistics) + ReLU = the fused kernels of spconv.norm, max over
+    the points = dense_ops.segment_max.  The conv over cat([global.expand, local]) is local W_l^T + (global W_g^T)[object] + b."""
+    from ... import dense_ops as D
+    from ...spconv import norm
+    c1, c2 = enc.mlp_conv1, enc.mlp_conv2
+    f = norm.batch_norm_relu(c1[1], D.linear(pts_rows, c1[0].weight.squeeze(-1), c1[0].bias), True)
+    local = D.linear(f, c1[3].weight.squeeze(-1), c1[3].bias)                             # (B n, 256)
+    g1 = D.segment_max(local, n)                                                          # (B, 256)
+    cg = g1.shape[1]
+    w2 = c2[0].weight.squeeze(-1)
+    gb = D.linear(g1, w2[:, :cg], None)                                                   # the global half: one row per object
+    f2 = norm.batch_norm_relu(c2[1], D.linear(local, w2[:, cg:], c2[0].bias, group_bias=gb, rows_per_group=n), True)
+    return D.segment_max(D.linear(f2, c2[3].weight.squeeze(-1), c2[3].bias), n)           # (B, 1024)
+
+
+def run_fc_train(seq, x, hidden_act_slope=None):
+    """An nn.Sequential of Linear [+ ReLU / LeakyReLU] modules on dense_ops.linear (activation fused into the layer in front of it)."""
+    from ... import dense_ops as D
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        act = D.ACT_RELU if isinstance(nxt, nn.ReLU) else D.ACT_LRELU if isinstance(nxt, nn.LeakyReLU) else D.ACT_NONE
+        x = D.linear(x, mods[i].weight, mods[i].bias, act, nxt.negative_slope if act == D.ACT_LRELU else 0.0)
+        i += 2 if act != D.ACT_NONE else 1
     return x

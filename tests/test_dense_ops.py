@@ -1,0 +1,134 @@
+"""Training-side dense-layer kernels (csrc/dense_train.hip) and the autograd functions over them (seevcn_amd/dense_ops.py) against plain torch fp32
+ops of the same layers, and VCN_VC / VCN_CN in training mode on them against the same graph on torch modules (tolerances written per check)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+
+def _close(a, b, rtol, name, atol=1e-12):
+    """|a - b| <= rtol * max|b| + atol (a GEMM's sums of 10^2..10^5 fp32 products: error relative to the tensor's scale)"""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err, scale = float((a - b).abs().max()), float(b.abs().max())
+    assert err <= rtol * scale + atol, (name, err, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(65536, 128, 64), (13001, 1024, 512), (512, 256, 27648), (4096, 9, 512), (65536, 128, 3), (100, 64, 64), (37, 5, 7), (1, 64, 64)])
+def test_hip_gemm_tn_matches_torch(cuda, hip_lib, M, N, K):
+    """dW = dY^T X (sv_gemm_tn: matrix-core path with M split over workgroups, or the strided path for odd shapes) vs float64; twice: bitwise equal"""
+    from seevcn_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = torch.randn(M, N, generator=g).to(cuda), torch.randn(M, K, generator=g).to(cuda)
+    sc = torch.empty(hip_lib.sv_gemm_tn_scratch_bytes(M, N, K), dtype=torch.uint8, device=cuda)
+    outs = []
+    for _ in range(2):
+        c = torch.full((N, K), float("nan"), device=cuda)
+        _lib.check(hip_lib.sv_gemm_tn(a.data_ptr(), N, b.data_ptr(), K, c.data_ptr(), K, M, N, K, sc.data_ptr(), _lib.stream()), "sv_gemm_tn")
+        outs.append(c)
+    _close(outs[0], a.double().t() @ b.double(), 2e-5, "gemm_tn")
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_hip_column_sums_and_segments_match_torch(cuda, hip_lib):
+    from seevcn_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8 * 1024, 96, generator=g).to(cuda)
+    sc = torch.empty(hip_lib.sv_column_sums_scratch_bytes(x.shape[0], 96), dtype=torch.uint8, device=cuda)
+    out = torch.empty(96, device=cuda)
+    _lib.check(hip_lib.sv_column_sums(x.data_ptr(), 96, x.shape[0], 96, out.data_ptr(), sc.data_ptr(), _lib.stream()), "sv_column_sums")
+    _close(out, x.double().sum(0), 1e-5, "column sums")
+    mx, arg = torch.empty(8, 96, device=cuda), torch.empty(8, 96, dtype=torch.int32, device=cuda)
+    _lib.check(hip_lib.sv_segment_max(x.data_ptr(), 96, 8, 1024, 96, mx.data_ptr(), arg.data_ptr(), _lib.stream()), "sv_segment_max")
+    want, widx = x.view(8, 1024, 96).max(dim=1)
+    assert torch.equal(mx, want) and torch.equal(x.view(8, 1024, 96).gather(1, arg.long()[:, None, :])[:, 0], want)
+    dout = torch.randn(8, 96, generator=g).to(cuda)
+    dx = torch.full_like(x, float("nan"))
+    _lib.check(hip_lib.sv_segment_max_backward(dout.data_ptr(), arg.data_ptr(), 8, 1024, 96, dx.data_ptr(), 96, _lib.stream()), "sv_segment_max_backward")
+    ref = torch.zeros(8, 1024, 96, device=cuda).scatter_(1, arg.long()[:, None, :], dout[:, None, :])
+    assert torch.equal(dx.view(8, 1024, 96), ref)
+    ss = torch.empty(8, 96, device=cuda)
+    _lib.check(hip_lib.sv_segment_sum(x.data_ptr(), 96, 8, 1024, 96, ss.data_ptr(), _lib.stream()), "sv_segment_sum")
+    _close(ss, x.view(8, 1024, 96).double().sum(1), 1e-5, "segment sum")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,act,gb", [(4096, 3, 64, 2, False), (4096, 64, 128, 2, False), (8192, 256, 512, 0, True), (64, 1024, 9, 0, False), (64, 512, 3072, 1, False),
+                                           (300, 640, 128, 1, False)])
+def test_hip_linear_function_matches_torch_autograd(cuda, hip_lib, M, K, N, act, gb):
+    """dense_ops.linear: forward and every gradient (input, weight, bias, group bias) vs torch.nn.functional.linear + activation under autograd"""
+    from seevcn_amd import dense_ops as D
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(cuda).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(cuda).requires_grad_(True)
+    rpg = 1024
+    gbt = torch.randn(M // rpg, N, generator=g).to(cuda).requires_grad_(True) if gb else None
+    up = torch.randn(M, N, generator=g).to(cuda)
+    y = D.linear(x, w, b, act, 0.01, gbt, rpg if gb else 1)
+    (y * up).sum().backward()
+    got = [y] + [t.grad.clone() for t in (x, w, b) + ((gbt,) if gb else ())]
+    for t in (x, w, b) + ((gbt,) if gb else ()):
+        t.grad = None
+    z = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    if gb:
+        z = z + gbt.double().repeat_interleave(rpg, dim=0)
+    yr = z if act == 0 else torch.relu(z) if act == 1 else torch.nn.functional.leaky_relu(z, 0.01)
+    (yr * up.double()).sum().backward()
+    want = [yr] + [t.grad for t in (x, w, b) + ((gbt,) if gb else ())]
+    for name, a_, b_ in zip(("y", "dx", "dw", "db", "dgb"), got, want):
+        _close(a_, b_, 5e-5, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["VCN_VC", "VCN_CN"])
+def test_hip_vcn_training_forward_backward_on_own_kernels_matches_torch_modules(cuda, hip_lib, name):
+    """VCN in TRAINING mode (batch-statistics BatchNorm): the forward on dense_ops / fused BatchNorm / segment max and its hand-written backward
+    against the reference's graph on torch modules with the same weights and inputs: outputs, every parameter gradient, running statistics.
+    Tolerance: 2e-3 of each tensor's largest entry (fp32 sums over 65 536 rows in different orders; the torch side may run TF32-free fp32 GEMMs)."""
+    import seevcn_amd.synth as synth
+    import seevcn_amd.vcn as V
+    import seevcn_amd.vcn.models.VCN_VC as vc_mod
+    from seeding import seeded_state_dict
+    clouds, boxes = synth.make_object_batch(8, seed=1000)
+    x, bx = torch.from_numpy(clouds).to(cuda), torch.from_numpy(boxes).to(cuda)
+    m1 = V.MODELS.build({"NAME": name})
+    m1.load_state_dict(seeded_state_dict(m1, seed=0))
+    m1 = m1.to(cuda).train()
+    m2 = copy.deepcopy(m1)
+    res = []
+    for m, on_torch in ((m1, False), (m2, True)):
+        saved, vc_mod.TRAIN_ON_TORCH = vc_mod.TRAIN_ON_TORCH, on_torch
+        try:
+            out = m({"input": x, "gt_boxes": bx})
+        finally:
+            vc_mod.TRAIN_ON_TORCH = saved
+        up = torch.randn(out["coarse"].shape, generator=torch.Generator().manual_seed(1)).to(cuda)
+        loss = (out["coarse"] * up).sum() + sum(v.sum() for k, v in out.items() if k != "coarse")
+        loss.backward()
+        res.append((out, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, {k: b.clone() for k, b in m.named_buffers()}))
+    (o1, g1, b1), (o2, g2, b2) = res
+    for k in o2:
+        _close(o1[k], o2[k], 2e-3, f"{name} {k}")
+    assert sorted(g1) == sorted(g2) and len(g1) >= 10
+    # a conv bias directly in front of a batch-statistics BatchNorm has an exactly zero gradient (the norm removes the mean): both sides hold
+    # rounding noise there, so the absolute floor is 1e-6 of the model's largest gradient entry
+    gmax = max(float(v.abs().max()) for v in g2.values())
+    for k in g2:
+        if k.endswith(("mlp_conv1.0.bias", "mlp_conv2.0.bias")):       # zero in exact arithmetic: noise on both sides, 1e-5 of the largest gradient at most
+            assert float(g1[k].abs().max()) <= 1e-5 * gmax and float(g2[k].abs().max()) <= 1e-5 * gmax, k
+            continue
+        _close(g1[k], g2[k], 2e-3, f"{name} grad {k}", atol=1e-6 * gmax)
+    for k in b2:
+        _close(b1[k].float(), b2[k].float(), 1e-4, f"{name} buffer {k}")
+
+
+def test_dense_ops_refuse_cpu(hip_lib):
+    from seevcn_amd import _lib, dense_ops as D
+    with pytest.raises(_lib.SeevcnHipError):
+        D.linear(torch.zeros(4, 32), torch.zeros(8, 32))
+    with pytest.raises(_lib.SeevcnHipError):
+        D.segment_max(torch.zeros(8, 4), 4)
