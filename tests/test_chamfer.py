@@ -27,15 +27,21 @@ def test_oracle_chamfer_vs_ckdtree():
         assert np.array_equal(ii, i2[k]) and np.allclose(dd ** 2, d2[k], rtol=1e-5, atol=1e-7)
 
 
-def test_vcn_train_forward_and_loss_match_reference_golden_cpu(golden_dir):
-    """train-mode forward is plain torch: checked on CPU against the reference's own train-mode forward; the three losses that
-    need no CUDA op (dims, translation, rotation) against the reference's get_loss."""
+def test_vcn_train_forward_and_loss_match_reference_golden_cpu(golden_dir, monkeypatch):
+    """The torch-module statement of the train-mode forward (SEEVCN_VCN_TRAIN_TORCH: the cross-check of the own-kernel path, tests/test_dense_ops.py)
+    against the reference's own train-mode forward on CPU; the three losses that need no CUDA op (dims, translation, rotation) against the
+    reference's get_loss.  The default train-mode forward runs on the library's kernels and refuses CPU tensors."""
     import seevcn_amd.vcn as V
+    import seevcn_amd.vcn.models.VCN_VC as vc_mod
+    from seevcn_amd import _lib
     g = np.load(os.path.join(golden_dir, "vcn_loss.npz"))
     inp, complete, gt = make_batch()
     m = V.MODELS.build({"NAME": "VCN_VC"})
     m.load_state_dict(seeded_state_dict(m, seed=0))
     m.train()
+    with pytest.raises(_lib.SeevcnHipError):
+        m({"input": torch.from_numpy(inp)})
+    monkeypatch.setattr(vc_mod, "TRAIN_ON_TORCH", True)
     ret = m({"input": torch.from_numpy(inp)})
     for k in ("coarse", "reg_rot", "reg_centre"):
         assert np.abs(ret[k].detach().numpy() - g[k]).max() <= 1e-3 * np.abs(g[k]).max() + 1e-5, k
@@ -44,13 +50,15 @@ def test_vcn_train_forward_and_loss_match_reference_golden_cpu(golden_dir):
         assert abs(float(ld[k]) - float(g["loss_" + k])) <= 1e-3 * abs(float(g["loss_" + k])) + 1e-6, k
 
 
-def test_vcn_cn_train_forward_matches_reference_golden_cpu(golden_dir):
+def test_vcn_cn_train_forward_matches_reference_golden_cpu(golden_dir, monkeypatch):
     import seevcn_amd.vcn as V
+    import seevcn_amd.vcn.models.VCN_VC as vc_mod
     g = np.load(os.path.join(golden_dir, "vcn_loss.npz"))
     inp, complete, gt = make_batch()
     m = V.MODELS.build({"NAME": "VCN_CN"})
     m.load_state_dict(seeded_state_dict(m, seed=1))
     m.train()
+    monkeypatch.setattr(vc_mod, "TRAIN_ON_TORCH", True)       # the torch-module statement; the default (own kernels) is GPU-only
     ret = m({"input": torch.from_numpy(inp), "gt_boxes": torch.from_numpy(gt)})
     assert np.abs(ret["coarse"].detach().numpy() - g["cn_coarse"]).max() <= 1e-3 * np.abs(g["cn_coarse"]).max() + 1e-5
     assert m.get_loss(ret, {"gt_boxes": torch.from_numpy(gt), "training": False}) == {}
