@@ -120,28 +120,39 @@ def device_spinup(seconds, device):
 
 
 class Prefetch:
-    """The input side of batch N + 1 (SceneStep.front: stage A, voxelisation, rulebooks, plans -- no weights involved) on a side stream AND a
-    host thread of its own while batch N trains on the main stream / main thread: the role of the reference's dataloader workers + offline
-    completion, which also run beside the training step (tools/train_utils/train_utils.py:22-29 fetches the next batch while the GPU works).
-    Every step still does one front and one compute.  The front's device -> host reads (voxel / site counts) block only its own thread and
-    wait for the side stream only; measured before the thread: the step was bound by the ONE host thread that enqueued the trained side
-    (~2.5 ms) and then sat in the front's reads (~3 ms) while the main stream ran dry (trained side alone: 3.9 ms per step)."""
+    """The input side of batch N + 1 (SceneStep.front: stage A, voxelisation, rulebooks, plans -- no weights involved) on a side stream while batch N
+    trains on the main stream: the role of the reference's offline completion (SEE_VCN.py:85-115) and its dataloader workers
+    (tools/train_utils/train_utils.py:22-29 fetches the next batch while the GPU works).  Every step still does one front and one compute.
+    SEEVCN_BENCH_PREFETCH_DEPTH=2 (A/B): two stages -- front_b(N + 1) (voxelise + index, the one blocking read) first, then front_a(N + 2) (stage A of the
+    batch after next, no read), so that the read no longer waits for stage A's kernels.  Measured (tools/step_hosttime.py): the host then needs
+    3.1 ms per step instead of 4.1, and the step takes the same 4.13-4.21 ms either way -- with the one-read input side the step is bound by the
+    GPU (trained side alone: 3.26 ms; the input side's 2.0 ms of side-stream kernels cost the resident conv launches ~0.9 ms), not by the host."""
 
     def __init__(self, model, inputs, threaded=False):
         from concurrent.futures import ThreadPoolExecutor
         self.model, self.inputs = model, inputs
-        self.side = torch.cuda.Stream(priority=-1)
+        # side-stream priority: -1 (high) by default; SEEVCN_BENCH_SIDE_PRIORITY for A/B (HIP's range on this device is printed by tools/stream_priority.py)
+        self.side = torch.cuda.Stream(priority=int(os.environ.get("SEEVCN_BENCH_SIDE_PRIORITY", "-1")))
         self.device = torch.cuda.current_device()
         self.pool = ThreadPoolExecutor(max_workers=1) if threaded else None
         if threaded:
             sys.setswitchinterval(float(os.environ.get("SEEVCN_BENCH_SWITCH_S", "2e-5")))   # default 5 ms: two launch-bound threads would take turns in 5 ms slices
+        self.depth = int(os.environ.get("SEEVCN_BENCH_PREFETCH_DEPTH", "1"))
         self.pending = None
+        self.pasted = None                 # front_a's output waiting for its front_b (depth 2)
         self.first = True
 
     def _front(self):
         torch.cuda.set_device(self.device)
         with torch.cuda.stream(self.side):
-            bd = self.model.front(*self.inputs, SCENES_PER_GPU)
+            if self.depth < 2:
+                bd = self.model.front(*self.inputs, SCENES_PER_GPU)
+            else:
+                pts = self.pasted if self.pasted is not None else self.model.front_a(*self.inputs)
+                bd = self.model.front_b(pts, SCENES_PER_GPU, flush=False)          # a check parked by the front_a below rides on the NEXT step's read
+                ev = self.side.record_event()                                       # batch N + 1 is ready here: the main stream must not wait for stage A of N + 2
+                self.pasted = self.model.front_a(*self.inputs)
+                return bd, ev
             ev = self.side.record_event()
         return bd, ev
 
@@ -173,10 +184,13 @@ class Prefetch:
             self.pending.result()
 
     def close(self):
+        from seevcn_amd import _lib
         if self.pool is not None:
             if self.pending is not None and not isinstance(self.pending, tuple):
                 self.pending.result()
             self.pool.shutdown(wait=True)
+        with torch.cuda.stream(self.side):
+            _lib.flush_checks()                # the last front_a's parked check (its batch is never trained on)
 
 
 def _compute_gen(model, opt, params, bd, world, out):

@@ -277,6 +277,13 @@ int sv_sparse_conv_wgrad(const float* X, int64_t n_src, const int32_t* nbr, cons
  * address a permutation of the K * C_in * C_out slab. */
 int sv_sparse_conv_wgrad_strided(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin,
                                  int Cout, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, void* scratch, void* stream);
+/* The two stages apart, for a backward pass that runs many layers: stage 1 (partial slabs into `partial`, sv_sparse_conv_wgrad_partial_bytes; *job = 10 int64
+ * on the host describing the pending sum) per layer, then sv_sparse_conv_wgrad_reduce_batch(jobs, n_jobs) sums the slabs of all layers in one launch -- bitwise the
+ * values sv_sparse_conv_wgrad_strided writes. */
+size_t sv_sparse_conv_wgrad_partial_bytes(int64_t n_rows, int K, int Cin, int Cout);
+int sv_sparse_conv_wgrad_stage1(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin, int Cout,
+                                int64_t stride_k, int64_t stride_cin, int64_t stride_cout, void* partial, int64_t* job, void* stream);
+int sv_sparse_conv_wgrad_reduce_batch(const int64_t* jobs_host, int n_jobs, void* stream);
 
 /* SparseConvTensor.dense(): (N,C) + coords -> (B, C, D, H, W), every element written once */
 size_t sv_sparse_to_dense_scratch_bytes(int batch, int D, int H, int W);
@@ -501,6 +508,9 @@ int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float*
  *   SV_OP_BN_BWD        sv_batchnorm_relu_backward (i2 = 0) / _backward_partial (i2 = number of partials): p = x, dy, gamma, beta, save_mean,
  *                       save_invstd, scratch, dx, dgamma, dbeta; n = rows; i = channels, relu, n_partials
  *   SV_OP_WGRAD         sv_sparse_conv_wgrad_strided: p = X, nbr, dY, dW, scratch; n = n_rows, stride_k, stride_cin, stride_cout; i = K, Cin, Cout, n_src
+ *   SV_OP_WGRAD_DEFERRED  the same fields as SV_OP_WGRAD, but only stage 1 runs in place (sv_sparse_conv_wgrad_stage1; p4 = this layer's OWN partial region of
+ *                       sv_sparse_conv_wgrad_partial_bytes) and the slabs of every deferred layer are summed by ONE launch at the end of the list
+ *                       (sv_sparse_conv_wgrad_reduce_batch): the gradients are complete when sv_run_ops returns, bitwise the values of SV_OP_WGRAD
  *   SV_OP_DGRAD_PLANNED_BN  sv_sparse_conv_dgrad_planned_bn: p = dZ, table_rows, perm, masks_p, tile_of, wfrag, dY, bn_x, bn_mean, bn_invstd, bn_gamma,
  *                       bn_beta, bn_partial; n = n_src, n_rows; i = tiles_per_wave, K, Kd, Nc, table_k_reversed, bn_relu
  * Used by seevcn_amd/spconv/chain.py: the forward and the backward of a conv -> BatchNorm -> ReLU chain (VoxelBackBone8x, spconv_backbone.py:128-180)
@@ -512,6 +522,7 @@ int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float*
 #define SV_OP_BN_BWD 5
 #define SV_OP_WGRAD 6
 #define SV_OP_DGRAD_PLANNED_BN 7
+#define SV_OP_WGRAD_DEFERRED 8
 int sv_run_ops(const int64_t* ops, int n_ops, void* stream);
 
 /* ---- BatchNorm1d (+ReLU) on (N,C) voxel features: the norm_fn -> ReLU tail of post_act_block

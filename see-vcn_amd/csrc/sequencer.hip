@@ -23,6 +23,9 @@ inline T* ptr_of(int64_t v) { return reinterpret_cast<T*>(static_cast<uintptr_t>
 
 extern "C" int sv_run_ops(const int64_t* ops, int n_ops, void* stream) {
   SV_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "sv_run_ops: null list");
+  constexpr int MAX_DEFERRED = 64;
+  int64_t deferred[MAX_DEFERRED * 10];       // stage-2 jobs of the SV_OP_WGRAD_DEFERRED operations of this list
+  int n_deferred = 0;
   for (int k = 0; k < n_ops; ++k) {
     const int64_t* o = ops + (size_t)k * SV_OP_WORDS;
     const int64_t* i = o + 1;       // 8 small integers
@@ -75,11 +78,22 @@ extern "C" int sv_run_ops(const int64_t* ops, int n_ops, void* stream) {
         rc = sv_sparse_conv_wgrad_strided(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
                                           (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<void>(p[4]), stream);
         break;
+      case SV_OP_WGRAD_DEFERRED:
+        if (n_deferred == MAX_DEFERRED) {     // more than a list's worth: sum what is pending, go on
+          rc = sv_sparse_conv_wgrad_reduce_batch(deferred, n_deferred, stream);
+          n_deferred = 0;
+          if (rc != SV_OK) return rc;
+        }
+        rc = sv_sparse_conv_wgrad_stage1(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
+                                         (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<void>(p[4]), deferred + 10 * n_deferred, stream);
+        ++n_deferred;
+        break;
       default:
         sv_set_error("sv_run_ops: unknown operation %lld at position %d", (long long)o[0], k);
         return SV_ERR_ARG;
     }
     if (rc != SV_OK) return rc;     // sv_last_error() names the failing entry point; `k` operations were enqueued
   }
+  if (n_deferred > 0) return sv_sparse_conv_wgrad_reduce_batch(deferred, n_deferred, stream);     // every deferred weight gradient: one launch at the end of the list
   return SV_OK;
 }

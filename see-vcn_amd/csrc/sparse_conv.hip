@@ -1960,11 +1960,21 @@ static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, false>), dim3(blocks), dim3(256), 0, st, a);
 }
 
+// One pending stage-2 reduction (sv_sparse_conv_wgrad_stage1 -> sv_sparse_conv_wgrad_reduce_batch)
+struct WgradReduceJob {
+  const float* partial;
+  float* dW;
+  int64_t slab;          // K * Cin * Cout
+  int nslabs, wg0;
+  WgradOut out;
+};
+
 static int wgrad_run(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
-                                    int Cin, int Cout, void* scratch, void* stream, WgradOut out) {
+                                    int Cin, int Cout, void* scratch, void* stream, WgradOut out, WgradReduceJob* defer = nullptr) {
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Cin > 0 && Cout > 0 && dW, "sparse_conv_wgrad: bad arguments");
   hipStream_t st = sv_stream(stream);
   const int64_t slab = (int64_t)K * Cin * Cout;
+  if (defer) defer->partial = nullptr, defer->nslabs = 0;
   if (n_rows == 0) {
     SV_HIP(hipMemsetAsync(dW, 0, (size_t)slab * 4, st));      // every element, whatever the layout (the strided form is a permutation of the slab)
     return SV_OK;
@@ -2001,6 +2011,11 @@ static int wgrad_run(const float* X, int64_t n_src, const int32_t* nbr, const fl
     hipLaunchKernelGGL(k_spconv_wgrad_valu, dim3(a.nchunks, K), dim3(256), 0, st, a);
     nslabs = a.nchunks;
   }
+  if (defer && slab % 4 == 0 && Cout % 4 == 0 && (uintptr_t)dW % 16 == 0 && (uintptr_t)a.partial % 16 == 0) {
+    defer->partial = a.partial, defer->dW = dW, defer->slab = slab, defer->nslabs = nslabs, defer->out = out;     // summed later, with the other layers' slabs
+    SV_LAUNCH_CHECK();
+    return SV_OK;
+  }
   if (slab % 4 == 0 && Cout % 4 == 0 && (uintptr_t)dW % 16 == 0 && (uintptr_t)a.partial % 16 == 0)
     hipLaunchKernelGGL(k_wgrad_reduce4, dim3(sv_div_up(slab / 4, 64)), dim3(256), 0, st, a.partial, nslabs, slab / 4, dW, out);
   else
@@ -2019,4 +2034,100 @@ extern "C" int sv_sparse_conv_wgrad_strided(const float* X, int64_t n_src, const
                                     int Cin, int Cout, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, void* scratch, void* stream) {
   SV_CHECK_ARG(stride_k > 0 && stride_cin > 0 && stride_cout > 0, "sparse_conv_wgrad_strided: strides must be positive");
   return wgrad_run(X, n_src, nbr, dY, dW, n_rows, K, Cin, Cout, scratch, stream, WgradOut{stride_k, stride_cin, stride_cout, Cin, Cout, 0});
+}
+
+
+// ---- stage 2 of SEVERAL layers in one launch: the backward of a backbone runs 12 weight gradients, each followed by a ~6 us reduction launch of its
+// own; their results are only needed by the optimiser, so the slabs of every layer can be summed together at the end (same fixed order per element:
+// bitwise the same values as k_wgrad_reduce4).
+constexpr int WGR_MAX = 16;
+struct WgradReduceBatch {
+  WgradReduceJob j[WGR_MAX];
+  int n;
+};
+static_assert(sizeof(WgradReduceBatch) <= 3900, "kernel argument block");
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce4_batch(WgradReduceBatch b) {
+  __shared__ f32x4 s_q[4][64];
+  int ji = 0;
+#pragma unroll
+  for (int q = 1; q < WGR_MAX; ++q) ji += (q < b.n && (int)blockIdx.x >= b.j[q].wg0) ? 1 : 0;
+  const WgradReduceJob& J = b.j[ji];
+  const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t slab4 = J.slab / 4, e = (int64_t)((int)blockIdx.x - J.wg0) * 64 + col;
+  const int c0 = (int)((int64_t)J.nslabs * q / 4), c1 = (int)((int64_t)J.nslabs * (q + 1) / 4);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (e < slab4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(J.partial) + e;
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) s += __builtin_nontemporal_load(p + (int64_t)c * slab4);
+  }
+  s_q[q][col] = s;
+  __syncthreads();
+  if (q == 0 && e < slab4) {
+    const f32x4 v = (s_q[0][col] + s_q[1][col]) + (s_q[2][col] + s_q[3][col]);
+    if (J.out.dense) {
+      reinterpret_cast<f32x4*>(J.dW)[e] = v;
+    } else {
+      const int64_t o = J.out.at(e * 4);
+      J.dW[o] = v.x, J.dW[o + J.out.so] = v.y, J.dW[o + 2 * J.out.so] = v.z, J.dW[o + 3 * J.out.so] = v.w;
+    }
+  }
+}
+
+// bytes of partial slabs stage 1 writes for this layer (exact: the chunking sv_sparse_conv_wgrad will choose), for callers that keep one region per layer
+extern "C" size_t sv_sparse_conv_wgrad_partial_bytes(int64_t n_rows, int K, int Cin, int Cout) {
+  if (n_rows <= 0 || K <= 0 || Cin <= 0 || Cout <= 0) return 256;
+  const int ct = (Cin + 15) / 16, nt = Cout / 16;
+  int tiles_c = 1, tiles_n = 1;
+  const bool mfma = Cout % 16 == 0 && (Cin % 16 == 0 || Cin < 16);
+  if (mfma) {
+    if (ct % 4 == 0 && nt % 4 == 0) { tiles_c = 4; tiles_n = 4; }
+    else if (ct % 2 == 0 && nt % 4 == 0) { tiles_c = 2; tiles_n = 4; }
+    else if (ct % 2 == 0 && nt % 2 == 0) { tiles_c = 2; tiles_n = 2; }
+    else if (nt % 2 == 0) { tiles_c = 1; tiles_n = 2; }
+  }
+  const int groups = mfma ? (ct / tiles_c) * (nt / tiles_n) : 1;
+  const int chunk_rows = wgrad_chunk_rows(n_rows, K, groups, Cin);
+  const int64_t nchunks = (n_rows + chunk_rows - 1) / chunk_rows;
+  return ((size_t)nchunks * K * Cin * Cout * sizeof(float) + 255) / 256 * 256;
+}
+
+// Stage 1 of sv_sparse_conv_wgrad_strided only: the partial slabs go to `partial` (sv_sparse_conv_wgrad_partial_bytes) and *job (10 int64, host) receives
+// {partial, dW, slab, nslabs, stride_k, stride_cin, stride_cout, Cin, Cout, dense = 0} for sv_sparse_conv_wgrad_reduce_batch; layers stage 2 does not
+// take in batch form (odd slab sizes, n_rows = 0) are finished here and leave nslabs = 0.
+extern "C" int sv_sparse_conv_wgrad_stage1(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin,
+                                           int Cout, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, void* partial, int64_t* job, void* stream) {
+  SV_CHECK_ARG(job && stride_k > 0 && stride_cin > 0 && stride_cout > 0, "sparse_conv_wgrad_stage1: bad arguments");
+  WgradReduceJob d{};
+  int rc = wgrad_run(X, n_src, nbr, dY, dW, n_rows, K, Cin, Cout, partial, stream, WgradOut{stride_k, stride_cin, stride_cout, Cin, Cout, 0}, &d);
+  job[0] = (int64_t)(uintptr_t)d.partial, job[1] = (int64_t)(uintptr_t)d.dW, job[2] = d.slab, job[3] = d.nslabs;
+  job[4] = stride_k, job[5] = stride_cin, job[6] = stride_cout, job[7] = Cin, job[8] = Cout, job[9] = 0;
+  return rc;
+}
+
+// jobs_host: n_jobs rows of 10 int64 as written by sv_sparse_conv_wgrad_stage1 (rows with nslabs = 0 are skipped): every layer's slabs summed in one launch
+extern "C" int sv_sparse_conv_wgrad_reduce_batch(const int64_t* jobs_host, int n_jobs, void* stream) {
+  SV_CHECK_ARG(n_jobs >= 0 && (jobs_host || n_jobs == 0), "sparse_conv_wgrad_reduce_batch: bad arguments");
+  hipStream_t st = sv_stream(stream);
+  WgradReduceBatch b;
+  b.n = 0;
+  int wgs = 0;
+  for (int q = 0; q < n_jobs; ++q) {
+    const int64_t* r = jobs_host + 10 * q;
+    if (r[3] <= 0) continue;
+    SV_CHECK_ARG(r[0] && r[1] && r[2] > 0 && r[2] % 4 == 0, "sparse_conv_wgrad_reduce_batch: job %d: bad slab", q);
+    WgradReduceJob& J = b.j[b.n];
+    J.partial = reinterpret_cast<const float*>((uintptr_t)r[0]), J.dW = reinterpret_cast<float*>((uintptr_t)r[1]), J.slab = r[2], J.nslabs = (int)r[3];
+    J.out = WgradOut{r[4], r[5], r[6], (int)r[7], (int)r[8], (int)r[9]};
+    J.wg0 = wgs;
+    wgs += sv_div_up(r[2] / 4, 64);
+    if (++b.n == WGR_MAX) {
+      hipLaunchKernelGGL(k_wgrad_reduce4_batch, dim3(wgs), dim3(256), 0, st, b);
+      b.n = 0, wgs = 0;
+    }
+  }
+  if (b.n > 0) hipLaunchKernelGGL(k_wgrad_reduce4_batch, dim3(wgs), dim3(256), 0, st, b);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
 }

@@ -52,26 +52,37 @@ class SceneStep(nn.Module):
         clustered, _ = get_largest_cluster_batch_device(surface, eps=self.cluster_eps, min_points=2, total_pts=coarse.shape[1], defer_check=True)
         return complete_scene_batch_device(points, clustered, object_scene, 0.1, compact=False)   # replaced points: scene id -1, dropped by the VFE
 
-    def front(self, points, objects, object_scene, batch_size):
-        """The INPUT side of the step -- everything that depends on the scene batch only, not on the trained weights: stage A (frozen VCN,
-        surface selection, cluster, merge), dynamic voxelisation + mean VFE, and every rulebook / convolution plan of the backbone.  No
-        gradients.  This is what the reference does ahead of the training step (SEE-VCN writes completed clouds offline, SEE_VCN.py:85-115;
-        pcdet voxelises in dataloader workers, dataset.py:126-160); here it may run on a side stream for batch N + 1 while batch N trains
-        (bench.py), and its device -> host reads (voxel counts) then wait for index kernels only."""
+    def front_a(self, points, objects, object_scene):
+        """First half of the input side: stage A (frozen VCN, surface selection, largest cluster) and the merge into the scenes -> the pasted
+        point rows (SP', 4).  No device -> host read (the empty-cluster check is parked on the stream, _lib.defer_check)."""
+        with torch.no_grad():
+            return self.complete_and_paste(points, objects, object_scene)
+
+    def front_b(self, pts, batch_size, flush=True):
+        """Second half: dynamic voxelisation + mean VFE and every rulebook / convolution plan of the backbone, with the input side's ONE
+        device -> host read (voxel count + the strided levels' site counts; checks parked on this stream ride on it)."""
         from . import spconv
         with torch.no_grad():
-            pts = self.complete_and_paste(points, objects, object_scene)
-            # ONE device -> host read for the whole input side: the voxel count stays on the device until the strided levels of the backbone
-            # have been counted there too (spconv.prebuild_rulebooks -> Fsp.build_network_index); the empty-cluster check rides on the same read
+            # the voxel count stays on the device until the strided levels of the backbone have been counted there too
+            # (spconv.prebuild_rulebooks -> Fsp.build_network_index)
             bd = self.vfe({'batch_size': batch_size, 'points': pts}, lazy_count=True)
             sp = spconv.SparseConvTensor(features=bd['voxel_features'], indices=bd['voxel_coords'], spatial_shape=self.backbone_3d.sparse_shape,
                                          batch_size=batch_size)
             spconv.prebuild_rulebooks(self.backbone_3d, sp, with_backward=self.training, n0_dev=bd.pop('voxel_count_device'))
-            _lib.flush_checks()                                   # nothing parked survives the front (normally taken by the one read above)
+            if flush:
+                _lib.flush_checks()                               # nothing parked survives the front (normally taken by the one read above)
             bd['voxel_features'] = sp.features
             bd['voxel_coords'] = sp.indices                       # the very tensor the rulebooks are bound to
             bd['spconv_indice_dict'] = sp.indice_dict
         return bd
+
+    def front(self, points, objects, object_scene, batch_size):
+        """The INPUT side of the step -- everything that depends on the scene batch only, not on the trained weights: stage A (frozen VCN,
+        surface selection, cluster, merge), dynamic voxelisation + mean VFE, and every rulebook / convolution plan of the backbone.  No
+        gradients.  This is what the reference does ahead of the training step (SEE-VCN writes completed clouds offline, SEE_VCN.py:85-115;
+        pcdet voxelises in dataloader workers, dataset.py:126-160); here it may run on a side stream for later batches while batch N trains
+        (bench.py: front_b of batch N + 1 and front_a of batch N + 2), and its one device -> host read then waits for index kernels only."""
+        return self.front_b(self.front_a(points, objects, object_scene), batch_size)
 
     def compute(self, bd):
         """The trained side: VoxelBackBone8x over the prebuilt rulebooks -> HeightCompression (autograd graph starts here)."""

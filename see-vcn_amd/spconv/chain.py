@@ -22,7 +22,10 @@ CHAIN_OFF = os.environ.get("SEEVCN_CHAIN", "1") == "0"          # 0: every block
 # instead of reducing them in a pass of its own.  Built, tested, and OFF by default: same-box A/B 5.13-5.26 ms without, 5.26-5.56 ms with -- the
 # 11 saved reduce launches (12 us each) are paid back by the epilogues' 16 extra row reads per tile (conv launches +3.4 .. +8.6 us each).
 BWD_SUMS_IN_CONV = os.environ.get("SEEVCN_BN_BWD_IN_CONV", "0") == "1"
-OP_CONV_PLANNED, OP_CONV_PLAIN, OP_BN_FWD, OP_BN_BWD, OP_WGRAD, OP_DGRAD_PLANNED_BN = 1, 2, 3, 5, 6, 7
+# 0: every weight gradient is followed by its own slab-reduction launch (SV_OP_WGRAD) instead of ONE reduction launch for all layers at the end of the backward
+# list (SV_OP_WGRAD_DEFERRED: bitwise the same gradients) -- A/B runs
+DEFER_WGRAD_REDUCE = os.environ.get("SEEVCN_WGRAD_DEFER", "1") != "0"
+OP_CONV_PLANNED, OP_CONV_PLAIN, OP_BN_FWD, OP_BN_BWD, OP_WGRAD, OP_DGRAD_PLANNED_BN, OP_WGRAD_DEFERRED = 1, 2, 3, 5, 6, 7, 8
 WORDS = 32
 
 
@@ -184,17 +187,22 @@ class SparseChainFunction(torch.autograd.Function):
             ext[L - 1] = torch.zeros((rulebooks[-1].n_out, blocks[-1].cout), dtype=torch.float32, device=dev)
         # one allocation for the work buffers: per block [gradient of the conv output | gradient of the block's input (blocks >= 1) | dgamma | dbeta],
         # one for the weight gradients (in the parameters' own layout)
-        boffs, total, woffs, wtotal, wbytes = [], 0, [], 0, 0
+        boffs, total, woffs, wtotal, wbytes, poffs = [], 0, [], 0, 0, []
         for k, (b, rb) in enumerate(zip(blocks, rulebooks)):
             n, nin = rb.n_out * b.cout, (rb.n_in * b.cin if k > 0 else 0)
             boffs.append((total, total + n, total + n + nin, total + n + nin + b.cout))
             total += n + nin + 2 * b.cout
             woffs.append(wtotal)
             wtotal += b.K * b.cin * b.cout
-            wbytes = max(wbytes, lib.sv_sparse_conv_wgrad_scratch_bytes(rb.n_out, b.K, b.cin, b.cout))
+            if DEFER_WGRAD_REDUCE:                                   # every layer keeps its own partial slabs until the one reduction at the end of the list
+                poffs.append(wbytes)
+                wbytes += lib.sv_sparse_conv_wgrad_partial_bytes(rb.n_out, b.K, b.cin, b.cout)
+            else:
+                poffs.append(0)
+                wbytes = max(wbytes, lib.sv_sparse_conv_wgrad_scratch_bytes(rb.n_out, b.K, b.cin, b.cout))
         work = torch.empty((total,), dtype=torch.float32, device=dev)
         wgrads = torch.empty((wtotal,), dtype=torch.float32, device=dev)
-        wscratch = _lib.workspace.scratch("wgrad", wbytes, dev)
+        wscratch = _lib.workspace.scratch("wgrad_layers" if DEFER_WGRAD_REDUCE else "wgrad", wbytes, dev)
         base, abase, wbase = work.data_ptr(), arena.data_ptr(), wgrads.data_ptr()
         rows = []
         n_part, n_part_bwd = lib.sv_conv_planned_partials(), 0          # n_part_bwd: partials the data-gradient launch above left for this BatchNorm
@@ -209,8 +217,8 @@ class SparseChainFunction(torch.autograd.Function):
             rows.append(_row(OP_BN_BWD, i=(b.cout, int(b.relu), n_part_bwd), n=(rb.n_out,),
                              p=(a_conv, dy_ptr, gamma.data_ptr(), beta.data_ptr(), a_mean, a_istd, scratch.data_ptr(), o_dconv, o_dg, o_db)))
             n_part_bwd = 0
-            rows.append(_row(OP_WGRAD, i=(b.K, b.cin, b.cout, rb.n_in), n=(rb.n_out, b.cin, 1, b.K * b.cin),
-                             p=(x_in, rb.addr("nbr_out"), o_dconv, wbase + 4 * woffs[k], wscratch.data_ptr())))
+            rows.append(_row(OP_WGRAD_DEFERRED if DEFER_WGRAD_REDUCE else OP_WGRAD, i=(b.K, b.cin, b.cout, rb.n_in), n=(rb.n_out, b.cin, 1, b.K * b.cin),
+                             p=(x_in, rb.addr("nbr_out"), o_dconv, wbase + 4 * woffs[k], wscratch.data_ptr() + poffs[k])))
             if k > 0:
                 a_rows, a_perm, a_masks_p, a_tiles, g, rev = rb.plan_addrs("bwd", b.cout, b.cin)
                 res = ext[k - 1]

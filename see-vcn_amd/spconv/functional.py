@@ -445,7 +445,14 @@ def build_network_index(coords, batch_size, spatial_shape, specs, n0_dev=None, w
             row(2, level_sites[l], maps[l + 1].data_ptr(), addr(t["nbr_in"]), addr(t["in_block"]), addr(t["in_block"], 32 * ni), ni,
                 *shapes[l], *shapes[l + 1], *sp.ksize, 1, 1, 1, *sp.padding, *[-d for d in sp.dilation], *sp.stride, B)
     arr = np.array(jobs, dtype=np.int64)
-    _lib.check(lib.sv_rulebook_batch(arr.ctypes.data, len(jobs), _lib.stream()), "sv_rulebook_batch")
+    try:
+        _lib.check(lib.sv_rulebook_batch(arr.ctypes.data, len(jobs), _lib.stream()), "sv_rulebook_batch")
+    except BaseException:
+        for w in (works if L else []):                                 # a refused batch leaves phase 1's marks (and maybe map entries) behind:
+            w.zero_()                                                  # the persistent workspaces must be all-zero for the next call
+        for m in maps:
+            m.zero_()
+        raise
     # ---- all plans in one launch
     pj = []
     for t in tables.values():

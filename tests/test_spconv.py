@@ -906,3 +906,34 @@ def test_hip_chain_stands_down_for_hooks_on_any_walked_module(cuda, hip_lib):
     net.conv3[1][1].momentum = None
     out = run()['encoded_spconv_tensor'].features                  # no TypeError: module path, torch's cumulative moving average
     assert type(out.grad_fn).__name__ != "SparseChainFunctionBackward" and torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+def test_hip_deferred_weight_gradient_reduction_is_bitwise_the_per_layer_one(cuda, hip_lib):
+    """The chain's backward list with ONE slab-reduction launch for all layers at its end (SV_OP_WGRAD_DEFERRED, the default) against a reduction launch
+    behind every weight gradient (SV_OP_WGRAD): the same partial slabs summed in the same order -- every gradient bit-identical."""
+    import copy
+    import seevcn_amd.synth as synth
+    from seevcn_amd.pcdet.models import backbones_3d
+    from seevcn_amd.pcdet.ops import voxel_ops
+    from seevcn_amd.spconv import chain
+    pts, _ = synth.make_scene_batch(2, seed=2004, n_az=120)
+    g = dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.05, 0.05, 0.1], grid_size=[1408, 1600, 40])
+    f, c, _ = voxel_ops.voxelize_dynamic(torch.from_numpy(pts).to(cuda), g["point_cloud_range"], g["voxel_size"], g["grid_size"], 2)
+    torch.manual_seed(3)
+    net1 = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size']).to(cuda).train()
+    net2 = copy.deepcopy(net1)
+    res = []
+    for net, defer in ((net1, True), (net2, False)):
+        saved, chain.DEFER_WGRAD_REDUCE = chain.DEFER_WGRAD_REDUCE, defer
+        try:
+            bd = net({'batch_size': 2, 'voxel_features': f.clone(), 'voxel_coords': c.clone()})
+            out = bd['encoded_spconv_tensor'].features
+            assert type(out.grad_fn).__name__ == "SparseChainFunctionBackward"
+            out.square().sum().backward()
+        finally:
+            chain.DEFER_WGRAD_REDUCE = saved
+        res.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+    assert all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for k, v in res[0].items() if k.endswith("0.weight"))
