@@ -246,6 +246,24 @@ __device__ __forceinline__ void wave_key_groups(int key, bool live, int& rank, i
   }
 }
 
+// The same three answers for keys of at most BITS bits in a FIXED number of steps: lanes with an equal key are the intersection, over the key's bits,
+// of the lanes that agree with this lane on that bit (one ballot per bit) -- 12 ballots for a class key whatever the number of distinct keys among the
+// 64 rows (the loop above runs once per distinct key: ~20 on consecutive rows of a LiDAR table, and the deterministic plan runs it for every row).
+template <int BITS>
+__device__ __forceinline__ void wave_key_groups_bits(int key, bool live, int& rank, int& size, int& first_lane) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long same = __ballot(live);
+#pragma unroll
+  for (int b = 0; b < BITS; ++b) {
+    const bool bit = (key >> b) & 1;
+    const unsigned long long m = __ballot(bit);
+    same &= bit ? m : ~m;
+  }
+  rank = __popcll(same & ((1ull << lane) - 1ull));
+  size = __popcll(same);
+  first_lane = live ? __ffsll((long long)same) - 1 : lane;
+}
+
 struct PlanArgs {
   const int32_t* masks;   // (n_rows) neighbour mask of every row (written by the rulebook builders)
   int64_t n_rows;
@@ -771,7 +789,7 @@ __device__ __forceinline__ void plan_region_body_stable(const PlanFusedArgs& a, 
       const bool live = m[u] != 0xFFFFFFFFu;
       const int key = live ? class_key(m[u]) : 0;
       int rank, size, first_lane;
-      wave_key_groups(key, live, rank, size, first_lane);
+      wave_key_groups_bits<12>(key, live, rank, size, first_lane);
       uint32_t old = 0;
       if (live && rank == 0) old = atomicAdd(&my_wc[key], (uint32_t)size << sh);
       old = (uint32_t)__shfl((int)old, first_lane);
@@ -793,7 +811,7 @@ __device__ __forceinline__ void plan_region_body_stable(const PlanFusedArgs& a, 
     const bool live = t < t1;
     const int c = live ? min(__popc(s_tmask[t]), 31) : 0;
     int rank, size, first_lane;
-    wave_key_groups(c, live, rank, size, first_lane);
+    wave_key_groups_bits<5>(c, live, rank, size, first_lane);
     if (live && rank == 0) s_wcnt[wid][c] += size;                     // the wave's own row of counters: no other wave touches it
   }
   __syncthreads();
@@ -820,7 +838,7 @@ __device__ __forceinline__ void plan_region_body_stable(const PlanFusedArgs& a, 
     const bool live = t < t1;
     const int c = live ? min(__popc(s_tmask[t]), 31) : 0;
     int rank, size, first_lane;
-    wave_key_groups(c, live, rank, size, first_lane);
+    wave_key_groups_bits<5>(c, live, rank, size, first_lane);
     int off = 0;
     if (live && rank == 0) off = s_wcnt[wid][c], s_wcnt[wid][c] = off + size;
     off = __shfl(off, first_lane);
