@@ -256,7 +256,8 @@ def measure_dominant_kernel(model, inputs, reps=5):
         s.record()
         out = orig(a, w, *args, **kw)
         e.record()
-        records.append((2.0 * a.shape[0] * a.shape[1] * w.shape[0], s, e))
+        # rows actually computed: with a device-side row count (m_dev, the lazy-row forward) a.shape[0] is only the capacity
+        records.append((kw.get("m_dev"), a.shape[0], 2.0 * a.shape[1] * w.shape[0], s, e))
         return out
 
     L.gemm = timed
@@ -266,8 +267,8 @@ def measure_dominant_kernel(model, inputs, reps=5):
         torch.cuda.synchronize()
     finally:
         L.gemm = orig
-    ms = sum(s.elapsed_time(e) for _, s, e in records)
-    executed = sum(f for f, _, _ in records)
+    ms = sum(s.elapsed_time(e) for *_, s, e in records)
+    executed = sum((int(m_dev.item()) if m_dev is not None else rows) * f for m_dev, rows, f, _, _ in records)
     launches = len(records)
     return ms / launches, executed / reps, launches // reps, ms / reps
 
@@ -642,6 +643,8 @@ def kernel_rooflines(out, model, opt, params, inputs):
     algo_flop_per_launch = VCN_FLOP_PER_OBJECT * OBJECTS_PER_GPU / launches
     achieved = algo_flop_per_launch / (avg_ms * 1e-3) / 1e12
     exec_tf = executed_flop / (vcn_gemm_ms * 1e-3) / 1e12
+    if exec_tf > PEAK_F32_MFMA_TFLOPS:
+        raise RuntimeError(f"VCN GEMM accounting: {exec_tf:.1f} TFLOP/s executed is above the fp32 MFMA peak -- rows or time are miscounted")
     vcn_roof = {"bound": "mfma", "kernel": "k_gemm_f32 (sv_gemm_bias_act[_ragged], v_mfma_f32_32x32x2_f32)",
                 "achieved": round(exec_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(exec_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
