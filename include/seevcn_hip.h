@@ -267,6 +267,10 @@ int sv_conv_planned_partials(void);
  * (s_memtime at start / after the prologue / after the main loop / at the end, HW_ID, XCC_ID, tile-offset steps, block << 8 | wave);
  * buf holds grid.x * grid.y * 4 slots of 64 bytes (size it as 8 * (n_tiles + 64) * columns / 64 slots).  Not for production use. */
 int sv_debug_conv_trace(void* buf);
+/* The same for the MFMA weight gradient (tools/wgrad_trace.py; the 64 -> 64 channel instance only): per wave s_memtime at start, ticks spent in the
+ * pass prologues (table read + compaction), ticks in the MFMA loops, s_memtime at the end, XCC_ID << 32 | HW_ID, s_memtime after the last pass,
+ * passes << 32 | pairs, offset << 32 | chunk; buf holds 4 x workgroups slots of 64 bytes.  Not for production use. */
+int sv_debug_wgrad_trace(void* buf);
 /* dW (K, C_in, C_out) = sum_o X[nbr[k][o]]^T dY[o]; deterministic two-stage reduction.  n_src = rows of X (every table entry is < n_src): when
  * n_src * C_in * 4 < 2^32 the operand rows are addressed with 32-bit byte offsets from uniform bases; n_src <= 0 = unknown (64-bit addresses). */
 size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int Cin, int Cout);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "sv_conv_planned_partials": (c_i, []),
     "sv_batchnorm_relu_forward_partial": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_debug_conv_trace": (c_i, [c_p]),
+    "sv_debug_wgrad_trace": (c_i, [c_p]),
     "sv_conv_tiles_per_wave": (c_i, [c_i64, c_i, c_i]),
     "sv_conv_plan_tiles_bytes": (c_sz, [c_i64, c_i]),
     "sv_conv_weight_fragments_batch": (c_i, [c_p, c_i, c_i64, c_p]),

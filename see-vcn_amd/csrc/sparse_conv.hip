@@ -1669,6 +1669,7 @@ struct WgradArgs {
   int K, Cin, Cout, nchunks, chunk_rows;
   int xcd_order;         // workgroup -> (chunk, offset, tile group) decoded per XCD (k_spconv_wgrad)
   int64_t n_src;         // rows of X, or <= 0 when the caller does not know (then no 32-bit offsets)
+  unsigned long long* trace;   // measurement only (sv_debug_wgrad_trace, instance DBG = 16): 8 words per wave, or null
 };
 
 template <int N> struct WgVec;
@@ -1733,6 +1734,9 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad(WgradA
   const int c_base = (zgroup / ngroups_n) * CT * 16, n_base = (zgroup % ngroups_n) * NTL * 16;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, kk = lane >> 4;
+  const unsigned long long t_start = (DBG & 16) ? __builtin_amdgcn_s_memtime() : 0ull;     // per-wave stamps: the trace instance only
+  unsigned long long t_pro = 0ull, t_loop = 0ull, t_mark = t_start;
+  unsigned tr_pairs = 0, tr_passes = 0;
   f32x4 acc[CT][NTL];
 #pragma unroll
   for (int c = 0; c < CT; ++c)
@@ -1836,6 +1840,10 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad(WgradA
     // vmcnt(6): no conditional issue, so each stage register has one definition per slot and hipcc never copies a stage whose
     // load is still in flight (a copied stage lets the late load land in a register that has been handed to something else).
     static_assert(WG_DEPTH == 4, "the wait count in consume() is written for a 4-deep ring");
+    if constexpr (DBG & 16) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_pro += t - t_mark, t_mark = t, tr_pairs += (unsigned)cnt, ++tr_passes;
+    }
     XV x0, x1, x2, x3;
     YV y0, y1, y2, y3;
     issue(kk, cnt, x0, y0);
@@ -1852,7 +1860,12 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad(WgradA
       consume(p0 + 12, cnt, x3, y3);
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2));   // retire the tail's dummy loads
+    if constexpr (DBG & 16) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_loop += t - t_mark, t_mark = t;
+    }
   }
+  const unsigned long long t_body = (DBG & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   if constexpr (DBG & 4) {                                   // measurement: no reduction, no slab store (one value keeps the accumulators alive)
     float sacc = 0.f;
 #pragma unroll
@@ -1886,6 +1899,25 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad(WgradA
     const int crow = c_base + CT * ((ln >> 4) * 4 + r) + c;
     if (crow < a.Cin) out[(int64_t)crow * a.Cout + n_base + NTL * (ln & 15) + t] = red[e];
   }
+  if constexpr (DBG & 16) {
+    if (a.trace && lane == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+      unsigned hw = 0, xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long* o = a.trace + ((size_t)blockIdx.x * 4 + wid) * 8;
+      o[0] = t_start, o[1] = t_pro, o[2] = t_loop, o[3] = t_end, o[4] = ((unsigned long long)xcc << 32) | hw, o[5] = t_body,
+      o[6] = ((unsigned long long)tr_passes << 32) | tr_pairs, o[7] = ((unsigned long long)k << 32) | (unsigned)chunk;
+    }
+  }
+}
+
+// measurement only: per-wave time stamps of the next MFMA weight-gradient launches (<4,4> instance) go to `buf` (8 x uint64 per wave: 4 per workgroup); null = off
+static unsigned long long* g_wgrad_trace = nullptr;
+extern "C" int sv_debug_wgrad_trace(void* buf) {
+  g_wgrad_trace = static_cast<unsigned long long*>(buf);
+  return SV_OK;
 }
 
 // generic (any Cin/Cout) stage 1: one thread per (c, n) element, rows of the chunk streamed
@@ -1957,6 +1989,30 @@ extern "C" size_t sv_sparse_conv_wgrad_scratch_bytes(int64_t n_rows, int K, int 
   return (size_t)(nchunks > 0 ? nchunks : 1) * K * Cin * Cout * sizeof(float);
 }
 
+// The launch shape of stage 1 for a layer: register tile grid, tile groups, chunk rows -- a function of the layer's sizes only (the same table gives the
+// same slabs and the same summation order in every run)
+struct WgradShape {
+  bool mfma;
+  int tiles_c, tiles_n, groups, chunk_rows, nchunks;
+};
+static WgradShape wgrad_shape(int64_t n_rows, int K, int Cin, int Cout) {
+  WgradShape w{};
+  const int ct = (Cin + 15) / 16, nt = Cout / 16;
+  w.tiles_c = w.tiles_n = 1;
+  // C_in that is not a multiple of 16 (the 3-channel input layer) runs on the MFMA path with zero-padded rows
+  w.mfma = Cout % 16 == 0 && (Cin % 16 == 0 || Cin < 16);
+  if (w.mfma) {
+    if (ct % 4 == 0 && nt % 4 == 0) { w.tiles_c = 4; w.tiles_n = 4; }
+    else if (ct % 2 == 0 && nt % 4 == 0) { w.tiles_c = 2; w.tiles_n = 4; }
+    else if (ct % 2 == 0 && nt % 2 == 0) { w.tiles_c = 2; w.tiles_n = 2; }
+    else if (nt % 2 == 0) { w.tiles_c = 1; w.tiles_n = 2; }
+  }
+  w.groups = w.mfma ? (ct / w.tiles_c) * (nt / w.tiles_n) : 1;
+  w.chunk_rows = wgrad_chunk_rows(n_rows, K, w.groups, Cin);
+  w.nchunks = (int)((n_rows + w.chunk_rows - 1) / w.chunk_rows);
+  return w;
+}
+
 template <int CT, int NTL>
 static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
   const int groups = (((a.Cin + 15) / 16) / CT) * ((a.Cout / 16) / NTL);
@@ -1967,6 +2023,12 @@ static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
   const bool off32 = off32_env && a.n_src > 0 && (uint64_t)a.n_src * (uint64_t)a.Cin * 4u < 0xffffffffull && (uint64_t)a.chunk_rows * a.Cout * 4u < 0xffffffffull;
   static const int wg_debug = getenv("SEEVCN_WGRAD_DEBUG") ? atoi(getenv("SEEVCN_WGRAD_DEBUG")) : 0;
   if constexpr (CT == 4 && NTL == 4) {
+    if (off32 && g_wgrad_trace) {
+      WgradArgs t = a;
+      t.trace = g_wgrad_trace;
+      hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true, 16>), dim3(blocks), dim3(256), 0, st, t);
+      return;
+    }
     if (off32 && wg_debug == 1) { hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true, 1>), dim3(blocks), dim3(256), 0, st, a); return; }
     if (off32 && wg_debug == 2) { hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true, 2>), dim3(blocks), dim3(256), 0, st, a); return; }
     if (off32 && wg_debug == 4) { hipLaunchKernelGGL((k_spconv_wgrad<CT, NTL, true, 4>), dim3(blocks), dim3(256), 0, st, a); return; }
@@ -1998,18 +2060,7 @@ static int wgrad_run(const float* X, int64_t n_src, const int32_t* nbr, const fl
     return SV_OK;
   }
   SV_CHECK_ARG(X && nbr && dY && scratch, "sparse_conv_wgrad: null pointer");
-  const int ct = (Cin + 15) / 16, nt = Cout / 16;
-  int tiles_c = 1, tiles_n = 1;
-  // C_in that is not a multiple of 16 (the 3-channel input layer) runs on the MFMA path with zero-padded rows
-  const bool mfma = Cout % 16 == 0 && (Cin % 16 == 0 || Cin < 16);
-  if (mfma) {
-    if (ct % 4 == 0 && nt % 4 == 0) { tiles_c = 4; tiles_n = 4; }
-    else if (ct % 2 == 0 && nt % 4 == 0) { tiles_c = 2; tiles_n = 4; }
-    else if (ct % 2 == 0 && nt % 2 == 0) { tiles_c = 2; tiles_n = 2; }
-    else if (nt % 2 == 0) { tiles_c = 1; tiles_n = 2; }
-  }
-  const int groups = mfma ? (ct / tiles_c) * (nt / tiles_n) : 1;
-  const int chunk_rows = wgrad_chunk_rows(n_rows, K, groups, Cin);
+  const WgradShape w = wgrad_shape(n_rows, K, Cin, Cout);
   // workgroup order: the narrow layers (C_in <= 32: little matrix work per gathered byte) run the chunks of an eighth of the rows on ONE XCD, so that
   // a scene's rows go through one L2 for all 27 offsets -- measured after the loop's instruction stream was trimmed: 16->16 32.7 -> 26.5 us,
   // 16->32 35.1 -> 29.7, 32->32 87.7 -> 74.7, 32->64 56.2 -> 54.0; the 64-channel layers lose with it (135 -> 144 us: they are bound by their
@@ -2017,24 +2068,24 @@ static int wgrad_run(const float* X, int64_t n_src, const int32_t* nbr, const fl
   // order 2, 135 -> 158 us).  SEEVCN_WGRAD_XCD=0/1/2 forces one order for all layers (measurement).
   static const int xcd_env = getenv("SEEVCN_WGRAD_XCD") ? atoi(getenv("SEEVCN_WGRAD_XCD")) : -1;
   const int xcd_order = xcd_env >= 0 ? xcd_env : (Cin <= 32 ? 1 : 0);
-  WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, (int)((n_rows + chunk_rows - 1) / chunk_rows), chunk_rows, xcd_order, n_src};
-  int nslabs = a.nchunks;
-  if (mfma) {
-    if (tiles_c == 4) launch_wgrad<4, 4>(a, st);
-    else if (tiles_c == 2 && tiles_n == 4) launch_wgrad<2, 4>(a, st);
-    else if (tiles_c == 2) launch_wgrad<2, 2>(a, st);
-    else if (tiles_n == 2) launch_wgrad<1, 2>(a, st);
+  const bool reduce4 = slab % 4 == 0 && Cout % 4 == 0 && (uintptr_t)dW % 16 == 0 && (uintptr_t)scratch % 16 == 0;
+  WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, w.nchunks, w.chunk_rows, xcd_order, n_src};
+  const int nslabs = a.nchunks;
+  if (w.mfma) {
+    if (w.tiles_c == 4) launch_wgrad<4, 4>(a, st);
+    else if (w.tiles_c == 2 && w.tiles_n == 4) launch_wgrad<2, 4>(a, st);
+    else if (w.tiles_c == 2) launch_wgrad<2, 2>(a, st);
+    else if (w.tiles_n == 2) launch_wgrad<1, 2>(a, st);
     else launch_wgrad<1, 1>(a, st);
   } else {
     hipLaunchKernelGGL(k_spconv_wgrad_valu, dim3(a.nchunks, K), dim3(256), 0, st, a);
-    nslabs = a.nchunks;
   }
-  if (defer && slab % 4 == 0 && Cout % 4 == 0 && (uintptr_t)dW % 16 == 0 && (uintptr_t)a.partial % 16 == 0) {
+  if (defer && reduce4) {
     defer->partial = a.partial, defer->dW = dW, defer->slab = slab, defer->nslabs = nslabs, defer->out = out;     // summed later, with the other layers' slabs
     SV_LAUNCH_CHECK();
     return SV_OK;
   }
-  if (slab % 4 == 0 && Cout % 4 == 0 && (uintptr_t)dW % 16 == 0 && (uintptr_t)a.partial % 16 == 0)
+  if (reduce4)
     hipLaunchKernelGGL(k_wgrad_reduce4, dim3(sv_div_up(slab / 4, 64)), dim3(256), 0, st, a.partial, nslabs, slab / 4, dW, out);
   else
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(sv_grid_1d(slab, 256)), dim3(256), 0, st, a.partial, nslabs, slab, dW, out);
@@ -2096,19 +2147,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce4_batch(WgradReduceBatch b)
 // bytes of partial slabs stage 1 writes for this layer (exact: the chunking sv_sparse_conv_wgrad will choose), for callers that keep one region per layer
 extern "C" size_t sv_sparse_conv_wgrad_partial_bytes(int64_t n_rows, int K, int Cin, int Cout) {
   if (n_rows <= 0 || K <= 0 || Cin <= 0 || Cout <= 0) return 256;
-  const int ct = (Cin + 15) / 16, nt = Cout / 16;
-  int tiles_c = 1, tiles_n = 1;
-  const bool mfma = Cout % 16 == 0 && (Cin % 16 == 0 || Cin < 16);
-  if (mfma) {
-    if (ct % 4 == 0 && nt % 4 == 0) { tiles_c = 4; tiles_n = 4; }
-    else if (ct % 2 == 0 && nt % 4 == 0) { tiles_c = 2; tiles_n = 4; }
-    else if (ct % 2 == 0 && nt % 2 == 0) { tiles_c = 2; tiles_n = 2; }
-    else if (nt % 2 == 0) { tiles_c = 1; tiles_n = 2; }
-  }
-  const int groups = mfma ? (ct / tiles_c) * (nt / tiles_n) : 1;
-  const int chunk_rows = wgrad_chunk_rows(n_rows, K, groups, Cin);
-  const int64_t nchunks = (n_rows + chunk_rows - 1) / chunk_rows;
-  return ((size_t)nchunks * K * Cin * Cout * sizeof(float) + 255) / 256 * 256;
+  const WgradShape w = wgrad_shape(n_rows, K, Cin, Cout);
+  return ((size_t)w.nchunks * K * Cin * Cout * sizeof(float) + 255) / 256 * 256;
 }
 
 // Stage 1 of sv_sparse_conv_wgrad_strided only: the partial slabs go to `partial` (sv_sparse_conv_wgrad_partial_bytes) and *job (10 int64, host) receives

@@ -937,3 +937,4 @@ def test_hip_deferred_weight_gradient_reduction_is_bitwise_the_per_layer_one(cud
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k
     assert all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for k, v in res[0].items() if k.endswith("0.weight"))
+
