@@ -517,6 +517,14 @@ def main():
     inputs = (points, objects, scene)
 
     device_spinup(args.spinup, device)
+    # SEEVCN_BENCH_MAIN_PRIORITY (A/B): the trained side on a stream of its own with this priority instead of the default stream (priority 0)
+    import contextlib
+    main_ctx = contextlib.nullcontext()
+    if os.environ.get("SEEVCN_BENCH_MAIN_PRIORITY") is not None:
+        main_stream = torch.cuda.Stream(priority=int(os.environ["SEEVCN_BENCH_MAIN_PRIORITY"]))
+        main_stream.wait_stream(torch.cuda.current_stream())
+        main_ctx = torch.cuda.stream(main_stream)
+    main_ctx.__enter__()
     pre = None if args.no_prefetch else Prefetch(model, inputs, threaded=args.prefetch_thread)
     step = (lambda: run_step(model, opt, params, inputs, world)) if pre is None else (lambda: run_step_prefetched(model, opt, params, pre, world, not args.no_interleave))
     for _ in range(args.warmup):
@@ -538,6 +546,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if pre is not None:
         pre.close()
+    main_ctx.__exit__(None, None, None)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -288,6 +288,31 @@ size_t sv_sparse_conv_wgrad_partial_bytes(int64_t n_rows, int K, int Cin, int Co
 int sv_sparse_conv_wgrad_stage1(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin, int Cout,
                                 int64_t stride_k, int64_t stride_cin, int64_t stride_cout, void* partial, int64_t* job, void* stream);
 int sv_sparse_conv_wgrad_reduce_batch(const int64_t* jobs_host, int n_jobs, void* stream);
+/* Weight gradient on EQUAL PIECES (the default of the trained path; replaces the role of spconv's indice_conv_backward filter gradient as the entries above do).
+ * The chunked stage 1 above gives every (row chunk, offset) a workgroup: an offset's work follows its density, and the launch ends when the unluckiest CU
+ * does (pairs per SIMD max / mean 1.4-1.6 on a LiDAR rulebook, tools/wgrad_trace.py).  Here a per-TABLE plan cuts the table's pairs, offset-major, into
+ * sv_wgrad_plan_pieces(Cin, Cout) pieces of equal pair count (up to one 64-row unit) -- as many as workgroups are resident -- and stage 1 runs one
+ * workgroup per piece (one (Cin, Cout) slab per offset a piece touches).  A plan is a function of (table, pieces) only: build it once per rulebook
+ * table, use it for every layer on that table whose sv_wgrad_plan_pieces agrees.  Results are bitwise reproducible; they differ from the chunked
+ * form's in the last bits (other partial sums).
+ *   sv_wgrad_plan_bytes          bytes of a plan (device memory, caller-owned)
+ *   sv_wgrad_plan_build          nbr (K, n_rows) -> plan; 2 launches
+ *   sv_wgrad_planned_applies     1 iff the layer runs on this path (MFMA tile shape, 32-bit addressable operands); otherwise use sv_sparse_conv_wgrad*
+ *   sv_sparse_conv_wgrad_planned_bytes   bytes of `partial`
+ *   sv_sparse_conv_wgrad_planned         both stages; strides all 0 = contiguous (K, Cin, Cout) dW, else as sv_sparse_conv_wgrad_strided
+ *   sv_sparse_conv_wgrad_planned_stage1  stage 1 only; *job for sv_sparse_conv_wgrad_reduce_batch */
+size_t sv_wgrad_plan_bytes(int64_t n_rows, int K, int pieces);
+int sv_wgrad_plan_pieces(int Cin, int Cout);
+int sv_wgrad_plan_build(const int32_t* nbr, int64_t n_rows, int K, int pieces, void* plan, void* stream);
+/* the plans of several tables in two launches; jobs_host: n_jobs rows of 8 int64 = {nbr, n_rows, K, pieces, plan, 0, 0, 0} (device addresses) */
+int sv_wgrad_plan_build_batch(const int64_t* jobs_host, int n_jobs, void* stream);
+int sv_wgrad_planned_applies(int64_t n_src, int64_t n_rows, int K, int Cin, int Cout);
+size_t sv_sparse_conv_wgrad_planned_bytes(int K, int Cin, int Cout);
+int sv_sparse_conv_wgrad_planned(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin, int Cout,
+                                 int64_t stride_k, int64_t stride_cin, int64_t stride_cout, const void* plan, void* partial, void* stream);
+int sv_sparse_conv_wgrad_planned_stage1(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin,
+                                        int Cout, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, const void* plan, void* partial, int64_t* job,
+                                        void* stream);
 
 /* SparseConvTensor.dense(): (N,C) + coords -> (B, C, D, H, W), every element written once */
 size_t sv_sparse_to_dense_scratch_bytes(int batch, int D, int H, int W);
@@ -511,7 +536,8 @@ int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float*
  *                       f = momentum, eps
  *   SV_OP_BN_BWD        sv_batchnorm_relu_backward (i2 = 0) / _backward_partial (i2 = number of partials): p = x, dy, gamma, beta, save_mean,
  *                       save_invstd, scratch, dx, dgamma, dbeta; n = rows; i = channels, relu, n_partials
- *   SV_OP_WGRAD         sv_sparse_conv_wgrad_strided: p = X, nbr, dY, dW, scratch; n = n_rows, stride_k, stride_cin, stride_cout; i = K, Cin, Cout, n_src
+ *   SV_OP_WGRAD         sv_sparse_conv_wgrad_strided: p = X, nbr, dY, dW, scratch; n = n_rows, stride_k, stride_cin, stride_cout; i = K, Cin, Cout, n_src;
+ *                       p5 = equal-pieces plan of the table (then sv_sparse_conv_wgrad_planned, p4 = sv_sparse_conv_wgrad_planned_bytes) or 0
  *   SV_OP_WGRAD_DEFERRED  the same fields as SV_OP_WGRAD, but only stage 1 runs in place (sv_sparse_conv_wgrad_stage1; p4 = this layer's OWN partial region of
  *                       sv_sparse_conv_wgrad_partial_bytes) and the slabs of every deferred layer are summed by ONE launch at the end of the list
  *                       (sv_sparse_conv_wgrad_reduce_batch): the gradients are complete when sv_run_ops returns, bitwise the values of SV_OP_WGRAD

@@ -83,6 +83,14 @@ SIGNATURES = {
     "sv_sparse_conv_wgrad_partial_bytes": (c_sz, [c_i64, c_i, c_i, c_i]),
     "sv_sparse_conv_wgrad_stage1": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "sv_sparse_conv_wgrad_reduce_batch": (c_i, [c_p, c_i, c_p]),
+    "sv_wgrad_plan_bytes": (c_sz, [c_i64, c_i, c_i]),
+    "sv_wgrad_plan_pieces": (c_i, [c_i, c_i]),
+    "sv_wgrad_plan_build": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p]),
+    "sv_wgrad_plan_build_batch": (c_i, [c_p, c_i, c_p]),
+    "sv_wgrad_planned_applies": (c_i, [c_i64, c_i64, c_i, c_i, c_i]),
+    "sv_sparse_conv_wgrad_planned_bytes": (c_sz, [c_i, c_i, c_i]),
+    "sv_sparse_conv_wgrad_planned": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "sv_sparse_conv_wgrad_planned_stage1": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "sv_sparse_to_dense_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "sv_sparse_to_dense": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_dense_to_sparse": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),

@@ -75,6 +75,10 @@ extern "C" int sv_run_ops(const int64_t* ops, int n_ops, void* stream) {
                                         ptr_of<float>(p[7]), ptr_of<float>(p[8]), ptr_of<float>(p[9]), stream);
         break;
       case SV_OP_WGRAD:
+        if (p[5])
+          rc = sv_sparse_conv_wgrad_planned(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
+                                            (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<const void>(p[5]), ptr_of<void>(p[4]), stream);
+        else
         rc = sv_sparse_conv_wgrad_strided(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
                                           (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<void>(p[4]), stream);
         break;
@@ -84,6 +88,11 @@ extern "C" int sv_run_ops(const int64_t* ops, int n_ops, void* stream) {
           n_deferred = 0;
           if (rc != SV_OK) return rc;
         }
+        if (p[5])
+          rc = sv_sparse_conv_wgrad_planned_stage1(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
+                                                   (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<const void>(p[5]), ptr_of<void>(p[4]),
+                                                   deferred + 10 * n_deferred, stream);
+        else
         rc = sv_sparse_conv_wgrad_stage1(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
                                          (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<void>(p[4]), deferred + 10 * n_deferred, stream);
         ++n_deferred;

@@ -1960,16 +1960,32 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 // slab % 4 == 0: 64 float4 columns x 4 quarters of the chunk range per workgroup -- four times the loads in flight of the scalar
 // kernel, partial sums combined in a fixed order ((q0 + q1) + (q2 + q3)): still bitwise reproducible
-__global__ __launch_bounds__(256) void k_wgrad_reduce4(const float* __restrict__ partial, int nchunks, int64_t slab4, float* __restrict__ dW, WgradOut o) {
+// The slabs that hold element e (float4 index into the (K, Cin, Cout) gradient): first one, their number, their stride.  Chunked stage 1: slab c of
+// nchunks at c * slab4.  Stage 1 on equal pieces (k_spconv_wgrad_eq): one (Cin, Cout) slab per (piece, offset it touches), the slabs of offset k
+// back to back from runs[2k] on, runs[2k + 1] of them.
+struct WgradSlabRun {
+  const f32x4* p;
+  int n;
+  int64_t stride;
+};
+__device__ __forceinline__ WgradSlabRun wgrad_slab_run(const float* partial, int nchunks, int64_t slab4, const int32_t* runs, int cc4, int64_t e) {
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(partial);
+  if (!runs) return WgradSlabRun{p4 + e, nchunks, slab4};
+  const int k = (int)(e / cc4);
+  return WgradSlabRun{p4 + (int64_t)runs[2 * k] * cc4 + (e - (int64_t)k * cc4), runs[2 * k + 1], cc4};
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce4(const float* __restrict__ partial, int nchunks, int64_t slab4, float* __restrict__ dW, WgradOut o,
+                                                       const int32_t* __restrict__ runs) {
   __shared__ f32x4 s_q[4][64];
   const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t e = (int64_t)blockIdx.x * 64 + col;
-  const int c0 = (int)((int64_t)nchunks * q / 4), c1 = (int)((int64_t)nchunks * (q + 1) / 4);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (e < slab4) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(partial) + e;
+    const WgradSlabRun r = wgrad_slab_run(partial, nchunks, slab4, runs, o.Cin * o.Cout / 4, e);
+    const int c0 = (int)((int64_t)r.n * q / 4), c1 = (int)((int64_t)r.n * (q + 1) / 4);
 #pragma unroll 4
-    for (int c = c0; c < c1; ++c) s += __builtin_nontemporal_load(p + (int64_t)c * slab4);
+    for (int c = c0; c < c1; ++c) s += __builtin_nontemporal_load(r.p + (int64_t)c * r.stride);
   }
   s_q[q][col] = s;
   __syncthreads();
@@ -2046,6 +2062,7 @@ struct WgradReduceJob {
   float* dW;
   int64_t slab;          // K * Cin * Cout
   int nslabs, wg0;
+  const int32_t* runs;   // per-offset slab runs of a stage 1 on equal pieces (wgrad_slab_run), or null: nslabs chunk slabs
   WgradOut out;
 };
 
@@ -2081,12 +2098,12 @@ static int wgrad_run(const float* X, int64_t n_src, const int32_t* nbr, const fl
     hipLaunchKernelGGL(k_spconv_wgrad_valu, dim3(a.nchunks, K), dim3(256), 0, st, a);
   }
   if (defer && reduce4) {
-    defer->partial = a.partial, defer->dW = dW, defer->slab = slab, defer->nslabs = nslabs, defer->out = out;     // summed later, with the other layers' slabs
+    defer->partial = a.partial, defer->dW = dW, defer->slab = slab, defer->nslabs = nslabs, defer->runs = nullptr, defer->out = out;     // summed later, with the other layers' slabs
     SV_LAUNCH_CHECK();
     return SV_OK;
   }
   if (reduce4)
-    hipLaunchKernelGGL(k_wgrad_reduce4, dim3(sv_div_up(slab / 4, 64)), dim3(256), 0, st, a.partial, nslabs, slab / 4, dW, out);
+    hipLaunchKernelGGL(k_wgrad_reduce4, dim3(sv_div_up(slab / 4, 64)), dim3(256), 0, st, a.partial, nslabs, slab / 4, dW, out, nullptr);
   else
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(sv_grid_1d(slab, 256)), dim3(256), 0, st, a.partial, nslabs, slab, dW, out);
   SV_LAUNCH_CHECK();
@@ -2124,12 +2141,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce4_batch(WgradReduceBatch b)
   const WgradReduceJob& J = b.j[ji];
   const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t slab4 = J.slab / 4, e = (int64_t)((int)blockIdx.x - J.wg0) * 64 + col;
-  const int c0 = (int)((int64_t)J.nslabs * q / 4), c1 = (int)((int64_t)J.nslabs * (q + 1) / 4);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (e < slab4) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(J.partial) + e;
+    const WgradSlabRun r = wgrad_slab_run(J.partial, J.nslabs, slab4, J.runs, J.out.Cin * J.out.Cout / 4, e);
+    const int c0 = (int)((int64_t)r.n * q / 4), c1 = (int)((int64_t)r.n * (q + 1) / 4);
 #pragma unroll 4
-    for (int c = c0; c < c1; ++c) s += __builtin_nontemporal_load(p + (int64_t)c * slab4);
+    for (int c = c0; c < c1; ++c) s += __builtin_nontemporal_load(r.p + (int64_t)c * r.stride);
   }
   s_q[q][col] = s;
   __syncthreads();
@@ -2152,7 +2169,7 @@ extern "C" size_t sv_sparse_conv_wgrad_partial_bytes(int64_t n_rows, int K, int 
 }
 
 // Stage 1 of sv_sparse_conv_wgrad_strided only: the partial slabs go to `partial` (sv_sparse_conv_wgrad_partial_bytes) and *job (10 int64, host) receives
-// {partial, dW, slab, nslabs, stride_k, stride_cin, stride_cout, Cin, Cout, dense = 0} for sv_sparse_conv_wgrad_reduce_batch; layers stage 2 does not
+// {partial, dW, slab, nslabs, stride_k, stride_cin, stride_cout, Cin, Cout, slab runs (device address, 0 = chunk slabs)} for sv_sparse_conv_wgrad_reduce_batch; layers stage 2 does not
 // take in batch form (odd slab sizes, n_rows = 0) are finished here and leave nslabs = 0.
 extern "C" int sv_sparse_conv_wgrad_stage1(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin,
                                            int Cout, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, void* partial, int64_t* job, void* stream) {
@@ -2160,7 +2177,7 @@ extern "C" int sv_sparse_conv_wgrad_stage1(const float* X, int64_t n_src, const 
   WgradReduceJob d{};
   int rc = wgrad_run(X, n_src, nbr, dY, dW, n_rows, K, Cin, Cout, partial, stream, WgradOut{stride_k, stride_cin, stride_cout, Cin, Cout, 0}, &d);
   job[0] = (int64_t)(uintptr_t)d.partial, job[1] = (int64_t)(uintptr_t)d.dW, job[2] = d.slab, job[3] = d.nslabs;
-  job[4] = stride_k, job[5] = stride_cin, job[6] = stride_cout, job[7] = Cin, job[8] = Cout, job[9] = 0;
+  job[4] = stride_k, job[5] = stride_cin, job[6] = stride_cout, job[7] = Cin, job[8] = Cout, job[9] = (int64_t)(uintptr_t)d.runs;
   return rc;
 }
 
@@ -2177,7 +2194,8 @@ extern "C" int sv_sparse_conv_wgrad_reduce_batch(const int64_t* jobs_host, int n
     SV_CHECK_ARG(r[0] && r[1] && r[2] > 0 && r[2] % 4 == 0, "sparse_conv_wgrad_reduce_batch: job %d: bad slab", q);
     WgradReduceJob& J = b.j[b.n];
     J.partial = reinterpret_cast<const float*>((uintptr_t)r[0]), J.dW = reinterpret_cast<float*>((uintptr_t)r[1]), J.slab = r[2], J.nslabs = (int)r[3];
-    J.out = WgradOut{r[4], r[5], r[6], (int)r[7], (int)r[8], (int)r[9]};
+    J.out = WgradOut{r[4], r[5], r[6], (int)r[7], (int)r[8], 0};
+    J.runs = reinterpret_cast<const int32_t*>((uintptr_t)r[9]);
     J.wg0 = wgs;
     wgs += sv_div_up(r[2] / 4, 64);
     if (++b.n == WGR_MAX) {
@@ -2188,4 +2206,590 @@ extern "C" int sv_sparse_conv_wgrad_reduce_batch(const int64_t* jobs_host, int n
   if (b.n > 0) hipLaunchKernelGGL(k_wgrad_reduce4_batch, dim3(wgs), dim3(256), 0, st, b);
   SV_LAUNCH_CHECK();
   return SV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on EQUAL PIECES.
+// What tools/wgrad_trace.py measured on the chunked kernel above (64 -> 64 at 139 k rows, 134 us, 76 TFLOP/s): the busiest SIMD needs 0.77-0.83 of
+// the launch's span for its MFMAs alone while the average SIMD needs 0.54 -- pairs per SIMD max / mean = 1.4-1.6.  A (chunk, offset) workgroup's
+// work follows the offset's density (centre offset: a pair for every row; out-of-plane corners: one row in nine), the dispatcher places workgroups
+// by free slots, not by work, and a workgroup is 40 % of a CU's fair share: the launch ends when its unluckiest CU does.  Dispatch order (heavy
+// offsets first) and half chunks for the heavy offsets were tried and changed nothing (profiles/r04_wgrad_trace.txt).
+// Here the work is cut to fit the machine instead: the table's pairs, in offset-major order, are cut into exactly as many pieces as workgroups are
+// resident (4 or 8 per CU), each piece the same number of pairs up to one 64-row unit.  A piece is a run of 64-row units; it touches one to three
+// offsets and writes one (Cin, Cout) slab per offset it touches (fewer slabs than the chunked form: pieces + K against chunks x K); inside a piece
+// the four waves take pair-exact quarters, so a SIMD's share is even too.  The cuts come from a per-table plan (sv_wgrad_plan_build: unit pair
+// counts, their prefix sums, the cuts, the first slab of every piece, the slab run of every offset), a function of the table alone: same table,
+// same slabs, same summation order -- bitwise reproducible like the chunked form (the VALUES differ from the chunked form's in the last bits: other
+// partial sums).
+// ------------------------------------------------------------------------------------------------
+constexpr int WGE_CUS = 256;              // MI355X
+constexpr int WGE_UNIT = 64;              // rows per unit
+constexpr int WGE_MAX_PIECES = WGE_CUS * 8;
+
+// plan layout (int32; every part padded to a multiple of 4): cut[pieces + 1] | slab0[pieces + 1] | runs[2 K] | prefix[U + 1] (pairs in front of every 64-row unit, offset-major; U = K * units per offset)
+struct WgradPlanPtrs {
+  int32_t *cut, *slab0, *runs, *pre;
+};
+static int wgp_pad4(int n) { return (n + 3) & ~3; }
+static WgradPlanPtrs wgrad_plan_ptrs(void* plan, int pieces, int K) {
+  WgradPlanPtrs p;
+  p.cut = static_cast<int32_t*>(plan);
+  p.slab0 = p.cut + wgp_pad4(pieces + 1);
+  p.runs = p.slab0 + wgp_pad4(pieces + 1);
+  p.pre = p.runs + wgp_pad4(2 * K);
+  return p;
+}
+static int64_t wgrad_units_per_offset(int64_t n_rows) { return (n_rows + WGE_UNIT - 1) / WGE_UNIT; }
+
+extern "C" size_t sv_wgrad_plan_bytes(int64_t n_rows, int K, int pieces) {
+  if (n_rows < 0 || K <= 0 || pieces <= 0) return 0;
+  const int64_t U = wgrad_units_per_offset(n_rows) * K;
+  return ((size_t)(2 * wgp_pad4(pieces + 1) + wgp_pad4(2 * K) + U + 1) * sizeof(int32_t) + 255) / 256 * 256;
+}
+
+// pieces the kernel instance of a layer shape is cut for: four workgroups per CU for the 64-channel-multiple layers (122 VGPRs: four waves per
+// SIMD), eight for the narrower instances (their workgroups are short and latency-bound: the chunked form also ran them on twice the workgroups)
+extern "C" int sv_wgrad_plan_pieces(int Cin, int Cout) {
+  const int ct = (Cin + 15) / 16, nt = Cout / 16;
+  static const int per_cu = getenv("SEEVCN_WGRAD_PIECES_PER_CU") ? atoi(getenv("SEEVCN_WGRAD_PIECES_PER_CU")) : 0;      // measurement switch (1..8)
+  if (per_cu >= 1 && per_cu <= 8) return WGE_CUS * per_cu;
+  return (ct % 4 == 0 && nt % 4 == 0) ? WGE_CUS * 4 : WGE_CUS * 8;
+}
+
+// one workgroup per table: counts -> exclusive prefix (in place; pre[U] = all pairs), the cuts, the first slab of every piece, the slab run of every offset.
+// (The first version walked a thread's ~58 counts with one dependent load per iteration: 47-98 us per table.  Here a thread's run is a whole number of
+// int4, loaded four at a time.)
+struct WgradPlanJob {
+  const int32_t* nbr;
+  int64_t n_rows;
+  int32_t *pre, *cut, *slab0, *runs;
+  int U, nbu, K, pieces, wg0;          // wg0: first workgroup of this table in the batched count launch
+};
+constexpr int WGP_MAX = 12;
+struct WgradPlanBatch {
+  WgradPlanJob j[WGP_MAX];
+  int n;
+};
+static_assert(sizeof(WgradPlanBatch) <= 3900, "kernel argument block");
+
+// pairs of every 64-row unit of every table.  A wave reads 256 consecutive rows of one offset with one int4 per lane (lane l: rows 4 l .. 4 l + 3, so
+// unit j of the four is lanes 16 j .. 16 j + 15) and counts each unit from the four component ballots; a workgroup = 4 waves x WGP_LOADS such loads.
+// (First version: one 4-byte load per lane and one unit per wave, 29 k workgroups for the three tables of a step: 32 us.)
+constexpr int WGP_LOADS = 4;
+constexpr int WGP_ROWS = 4 * 256 * WGP_LOADS;     // rows of one offset per workgroup
+__global__ __launch_bounds__(256) void k_wgrad_plan_count(WgradPlanBatch b) {
+  int ji = 0;
+#pragma unroll
+  for (int q = 1; q < WGP_MAX; ++q) ji += (q < b.n && (int)blockIdx.x >= b.j[q].wg0) ? 1 : 0;
+  const WgradPlanJob& J = b.j[ji];
+  const int wgs_per_k = (int)((J.n_rows + WGP_ROWS - 1) / WGP_ROWS), local = (int)blockIdx.x - J.wg0;
+  const int k = local / wgs_per_k, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int32_t* __restrict__ nb = J.nbr + (int64_t)k * J.n_rows;
+  const bool aligned = ((uintptr_t)nb & 15) == 0;                       // n_rows % 4 != 0 shifts the offsets' rows off 16 bytes
+  const int64_t r0 = (int64_t)(local % wgs_per_k) * WGP_ROWS + (int64_t)wid * (256 * WGP_LOADS);
+  int4 v[WGP_LOADS];
+#pragma unroll
+  for (int q = 0; q < WGP_LOADS; ++q) {
+    const int64_t r = r0 + q * 256 + 4 * lane;
+    if (aligned && r + 3 < J.n_rows) v[q] = *reinterpret_cast<const int4*>(nb + r);
+    else {
+      v[q].x = r < J.n_rows ? nb[r] : -1, v[q].y = r + 1 < J.n_rows ? nb[r + 1] : -1;
+      v[q].z = r + 2 < J.n_rows ? nb[r + 2] : -1, v[q].w = r + 3 < J.n_rows ? nb[r + 3] : -1;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < WGP_LOADS; ++q) {
+    const unsigned long long m0 = __ballot(v[q].x >= 0), m1 = __ballot(v[q].y >= 0), m2 = __ballot(v[q].z >= 0), m3 = __ballot(v[q].w >= 0);
+    if (lane < 4) {
+      const unsigned long long mask = 0xffffull << (16 * lane);
+      const int64_t unit = (r0 + q * 256) / WGE_UNIT + lane;
+      if (unit < J.nbu) J.pre[(int64_t)k * J.nbu + unit] = __popcll(m0 & mask) + __popcll(m1 & mask) + __popcll(m2 & mask) + __popcll(m3 & mask);
+    }
+  }
+}
+
+// 1024 threads: inclusive scan of one value per thread -- shuffles inside a wave, the 16 wave totals through LDS (two barriers)
+__device__ __forceinline__ int wgp_block_scan_inclusive(int* s_wave, int v, int tid) {
+  const int lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  __syncthreads();                                       // s_wave may still be read from the previous scan
+  if (lane == 63) s_wave[wid] = v;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) base += w < wid ? s_wave[w] : 0;
+  return v + base;
+}
+
+__global__ __launch_bounds__(1024) void k_wgrad_plan_cuts(WgradPlanBatch b) {
+  __shared__ int s_wave[16];
+  __shared__ int s_run[1025];                            // pairs in front of every thread's run of units (+ the total): the coarse level of the cut search
+  const WgradPlanJob& J = b.j[blockIdx.x];
+  int32_t* __restrict__ pre = J.pre;
+  const int U = J.U, nbu = J.nbu, K = J.K, pieces = J.pieces;
+  const int tid = threadIdx.x;
+  // a thread's run: `per` counts, a multiple of 16, so that it is whole groups of four int4 (pre is 16-byte aligned: the plan's parts are multiples
+  // of 4 ints); only the table's last run has a remainder
+  const int per = (((U + 1023) / 1024) + 15) & ~15, b0 = min(U, tid * per), b1 = min(U, b0 + per);
+  // runs of at most 64 counts (tables up to 65 k units: every table of the benchmarked step) stay in registers between the sum and the write-back:
+  // sixteen int4 loads in flight once, instead of two passes of four dependent rounds
+  const bool in_regs = per <= 64;
+  int4 keep[16];
+  int sum = 0;
+  if (in_regs) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int u = b0 + 4 * q;
+      if (u + 4 <= b1) keep[q] = *reinterpret_cast<const int4*>(pre + u);
+      else keep[q] = make_int4(u < b1 ? pre[u] : 0, u + 1 < b1 ? pre[u + 1] : 0, u + 2 < b1 ? pre[u + 2] : 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum += (keep[q].x + keep[q].y) + (keep[q].z + keep[q].w);
+  } else {
+    int u = b0;
+    for (; u + 16 <= b1; u += 16) {
+      const int4 v0 = *reinterpret_cast<const int4*>(pre + u), v1 = *reinterpret_cast<const int4*>(pre + u + 4);
+      const int4 v2 = *reinterpret_cast<const int4*>(pre + u + 8), v3 = *reinterpret_cast<const int4*>(pre + u + 12);
+      sum += (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w) + (v2.x + v2.y + v2.z + v2.w) + (v3.x + v3.y + v3.z + v3.w);
+    }
+    for (; u < b1; ++u) sum += pre[u];
+  }
+  const int incl = wgp_block_scan_inclusive(s_wave, sum, tid);
+  s_run[tid] = incl - sum;
+  if (tid == 1023) s_run[1024] = incl;
+  if (in_regs) {
+    int run = incl - sum;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int u = b0 + 4 * q;
+      int4 o;
+      o.x = run, run += keep[q].x;
+      o.y = run, run += keep[q].y;
+      o.z = run, run += keep[q].z;
+      o.w = run, run += keep[q].w;
+      if (u + 4 <= b1) *reinterpret_cast<int4*>(pre + u) = o;
+      else {
+        if (u < b1) pre[u] = o.x;
+        if (u + 1 < b1) pre[u + 1] = o.y;
+        if (u + 2 < b1) pre[u + 2] = o.z;
+      }
+    }
+  } else {
+    int run = incl - sum, u = b0;
+    for (; u + 16 <= b1; u += 16) {
+      int4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const int4*>(pre + u + 4 * q);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int4 o;
+        o.x = run, run += v[q].x;
+        o.y = run, run += v[q].y;
+        o.z = run, run += v[q].z;
+        o.w = run, run += v[q].w;
+        *reinterpret_cast<int4*>(pre + u + 4 * q) = o;
+      }
+    }
+    for (; u < b1; ++u) {
+      const int c = pre[u];
+      pre[u] = run;
+      run += c;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const long long total = s_run[1024];
+  if (tid == 0) pre[U] = (int)total;
+  int32_t* __restrict__ cut = J.cut;
+  // cut[i] = first unit whose pairs-before reach i * total / pieces (a unit belongs to the piece its FIRST pair falls into; empty units go with a
+  // neighbour); pieces may be empty (a table with fewer units than pieces).  Two levels: the run in LDS, then the unit inside the run.
+  for (int i = tid; i <= pieces; i += 1024) {
+    const long long target = total * i / pieces;
+    int lo;
+    if (i == pieces) lo = U;
+    else if (i == 0) lo = 0;
+    else {
+      // last run t whose first unit has fewer than `target` pairs in front of it: the answer lies in (t * per, (t + 1) * per]
+      int a = 0, c = 1023;
+      while (a < c) {
+        const int mid = (a + c + 1) >> 1;
+        if (s_run[mid] < target && mid * per < U) a = mid;
+        else c = mid - 1;
+      }
+      lo = min(U, a * per);
+      int hi = min(U, (a + 1) * per);                   // pre[hi] >= target (the next run's first unit, or the total)
+      while (lo < hi) {                                  // smallest u in [lo, hi] with pre[u] >= target
+        const int mid = (lo + hi) >> 1;
+        const int pm = mid == U ? (int)total : pre[mid];
+        if (pm >= target) hi = mid;
+        else lo = mid + 1;
+      }
+    }
+    cut[i] = lo;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // slabs: one per (piece, offset it touches), numbered in piece order
+  static_assert(WGE_MAX_PIECES <= 2048, "two pieces per thread");
+  int seg[2] = {0, 0}, first[2];
+  for (int q = 0; q < 2; ++q) {
+    const int i = tid + q * 1024;
+    if (i < pieces) {
+      const int u0 = cut[i], u1 = cut[i + 1];
+      seg[q] = u0 < u1 ? (u1 - 1) / nbu - u0 / nbu + 1 : 0;
+    }
+  }
+  int carry = 0;
+  for (int q = 0; q < 2; ++q) {
+    const int inc = wgp_block_scan_inclusive(s_wave, seg[q], tid);
+    first[q] = carry + inc - seg[q];
+    __syncthreads();
+    if (tid == 1023) s_run[0] = inc;
+    __syncthreads();
+    carry += s_run[0];
+  }
+  int32_t* __restrict__ slab0 = J.slab0;
+  int32_t* __restrict__ runs = J.runs;
+  for (int q = 0; q < 2; ++q) {
+    const int i = tid + q * 1024;
+    if (i < pieces) {
+      slab0[i] = first[q];
+      if (i == pieces - 1) slab0[pieces] = first[q] + seg[q];
+      const int u0 = cut[i], u1 = cut[i + 1];
+      if (u0 < u1) {
+        const int kf = u0 / nbu, kl = (u1 - 1) / nbu;
+        for (int k = kf; k <= kl; ++k) {
+          if (u0 <= k * nbu) runs[2 * k] = first[q] + (k - kf);                     // holds the offset's first unit: its run starts here
+          if (u1 >= (k + 1) * nbu) runs[2 * k + 1] = first[q] + (k - kf);           // holds its last unit: the run's last slab (turned into a count below)
+        }
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int k = tid; k < K; k += 1024) runs[2 * k + 1] = runs[2 * k + 1] - runs[2 * k] + 1;
+}
+
+static int wgrad_plan_job(WgradPlanJob& J, const int32_t* nbr, int64_t n_rows, int K, int pieces, void* plan, const char* who) {
+  SV_CHECK_ARG(n_rows >= 1 && K >= 1 && K <= 1024 && plan && nbr, "%s: bad arguments", who);
+  SV_CHECK_ARG(pieces >= 1 && pieces <= WGE_MAX_PIECES, "%s: 1..%d pieces", who, WGE_MAX_PIECES);
+  SV_CHECK_ARG((uintptr_t)plan % 16 == 0, "%s: the plan must be 16-byte aligned", who);
+  const int64_t nbu = wgrad_units_per_offset(n_rows), U = nbu * K;
+  SV_CHECK_ARG(U < (1ll << 30) && n_rows * (int64_t)K < (1ll << 31), "%s: table too large for 32-bit unit indices / pair counts", who);
+  const WgradPlanPtrs p = wgrad_plan_ptrs(plan, pieces, K);
+  J.nbr = nbr, J.n_rows = n_rows, J.pre = p.pre, J.cut = p.cut, J.slab0 = p.slab0, J.runs = p.runs;
+  J.U = (int)U, J.nbu = (int)nbu, J.K = K, J.pieces = pieces, J.wg0 = 0;
+  return SV_OK;
+}
+static void wgrad_plan_launch(WgradPlanBatch& b, int wgs, hipStream_t st) {
+  hipLaunchKernelGGL(k_wgrad_plan_count, dim3(wgs), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(k_wgrad_plan_cuts, dim3(b.n), dim3(1024), 0, st, b);
+}
+
+extern "C" int sv_wgrad_plan_build(const int32_t* nbr, int64_t n_rows, int K, int pieces, void* plan, void* stream) {
+  WgradPlanBatch b;
+  b.n = 1;
+  if (int rc = wgrad_plan_job(b.j[0], nbr, n_rows, K, pieces, plan, "sv_wgrad_plan_build")) return rc;
+  wgrad_plan_launch(b, (int)((n_rows + WGP_ROWS - 1) / WGP_ROWS) * K, sv_stream(stream));
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// the plans of several tables in two launches; jobs_host: n_jobs rows of 8 int64 = {nbr, n_rows, K, pieces, plan, 0, 0, 0} (device addresses)
+extern "C" int sv_wgrad_plan_build_batch(const int64_t* jobs_host, int n_jobs, void* stream) {
+  SV_CHECK_ARG(n_jobs >= 0 && (jobs_host || n_jobs == 0), "sv_wgrad_plan_build_batch: bad arguments");
+  hipStream_t st = sv_stream(stream);
+  WgradPlanBatch b;
+  b.n = 0;
+  int wgs = 0;
+  for (int q = 0; q < n_jobs; ++q) {
+    const int64_t* r = jobs_host + 8 * q;
+    WgradPlanJob& J = b.j[b.n];
+    if (int rc = wgrad_plan_job(J, reinterpret_cast<const int32_t*>((uintptr_t)r[0]), r[1], (int)r[2], (int)r[3], reinterpret_cast<void*>((uintptr_t)r[4]),
+                                "sv_wgrad_plan_build_batch"))
+      return rc;
+    J.wg0 = wgs;
+    wgs += (int)((J.n_rows + WGP_ROWS - 1) / WGP_ROWS) * J.K;
+    if (++b.n == WGP_MAX) {
+      wgrad_plan_launch(b, wgs, st);
+      b.n = 0, wgs = 0;
+    }
+  }
+  if (b.n > 0) wgrad_plan_launch(b, wgs, st);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+struct WgradPlanView {
+  const int32_t* cut;
+  const int32_t* slab0;
+  const int32_t* pre;       // pairs in front of every unit (U + 1)
+  int pieces, nbu;
+};
+
+// One workgroup per piece.  Per offset the piece touches (a segment): the four waves compact the segment's pairs into ONE list in LDS -- each wave a
+// contiguous quarter of the units, written at the position the plan's prefix sums give (so the list is in row order and no counts are exchanged) --
+// and then take PAIR-EXACT quarters of the list through the operand ring of the chunked kernel.  Units are 64 rows: dealt to the waves unit by unit a
+// centre-offset piece (19 units) gave its waves 5 / 5 / 5 / 4 units, the fourth SIMD of every CU 20 % less work and every workgroup a wait at its
+// reduction (pairs per SIMD max / mean 1.13); and an out-of-plane offset (7 pairs per unit) started an MFMA loop per ~28 pairs (30-50 % of such a
+// piece's life in loop start-ups).  Here a wave starts ONE loop per segment, over a quarter of its pairs up to one 4-pair step.
+// A segment longer than the list (tables with more than WGE_LIST_CAP pairs per piece) runs in several chunks, cut at units by the prefix sums.
+constexpr int WGE_LIST_CAP = 1536;         // pairs per chunk: 12 KB
+constexpr int WGE_READ = 8;                // units whose table entries a wave requests at once
+
+template <int CT, int NTL, int DBG = 0>
+__global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad_eq(WgradArgs a, WgradPlanView pl) {
+  __shared__ int2 plist[WGE_LIST_CAP + 32];
+  __shared__ float red[CT * NTL * 256];
+  __shared__ int s_chunk[2];
+  const int piece = blockIdx.x % pl.pieces, zgroup = blockIdx.x / pl.pieces;
+  const int u0 = pl.cut[piece], u1 = pl.cut[piece + 1];
+  if (u0 >= u1) return;
+  int slab = pl.slab0[piece];
+  const int ngroups_n = (a.Cout / 16) / NTL;
+  const int c_base = (zgroup / ngroups_n) * CT * 16, n_base = (zgroup % ngroups_n) * NTL * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, kk = lane >> 4;
+  const unsigned long long t_start = (DBG & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long t_pro = 0ull, t_loop = 0ull, t_mark = t_start, t_tail = 0ull;
+  unsigned tr_pairs = 0, tr_passes = 0;
+  using XV = typename WgVec<CT>::type;
+  using YV = typename WgVec<NTL>::type;
+  const bool x_in = CT > 1 || c_base + li < a.Cin;
+  const uint32_t xconst = (uint32_t)(x_in ? c_base + CT * li : 0) * 4u, yconst = (uint32_t)(n_base + NTL * li) * 4u;
+  const uint32_t xrow = (uint32_t)a.Cin * 4u, yrow = (uint32_t)a.Cout * 4u;
+  f32x4 acc[CT][NTL];
+  auto issue = [&](int p, XV& xs, YV& ys) {
+    const int2 jr = plist[p];                                // byte offsets; entries past the wave's share are other pairs or the padding (row 0)
+    wg_gload_s(xs, (uint32_t)jr.x + xconst, a.X);
+    wg_gload_s(ys, (uint32_t)jr.y + yconst, a.dY);
+  };
+  auto consume = [&](int p0, int pend, XV& xs, YV& ys) {
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(xs), "+v"(ys));
+    if (p0 >= pend) return;                                  // wave-uniform: a dummy step of the ring's tail
+    if (p0 + 4 > pend || !(CT > 1 || c_base + 16 <= a.Cin)) {                      // wave-uniform: the tail mask only in a share's last step
+      const bool ok = p0 + kk < pend;
+      if (!(ok && x_in)) xs = XV{};
+      if (!ok) ys = YV{};
+      asm volatile("" : "+v"(xs), "+v"(ys));                 // keeps this a BRANCH: if-converted, its selects ran in every step
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg_elem(xs, c), wg_elem(ys, t), acc[c][t], 0, 0, 0);
+  };
+
+  for (int us = u0; us < u1;) {                              // one segment per offset the piece touches
+    const int k = us / pl.nbu, ue = min(u1, (k + 1) * pl.nbu);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int32_t* nb = a.nbr + (int64_t)k * a.n_rows;
+    for (int uc = us; uc < ue;) {                            // chunks of at most WGE_LIST_CAP pairs (normally one: a piece is total / pieces pairs)
+      if (tid == 0) {
+        const int p_first = pl.pre[uc];
+        int nu = ue - uc;
+        if (pl.pre[ue] - p_first > WGE_LIST_CAP) {           // largest run of units that fits (a unit is at most 64 pairs: at least 24 units)
+          int lo = 1, hi = nu;
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pl.pre[uc + mid] - p_first <= WGE_LIST_CAP) lo = mid;
+            else hi = mid - 1;
+          }
+          nu = lo;
+        }
+        s_chunk[0] = nu, s_chunk[1] = pl.pre[uc + nu] - p_first;
+      }
+      __syncthreads();                                       // also: every wave is done with the previous chunk's list
+      const int nu = s_chunk[0], n = s_chunk[1];
+      // the short compaction goes in front of the other waves' MFMA streams: the fourth workgroup of a CU (youngest waves) spent 100 k cycles in it behind
+      // three older waves' loops, the first 40 k (tools/wgrad_trace.py); 108.1 -> 106.6 us at 139 k rows.  SEEVCN_WGRAD_PRIO=0: off (A/B)
+      if (a.xcd_order) __builtin_amdgcn_s_setprio(3);
+      // compaction: wave w takes the units [uc + w nu / 4, uc + (w + 1) nu / 4) and writes their pairs where the prefix sums put them
+      {
+        const int ua = uc + (int)((int64_t)nu * wid / 4), ub = uc + (int)((int64_t)nu * (wid + 1) / 4);
+        int pos0 = ua < ub ? pl.pre[ua] - pl.pre[uc] : 0;
+        for (int u = ua; u < ub; u += WGE_READ) {
+          int32_t jv[WGE_READ];
+#pragma unroll
+          for (int s = 0; s < WGE_READ; ++s) {
+            const int64_t r = (int64_t)(u + s - k * pl.nbu) * WGE_UNIT + lane;
+            jv[s] = (u + s < ub && r < a.n_rows) ? nb[r] : -1;
+          }
+#pragma unroll
+          for (int s = 0; s < WGE_READ; ++s) {
+            const unsigned long long m = __ballot(jv[s] >= 0);
+            if (jv[s] >= 0) {
+              const uint32_t r = (uint32_t)((u + s - k * pl.nbu) * WGE_UNIT + lane);
+              plist[pos0 + __popcll(m & ((1ull << lane) - 1ull))] = make_int2((int)((uint32_t)jv[s] * xrow), (int)(r * yrow));
+            }
+            pos0 += __popcll(m);
+          }
+        }
+        if (wid == 0 && lane < 32) plist[n + lane] = make_int2(0, 0);     // what the ring's tail loads of the last share read: row 0, masked
+      }
+      __syncthreads();
+      if constexpr (DBG & 16) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        t_pro += t - t_mark, t_mark = t, ++tr_passes;
+      }
+      if (a.xcd_order) __builtin_amdgcn_s_setprio(0);
+      // pair-exact shares, whole 4-pair steps: wave w takes the pairs [w q, min(n, (w + 1) q))
+      const int q = ((n + 15) >> 4) << 2, pb = wid * q, pend = min(n, pb + q);
+      if (pb < pend) {
+        if constexpr (DBG & 16) tr_pairs += (unsigned)(pend - pb);
+        XV x0, x1, x2, x3;
+        YV y0, y1, y2, y3;
+        issue(pb + kk, x0, y0);
+        issue(pb + 4 + kk, x1, y1);
+        issue(pb + 8 + kk, x2, y2);
+        for (int p0 = pb; p0 < pend; p0 += 16) {
+          issue(p0 + 12 + kk, x3, y3);
+          consume(p0, pend, x0, y0);
+          issue(p0 + 16 + kk, x0, y0);
+          consume(p0 + 4, pend, x1, y1);
+          issue(p0 + 20 + kk, x1, y1);
+          consume(p0 + 8, pend, x2, y2);
+          issue(p0 + 24 + kk, x2, y2);
+          consume(p0 + 12, pend, x3, y3);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2));   // retire the tail's dummy loads
+      }
+      if constexpr (DBG & 16) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        t_loop += t - t_mark, t_mark = t;
+      }
+      uc += nu;
+    }
+    // fixed-order reduction over the 4 waves (wave 0 stores, waves 1..3 add in turn), then the segment's slab
+    for (int w = 0; w < 4; ++w) {
+      if (wid == w) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+          for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* d = &red[((c * NTL + t) * 4 + r) * 64 + lane];
+              *d = (w == 0 ? 0.f : *d) + acc[c][t][r];
+            }
+      }
+      __syncthreads();
+    }
+    float* out = a.partial + ((int64_t)slab * a.Cin) * a.Cout;
+    for (int e = tid; e < CT * NTL * 256; e += 256) {
+      const int ln = e & 63, r = (e >> 6) & 3, tile = e >> 8;
+      const int c = tile / NTL, t = tile - c * NTL;
+      const int crow = c_base + CT * ((ln >> 4) * 4 + r) + c;
+      if (crow < a.Cin) out[(int64_t)crow * a.Cout + n_base + NTL * (ln & 15) + t] = red[e];
+    }
+    ++slab, us = ue;
+    __syncthreads();                                         // `red` is rewritten by the next segment's reduction
+    if constexpr (DBG & 16) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_tail += t - t_mark, t_mark = t;
+    }
+  }
+  if constexpr (DBG & 16) {
+    if (a.trace && lane == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+      unsigned hw = 0, xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long* o = a.trace + ((size_t)blockIdx.x * 4 + wid) * 8;
+      // word 5: t_end - (time behind the last loop of every segment), so that tools/wgrad_trace.py's "after the last pass" is the sum over segments
+      o[0] = t_start, o[1] = t_pro, o[2] = t_loop, o[3] = t_end, o[4] = ((unsigned long long)xcc << 32) | hw, o[5] = t_end - t_tail,
+      o[6] = ((unsigned long long)tr_passes << 32) | tr_pairs, o[7] = ((unsigned long long)(u0 / pl.nbu) << 32) | (unsigned)piece;
+    }
+  }
+}
+
+template <int CT, int NTL>
+static void launch_wgrad_eq(const WgradArgs& a, const WgradPlanView& pl, hipStream_t st) {
+  const int groups = (((a.Cin + 15) / 16) / CT) * ((a.Cout / 16) / NTL);
+  const unsigned blocks = (unsigned)(pl.pieces * groups);
+  if constexpr (CT == 4 && NTL == 4) {
+    if (g_wgrad_trace) {
+      WgradArgs t = a;
+      t.trace = g_wgrad_trace;
+      hipLaunchKernelGGL((k_spconv_wgrad_eq<CT, NTL, 16>), dim3(blocks), dim3(256), 0, st, t, pl);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_spconv_wgrad_eq<CT, NTL>), dim3(blocks), dim3(256), 0, st, a, pl);
+}
+
+// 1 iff the equal-pieces kernel takes this layer: an MFMA tile shape, operand rows addressable with 32-bit byte offsets
+// -- AND it pays: the 64-channel-multiple layers (MFMA-bound: 133 -> 121 us at 139 k rows) with enough table to give the chunked form its ~1000
+// workgroups.  The narrow layers are bound by their gathers, not by the matrix pipe: offset-major pieces take their rows through eight L2s 27 times
+// (16 -> 16 at 240 k rows: 27 -> 79 us), and a small table pays for pieces + K slabs it does not need (64 -> 128, K = 3, 59 k rows: 42 -> 57 us).
+extern "C" int sv_wgrad_planned_applies(int64_t n_src, int64_t n_rows, int K, int Cin, int Cout) {
+  const WgradShape w = wgrad_shape(n_rows > 0 ? n_rows : 1, K, Cin, Cout);
+  if (!w.mfma || n_rows < 1 || n_src < 1) return 0;
+  const char* fe = getenv("SEEVCN_WGRAD_PLANNED_ALL");       // tests: every MFMA shape and size (read per call: a test sets it for itself)
+  const int force = fe ? atoi(fe) : 0;
+  if (!force && !(w.tiles_c == 4 && w.tiles_n == 4 && n_rows * (int64_t)K >= (1 << 20))) return 0;
+  if ((uint64_t)n_src * (uint64_t)Cin * 4u >= 0xffffffffull || (uint64_t)n_rows * (uint64_t)Cout * 4u >= 0xffffffffull) return 0;
+  return ((int64_t)K * Cin * Cout) % 4 == 0 && Cout % 4 == 0;
+}
+
+// bytes of partial slabs the equal-pieces stage 1 writes: one (Cin, Cout) slab per (piece, offset it touches) <= pieces + K - 1
+extern "C" size_t sv_sparse_conv_wgrad_planned_bytes(int K, int Cin, int Cout) {
+  return ((size_t)(sv_wgrad_plan_pieces(Cin, Cout) + K) * Cin * Cout * sizeof(float) + 255) / 256 * 256;
+}
+
+static int wgrad_planned_run(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin, int Cout,
+                             const void* plan, void* partial, void* stream, WgradOut out, WgradReduceJob* defer) {
+  SV_CHECK_ARG(X && nbr && dY && dW && plan && partial, "sparse_conv_wgrad_planned: null pointer");
+  SV_CHECK_ARG(sv_wgrad_planned_applies(n_src, n_rows, K, Cin, Cout), "sparse_conv_wgrad_planned: not for this layer (ask sv_wgrad_planned_applies first)");
+  SV_CHECK_ARG((uintptr_t)dW % 16 == 0 && (uintptr_t)partial % 16 == 0, "sparse_conv_wgrad_planned: 16-byte alignment");
+  const int pieces = sv_wgrad_plan_pieces(Cin, Cout);
+  const WgradPlanPtrs p = wgrad_plan_ptrs(const_cast<void*>(plan), pieces, K);
+  const WgradShape w = wgrad_shape(n_rows, K, Cin, Cout);
+  hipStream_t st = sv_stream(stream);
+  static const int prio = getenv("SEEVCN_WGRAD_PRIO") ? atoi(getenv("SEEVCN_WGRAD_PRIO")) : 1;
+  WgradArgs a{X, nbr, dY, static_cast<float*>(partial), n_rows, K, Cin, Cout, 0, 0, prio, n_src};
+  const WgradPlanView pl{p.cut, p.slab0, p.pre, pieces, (int)wgrad_units_per_offset(n_rows)};
+  if (w.tiles_c == 4) launch_wgrad_eq<4, 4>(a, pl, st);
+  else if (w.tiles_c == 2 && w.tiles_n == 4) launch_wgrad_eq<2, 4>(a, pl, st);
+  else if (w.tiles_c == 2) launch_wgrad_eq<2, 2>(a, pl, st);
+  else if (w.tiles_n == 2) launch_wgrad_eq<1, 2>(a, pl, st);
+  else launch_wgrad_eq<1, 1>(a, pl, st);
+  const int64_t slab = (int64_t)K * Cin * Cout;
+  if (defer) {
+    defer->partial = a.partial, defer->dW = dW, defer->slab = slab, defer->nslabs = 1, defer->runs = p.runs, defer->out = out;
+  } else {
+    hipLaunchKernelGGL(k_wgrad_reduce4, dim3(sv_div_up(slab / 4, 64)), dim3(256), 0, st, a.partial, 1, slab / 4, dW, out, p.runs);
+  }
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// dW as sv_sparse_conv_wgrad_strided writes it (stride_k = 0: contiguous (K, Cin, Cout)), stage 1 on the equal pieces of `plan` (sv_wgrad_plan_build of
+// THIS table with sv_wgrad_plan_pieces(Cin, Cout) pieces); partial: sv_sparse_conv_wgrad_planned_bytes
+extern "C" int sv_sparse_conv_wgrad_planned(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin, int Cout,
+                                            int64_t stride_k, int64_t stride_cin, int64_t stride_cout, const void* plan, void* partial, void* stream) {
+  SV_CHECK_ARG((stride_k == 0 && stride_cin == 0 && stride_cout == 0) || (stride_k > 0 && stride_cin > 0 && stride_cout > 0),
+               "sparse_conv_wgrad_planned: strides all zero (contiguous) or all positive");
+  const WgradOut out = stride_k ? WgradOut{stride_k, stride_cin, stride_cout, Cin, Cout, 0} : WgradOut{0, 0, 0, Cin, Cout, 1};
+  return wgrad_planned_run(X, n_src, nbr, dY, dW, n_rows, K, Cin, Cout, plan, partial, stream, out, nullptr);
+}
+
+// stage 1 only; *job as sv_sparse_conv_wgrad_stage1 writes it, for sv_sparse_conv_wgrad_reduce_batch
+extern "C" int sv_sparse_conv_wgrad_planned_stage1(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin,
+                                                   int Cout, int64_t stride_k, int64_t stride_cin, int64_t stride_cout, const void* plan, void* partial, int64_t* job,
+                                                   void* stream) {
+  SV_CHECK_ARG(job && stride_k > 0 && stride_cin > 0 && stride_cout > 0, "sparse_conv_wgrad_planned_stage1: bad arguments");
+  WgradReduceJob d{};
+  int rc = wgrad_planned_run(X, n_src, nbr, dY, dW, n_rows, K, Cin, Cout, plan, partial, stream, WgradOut{stride_k, stride_cin, stride_cout, Cin, Cout, 0}, &d);
+  job[0] = (int64_t)(uintptr_t)d.partial, job[1] = (int64_t)(uintptr_t)d.dW, job[2] = d.slab, job[3] = d.nslabs;
+  job[4] = stride_k, job[5] = stride_cin, job[6] = stride_cout, job[7] = Cin, job[8] = Cout, job[9] = (int64_t)(uintptr_t)d.runs;
+  return rc;
 }

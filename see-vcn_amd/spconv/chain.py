@@ -187,19 +187,22 @@ class SparseChainFunction(torch.autograd.Function):
             ext[L - 1] = torch.zeros((rulebooks[-1].n_out, blocks[-1].cout), dtype=torch.float32, device=dev)
         # one allocation for the work buffers: per block [gradient of the conv output | gradient of the block's input (blocks >= 1) | dgamma | dbeta],
         # one for the weight gradients (in the parameters' own layout)
-        boffs, total, woffs, wtotal, wbytes, poffs = [], 0, [], 0, 0, []
+        boffs, total, woffs, wtotal, wbytes, poffs, wplans = [], 0, [], 0, 0, [], []
         for k, (b, rb) in enumerate(zip(blocks, rulebooks)):
             n, nin = rb.n_out * b.cout, (rb.n_in * b.cin if k > 0 else 0)
             boffs.append((total, total + n, total + n + nin, total + n + nin + b.cout))
             total += n + nin + 2 * b.cout
             woffs.append(wtotal)
             wtotal += b.K * b.cin * b.cout
+            wp = rb.wgrad_plan(b.cin, b.cout)                        # equal-pieces plan of the table (built with the index; here only if it was not)
+            wplans.append(0 if wp is None else wp.data_ptr())
             if DEFER_WGRAD_REDUCE:                                   # every layer keeps its own partial slabs until the one reduction at the end of the list
                 poffs.append(wbytes)
-                wbytes += lib.sv_sparse_conv_wgrad_partial_bytes(rb.n_out, b.K, b.cin, b.cout)
+                wbytes += lib.sv_sparse_conv_wgrad_partial_bytes(rb.n_out, b.K, b.cin, b.cout) if wp is None else lib.sv_sparse_conv_wgrad_planned_bytes(b.K, b.cin, b.cout)
             else:
                 poffs.append(0)
-                wbytes = max(wbytes, lib.sv_sparse_conv_wgrad_scratch_bytes(rb.n_out, b.K, b.cin, b.cout))
+                wbytes = max(wbytes, lib.sv_sparse_conv_wgrad_scratch_bytes(rb.n_out, b.K, b.cin, b.cout) if wp is None
+                             else lib.sv_sparse_conv_wgrad_planned_bytes(b.K, b.cin, b.cout))
         work = torch.empty((total,), dtype=torch.float32, device=dev)
         wgrads = torch.empty((wtotal,), dtype=torch.float32, device=dev)
         wscratch = _lib.workspace.scratch("wgrad_layers" if DEFER_WGRAD_REDUCE else "wgrad", wbytes, dev)
@@ -218,7 +221,7 @@ class SparseChainFunction(torch.autograd.Function):
                              p=(a_conv, dy_ptr, gamma.data_ptr(), beta.data_ptr(), a_mean, a_istd, scratch.data_ptr(), o_dconv, o_dg, o_db)))
             n_part_bwd = 0
             rows.append(_row(OP_WGRAD_DEFERRED if DEFER_WGRAD_REDUCE else OP_WGRAD, i=(b.K, b.cin, b.cout, rb.n_in), n=(rb.n_out, b.cin, 1, b.K * b.cin),
-                             p=(x_in, rb.addr("nbr_out"), o_dconv, wbase + 4 * woffs[k], wscratch.data_ptr() + poffs[k])))
+                             p=(x_in, rb.addr("nbr_out"), o_dconv, wbase + 4 * woffs[k], wscratch.data_ptr() + poffs[k], wplans[k] or None)))
             if k > 0:
                 a_rows, a_perm, a_masks_p, a_tiles, g, rev = rb.plan_addrs("bwd", b.cout, b.cin)
                 res = ext[k - 1]

@@ -197,6 +197,8 @@ def prebuild_rulebooks(root, x, with_backward=True, n0_dev=None):
                 if rb.subm and rb.out_indices.data_ptr() == x.indices.data_ptr():
                     rb.out_indices = x.indices
                 x.indice_dict[key] = rb
+            if with_backward:                         # the weight gradients' equal-pieces plans, one per table, all in two launches behind the tables
+                Fsp.build_wgrad_plans([(rulebooks[sp.key], sp.cin, sp.cout) for sp in specs])
             return x
         if n0_dev is not None:
             from .. import _lib
@@ -234,6 +236,7 @@ def _prebuild_layer_by_layer(root, x, with_backward):
             rb.plan("fwd", m.in_channels, m.out_channels)
             if with_backward:
                 rb.plan("bwd", m.out_channels, m.in_channels)
+                rb.wgrad_plan(m.in_channels, m.out_channels)
         if not m.subm:
             idx, shape = rb.out_indices, list(rb.out_shape)
     for m, idx, shape in todo:                            # pass 2: no host reads from here on
@@ -247,6 +250,7 @@ def _prebuild_layer_by_layer(root, x, with_backward):
         rb.plan("fwd", m.in_channels, m.out_channels)
         if with_backward:
             rb.plan("bwd", m.out_channels, m.in_channels)
+            rb.wgrad_plan(m.in_channels, m.out_channels)
 
 
 def refresh_weight_fragments(root):

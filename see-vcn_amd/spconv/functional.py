@@ -208,6 +208,30 @@ class Rulebook(_ArenaViews):
         self._plan_results[key] = (out,)
         return out
 
+    def wgrad_plan(self, cin, cout):
+        """Device plan of the equal-pieces weight gradient (sv_wgrad_plan_build) for a (cin -> cout) layer on this table, or None when that kernel does
+        not take the layer (sv_wgrad_planned_applies; SEEVCN_WGRAD_PLANNED=0 forces the chunked kernel for A/B runs).  One plan per table and piece
+        count: the layers that share an indice_key share it."""
+        if not WGRAD_PLANNED or self.n_out == 0:
+            return None
+        key = ("wgrad", int(cin), int(cout))
+        hit = self._plan_results.get(key)
+        if hit is not None:
+            return hit[0]
+        lib = _lib.load()
+        out = None
+        if lib.sv_wgrad_planned_applies(int(self.n_in), int(self.n_out), int(self.K), int(cin), int(cout)):
+            pieces = lib.sv_wgrad_plan_pieces(int(cin), int(cout))
+            plans = self.__dict__.setdefault("_wgrad_plans", {})
+            if pieces not in plans:
+                nbr = self.nbr_out
+                buf = torch.empty((lib.sv_wgrad_plan_bytes(self.n_out, int(self.K), pieces),), dtype=torch.uint8, device=nbr.device)
+                _lib.check(lib.sv_wgrad_plan_build(_lib.ptr(nbr), self.n_out, int(self.K), pieces, buf.data_ptr(), _lib.stream()), "sv_wgrad_plan_build")
+                plans[pieces] = buf
+            out = plans[pieces]
+        self._plan_results[key] = (out,)
+        return out
+
     def pair_counts(self):
         lib = _lib.load()
         counts = torch.empty((self.K,), dtype=torch.int32, device=self.nbr_out.device)
@@ -220,6 +244,7 @@ class Rulebook(_ArenaViews):
 CELLMAP_MAX_BYTES = int(os.environ.get("SEEVCN_CELLMAP_MAX_BYTES", 24 << 30))
 FUSED_PLAN = os.environ.get("SEEVCN_FUSED_PLAN", "1") != "0"     # 0: plans built by the four separate kernels (A/B runs, tests)
 USE_PLAN = os.environ.get("SEEVCN_SPCONV_PLAN", "1") != "0"      # 0: every layer on the plain kernels (A/B runs, tests)
+WGRAD_PLANNED = os.environ.get("SEEVCN_WGRAD_PLANNED", "1") != "0"   # 0: weight gradients on (row chunk, offset) workgroups instead of equal pieces (A/B runs, tests)
 
 
 def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1)):
@@ -606,24 +631,69 @@ def gather_gemm(x, nbr, wt, n_rows, bias=None, scale=None, shift=None, residual=
     return y
 
 
-def wgrad(x, nbr, dy, K, cin, cout, like=None):
+def wgrad(x, nbr, dy, K, cin, cout, like=None, plan=None):
     """dW (K, C_in, C_out).  `like`: a (K, C_in, C_out) VIEW of the parameter (SparseConvolution.weight_kio()); the gradient is then written
     in that view's memory layout (same strides over a fresh dense buffer), so that autograd's way back through the permute / reshape of the
-    view is a view again instead of a transposing copy (one small launch per layer and step otherwise)."""
+    view is a view again instead of a transposing copy (one small launch per layer and step otherwise).  `plan`: Rulebook.wgrad_plan(cin, cout) of
+    the table -- stage 1 then runs on equal pieces (sv_sparse_conv_wgrad_planned) instead of (row chunk, offset) workgroups."""
     lib = _lib.load()
     n_rows = dy.shape[0]
-    scratch = _lib.workspace.scratch("wgrad", lib.sv_sparse_conv_wgrad_scratch_bytes(n_rows, K, cin, cout), dy.device)
     xs, ns, ds = (_lib.ptr(x) if x.numel() else None), (_lib.ptr(nbr) if nbr.numel() else None), (_lib.ptr(dy) if n_rows else None)
     st = None if like is None else tuple(int(v) for v in like.stride())
-    if st is not None and not like.is_contiguous() and min(st) > 0 and sorted(st)[0] == 1 and _dense_permutation(tuple(like.shape), st):
+    strided = st is not None and not like.is_contiguous() and min(st) > 0 and sorted(st)[0] == 1 and _dense_permutation(tuple(like.shape), st)
+    if strided:
         dw = torch.empty_strided((K, cin, cout), st, dtype=torch.float32, device=dy.device)
+    else:
+        dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dy.device)
+        st = (0, 0, 0)
+    if plan is not None:
+        partial = _lib.workspace.scratch("wgrad", lib.sv_sparse_conv_wgrad_planned_bytes(K, cin, cout), dy.device)
+        rc = lib.sv_sparse_conv_wgrad_planned(xs, int(x.shape[0]), ns, ds, dw.data_ptr(), n_rows, K, cin, cout, st[0], st[1], st[2], plan.data_ptr(),
+                                              _lib.ptr(partial), _lib.stream())
+        _lib.check(rc, "sv_sparse_conv_wgrad_planned")
+        return dw
+    scratch = _lib.workspace.scratch("wgrad", lib.sv_sparse_conv_wgrad_scratch_bytes(n_rows, K, cin, cout), dy.device)
+    if strided:
         rc = lib.sv_sparse_conv_wgrad_strided(xs, int(x.shape[0]), ns, ds, dw.data_ptr(), n_rows, K, cin, cout, st[0], st[1], st[2], _lib.ptr(scratch), _lib.stream())
         _lib.check(rc, "sv_sparse_conv_wgrad_strided")
         return dw
-    dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dy.device)
     rc = lib.sv_sparse_conv_wgrad(xs, int(x.shape[0]), ns, ds, _lib.ptr(dw), n_rows, K, cin, cout, _lib.ptr(scratch), _lib.stream())
     _lib.check(rc, "sv_sparse_conv_wgrad")
     return dw
+
+
+def build_wgrad_plans(items):
+    """Rulebook.wgrad_plan for several (rulebook, cin, cout) at once: the plans that are missing come out of ONE allocation and two launches
+    (sv_wgrad_plan_build_batch) instead of two launches per table."""
+    import numpy as np
+    if not WGRAD_PLANNED:
+        return
+    lib = _lib.load()
+    todo, seen, total = [], set(), 0
+    for rb, cin, cout in items:
+        key = ("wgrad", int(cin), int(cout))
+        if rb.n_out == 0 or key in rb._plan_results:
+            continue
+        if not lib.sv_wgrad_planned_applies(int(rb.n_in), int(rb.n_out), int(rb.K), int(cin), int(cout)):
+            rb._plan_results[key] = (None,)
+            continue
+        pieces = lib.sv_wgrad_plan_pieces(int(cin), int(cout))
+        plans = rb.__dict__.setdefault("_wgrad_plans", {})
+        if pieces not in plans and (id(rb), pieces) not in seen:
+            seen.add((id(rb), pieces))
+            nbytes = lib.sv_wgrad_plan_bytes(rb.n_out, int(rb.K), pieces)
+            todo.append((rb, pieces, total, nbytes))
+            total += nbytes
+    if todo:
+        dev = todo[0][0].out_indices.device
+        buf = torch.empty((total,), dtype=torch.uint8, device=dev)
+        jobs = np.zeros((len(todo), 8), dtype=np.int64)
+        for q, (rb, pieces, off, nbytes) in enumerate(todo):
+            jobs[q, :5] = (rb.addr("nbr_out"), rb.n_out, int(rb.K), pieces, buf.data_ptr() + off)
+            rb._wgrad_plans[pieces] = buf[off:off + nbytes]
+        _lib.check(lib.sv_wgrad_plan_build_batch(jobs.ctypes.data, len(todo), _lib.stream()), "sv_wgrad_plan_build_batch")
+    for rb, cin, cout in items:
+        rb.wgrad_plan(cin, cout)          # fills the per-layer cache from the per-table plans
 
 
 def _dense_permutation(shape, strides):
@@ -662,7 +732,7 @@ def _conv_backward(features, weight_kio, rb, frag_bwd, grad_out, need_input, nee
         else:
             gf = gather_gemm(grad_out, rb.table_for_backward_data(), weight_kio.detach(), rb.n_in)
     if need_weight:
-        gw = wgrad(features, rb.nbr_out, grad_out, K, cin, cout, like=weight_kio)
+        gw = wgrad(features, rb.nbr_out, grad_out, K, cin, cout, like=weight_kio, plan=rb.wgrad_plan(cin, cout))
     return gf, gw
 
 

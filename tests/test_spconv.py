@@ -938,3 +938,114 @@ def test_hip_deferred_weight_gradient_reduction_is_bitwise_the_per_layer_one(cud
         assert torch.equal(res[0][k], res[1][k]), k
     assert all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for k, v in res[0].items() if k.endswith("0.weight"))
 
+
+def _synthetic_lidar_table(n, K, cuda, seed=11):
+    """(K, n) table with the spread between offsets a LiDAR rulebook has: every row at the centre, 70 % in the dz = 0 plane, 15 % out of plane."""
+    g = torch.Generator(device=cuda).manual_seed(seed)
+    density = torch.tensor([1.0 if k == K // 2 else (0.7 if K // 3 <= k < 2 * K // 3 else 0.15) for k in range(K)], device=cuda)
+    keep = torch.rand((K, n), device=cuda, generator=g) < density[:, None]
+    src = (torch.arange(n, device=cuda, dtype=torch.int32)[None, :] * 7 + torch.arange(K, device=cuda, dtype=torch.int32)[:, None] * 1013) % n
+    return torch.where(keep, src, torch.full_like(src, -1)).contiguous()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,K,pieces", [(100_000, 27, 1024), (100_000, 27, 2048), (3_000, 27, 1024), (700, 3, 2048), (64, 27, 1024)])
+def test_hip_weight_gradient_plan_cuts_the_table_into_equal_pieces(cuda, hip_lib, n, K, pieces):
+    """sv_wgrad_plan_build: the cuts are monotone and cover every 64-row unit, a piece holds total / pieces pairs up to one unit (64 pairs), the slab
+    numbering follows the offsets a piece touches, and every offset's slabs are one contiguous run that covers exactly the pieces holding its units."""
+    import numpy as np
+    from seevcn_amd import _lib
+    lib = hip_lib
+    nbr = _synthetic_lidar_table(n, K, cuda)
+    plan = torch.zeros(lib.sv_wgrad_plan_bytes(n, K, pieces) // 4, dtype=torch.int32, device=cuda)
+    _lib.check(lib.sv_wgrad_plan_build(nbr.data_ptr(), n, K, pieces, plan.data_ptr(), _lib.stream()), "sv_wgrad_plan_build")
+    p = plan.cpu().numpy()
+    nbu = -(-n // 64)
+    U = nbu * K
+    pad4 = lambda v: (v + 3) & ~3          # every part of the plan starts on a multiple of 4 ints
+    o1 = pad4(pieces + 1)
+    o2 = o1 + pad4(pieces + 1)
+    o3 = o2 + pad4(2 * K)
+    cut, slab0, runs, pre = p[:pieces + 1], p[o1:o1 + pieces + 1], p[o2:o2 + 2 * K].reshape(K, 2), p[o3:o3 + U + 1]
+    valid = (nbr >= 0).cpu().numpy()
+    counts = np.zeros(U, dtype=np.int64)
+    for k in range(K):
+        counts[k * nbu:(k + 1) * nbu] = np.add.reduceat(valid[k], np.arange(0, n, 64))
+    assert np.array_equal(pre, np.concatenate([[0], np.cumsum(counts)]))
+    assert cut[0] == 0 and cut[-1] == U and np.all(np.diff(cut) >= 0)
+    total = int(counts.sum())
+    per_piece = np.array([counts[cut[i]:cut[i + 1]].sum() for i in range(pieces)])
+    assert per_piece.sum() == total
+    assert np.all(np.abs(per_piece - total / pieces) <= 64 + 1), (per_piece.min(), per_piece.max(), total / pieces)
+    nseg = np.array([0 if cut[i] == cut[i + 1] else (cut[i + 1] - 1) // nbu - cut[i] // nbu + 1 for i in range(pieces)])
+    assert np.array_equal(slab0, np.concatenate([[0], np.cumsum(nseg)]))
+    assert slab0[-1] <= pieces + K - 1
+    for k in range(K):
+        ids = [slab0[i] + (k - cut[i] // nbu) for i in range(pieces) if cut[i] < cut[i + 1] and cut[i] // nbu <= k <= (cut[i + 1] - 1) // nbu]
+        assert ids == list(range(runs[k, 0], runs[k, 0] + runs[k, 1])), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,K,cin,cout", [(100_000, 27, 64, 64), (220_000, 27, 64, 64), (60_000, 27, 64, 128), (90_000, 27, 32, 64), (50_000, 27, 32, 32), (50_000, 27, 16, 32),
+                                            (50_000, 27, 16, 16), (40_000, 27, 4, 16), (20_000, 3, 64, 128), (500, 27, 64, 64), (37, 27, 16, 16)])
+def test_hip_weight_gradient_on_equal_pieces(cuda, hip_lib, n, K, cin, cout, monkeypatch):
+    """sv_sparse_conv_wgrad_planned (every register-tile instance, tables with far fewer units than pieces included) against X[nbr[k]]^T dY in float64, in both
+    output layouts, run twice (bitwise the same), and in the two-stage form of the launch list (stage 1 + sv_sparse_conv_wgrad_reduce_batch: bitwise the same).
+    sv_wgrad_planned_applies sends only the large 64-channel-multiple layers here by default (where it is faster); SEEVCN_WGRAD_PLANNED_ALL lifts that.
+    220 k rows: 2 M pairs = 2 000 per piece, more than a workgroup's list holds (1 536): segments in several chunks."""
+    import ctypes
+    monkeypatch.setenv("SEEVCN_WGRAD_PLANNED_ALL", "1")
+    from seevcn_amd import _lib
+    from seevcn_amd.spconv import functional as Fsp
+    lib = hip_lib
+    nbr = _synthetic_lidar_table(n, K, cuda)
+    g = torch.Generator(device=cuda).manual_seed(5)
+    x = torch.randn(n, cin, device=cuda, generator=g)
+    dy = torch.randn(n, cout, device=cuda, generator=g)
+    want = torch.empty((K, cin, cout), dtype=torch.float64, device=cuda)
+    for k in range(K):
+        rows = torch.nonzero(nbr[k] >= 0).squeeze(1)
+        want[k] = x[nbr[k, rows].long()].double().T @ dy[rows].double()
+    assert lib.sv_wgrad_planned_applies(n, n, K, cin, cout) == 1
+    pieces = lib.sv_wgrad_plan_pieces(cin, cout)
+    plan = torch.empty(lib.sv_wgrad_plan_bytes(n, K, pieces), dtype=torch.uint8, device=cuda)
+    _lib.check(lib.sv_wgrad_plan_build(nbr.data_ptr(), n, K, pieces, plan.data_ptr(), _lib.stream()), "sv_wgrad_plan_build")
+    dw = Fsp.wgrad(x, nbr, dy, K, cin, cout, plan=plan)
+    scale = float(want.abs().max())
+    assert float((dw.double() - want).abs().max()) <= 2e-5 * scale
+    assert torch.equal(Fsp.wgrad(x, nbr, dy, K, cin, cout, plan=plan), dw)
+    # the chunked kernel computes the same sums in another order
+    assert float((Fsp.wgrad(x, nbr, dy, K, cin, cout) - dw).abs().max()) <= 2e-5 * scale
+    like = torch.empty((cout, K, cin), device=cuda).permute(1, 2, 0)          # the parameter's (C_out, k, C_in) memory order
+    dws = Fsp.wgrad(x, nbr, dy, K, cin, cout, like=like, plan=plan)
+    assert dws.stride() == like.stride() and torch.equal(dws, dw)
+    part = torch.empty(lib.sv_sparse_conv_wgrad_planned_bytes(K, cin, cout), dtype=torch.uint8, device=cuda)
+    dw2 = torch.empty((K, cin, cout), device=cuda)
+    job = (ctypes.c_int64 * 10)()
+    rc = lib.sv_sparse_conv_wgrad_planned_stage1(x.data_ptr(), n, nbr.data_ptr(), dy.data_ptr(), dw2.data_ptr(), n, K, cin, cout, cin * cout, cout, 1, plan.data_ptr(),
+                                                 part.data_ptr(), job, _lib.stream())
+    _lib.check(rc, "sv_sparse_conv_wgrad_planned_stage1")
+    assert job[3] > 0 and job[9] != 0
+    _lib.check(lib.sv_sparse_conv_wgrad_reduce_batch(job, 1, _lib.stream()), "sv_sparse_conv_wgrad_reduce_batch")
+    assert torch.equal(dw2, dw)
+
+
+@pytest.mark.gpu
+def test_hip_weight_gradient_plans_of_several_tables_in_one_batch(cuda, hip_lib):
+    """sv_wgrad_plan_build_batch (two launches for all tables) leaves exactly the plans sv_wgrad_plan_build makes one table at a time."""
+    import numpy as np
+    from seevcn_amd import _lib
+    lib = hip_lib
+    cases = [(100_000, 27, 1024), (30_000, 27, 2048), (9_000, 3, 1024)]
+    tables = [_synthetic_lidar_table(n, K, cuda, seed=3 + q) for q, (n, K, _) in enumerate(cases)]
+    single, batch = [], []
+    jobs = np.zeros((len(cases), 8), dtype=np.int64)
+    for q, ((n, K, pieces), nbr) in enumerate(zip(cases, tables)):
+        nb = lib.sv_wgrad_plan_bytes(n, K, pieces)
+        a, b = torch.zeros(nb, dtype=torch.uint8, device=cuda), torch.zeros(nb, dtype=torch.uint8, device=cuda)
+        _lib.check(lib.sv_wgrad_plan_build(nbr.data_ptr(), n, K, pieces, a.data_ptr(), _lib.stream()), "sv_wgrad_plan_build")
+        jobs[q, :5] = (nbr.data_ptr(), n, K, pieces, b.data_ptr())
+        single.append(a), batch.append(b)
+    _lib.check(lib.sv_wgrad_plan_build_batch(jobs.ctypes.data, len(cases), _lib.stream()), "sv_wgrad_plan_build_batch")
+    for a, b in zip(single, batch):
+        assert torch.equal(a, b)

@@ -96,7 +96,8 @@ def main():
                 fb = Fsp.fragment_cache.get(w)[1]
                 td = timeit(lambda: Fsp.gather_gemm_planned(dy, pb, fb, rb.n_in, K, cout, cin))
         if mode in ("all", "wgrad"):
-            tw = timeit(lambda: Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout))
+            wp = rb.wgrad_plan(cin, cout)                   # equal-pieces plan of the table (None with SEEVCN_WGRAD_PLANNED=0: the chunked kernel)
+            tw = timeit(lambda: Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout, plan=wp))
         fl = 2.0 * pairs * cin * cout
         print(f"{name:8s} {cin:3d}->{cout:3d} N_in={rb.n_in:7d} N_out={rb.n_out:7d} pairs={pairs:8d} rulebook {tb:7.1f} us plan {tplan:6.1f} us | "
               f"fwd {tf:7.1f} us ({fl / tf / 1e6:6.2f} TF) | bwd-data {td:7.1f} us ({fl / td / 1e6:6.2f} TF) | wgrad {tw:7.1f} us ({fl / tw / 1e6:6.2f} TF)")

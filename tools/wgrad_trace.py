@@ -37,11 +37,12 @@ def main():
     x = torch.randn(rb.n_in, cin, device=dev)
     dy = torch.randn(rb.n_out, cout, device=dev)
     K = rb.K
+    wp = rb.wgrad_plan(cin, cout)              # None with SEEVCN_WGRAD_PLANNED=0: the chunked kernel
     for _ in range(3):
-        Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout)
+        Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout, plan=wp)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout)
+    Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout, plan=wp)
     e.record()
     torch.cuda.synchronize()
     plain_us = s.elapsed_time(e) * 1e3
@@ -49,7 +50,7 @@ def main():
     lib = _lib.load()
     lib.sv_debug_wgrad_trace(buf.data_ptr())
     s.record()
-    Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout)
+    Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout, plan=wp)
     e.record()
     torch.cuda.synchronize()
     lib.sv_debug_wgrad_trace(None)
