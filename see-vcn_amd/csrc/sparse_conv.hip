@@ -1122,6 +1122,7 @@ struct PlanView {
   int debug;                // measurement only (SEEVCN_RS3_DEBUG; results are wrong): 1 no gathered-row loads, 2 no weight loads, 4 no MFMAs,
                             // 8 / 16 weight / row loads of a wave all at ONE address (one cache line per load instead of 16)
   unsigned long long* trace;   // measurement only (sv_debug_conv_trace): 8 words per wave, or null
+  int prio;                 // SEEVCN_RS3_PRIO (A/B): 1 = s_setprio 3 for a pass's prologue, 2 = for its epilogue too; the main loop runs at 0
 };
 
 template <int NT, int KQ, int RS_G, bool DBG = false>
@@ -1147,6 +1148,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
 #pragma nounroll
   for (int pass = 0; pass < pv.d.n_pass; ++pass) {
   if (my_tiles[pass * RS_G] < 0) break;                    // slots are filled front to back: an empty first slot ends the wave's list
+  if (pv.prio) __builtin_amdgcn_s_setprio(3);
   // the wave's rows of the regrouped table -> LDS; per-offset tile masks in lane k of maskreg
   unsigned maskreg = 0;
   {
@@ -1189,6 +1191,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   for (int g = 0; g < RS_G; ++g)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (pv.prio) __builtin_amdgcn_s_setprio(0);
 
   if (active) {
     // ring depth 3 = two steps of loads in flight.  Tried: 5 stages for the one-tile-per-wave instance (its registers allow it) -- slower,
@@ -1322,6 +1325,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // retire the dummy loads before the registers are reused
   }
+  if (pv.prio == 2) __builtin_amdgcn_s_setprio(3);
   if (DBG && pv.trace) {
     t_loop = __builtin_amdgcn_s_memtime();
     for (int k = 0; k < a.K; ++k) trace_work += __popc((unsigned)__builtin_amdgcn_readlane((int)maskreg, k));
@@ -1502,6 +1506,8 @@ static int conv_planned(const float* X, int64_t n_src, const int32_t* table_rows
   if (bnb) pv.bn_x = bnb->x, pv.bn_mean = bnb->mean, pv.bn_istd = bnb->istd, pv.bn_gamma = bnb->gamma, pv.bn_beta = bnb->beta, pv.bn_relu = bnb->relu;
   static const int debug = getenv("SEEVCN_RS3_DEBUG") ? atoi(getenv("SEEVCN_RS3_DEBUG")) : 0;
   pv.debug = debug;
+  static const int prio = getenv("SEEVCN_RS3_PRIO") ? atoi(getenv("SEEVCN_RS3_PRIO")) : 0;
+  pv.prio = prio;
   pv.trace = g_conv_trace;
   const int nc_blk = Nc > 64 ? 64 : Nc;
   const dim3 grid((unsigned)(PL_REGIONS * PL_REGION_WAVES / 4), (unsigned)(Nc / nc_blk));

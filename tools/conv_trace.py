@@ -50,9 +50,15 @@ def main():
     lib.sv_debug_conv_trace(None)
     t = buf.cpu().numpy()
     t = t[t[:, 3] != 0]
-    xcc_id = (t[:, 5] & 0xf).astype(int)
-    base = np.array([t[xcc_id == x, 0].min() if (xcc_id == x).any() else 0 for x in range(16)])      # s_memtime is per XCD
-    start, pro, loop, end = (t[:, i] - base[xcc_id] for i in range(4))
+    xcc_id = (t[:, 5] & 0xf).astype(np.int64)
+    # s_memtime counts shader cycles and is NOT comparable between CUs on this part (tools/wgrad_trace.py found offsets of millions of ticks inside one
+    # XCD): every CU gets workgroups at the start of the launch, so its earliest wave start is the launch's start on that CU's clock
+    cu_key = (xcc_id << 16) | (t[:, 4] & 0xff00)
+    _, cu_inv = np.unique(cu_key, return_inverse=True)
+    base = np.full(cu_inv.max() + 1, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(base, cu_inv, t[:, 0])
+    start, pro, loop, end = (t[:, i] - base[cu_inv] for i in range(4))
+    xcc_id = xcc_id.astype(int)
     total = end.max()
     print(f"{want} {cin}->{cout} rows {rb.n_out} G {plan[2]} waves {len(t)} launch {s.elapsed_time(e) * 1e3:.1f} us  span {total} ticks (s_memtime)")
     print(f"wave start: median {np.median(start):.0f} max {start.max():.0f} | prologue {np.median(pro - start):.0f} (p95 {np.percentile(pro - start, 95):.0f}) | "
