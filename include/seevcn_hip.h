@@ -86,6 +86,14 @@ int sv_fill_f32(float* dst, int64_t n, float value, void* stream);
 int sv_gemm_bias_act(const float* A, int lda, const float* W, int ldw, const float* bias,
                      const float* group_bias, int rows_per_group, float* C, int ldc, float* group_max,
                      int M, int N, int K, int act, float slope, void* stream);
+/* The same product (uniform groups, C stored, no column max) with K split over blockIdx.z when the output has few 128 x 128 tiles and K is long --
+ * the shared FC over the pooled RoI grid of PV-RCNN's head (pcdet/models/roi_heads/pvrcnn_head.py:44-61: 27 648 -> 256 on 512 RoIs: 8 tiles, 1.9 ms
+ * in one pass).  The split sums are added in split order by a second launch (bitwise reproducible), which also applies bias / group bias /
+ * activation.  sv_gemm_splitk_splits(M, N, K) = number of splits (1: the one-pass kernel runs); scratch: sv_gemm_splitk_scratch_bytes. */
+int sv_gemm_splitk_splits(int M, int N, int K);
+size_t sv_gemm_splitk_scratch_bytes(int M, int N, int K);
+int sv_gemm_bias_act_splitk(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias, int rows_per_group,
+                            float* C, int ldc, int M, int N, int K, int act, float slope, void* scratch, void* stream);
 
 /* out[m][c] = act(weight[c][0..2] . xyz[m] + bias[c])   (the Conv1d(3, C, 1) first layers; C % 4 == 0) */
 int sv_pointwise_conv3(const float* xyz, const float* weight, const float* bias, float* out, int64_t M,

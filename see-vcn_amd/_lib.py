@@ -30,6 +30,9 @@ SIGNATURES = {
     "sv_mean_vfe": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p, c_p]),
     "sv_fill_f32": (c_i, [c_p, c_i64, c_f, c_p]),
     "sv_gemm_bias_act": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "sv_gemm_splitk_splits": (c_i, [c_i, c_i, c_i]),
+    "sv_gemm_splitk_scratch_bytes": (c_sz, [c_i, c_i, c_i]),
+    "sv_gemm_bias_act_splitk": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "sv_pointwise_conv3": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_p]),
     "sv_pointwise_conv3_gather": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
     "sv_gemm_tn_scratch_bytes": (c_sz, [c_i64, c_i, c_i]),

@@ -15,7 +15,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int ACT_RELU = SV_ACT_RELU, ACT_LRELU = SV_ACT_LRELU;
-constexpr int EPI_STORE = 1, EPI_MAX = 2;
+constexpr int EPI_STORE = 1, EPI_MAX = 2, EPI_PARTIAL = 4;      // EPI_PARTIAL: split K, raw sums of blockIdx.z's K range to C[z][M][N]
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
@@ -52,6 +52,7 @@ struct GemmArgs {
   int M, N, K;
   int act; float slope;
   const int32_t* m_dev;     // optional: the true number of rows lives on the device (<= M, which then sizes the grid and the buffers)
+  int k_chunk;              // EPI_PARTIAL: K range of a split (a multiple of BK); workgroup z takes [z * k_chunk, min(K, (z + 1) * k_chunk))
 };
 
 template <int EPI>
@@ -103,14 +104,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = g.K / BK;
-  gload(0);
+  const int k_begin = (EPI & EPI_PARTIAL) ? (int)blockIdx.z * g.k_chunk : 0;
+  const int nk = ((EPI & EPI_PARTIAL) ? min(g.K - k_begin, g.k_chunk) : g.K) / BK;
+  gload(k_begin);
   lstore(0);
   __syncthreads();
   const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), kh = 4 * (lane >> 5);
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if (kt + 1 < nk) gload(k_begin + (kt + 1) * BK);
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
       float4 a[2], b[2];
@@ -157,6 +159,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (!cok || row >= g.M) continue;
+        if constexpr ((EPI & EPI_PARTIAL) != 0) {
+          g.C[((int64_t)blockIdx.z * g.M + row) * g.ldc + col] = acc[i][j][r];
+          continue;
+        }
         const int grp = g.row_group ? g.row_group[row] : row / g.rows_per_group;
         float v = acc[i][j][r] + bv;
         if (g.group_bias) v += g.group_bias[(int64_t)grp * g.N + col];
@@ -271,6 +277,38 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs g) {
   }
 }
 
+// ---- split K: a product with few output tiles and a long K (PV-RCNN's shared FC over the pooled RoI grid, roi_head_template / pvrcnn_head.py:
+// 512 RoIs x 27 648 -> 256 = 8 tiles walking K alone: 1.9 ms on 8 CUs) runs its K ranges on blockIdx.z and the raw sums meet in a second pass that
+// adds them in split order (fixed: bitwise reproducible), then bias, group bias and activation as the one-pass epilogue does.
+__global__ __launch_bounds__(256) void k_gemm_split_finish(const float* __restrict__ partial, int splits, GemmArgs g) {
+  const int64_t total = (int64_t)g.M * g.N;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int row = (int)(e / g.N), col = (int)(e % g.N);
+    float v = 0.f;
+    for (int p = 0; p < splits; ++p) v += partial[(int64_t)p * total + e];
+    if (g.bias) v += g.bias[col];
+    if (g.group_bias) v += g.group_bias[(int64_t)(row / g.rows_per_group) * g.N + col];
+    g.C[(int64_t)row * g.ldc + col] = apply_act(v, g.act, g.slope);
+  }
+}
+
+// splits the split-K form would use for this product (1 = it does not apply): fewer than 64 output tiles and at least 16 K-steps per split
+extern "C" int sv_gemm_splitk_splits(int M, int N, int K) {
+  if (M <= 64 || K % BK != 0) return 1;
+  const int tiles = sv_div_up(M, BM) * sv_div_up(N, BN);
+  if (tiles >= 64) return 1;
+  int s = sv_div_up(512, tiles);
+  const int most = K / (16 * BK);
+  if (s > most) s = most;
+  if (s < 2) return 1;
+  const int chunk = sv_div_up(sv_div_up(K, s), BK) * BK;
+  return sv_div_up(K, chunk);
+}
+extern "C" size_t sv_gemm_splitk_scratch_bytes(int M, int N, int K) {
+  const int s = sv_gemm_splitk_splits(M, N, K);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 256;
+}
+
 static int gemm_launch(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias, int rows_per_group,
                        const int32_t* row_group, float* C, int ldc, float* group_max, int M, int N, int K, int act, float slope,
                        void* stream, const int32_t* m_dev = nullptr) {
@@ -280,7 +318,7 @@ static int gemm_launch(const float* A, int lda, const float* W, int ldw, const f
   SV_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "gemm_bias_act: A/W must be 16-byte aligned");
   SV_CHECK_ARG(rows_per_group >= 1, "gemm_bias_act: rows_per_group must be >= 1");
   SV_CHECK_ARG(act >= 0 && act <= 2, "gemm_bias_act: unknown activation %d", act);
-  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, row_group, C, ldc, group_max, M, N, K, act, slope, m_dev};
+  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, row_group, C, ldc, group_max, M, N, K, act, slope, m_dev, 0};
   dim3 grid(sv_div_up(N, BN), sv_div_up(M, BM));
   hipStream_t st = sv_stream(stream);
   if (M <= 64 && C && !group_max && !group_bias && !row_group && !m_dev) {
@@ -302,6 +340,26 @@ extern "C" int sv_gemm_bias_act(const float* A, int lda, const float* W, int ldw
                                 const float* group_bias, int rows_per_group, float* C, int ldc, float* group_max,
                                 int M, int N, int K, int act, float slope, void* stream) {
   return gemm_launch(A, lda, W, ldw, bias, group_bias, rows_per_group, nullptr, C, ldc, group_max, M, N, K, act, slope, stream);
+}
+
+// sv_gemm_bias_act (uniform groups, no column max) in split-K form: scratch = sv_gemm_splitk_scratch_bytes(M, N, K); sv_gemm_splitk_splits == 1 runs
+// the one-pass kernel.  Same sums in another order: equal to the one-pass result up to fp32 rounding.
+extern "C" int sv_gemm_bias_act_splitk(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias, int rows_per_group,
+                                       float* C, int ldc, int M, int N, int K, int act, float slope, void* scratch, void* stream) {
+  const int splits = (M > 0 && N > 0 && K > 0) ? sv_gemm_splitk_splits(M, N, K) : 1;
+  if (splits <= 1) return gemm_launch(A, lda, W, ldw, bias, group_bias, rows_per_group, nullptr, C, ldc, nullptr, M, N, K, act, slope, stream);
+  SV_CHECK_ARG(A && W && C && scratch, "gemm_bias_act_splitk: null pointer");
+  SV_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= K, "gemm_bias_act_splitk: lda/ldw must be >= K and multiples of 4");
+  SV_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "gemm_bias_act_splitk: A/W must be 16-byte aligned");
+  SV_CHECK_ARG(rows_per_group >= 1 && act >= 0 && act <= 2 && ldc >= N, "gemm_bias_act_splitk: bad arguments");
+  const int chunk = sv_div_up(sv_div_up(K, splits), BK) * BK;
+  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, nullptr, reinterpret_cast<float*>(scratch), N, nullptr, M, N, K, act, slope, nullptr, chunk};
+  hipStream_t st = sv_stream(stream);
+  hipLaunchKernelGGL(k_gemm_f32<EPI_PARTIAL>, dim3(sv_div_up(N, BN), sv_div_up(M, BM), splits), dim3(256), 0, st, g);
+  g.C = C, g.ldc = ldc;
+  hipLaunchKernelGGL(k_gemm_split_finish, dim3(sv_grid_1d((int64_t)M * N, 256)), dim3(256), 0, st, reinterpret_cast<const float*>(scratch), splits, g);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
 }
 
 extern "C" int sv_gemm_bias_act_ragged(const float* A, int lda, const float* W, int ldw, const float* bias, const float* group_bias,

@@ -33,6 +33,11 @@ def _gemm_nt(a, w, bias, act, slope, group_bias=None, rows_per_group=1):
     if K == 3 and group_bias is None and N % 4 == 0:
         _lib.check(lib.sv_pointwise_conv3(_lib.ptr(a), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), M, N, int(act), float(slope), _lib.stream()), "sv_pointwise_conv3")
         return out
+    if K % 32 == 0 and lib.sv_gemm_splitk_splits(M, N, K) > 1:             # few output tiles, long K (the 27 648 -> 256 layer of PV-RCNN's RoI head)
+        sc = _scratch("dense_splitk", lib.sv_gemm_splitk_scratch_bytes(M, N, K), a.device)
+        _lib.check(lib.sv_gemm_bias_act_splitk(_lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(bias), _lib.ptr(group_bias), int(rows_per_group), _lib.ptr(out), N, M, N, K,
+                                               int(act), float(slope), _lib.ptr(sc), _lib.stream()), "sv_gemm_bias_act_splitk")
+        return out
     if K % 32 == 0:
         _lib.check(lib.sv_gemm_bias_act(_lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(bias), _lib.ptr(group_bias), int(rows_per_group), _lib.ptr(out), N, None, M, N, K,
                                         int(act), float(slope), _lib.stream()), "sv_gemm_bias_act")

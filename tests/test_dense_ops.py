@@ -57,10 +57,13 @@ def test_hip_column_sums_and_segments_match_torch(cuda, hip_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,K,N,act,gb", [(4096, 3, 64, 2, False), (4096, 64, 128, 2, False), (8192, 256, 512, 0, True), (64, 1024, 9, 0, False), (64, 512, 3072, 1, False),
-                                           (300, 640, 128, 1, False)])
+                                           (300, 640, 128, 1, False), (512, 27648, 256, 1, False), (2048, 2048, 128, 2, True)])
 def test_hip_linear_function_matches_torch_autograd(cuda, hip_lib, M, K, N, act, gb):
-    """dense_ops.linear: forward and every gradient (input, weight, bias, group bias) vs torch.nn.functional.linear + activation under autograd"""
+    """dense_ops.linear: forward and every gradient (input, weight, bias, group bias) vs torch.nn.functional.linear + activation under autograd.
+    (512, 27648, 256) is the shared FC over the pooled RoI grid of PV-RCNN's head and (2048, 2048, 128) another few-tile product: split-K forward."""
     from seevcn_amd import dense_ops as D
+    if K >= 2048:
+        assert hip_lib.sv_gemm_splitk_splits(M, N, K) > 1
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=g).to(cuda).requires_grad_(True)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda).requires_grad_(True)
