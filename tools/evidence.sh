@@ -23,7 +23,8 @@ timeout 300 python3 tools/host_time.py > gpurun_out/${TAG}_host_time.txt 2>&1
 for c in main pvrcnn centerpoint second; do timeout 300 python3 tools/sync_trace.py $c > gpurun_out/${TAG}_sync_trace_$c.txt 2>&1; done
 tools/timeline.sh ${TAG} > /dev/null 2>&1
 timeout 120 python3 tools/wgrad_uniform.py > gpurun_out/${TAG}_wgrad_uniform.txt 2>&1
-for d in 1 2 4 5 8 12; do echo "SEEVCN_WGRAD_DEBUG=$d" >> gpurun_out/${TAG}_wgrad_debug.txt; SEEVCN_WGRAD_DEBUG=$d MODE=wgrad LAYER=subm3 timeout 120 python3 tools/spconv_micro.py 2>&1 | grep subm3 >> gpurun_out/${TAG}_wgrad_debug.txt; done
+for d in 1 2 4 5 8 12; do echo "SEEVCN_WGRAD_DEBUG=$d" >> gpurun_out/${TAG}_wgrad_debug.txt; SEEVCN_WGRAD_PLANNED=0 SEEVCN_WGRAD_DEBUG=$d MODE=wgrad LAYER=subm3 timeout 120 python3 tools/spconv_micro.py 2>&1 | grep subm3 >> gpurun_out/${TAG}_wgrad_debug.txt; done
 (cd tools/ubench && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/mfma_rate mfma_rate.hip 2>/dev/null && /tmp/mfma_rate | tail -4) > gpurun_out/${TAG}_mfma_rate.txt 2>&1
+tools/wgrad_ab.sh ${TAG} > /dev/null 2>&1
 timeout 300 python3 tools/launch_sites.py pvrcnn 40 > gpurun_out/${TAG}_launch_sites_pvrcnn.txt 2>&1
 rm -rf gpurun_out/${TAG}_pmc_FETCH_SIZE gpurun_out/${TAG}_pmc_WRITE_SIZE gpurun_out/${TAG}_pmc_mfma gpurun_out/prof_*.log gpurun_out/tl_*.log
