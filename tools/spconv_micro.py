@@ -49,6 +49,10 @@ def main():
     dev = torch.device("cuda:0")
     bs = int(os.environ.get("BS", "16"))
     pts, _ = synth.make_scene_batch(bs, seed=2000, n_az=int(os.environ.get("N_AZ", "384")))
+    if os.environ.get("SAME_SCENE"):          # measurement: every scene of the batch the same one -- the eight regions of a plan then carry identical work
+        import numpy as np
+        one = pts[pts[:, 0] == int(os.environ["SAME_SCENE"])]
+        pts = np.concatenate([np.concatenate([np.full((len(one), 1), i, np.float32), one[:, 1:]], axis=1) for i in range(bs)], axis=0)
     g = dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.05, 0.05, 0.1], grid_size=[1408, 1600, 40])
     p = torch.from_numpy(pts).to(dev)
     feats, coords, _ = voxel_ops.voxelize_dynamic(p, g["point_cloud_range"], g["voxel_size"], g["grid_size"], bs)
