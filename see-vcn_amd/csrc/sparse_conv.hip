@@ -1125,7 +1125,8 @@ struct PlanView {
   int prio;                 // SEEVCN_RS3_PRIO (A/B): 1 = s_setprio 3 for a pass's prologue, 2 = for its epilogue too; the main loop runs at 0
 };
 
-template <int NT, int KQ, int RS_G, bool DBG = false>
+// DBG: 0 production; 1 the measurement switches of PlanView::debug (+ trace); 2 per-wave trace only (the production loop + a few s_memtime per pass)
+template <int NT, int KQ, int RS_G, int DBG = 0>
 __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs a, PlanView pv, const float* __restrict__ wfrag, uint32_t x_bytes,
                                                                         uint32_t w_bytes) {
   constexpr int Kd = KQ * 16;
@@ -1133,8 +1134,8 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int li = lane & 15, kk = lane >> 4;
   const int region = blockIdx.x % PL_REGIONS, lw = (blockIdx.x / PL_REGIONS) * 4 + wid;
-  const unsigned long long t_start = (DBG && pv.trace) ? __builtin_amdgcn_s_memtime() : 0ull;    // per-wave stamps: debug instances only
-  unsigned long long t_pro = 0ull, t_loop = 0ull;
+  const unsigned long long t_start = (DBG && pv.trace) ? __builtin_amdgcn_s_memtime() : 0ull;    // per-wave stamps: debug / trace instances only
+  unsigned long long t_pro = 0ull, t_loop = 0ull, t_mark = t_start;      // cycles in pass prologues / main loops, summed over the passes
   unsigned trace_work = 0;
   int32_t(*s_idx)[64] = s_idx_all[wid];
   const int nt_total = pv.nc_total / 16, col_tile0 = blockIdx.y * NT;
@@ -1182,8 +1183,11 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     maskreg = lane < a.K ? mk : 0u;
   }
   const unsigned long long active = __ballot(maskreg != 0);
-  if constexpr (DBG) {
-    if (pv.trace && pass == 0) t_pro = __builtin_amdgcn_s_memtime();
+  if constexpr (DBG != 0) {
+    if (pv.trace) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_pro += t - t_mark, t_mark = t;
+    }
   }
 
   f32x4 acc[RS_G][NT];
@@ -1227,14 +1231,14 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       for (int g = 0; g < RS_G; ++g) {
         const int32_t j = s_idx[pv.k_flip ? a.K - 1 - kl : kl][g * 16 + li];
         rowoff[g] = j >= 0 ? (uint32_t)(j * (Kd * 4) + kk * 16) : OOB;
-        if constexpr (DBG) {
+        if constexpr (DBG == 1) {
           if (pv.debug & 1) rowoff[g] = OOB;
           else if ((pv.debug & 16) && j >= 0) rowoff[g] = 0u;
         }
       }
     };
     read_j();
-    if constexpr (DBG) {
+    if constexpr (DBG == 1) {
       if (pv.debug & 2) wvoff = WOOB;
       else if (pv.debug & 8) wvoff = 0u;
     }
@@ -1293,7 +1297,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       // v_mfma_f32_16x16x4_f32 issues 47 cycles after its producer, an independent one after 32)
 #pragma unroll
       for (int g = 0; g < RS_G; ++g)
-        if (((mc >> g) & 1u) && !(DBG && (pv.debug & 4))) {
+        if (((mc >> g) & 1u) && !(DBG == 1 && (pv.debug & 4))) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g].x, Bs[t].x, acc[g][t], 0, 0, 0);
 #pragma unroll
@@ -1327,7 +1331,8 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   }
   if (pv.prio == 2) __builtin_amdgcn_s_setprio(3);
   if (DBG && pv.trace) {
-    t_loop = __builtin_amdgcn_s_memtime();
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    t_loop += t - t_mark, t_mark = t;
     for (int k = 0; k < a.K; ++k) trace_work += __popc((unsigned)__builtin_amdgcn_readlane((int)maskreg, k));
   }
   // D layout (16x16): col = lane&15, row = 4*(lane>>4) + reg
@@ -1406,6 +1411,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
         }
       }
   }
+    if (DBG && pv.trace) t_mark = __builtin_amdgcn_s_memtime();          // the pass's epilogue ends here: (life - prologues - loops) is epilogue time
   }   // pass
   if (pv.bn_partial) {
     // BatchNorm statistics of this launch's output: lane c holds column c of its wave -> the workgroup (4 waves, fixed order) -> one partial
@@ -1450,12 +1456,21 @@ template <int NT, int KQ>
 static void launch_rs3_g(const ConvArgs& a, const PlanView& pv, const float* wfrag, uint32_t xb, uint32_t wb, dim3 grid, hipStream_t st) {
   // tiles per pass: conv_tiles_per_wave (1 or 2 for the 64-column kernels, 4 for the narrow ones); the measurement switches of
   // SEEVCN_RS3_DEBUG live in instances of their own so that the production loop carries none of their tests
-  if (pv.debug || pv.trace) {
+  if (pv.debug) {
     if constexpr (NT == 4) {
-      if (pv.d.G == 1) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 1, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
-      else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+      if (pv.d.G == 1) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 1, 1>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+      else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2, 1>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
     } else {
-      hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 4, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+      hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 4, 1>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+    }
+    return;
+  }
+  if (pv.trace) {                      // the production loop with time stamps
+    if constexpr (NT == 4) {
+      if (pv.d.G == 1) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 1, 2>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+      else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2, 2>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+    } else {
+      hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 4, 2>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
     }
     return;
   }

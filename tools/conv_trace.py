@@ -41,8 +41,13 @@ def main():
     n_slots = 8 * 128 * 4 * 2 + 64
     buf = torch.zeros((n_slots, 8), dtype=torch.int64, device=dev)
     lib = _lib.load()
-    lib.sv_debug_conv_trace(buf.data_ptr())
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    Fsp.gather_gemm_planned(x, plan, ff, rb.n_out, rb.K, cin, cout)
+    e.record()
+    torch.cuda.synchronize()
+    plain_us = s.elapsed_time(e) * 1e3
+    lib.sv_debug_conv_trace(buf.data_ptr())
     s.record()
     Fsp.gather_gemm_planned(x, plan, ff, rb.n_out, rb.K, cin, cout)
     e.record()
@@ -51,55 +56,45 @@ def main():
     t = buf.cpu().numpy()
     t = t[t[:, 3] != 0]
     xcc_id = (t[:, 5] & 0xf).astype(np.int64)
+    hw = t[:, 4].astype(np.int64)
     # s_memtime counts shader cycles and is NOT comparable between CUs on this part (tools/wgrad_trace.py found offsets of millions of ticks inside one
     # XCD): every CU gets workgroups at the start of the launch, so its earliest wave start is the launch's start on that CU's clock
-    cu_key = (xcc_id << 16) | (t[:, 4] & 0xff00)
+    cu_key = (xcc_id << 16) | (hw & 0xff00)
     _, cu_inv = np.unique(cu_key, return_inverse=True)
     base = np.full(cu_inv.max() + 1, np.iinfo(np.int64).max, dtype=np.int64)
     np.minimum.at(base, cu_inv, t[:, 0])
-    start, pro, loop, end = (t[:, i] - base[cu_inv] for i in range(4))
-    xcc_id = xcc_id.astype(int)
-    total = end.max()
-    print(f"{want} {cin}->{cout} rows {rb.n_out} G {plan[2]} waves {len(t)} launch {s.elapsed_time(e) * 1e3:.1f} us  span {total} ticks (s_memtime)")
-    print(f"wave start: median {np.median(start):.0f} max {start.max():.0f} | prologue {np.median(pro - start):.0f} (p95 {np.percentile(pro - start, 95):.0f}) | "
-          f"loop {np.median(loop - pro):.0f} (min {np.min(loop - pro):.0f} p95 {np.percentile(loop - pro, 95):.0f} max {np.max(loop - pro):.0f}) | "
-          f"epilogue {np.median(end - loop):.0f} (p95 {np.percentile(end - loop, 95):.0f})")
-    print(f"wave end: p5 {np.percentile(end, 5):.0f} median {np.median(end):.0f} p95 {np.percentile(end, 95):.0f} max {end.max():.0f}")
-    work = t[:, 6].astype(float)
-    print(f"work per wave (tile-offset steps): mean {work.mean():.1f} min {work.min():.0f} max {work.max():.0f}; loop ticks per step: median {np.median((loop - pro) / np.maximum(work, 1)):.0f}")
-    # SIMD identity: xcc, se/sh/cu/simd from HW_ID (gfx9 layout: wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13])
-    hw, xcc = t[:, 4], t[:, 5] & 0xf
-    simd = (xcc << 16) | (hw & 0xfff0 & ~0xc0)
+    start, end = (t[:, 0] - base[cu_inv]).astype(float), (t[:, 3] - base[cu_inv]).astype(float)
+    pro, loop = t[:, 1].astype(float), t[:, 2].astype(float)          # cycles in pass prologues / main loops, summed over the wave's passes
+    life = end - start
+    epi = life - pro - loop
+    work = t[:, 6].astype(float)                                      # (tile, offset) steps
+    span = float(end.max())
+    nt, kq = min(cout, 64) // 16, cin // 16
+    step_cycles = kq * 4 * nt * 32                                    # MFMA pipe cycles of one (tile, offset) step
+    print(f"{want} {cin}->{cout} rows {rb.n_out} G {plan[2]} waves {len(t)}; plain launch {plain_us:.1f} us, traced launch {s.elapsed_time(e) * 1e3:.1f} us; span {span:.0f} cycles "
+          f"(per-CU last end: median {np.median([end[cu_inv == i].max() for i in range(cu_inv.max() + 1)]):.0f})")
+    print(f"wave life: mean {life.mean():.0f} median {np.median(life):.0f} p95 {np.percentile(life, 95):.0f} max {life.max():.0f};  of it prologues {pro.sum() / life.sum():.3f}, main loops "
+          f"{loop.sum() / life.sum():.3f}, epilogues {epi.sum() / life.sum():.3f};  wave end p5 {np.percentile(end, 5):.0f} median {np.median(end):.0f} p95 {np.percentile(end, 95):.0f}")
+    print(f"steps per wave: mean {work.mean():.1f} min {work.min():.0f} max {work.max():.0f};  loop cycles per step {loop.sum() / work.sum():.0f} (its MFMAs: {step_cycles} pipe cycles -> "
+          f"{step_cycles * work.sum() / loop.sum():.3f} of the pipe per looping wave)")
+    simd = (cu_key << 8) | (hw & 0x30)
     ids, inv = np.unique(simd, return_inverse=True)
-    per_simd_work = np.bincount(inv, weights=work)
-    per_simd_waves = np.bincount(inv)
-    per_simd_end = np.zeros(len(ids))
-    np.maximum.at(per_simd_end, inv, end)
-    print(f"SIMDs used {len(ids)}; waves per SIMD: {np.bincount(per_simd_waves)}; work per SIMD mean {per_simd_work.mean():.0f} max {per_simd_work.max():.0f} "
-          f"(max/mean {per_simd_work.max() / per_simd_work.mean():.3f}); SIMD end: p5 {np.percentile(per_simd_end, 5):.0f} median {np.median(per_simd_end):.0f} max {per_simd_end.max():.0f}")
-    # pipe time needed: steps * 16 * NT MFMAs * 32 cycles  (s_memtime ticks at 100 MHz? print ratio instead)
-    nt = min(cout, 64) // 16
-    kq = cin // 16
-    mfma_cycles = per_simd_work * kq * 4 * nt * 32
-    print(f"MFMA cycles per SIMD: mean {mfma_cycles.mean():.0f} max {mfma_cycles.max():.0f}; ticks per MFMA cycle at the busiest SIMD {per_simd_end.max() / mfma_cycles.max():.4f}")
-    if os.environ.get("MAP"):
-        blk = (t[:, 7] >> 8).astype(int)
-        wid = (t[:, 7] & 0xff).astype(int)
-        simd_id, cu_id, sh_id, se_id = (hw >> 4) & 3, (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 7
-        sel = np.nonzero((blk % 8 == 0))[0]
-        sel = sel[np.argsort(blk[sel] * 4 + wid[sel])]
-        print("block/8 wid -> xcc se sh cu simd   (region 0)")
-        for i in sel[:96]:
-            print(f"  j={blk[i] // 8:3d} w={wid[i]} -> xcc {xcc[i]} se {se_id[i]} sh {sh_id[i]} cu {cu_id[i]:2d} simd {simd_id[i]}   hw=0x{hw[i]:x}")
-        print("distinct (xcc) per region:", [sorted(set(xcc[blk % 8 == r].tolist())) for r in range(8)])
-    xw = np.bincount(xcc.astype(int), weights=work, minlength=8)
-    print("work per XCD:", (xw / xw.mean()).round(3))
+    per_work = np.bincount(inv, weights=work)
+    per_loop = np.bincount(inv, weights=loop)
+    per_pro = np.bincount(inv, weights=pro)
+    per_epi = np.bincount(inv, weights=epi)
+    per_end = np.zeros(len(ids))
+    np.maximum.at(per_end, inv, end)
+    mfma = per_work * step_cycles
+    print(f"SIMDs {len(ids)}; waves per SIMD: {np.bincount(np.bincount(inv))};  steps per SIMD max/mean {per_work.max() / per_work.mean():.3f};  SIMD last end p5 {np.percentile(per_end, 5):.0f} "
+          f"median {np.median(per_end):.0f} max {per_end.max():.0f}")
+    print(f"MFMA pipe cycles needed per SIMD: mean {mfma.mean():.0f} max {mfma.max():.0f} = {mfma.mean() / span:.3f} / {mfma.max() / span:.3f} of the span;  per SIMD, summed over its waves: "
+          f"loops {per_loop.mean() / span:.2f} x span, prologues {per_pro.mean() / span:.2f} x, epilogues {per_epi.mean() / span:.2f} x")
+    xw = np.bincount(xcc_id.astype(int), weights=work, minlength=8)[:8]
+    print("steps per XCD:", (xw / xw.mean()).round(3))
 
 
 if __name__ == "__main__":
     main()
 
 
-def dump_mapping():
-    """SEEVCN_TRACE_MAP=1: print how workgroups land on CUs / SIMDs (HW_ID fields) for region 0."""
-    pass
