@@ -562,6 +562,12 @@ int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float*
 #define SV_OP_DGRAD_PLANNED_BN 7
 #define SV_OP_WGRAD_DEFERRED 8
 int sv_run_ops(const int64_t* ops, int n_ops, void* stream);
+/* The same list with its weight gradients (SV_OP_WGRAD, SV_OP_WGRAD_DEFERRED, the deferred reduction) on `side_stream`: each goes behind an event recorded on
+ * `stream` after the operations in front of it; the other operations do not wait for it; `stream` waits for `side_stream` once, at the end, so that when
+ * the call returns everything is ordered on `stream` as after sv_run_ops.  A weight gradient only feeds the optimiser: the backward chain need not stop
+ * for it, and its matrix-core work fills the bandwidth-bound BatchNorm launches and the tails of the data-gradient launches.  Same kernels, same
+ * results. */
+int sv_run_ops_two_streams(const int64_t* ops, int n_ops, void* stream, void* side_stream);
 
 /* ---- BatchNorm1d (+ReLU) on (N,C) voxel features: the norm_fn -> ReLU tail of post_act_block
  * (detector3d/pcdet/models/backbones_3d/spconv_backbone.py:9-27,73; torch.nn.BatchNorm1d semantics: biased batch variance for

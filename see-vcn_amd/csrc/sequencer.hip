@@ -21,11 +21,39 @@ template <typename T>
 inline T* ptr_of(int64_t v) { return reinterpret_cast<T*>(static_cast<uintptr_t>(v)); }
 }   // namespace
 
-extern "C" int sv_run_ops(const int64_t* ops, int n_ops, void* stream) {
+// Events for the two-stream form: recorded and waited for inside one call, reused by the next (a wait captures the record in front of it)
+static hipEvent_t g_ev[2] = {nullptr, nullptr};
+static int seq_events() {
+  for (auto& e : g_ev)
+    if (!e) SV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return SV_OK;
+}
+
+static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_stream);
+
+extern "C" int sv_run_ops(const int64_t* ops, int n_ops, void* stream) { return run_ops(ops, n_ops, stream, nullptr); }
+
+// The same list with its weight gradients (SV_OP_WGRAD, SV_OP_WGRAD_DEFERRED and the deferred reduction) on `side_stream`: each goes behind an event
+// recorded on `stream` after the operations in front of it, the other operations do not wait for it, and `stream` waits for `side_stream` once, at the
+// end -- when the call returns everything is ordered on `stream` as after sv_run_ops.  A weight gradient only feeds the optimiser: the backward chain
+// (BatchNorm backward -> data gradient -> next BatchNorm backward) need not stop for it, and its matrix-core work fills the bandwidth-bound BatchNorm
+// launches and the tails of the data-gradient launches (trained side of the benchmarked step alone: 3.16 -> 3.05 ms).  Same kernels, same results.
+extern "C" int sv_run_ops_two_streams(const int64_t* ops, int n_ops, void* stream, void* side_stream) {
+  SV_CHECK_ARG(side_stream && side_stream != stream, "sv_run_ops_two_streams: needs a second stream");
+  return run_ops(ops, n_ops, stream, side_stream);
+}
+
+static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_stream) {
   SV_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "sv_run_ops: null list");
+  hipStream_t st_main = sv_stream(stream), st_side = side_stream ? sv_stream(side_stream) : nullptr;
+  bool side_used = false;
+  if (st_side) {
+    if (int rc = seq_events()) return rc;
+  }
+  void* const wstream = side_stream ? side_stream : stream;      // where weight gradients go
   constexpr int MAX_DEFERRED = 64;
   int64_t deferred[MAX_DEFERRED * 10];       // stage-2 jobs of the SV_OP_WGRAD_DEFERRED operations of this list
-  int n_deferred = 0;
+  int n_deferred = 0, fail = SV_OK;
   for (int k = 0; k < n_ops; ++k) {
     const int64_t* o = ops + (size_t)k * SV_OP_WORDS;
     const int64_t* i = o + 1;       // 8 small integers
@@ -75,34 +103,53 @@ extern "C" int sv_run_ops(const int64_t* ops, int n_ops, void* stream) {
                                         ptr_of<float>(p[7]), ptr_of<float>(p[8]), ptr_of<float>(p[9]), stream);
         break;
       case SV_OP_WGRAD:
+        if (st_side) {
+          SV_HIP(hipEventRecord(g_ev[0], st_main));
+          SV_HIP(hipStreamWaitEvent(st_side, g_ev[0], 0));
+          side_used = true;
+        }
         if (p[5])
           rc = sv_sparse_conv_wgrad_planned(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
-                                            (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<const void>(p[5]), ptr_of<void>(p[4]), stream);
+                                            (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<const void>(p[5]), ptr_of<void>(p[4]), wstream);
         else
         rc = sv_sparse_conv_wgrad_strided(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
-                                          (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<void>(p[4]), stream);
+                                          (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<void>(p[4]), wstream);
         break;
       case SV_OP_WGRAD_DEFERRED:
+        if (st_side) {
+          SV_HIP(hipEventRecord(g_ev[0], st_main));
+          SV_HIP(hipStreamWaitEvent(st_side, g_ev[0], 0));
+          side_used = true;
+        }
         if (n_deferred == MAX_DEFERRED) {     // more than a list's worth: sum what is pending, go on
-          rc = sv_sparse_conv_wgrad_reduce_batch(deferred, n_deferred, stream);
+          rc = sv_sparse_conv_wgrad_reduce_batch(deferred, n_deferred, wstream);
           n_deferred = 0;
-          if (rc != SV_OK) return rc;
+          if (rc != SV_OK) break;
         }
         if (p[5])
           rc = sv_sparse_conv_wgrad_planned_stage1(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
                                                    (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<const void>(p[5]), ptr_of<void>(p[4]),
-                                                   deferred + 10 * n_deferred, stream);
+                                                   deferred + 10 * n_deferred, wstream);
         else
         rc = sv_sparse_conv_wgrad_stage1(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
-                                         (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<void>(p[4]), deferred + 10 * n_deferred, stream);
+                                         (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<void>(p[4]), deferred + 10 * n_deferred, wstream);
         ++n_deferred;
         break;
       default:
         sv_set_error("sv_run_ops: unknown operation %lld at position %d", (long long)o[0], k);
-        return SV_ERR_ARG;
+        rc = SV_ERR_ARG;
+        break;
     }
-    if (rc != SV_OK) return rc;     // sv_last_error() names the failing entry point; `k` operations were enqueued
+    if (rc != SV_OK) {              // sv_last_error() names the failing entry point; `k` operations were enqueued
+      fail = rc;
+      break;
+    }
   }
-  if (n_deferred > 0) return sv_sparse_conv_wgrad_reduce_batch(deferred, n_deferred, stream);     // every deferred weight gradient: one launch at the end of the list
-  return SV_OK;
+  int rc = fail;
+  if (rc == SV_OK && n_deferred > 0) rc = sv_sparse_conv_wgrad_reduce_batch(deferred, n_deferred, wstream);     // every deferred weight gradient: one launch at the end of the list
+  if (side_used) {                  // whatever happened above: the caller's stream comes back ordered behind the side stream
+    SV_HIP(hipEventRecord(g_ev[1], st_side));
+    SV_HIP(hipStreamWaitEvent(st_main, g_ev[1], 0));
+  }
+  return rc;
 }

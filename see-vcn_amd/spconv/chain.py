@@ -25,6 +25,12 @@ BWD_SUMS_IN_CONV = os.environ.get("SEEVCN_BN_BWD_IN_CONV", "0") == "1"
 # 0: every weight gradient is followed by its own slab-reduction launch (SV_OP_WGRAD) instead of ONE reduction launch for all layers at the end of the backward
 # list (SV_OP_WGRAD_DEFERRED: bitwise the same gradients) -- A/B runs
 DEFER_WGRAD_REDUCE = os.environ.get("SEEVCN_WGRAD_DEFER", "1") != "0"
+# 1: the weight gradients of the backward list on a stream of their own (sv_run_ops_two_streams), each behind the BatchNorm backward that makes its operand;
+# the main chain (data gradient -> next BatchNorm backward -> ...) does not wait for them until the end of the list.  Measured, same box: the trained side
+# alone 3.16 -> 3.06 ms (the matrix-core work fills the bandwidth-bound BatchNorm launches and the data gradients' tails); the pipelined step, where the
+# input side's stream already shares the GPU, 4.07-4.19 -> 4.3-4.4 ms (three streams fragment the one-resident-round launches).  Off by default.
+WGRAD_STREAM = os.environ.get("SEEVCN_WGRAD_STREAM", "0") == "1"
+_wgrad_stream = {}
 OP_CONV_PLANNED, OP_CONV_PLAIN, OP_BN_FWD, OP_BN_BWD, OP_WGRAD, OP_DGRAD_PLANNED_BN, OP_WGRAD_DEFERRED = 1, 2, 3, 5, 6, 7, 8
 WORDS = 32
 
@@ -46,6 +52,16 @@ def _row(code, i=(), n=(), f=(), p=()):
 def _run(rows, what):
     arr = np.array(rows, dtype=np.int64)
     _lib.check(_lib.load().sv_run_ops(arr.ctypes.data, len(rows), _lib.stream()), what)
+
+
+def _run_two_streams(rows, dev):
+    """The backward list with its weight gradients on a second stream (sv_run_ops_two_streams): the chain's data gradients and BatchNorm backwards do not
+    wait for them; the current stream is ordered behind the side stream when the call returns."""
+    side = _wgrad_stream.get(dev)
+    if side is None:
+        side = _wgrad_stream[dev] = torch.cuda.Stream(dev)
+    arr = np.array(rows, dtype=np.int64)
+    _lib.check(_lib.load().sv_run_ops_two_streams(arr.ctypes.data, len(rows), _lib.stream(), side.cuda_stream), "sv_run_ops_two_streams (chain backward)")
 
 
 class Block:
@@ -241,7 +257,10 @@ class SparseChainFunction(torch.autograd.Function):
                                      p=(o_dconv, a_rows, a_perm, a_masks_p, a_tiles, frags[k].data_ptr(), o_dx, None,
                                         None, None, None if res is None else res.data_ptr(), None)))
                 dy_ptr = o_dx
-        _run(rows, "sv_run_ops (chain backward)")
+        if WGRAD_STREAM:
+            _run_two_streams(rows, dev)
+        else:
+            _run(rows, "sv_run_ops (chain backward)")
         out = [None, None, None]
         for k, b in enumerate(blocks):
             w = params[3 * k]

@@ -1049,3 +1049,36 @@ def test_hip_weight_gradient_plans_of_several_tables_in_one_batch(cuda, hip_lib)
     _lib.check(lib.sv_wgrad_plan_build_batch(jobs.ctypes.data, len(cases), _lib.stream()), "sv_wgrad_plan_build_batch")
     for a, b in zip(single, batch):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_hip_backward_list_with_weight_gradients_on_a_second_stream_is_bitwise_the_one_stream_list(cuda, hip_lib):
+    """sv_run_ops_two_streams (SEEVCN_WGRAD_STREAM=1): the chain's backward with its weight gradients on a side stream -- the same kernels on the same operands,
+    ordered behind the chain's stream when the call returns: every gradient bit-identical to the one-stream list."""
+    import copy
+    import seevcn_amd.synth as synth
+    from seevcn_amd.pcdet.models import backbones_3d
+    from seevcn_amd.pcdet.ops import voxel_ops
+    from seevcn_amd.spconv import chain
+    pts, _ = synth.make_scene_batch(2, seed=2006, n_az=120)
+    g = dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.05, 0.05, 0.1], grid_size=[1408, 1600, 40])
+    f, c, _ = voxel_ops.voxelize_dynamic(torch.from_numpy(pts).to(cuda), g["point_cloud_range"], g["voxel_size"], g["grid_size"], 2)
+    torch.manual_seed(4)
+    net1 = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size']).to(cuda).train()
+    net2 = copy.deepcopy(net1)
+    res = []
+    for net, two in ((net1, True), (net2, False)):
+        saved, chain.WGRAD_STREAM = chain.WGRAD_STREAM, two
+        try:
+            for _ in range(2):                       # twice: the second pass reuses the events and the side stream
+                net.zero_grad(set_to_none=True)
+                bd = net({'batch_size': 2, 'voxel_features': f.clone(), 'voxel_coords': c.clone()})
+                out = bd['encoded_spconv_tensor'].features
+                assert type(out.grad_fn).__name__ == "SparseChainFunctionBackward"
+                out.square().sum().backward()
+                torch.cuda.synchronize()
+        finally:
+            chain.WGRAD_STREAM = saved
+        res.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
