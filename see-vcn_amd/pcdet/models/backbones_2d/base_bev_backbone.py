@@ -1,3 +1,5 @@
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -8,6 +10,13 @@ from ...utils.common_utils import cfg_get
 def _conv_bn_relu(c_in, c_out, k, stride, padding):
     return [nn.Conv2d(c_in, c_out, kernel_size=k, stride=stride, padding=padding, bias=False),
             nn.BatchNorm2d(c_out, eps=1e-3, momentum=0.01), nn.ReLU()]
+
+
+# Memory format of the dense 2-D part (MIOpen's role is cuDNN's): 'auto' = channels_last (NHWC) from 8 scenes per batch on, NCHW below.  Measured on one
+# MI355X, forward + backward of this module (tools/bev_format_ab.py, profiles/r03_bev_format_ab.txt): 16 x 256 x 200 x 176 (SECOND) 74.0 ms NCHW / 68.9 ms
+# NHWC; 4 x 256 x 188 x 188 (PV-RCNN) 18.3 / 23.3 ms -- MIOpen picks NHWC implicit-GEMM kernels for the weight gradients either way and transposes around
+# them when fed NCHW; at small batch its NCHW Winograd forward wins by more than the transposes cost.  SEEVCN_BEV_FORMAT=nchw|nhwc forces one.
+BEV_FORMAT = os.environ.get("SEEVCN_BEV_FORMAT", "auto")
 
 
 class BaseBEVBackbone(nn.Module):
@@ -53,6 +62,11 @@ class BaseBEVBackbone(nn.Module):
         spatial_features = data_dict['spatial_features']
         ups = []
         x = spatial_features
+        if x.is_cuda and (BEV_FORMAT == "nhwc" or (BEV_FORMAT == "auto" and x.shape[0] >= 8)):
+            if not getattr(self, "_nhwc", False):
+                self.to(memory_format=torch.channels_last)           # parameters re-laid once; gradients follow their parameters' layout
+                self._nhwc = True
+            x = x.contiguous(memory_format=torch.channels_last)
         for i in range(len(self.blocks)):
             x = self.blocks[i](x)
             stride = int(spatial_features.shape[2] / x.shape[2])
