@@ -17,6 +17,7 @@ def _conv_bn_relu(c_in, c_out, k, stride, padding):
 # NHWC; 4 x 256 x 188 x 188 (PV-RCNN) 18.3 / 23.3 ms -- MIOpen picks NHWC implicit-GEMM kernels for the weight gradients either way and transposes around
 # them when fed NCHW; at small batch its NCHW Winograd forward wins by more than the transposes cost.  SEEVCN_BEV_FORMAT=nchw|nhwc forces one.
 BEV_FORMAT = os.environ.get("SEEVCN_BEV_FORMAT", "auto")
+BN_FUSED = os.environ.get("SEEVCN_BEV_BN_FUSED", "1")      # 0: channels_last activations still go through MIOpen's BatchNorm2d and torch's ReLU (A/B)
 
 
 class BaseBEVBackbone(nn.Module):
@@ -58,25 +59,55 @@ class BaseBEVBackbone(nn.Module):
                 nn.BatchNorm2d(c_in, eps=1e-3, momentum=0.01), nn.ReLU()))
         self.num_bev_features = c_in
 
+    @staticmethod
+    def _run(seq, x, nhwc):
+        """seq(x).  In channels_last an activation IS the (N H W, C) row matrix of the sparse backbone's BatchNorm kernels: every BatchNorm2d (+ ReLU behind
+        it) runs as ONE fused pass pair (spconv.norm: batch statistics in fp64 over fixed-order partials, ReLU inside, the backward recomputes the branch) in
+        place of MIOpen's BatchNorm + two elementwise ReLU passes.  Modules with hooks, odd channel counts or NCHW tensors go through the modules."""
+        if not nhwc or BN_FUSED == "0":
+            return seq(x)
+        from ....spconv import norm
+        mods, i = list(seq), 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            fuse = (isinstance(m, nn.BatchNorm2d) and x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and norm.channels_fusable(m.num_features)
+                    and m.momentum is not None and (m.training or m.track_running_stats) and (not x.requires_grad or m.training)
+                    and not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks))
+            if not fuse:
+                x = m(x)
+                i += 1
+                continue
+            relu = isinstance(nxt, nn.ReLU) and not (nxt._forward_hooks or nxt._forward_pre_hooks or nxt._backward_hooks)
+            n, c, h, w = x.shape
+            rows = x.permute(0, 2, 3, 1)                             # a view of a channels_last tensor; anything else is copied once
+            if not rows.is_contiguous():
+                rows = rows.contiguous()
+            y = norm.batch_norm_relu(m, rows.reshape(-1, c), relu)
+            x = y.view(n, h, w, c).permute(0, 3, 1, 2)
+            i += 2 if relu else 1
+        return x
+
     def forward(self, data_dict):
         spatial_features = data_dict['spatial_features']
         ups = []
         x = spatial_features
-        if x.is_cuda and (BEV_FORMAT == "nhwc" or (BEV_FORMAT == "auto" and x.shape[0] >= 8)):
+        nhwc = x.is_cuda and (BEV_FORMAT == "nhwc" or (BEV_FORMAT == "auto" and x.shape[0] >= 8))
+        if nhwc:
             if not getattr(self, "_nhwc", False):
                 self.to(memory_format=torch.channels_last)           # parameters re-laid once; gradients follow their parameters' layout
                 self._nhwc = True
             x = x.contiguous(memory_format=torch.channels_last)
         for i in range(len(self.blocks)):
-            x = self.blocks[i](x)
+            x = self._run(self.blocks[i], x, nhwc)
             stride = int(spatial_features.shape[2] / x.shape[2])
             data_dict['spatial_features_%dx' % stride] = x
-            ups.append(self.deblocks[i](x) if len(self.deblocks) > 0 else x)
+            ups.append(self._run(self.deblocks[i], x, nhwc) if len(self.deblocks) > 0 else x)
         if len(ups) > 1:
             x = torch.cat(ups, dim=1)
         elif len(ups) == 1:
             x = ups[0]
         if len(self.deblocks) > len(self.blocks):
-            x = self.deblocks[-1](x)
+            x = self._run(self.deblocks[-1], x, nhwc)
         data_dict['spatial_features_2d'] = x
         return data_dict

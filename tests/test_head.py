@@ -61,6 +61,49 @@ def test_hip_bev_backbone_matches_reference_golden(golden_dir, cuda, hip_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("training", [False, True])
+def test_hip_bev_backbone_channels_last_with_fused_batchnorm_equals_the_nchw_modules(golden_dir, cuda, hip_lib, training, monkeypatch):
+    """BaseBEVBackbone in channels_last (the default from 8 scenes per batch on) with every BatchNorm2d + ReLU on the fused (N H W, C) kernels of the sparse
+    backbone, against the same network in NCHW through MIOpen's BatchNorm2d and torch's ReLU: eval against the reference golden, training mode outputs,
+    every parameter gradient and the running statistics within 1e-4 of each tensor's scale."""
+    import copy
+    from seevcn_amd.pcdet.models import backbones_2d
+    from seevcn_amd.pcdet.models.backbones_2d import base_bev_backbone as B
+    g = np.load(os.path.join(golden_dir, "bev_backbone.npz"))
+    cfg = dict(C.SECOND_BACKBONE_2D, LAYER_NUMS=[2, 2], NUM_FILTERS=[32, 64], NUM_UPSAMPLE_FILTERS=[64, 64])
+    ref = backbones_2d.__all__["BaseBEVBackbone"](cfg, 48)
+    ref.load_state_dict(seeded_state_dict(ref, seed=2))
+    ref = ref.to(cuda).train(training)
+    new = copy.deepcopy(ref)
+    x0 = torch.from_numpy(g["spatial_features"]).to(cuda)
+    outs = []
+    for net, fmt in ((ref, "nchw"), (new, "nhwc")):
+        monkeypatch.setattr(B, "BEV_FORMAT", fmt)
+        x = x0.clone().requires_grad_(training)
+        with torch.set_grad_enabled(training):
+            y = net({"spatial_features": x})["spatial_features_2d"]
+            if training:
+                (y * torch.linspace(-1, 1, y.numel(), device=cuda).view_as(y)).sum().backward()
+        outs.append((y.detach(), x.grad))
+    assert outs[1][0].is_contiguous(memory_format=torch.channels_last)
+    if not training:
+        assert_close_per_channel(outs[1][0].cpu().numpy(), g["spatial_features_2d"], rtol=1e-3, atol_frac=1e-4, name="spatial_features_2d", channel_axis=1)
+        return
+    def close(a, b, name):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-4 * scale, (name, float((a - b).abs().max()), scale)
+    close(outs[1][0], outs[0][0], "output")
+    close(outs[1][1], outs[0][1], "input gradient")
+    for (k, p), (_, q) in zip(new.named_parameters(), ref.named_parameters()):
+        close(p.grad.contiguous(), q.grad.contiguous(), k)
+    for (k, p), (_, q) in zip(new.named_buffers(), ref.named_buffers()):
+        if p.dtype.is_floating_point:
+            close(p, q, k)
+        else:
+            assert torch.equal(p, q), k
+
+
+@pytest.mark.gpu
 def test_hip_anchor_head_matches_reference_golden(golden_dir, cuda, hip_lib):
     from seevcn_amd.pcdet.models import dense_heads
     g, feat = _golden(golden_dir)
