@@ -300,7 +300,8 @@ int sv_sparse_conv_wgrad_reduce_batch(const int64_t* jobs_host, int n_jobs, void
  * The chunked stage 1 above gives every (row chunk, offset) a workgroup: an offset's work follows its density, and the launch ends when the unluckiest CU
  * does (pairs per SIMD max / mean 1.4-1.6 on a LiDAR rulebook, tools/wgrad_trace.py).  Here a per-TABLE plan cuts the table's pairs, offset-major, into
  * sv_wgrad_plan_pieces(Cin, Cout) pieces of equal pair count (up to one 64-row unit) -- as many as workgroups are resident -- and stage 1 runs one
- * workgroup per piece (one (Cin, Cout) slab per offset a piece touches).  A plan is a function of (table, pieces) only: build it once per rulebook
+ * workgroup per piece (one (Cin, Cout) slab per (row eighth, offset) a piece touches; the order of the cut is row eighth, offset, row, so that an XCD's
+ * workgroups stay inside one eighth of the rows).  A plan is a function of (table, pieces) only: build it once per rulebook
  * table, use it for every layer on that table whose sv_wgrad_plan_pieces agrees.  Results are bitwise reproducible; they differ from the chunked
  * form's in the last bits (other partial sums).
  *   sv_wgrad_plan_bytes          bytes of a plan (device memory, caller-owned)

@@ -1981,19 +1981,29 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 // slab % 4 == 0: 64 float4 columns x 4 quarters of the chunk range per workgroup -- four times the loads in flight of the scalar
 // kernel, partial sums combined in a fixed order ((q0 + q1) + (q2 + q3)): still bitwise reproducible
-// The slabs that hold element e (float4 index into the (K, Cin, Cout) gradient): first one, their number, their stride.  Chunked stage 1: slab c of
-// nchunks at c * slab4.  Stage 1 on equal pieces (k_spconv_wgrad_eq): one (Cin, Cout) slab per (piece, offset it touches), the slabs of offset k
-// back to back from runs[2k] on, runs[2k + 1] of them.
-struct WgradSlabRun {
-  const f32x4* p;
-  int n;
-  int64_t stride;
-};
-__device__ __forceinline__ WgradSlabRun wgrad_slab_run(const float* partial, int nchunks, int64_t slab4, const int32_t* runs, int cc4, int64_t e) {
+// Stage 2 reads chunked stage-1 slabs (slab c of nchunks at c * slab4) or the slabs of a stage 1 on equal pieces (k_spconv_wgrad_eq: one (Cin, Cout) slab per
+// (piece, group it touches), the slabs of a group back to back).
+// quarter q of the four partial sums the reduction kernels make per element: chunk layout -- the q-th quarter of the chunk range; equal pieces -- the
+// slabs of the offset's groups in the row eighths 2q and 2q + 1 (runs[2 g], runs[2 g + 1]: first slab and number of slabs of group g = eighth * K + k)
+__device__ __forceinline__ f32x4 wgrad_quarter_sum(const float* partial, int nchunks, int64_t slab4, const int32_t* runs, int cc4, int64_t e, int q) {
   const f32x4* p4 = reinterpret_cast<const f32x4*>(partial);
-  if (!runs) return WgradSlabRun{p4 + e, nchunks, slab4};
-  const int k = (int)(e / cc4);
-  return WgradSlabRun{p4 + (int64_t)runs[2 * k] * cc4 + (e - (int64_t)k * cc4), runs[2 * k + 1], cc4};
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (!runs) {
+    const int c0 = (int)((int64_t)nchunks * q / 4), c1 = (int)((int64_t)nchunks * (q + 1) / 4);
+    const f32x4* p = p4 + e;
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) s += __builtin_nontemporal_load(p + (int64_t)c * slab4);
+    return s;
+  }
+  const int K = (int)(slab4 / cc4), k = (int)(e / cc4);
+  const int64_t within = e - (int64_t)k * cc4;
+  for (int x = 2 * q; x < 2 * q + 2; ++x) {
+    const int g = x * K + k, first = runs[2 * g], n = runs[2 * g + 1];
+    const f32x4* p = p4 + (int64_t)first * cc4 + within;
+#pragma unroll 4
+    for (int c = 0; c < n; ++c) s += __builtin_nontemporal_load(p + (int64_t)c * cc4);
+  }
+  return s;
 }
 
 __global__ __launch_bounds__(256) void k_wgrad_reduce4(const float* __restrict__ partial, int nchunks, int64_t slab4, float* __restrict__ dW, WgradOut o,
@@ -2002,12 +2012,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce4(const float* __restrict__
   const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t e = (int64_t)blockIdx.x * 64 + col;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (e < slab4) {
-    const WgradSlabRun r = wgrad_slab_run(partial, nchunks, slab4, runs, o.Cin * o.Cout / 4, e);
-    const int c0 = (int)((int64_t)r.n * q / 4), c1 = (int)((int64_t)r.n * (q + 1) / 4);
-#pragma unroll 4
-    for (int c = c0; c < c1; ++c) s += __builtin_nontemporal_load(r.p + (int64_t)c * r.stride);
-  }
+  if (e < slab4) s = wgrad_quarter_sum(partial, nchunks, slab4, runs, o.Cin * o.Cout / 4, e, q);
   s_q[q][col] = s;
   __syncthreads();
   if (q == 0 && e < slab4) {
@@ -2083,7 +2088,7 @@ struct WgradReduceJob {
   float* dW;
   int64_t slab;          // K * Cin * Cout
   int nslabs, wg0;
-  const int32_t* runs;   // per-offset slab runs of a stage 1 on equal pieces (wgrad_slab_run), or null: nslabs chunk slabs
+  const int32_t* runs;   // slab runs of a stage 1 on equal pieces (wgrad_quarter_sum), or null: nslabs chunk slabs
   WgradOut out;
 };
 
@@ -2163,12 +2168,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce4_batch(WgradReduceBatch b)
   const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t slab4 = J.slab / 4, e = (int64_t)((int)blockIdx.x - J.wg0) * 64 + col;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (e < slab4) {
-    const WgradSlabRun r = wgrad_slab_run(J.partial, J.nslabs, slab4, J.runs, J.out.Cin * J.out.Cout / 4, e);
-    const int c0 = (int)((int64_t)r.n * q / 4), c1 = (int)((int64_t)r.n * (q + 1) / 4);
-#pragma unroll 4
-    for (int c = c0; c < c1; ++c) s += __builtin_nontemporal_load(r.p + (int64_t)c * r.stride);
-  }
+  if (e < slab4) s = wgrad_quarter_sum(J.partial, J.nslabs, slab4, J.runs, J.out.Cin * J.out.Cout / 4, e, q);
   s_q[q][col] = s;
   __syncthreads();
   if (q == 0 && e < slab4) {
@@ -2246,9 +2246,10 @@ extern "C" int sv_sparse_conv_wgrad_reduce_batch(const int64_t* jobs_host, int n
 // ------------------------------------------------------------------------------------------------
 constexpr int WGE_CUS = 256;              // MI355X
 constexpr int WGE_UNIT = 64;              // rows per unit
+constexpr int WGE_EIGHTHS = 8;            // row eighths of the unit order: one per XCD
 constexpr int WGE_MAX_PIECES = WGE_CUS * 8;
 
-// plan layout (int32; every part padded to a multiple of 4): cut[pieces + 1] | slab0[pieces + 1] | runs[2 K] | prefix[U + 1] (pairs in front of every 64-row unit, offset-major; U = K * units per offset)
+// plan layout (int32; every part padded to a multiple of 4): cut[pieces + 1] | slab0[pieces + 1] | runs[2 * 8 K] | prefix[U + 1] (pairs in front of every 64-row unit in (eighth, offset, unit) order; U = 8 K * units per group)
 struct WgradPlanPtrs {
   int32_t *cut, *slab0, *runs, *pre;
 };
@@ -2258,15 +2259,23 @@ static WgradPlanPtrs wgrad_plan_ptrs(void* plan, int pieces, int K) {
   p.cut = static_cast<int32_t*>(plan);
   p.slab0 = p.cut + wgp_pad4(pieces + 1);
   p.runs = p.slab0 + wgp_pad4(pieces + 1);
-  p.pre = p.runs + wgp_pad4(2 * K);
+  p.pre = p.runs + wgp_pad4(2 * WGE_EIGHTHS * K);
   return p;
 }
-static int64_t wgrad_units_per_offset(int64_t n_rows) { return (n_rows + WGE_UNIT - 1) / WGE_UNIT; }
+// Unit order: (row eighth x, offset k, unit j inside the eighth) -- group g = x * K + k holds the WGE-unit slots of one offset inside one eighth of the
+// rows; unit u of group g is rows [64 r, 64 r + 64), r = x * nbu8 + (u - g * nbu8).  Pieces are cut along this order and workgroup b takes piece
+// (b % 8) * (pieces / 8) + b / 8: the pieces of XCD x (workgroup b runs on XCD b % 8) lie in the x-th eighth of the order, i.e. (up to the drift of
+// the cuts) in the x-th eighth of the ROWS -- a row's X / dY go through one L2 for all 27 offsets instead of through eight.  (Offset-major over the
+// whole table, the first version, pulled 4.7x the algorithmic bytes: profiles/r04_d_traffic.json.)
+static int64_t wgrad_units_per_group(int64_t n_rows) {
+  const int64_t nbu = (n_rows + WGE_UNIT - 1) / WGE_UNIT;
+  return (nbu + WGE_EIGHTHS - 1) / WGE_EIGHTHS;
+}
 
 extern "C" size_t sv_wgrad_plan_bytes(int64_t n_rows, int K, int pieces) {
   if (n_rows < 0 || K <= 0 || pieces <= 0) return 0;
-  const int64_t U = wgrad_units_per_offset(n_rows) * K;
-  return ((size_t)(2 * wgp_pad4(pieces + 1) + wgp_pad4(2 * K) + U + 1) * sizeof(int32_t) + 255) / 256 * 256;
+  const int64_t U = wgrad_units_per_group(n_rows) * WGE_EIGHTHS * K;
+  return ((size_t)(2 * wgp_pad4(pieces + 1) + wgp_pad4(2 * WGE_EIGHTHS * K) + U + 1) * sizeof(int32_t) + 255) / 256 * 256;
 }
 
 // pieces the kernel instance of a layer shape is cut for: four workgroups per CU for the 64-channel-multiple layers (122 VGPRs: four waves per
@@ -2285,7 +2294,7 @@ struct WgradPlanJob {
   const int32_t* nbr;
   int64_t n_rows;
   int32_t *pre, *cut, *slab0, *runs;
-  int U, nbu, K, pieces, wg0;          // wg0: first workgroup of this table in the batched count launch
+  int U, nbu, K, pieces, wg0;          // nbu: unit slots per group (wgrad_units_per_group); wg0: first workgroup of this table in the batched count launch
 };
 constexpr int WGP_MAX = 12;
 struct WgradPlanBatch {
@@ -2304,7 +2313,8 @@ __global__ __launch_bounds__(256) void k_wgrad_plan_count(WgradPlanBatch b) {
 #pragma unroll
   for (int q = 1; q < WGP_MAX; ++q) ji += (q < b.n && (int)blockIdx.x >= b.j[q].wg0) ? 1 : 0;
   const WgradPlanJob& J = b.j[ji];
-  const int wgs_per_k = (int)((J.n_rows + WGP_ROWS - 1) / WGP_ROWS), local = (int)blockIdx.x - J.wg0;
+  const int64_t rows_cov = (int64_t)J.nbu * WGE_EIGHTHS * WGE_UNIT;      // every unit slot of every group, the empty ones past the table's end included
+  const int wgs_per_k = (int)((rows_cov + WGP_ROWS - 1) / WGP_ROWS), local = (int)blockIdx.x - J.wg0;
   const int k = local / wgs_per_k, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int32_t* __restrict__ nb = J.nbr + (int64_t)k * J.n_rows;
   const bool aligned = ((uintptr_t)nb & 15) == 0;                       // n_rows % 4 != 0 shifts the offsets' rows off 16 bytes
@@ -2324,8 +2334,11 @@ __global__ __launch_bounds__(256) void k_wgrad_plan_count(WgradPlanBatch b) {
     const unsigned long long m0 = __ballot(v[q].x >= 0), m1 = __ballot(v[q].y >= 0), m2 = __ballot(v[q].z >= 0), m3 = __ballot(v[q].w >= 0);
     if (lane < 4) {
       const unsigned long long mask = 0xffffull << (16 * lane);
-      const int64_t unit = (r0 + q * 256) / WGE_UNIT + lane;
-      if (unit < J.nbu) J.pre[(int64_t)k * J.nbu + unit] = __popcll(m0 & mask) + __popcll(m1 & mask) + __popcll(m2 & mask) + __popcll(m3 & mask);
+      const int64_t unit = (r0 + q * 256) / WGE_UNIT + lane;          // row unit of the table
+      if (unit < (int64_t)J.nbu * WGE_EIGHTHS) {
+        const int x = (int)(unit / J.nbu), j = (int)(unit % J.nbu);
+        J.pre[((int64_t)x * J.K + k) * J.nbu + j] = __popcll(m0 & mask) + __popcll(m1 & mask) + __popcll(m2 & mask) + __popcll(m3 & mask);
+      }
     }
   }
 }
@@ -2352,7 +2365,7 @@ __global__ __launch_bounds__(1024) void k_wgrad_plan_cuts(WgradPlanBatch b) {
   __shared__ int s_run[1025];                            // pairs in front of every thread's run of units (+ the total): the coarse level of the cut search
   const WgradPlanJob& J = b.j[blockIdx.x];
   int32_t* __restrict__ pre = J.pre;
-  const int U = J.U, nbu = J.nbu, K = J.K, pieces = J.pieces;
+  const int U = J.U, nbu = J.nbu, K = J.K * WGE_EIGHTHS, pieces = J.pieces;      // K here: GROUPS (eighth, offset)
   const int tid = threadIdx.x;
   // a thread's run: `per` counts, a multiple of 16, so that it is whole groups of four int4 (pre is 16-byte aligned: the plan's parts are multiples
   // of 4 ints); only the table's last run has a remainder
@@ -2500,7 +2513,8 @@ static int wgrad_plan_job(WgradPlanJob& J, const int32_t* nbr, int64_t n_rows, i
   SV_CHECK_ARG(n_rows >= 1 && K >= 1 && K <= 1024 && plan && nbr, "%s: bad arguments", who);
   SV_CHECK_ARG(pieces >= 1 && pieces <= WGE_MAX_PIECES, "%s: 1..%d pieces", who, WGE_MAX_PIECES);
   SV_CHECK_ARG((uintptr_t)plan % 16 == 0, "%s: the plan must be 16-byte aligned", who);
-  const int64_t nbu = wgrad_units_per_offset(n_rows), U = nbu * K;
+  const int64_t nbu = wgrad_units_per_group(n_rows), U = nbu * WGE_EIGHTHS * K;
+  SV_CHECK_ARG(pieces % WGE_EIGHTHS == 0, "%s: the piece count must be a multiple of %d", who, WGE_EIGHTHS);
   SV_CHECK_ARG(U < (1ll << 30) && n_rows * (int64_t)K < (1ll << 31), "%s: table too large for 32-bit unit indices / pair counts", who);
   const WgradPlanPtrs p = wgrad_plan_ptrs(plan, pieces, K);
   J.nbr = nbr, J.n_rows = n_rows, J.pre = p.pre, J.cut = p.cut, J.slab0 = p.slab0, J.runs = p.runs;
@@ -2516,7 +2530,7 @@ extern "C" int sv_wgrad_plan_build(const int32_t* nbr, int64_t n_rows, int K, in
   WgradPlanBatch b;
   b.n = 1;
   if (int rc = wgrad_plan_job(b.j[0], nbr, n_rows, K, pieces, plan, "sv_wgrad_plan_build")) return rc;
-  wgrad_plan_launch(b, (int)((n_rows + WGP_ROWS - 1) / WGP_ROWS) * K, sv_stream(stream));
+  wgrad_plan_launch(b, (int)(((int64_t)b.j[0].nbu * WGE_EIGHTHS * WGE_UNIT + WGP_ROWS - 1) / WGP_ROWS) * K, sv_stream(stream));
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -2535,7 +2549,7 @@ extern "C" int sv_wgrad_plan_build_batch(const int64_t* jobs_host, int n_jobs, v
                                 "sv_wgrad_plan_build_batch"))
       return rc;
     J.wg0 = wgs;
-    wgs += (int)((J.n_rows + WGP_ROWS - 1) / WGP_ROWS) * J.K;
+    wgs += (int)(((int64_t)J.nbu * WGE_EIGHTHS * WGE_UNIT + WGP_ROWS - 1) / WGP_ROWS) * J.K;
     if (++b.n == WGP_MAX) {
       wgrad_plan_launch(b, wgs, st);
       b.n = 0, wgs = 0;
@@ -2568,7 +2582,8 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad_eq(Wgr
   __shared__ int2 plist[WGE_LIST_CAP + 32];
   __shared__ float red[CT * NTL * 256];
   __shared__ int s_chunk[2];
-  const int piece = blockIdx.x % pl.pieces, zgroup = blockIdx.x / pl.pieces;
+  const int bl = blockIdx.x % pl.pieces, zgroup = blockIdx.x / pl.pieces;
+  const int piece = (bl % WGE_EIGHTHS) * (pl.pieces / WGE_EIGHTHS) + bl / WGE_EIGHTHS;      // XCD bl % 8 works in the bl % 8-th eighth of the unit order
   const int u0 = pl.cut[piece], u1 = pl.cut[piece + 1];
   if (u0 >= u1) return;
   int slab = pl.slab0[piece];
@@ -2605,8 +2620,9 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad_eq(Wgr
       for (int t = 0; t < NTL; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg_elem(xs, c), wg_elem(ys, t), acc[c][t], 0, 0, 0);
   };
 
-  for (int us = u0; us < u1;) {                              // one segment per offset the piece touches
-    const int k = us / pl.nbu, ue = min(u1, (k + 1) * pl.nbu);
+  for (int us = u0; us < u1;) {                              // one segment per (row eighth, offset) group the piece touches
+    const int grp = us / pl.nbu, ue = min(u1, (grp + 1) * pl.nbu);        // group = (row eighth, offset)
+    const int k = grp % a.K, ru0 = (grp / a.K) * pl.nbu - grp * pl.nbu;    // row unit of unit u: u + ru0
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -2640,14 +2656,14 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad_eq(Wgr
           int32_t jv[WGE_READ];
 #pragma unroll
           for (int s = 0; s < WGE_READ; ++s) {
-            const int64_t r = (int64_t)(u + s - k * pl.nbu) * WGE_UNIT + lane;
+            const int64_t r = (int64_t)(u + s + ru0) * WGE_UNIT + lane;
             jv[s] = (u + s < ub && r < a.n_rows) ? nb[r] : -1;
           }
 #pragma unroll
           for (int s = 0; s < WGE_READ; ++s) {
             const unsigned long long m = __ballot(jv[s] >= 0);
             if (jv[s] >= 0) {
-              const uint32_t r = (uint32_t)((u + s - k * pl.nbu) * WGE_UNIT + lane);
+              const uint32_t r = (uint32_t)((u + s + ru0) * WGE_UNIT + lane);
               plist[pos0 + __popcll(m & ((1ull << lane) - 1ull))] = make_int2((int)((uint32_t)jv[s] * xrow), (int)(r * yrow));
             }
             pos0 += __popcll(m);
@@ -2727,7 +2743,7 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad_eq(Wgr
       unsigned long long* o = a.trace + ((size_t)blockIdx.x * 4 + wid) * 8;
       // word 5: t_end - (time behind the last loop of every segment), so that tools/wgrad_trace.py's "after the last pass" is the sum over segments
       o[0] = t_start, o[1] = t_pro, o[2] = t_loop, o[3] = t_end, o[4] = ((unsigned long long)xcc << 32) | hw, o[5] = t_end - t_tail,
-      o[6] = ((unsigned long long)tr_passes << 32) | tr_pairs, o[7] = ((unsigned long long)(u0 / pl.nbu) << 32) | (unsigned)piece;
+      o[6] = ((unsigned long long)tr_passes << 32) | tr_pairs, o[7] = ((unsigned long long)((u0 / pl.nbu) % a.K) << 32) | (unsigned)piece;
     }
   }
 }
@@ -2761,9 +2777,9 @@ extern "C" int sv_wgrad_planned_applies(int64_t n_src, int64_t n_rows, int K, in
   return ((int64_t)K * Cin * Cout) % 4 == 0 && Cout % 4 == 0;
 }
 
-// bytes of partial slabs the equal-pieces stage 1 writes: one (Cin, Cout) slab per (piece, offset it touches) <= pieces + K - 1
+// bytes of partial slabs the equal-pieces stage 1 writes: one (Cin, Cout) slab per (piece, group it touches) <= pieces + 8 K - 1
 extern "C" size_t sv_sparse_conv_wgrad_planned_bytes(int K, int Cin, int Cout) {
-  return ((size_t)(sv_wgrad_plan_pieces(Cin, Cout) + K) * Cin * Cout * sizeof(float) + 255) / 256 * 256;
+  return ((size_t)(sv_wgrad_plan_pieces(Cin, Cout) + WGE_EIGHTHS * K) * Cin * Cout * sizeof(float) + 255) / 256 * 256;
 }
 
 static int wgrad_planned_run(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin, int Cout,
@@ -2777,7 +2793,7 @@ static int wgrad_planned_run(const float* X, int64_t n_src, const int32_t* nbr, 
   hipStream_t st = sv_stream(stream);
   static const int prio = getenv("SEEVCN_WGRAD_PRIO") ? atoi(getenv("SEEVCN_WGRAD_PRIO")) : 1;
   WgradArgs a{X, nbr, dY, static_cast<float*>(partial), n_rows, K, Cin, Cout, 0, 0, prio, n_src};
-  const WgradPlanView pl{p.cut, p.slab0, p.pre, pieces, (int)wgrad_units_per_offset(n_rows)};
+  const WgradPlanView pl{p.cut, p.slab0, p.pre, pieces, (int)wgrad_units_per_group(n_rows)};
   if (w.tiles_c == 4) launch_wgrad_eq<4, 4>(a, pl, st);
   else if (w.tiles_c == 2 && w.tiles_n == 4) launch_wgrad_eq<2, 4>(a, pl, st);
   else if (w.tiles_c == 2) launch_wgrad_eq<2, 2>(a, pl, st);

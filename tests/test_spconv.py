@@ -951,8 +951,9 @@ def _synthetic_lidar_table(n, K, cuda, seed=11):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,K,pieces", [(100_000, 27, 1024), (100_000, 27, 2048), (3_000, 27, 1024), (700, 3, 2048), (64, 27, 1024)])
 def test_hip_weight_gradient_plan_cuts_the_table_into_equal_pieces(cuda, hip_lib, n, K, pieces):
-    """sv_wgrad_plan_build: the cuts are monotone and cover every 64-row unit, a piece holds total / pieces pairs up to one unit (64 pairs), the slab
-    numbering follows the offsets a piece touches, and every offset's slabs are one contiguous run that covers exactly the pieces holding its units."""
+    """sv_wgrad_plan_build: units in (row eighth, offset, unit) order; the cuts are monotone and cover every 64-row unit slot, a piece holds total / pieces
+    pairs up to one unit (64 pairs), the slab numbering follows the (eighth, offset) groups a piece touches, and every group's slabs are one contiguous
+    run that covers exactly the pieces holding its units."""
     import numpy as np
     from seevcn_amd import _lib
     lib = hip_lib
@@ -960,17 +961,20 @@ def test_hip_weight_gradient_plan_cuts_the_table_into_equal_pieces(cuda, hip_lib
     plan = torch.zeros(lib.sv_wgrad_plan_bytes(n, K, pieces) // 4, dtype=torch.int32, device=cuda)
     _lib.check(lib.sv_wgrad_plan_build(nbr.data_ptr(), n, K, pieces, plan.data_ptr(), _lib.stream()), "sv_wgrad_plan_build")
     p = plan.cpu().numpy()
-    nbu = -(-n // 64)
-    U = nbu * K
+    nbu = -(-(-(-n // 64)) // 8)             # unit slots per group
+    G = 8 * K
+    U = nbu * G
     pad4 = lambda v: (v + 3) & ~3          # every part of the plan starts on a multiple of 4 ints
     o1 = pad4(pieces + 1)
     o2 = o1 + pad4(pieces + 1)
-    o3 = o2 + pad4(2 * K)
-    cut, slab0, runs, pre = p[:pieces + 1], p[o1:o1 + pieces + 1], p[o2:o2 + 2 * K].reshape(K, 2), p[o3:o3 + U + 1]
+    o3 = o2 + pad4(2 * G)
+    cut, slab0, runs, pre = p[:pieces + 1], p[o1:o1 + pieces + 1], p[o2:o2 + 2 * G].reshape(G, 2), p[o3:o3 + U + 1]
     valid = (nbr >= 0).cpu().numpy()
-    counts = np.zeros(U, dtype=np.int64)
+    per_unit = np.zeros((K, 8 * nbu), dtype=np.int64)                       # pairs of every row unit (slots past the table's end: 0)
     for k in range(K):
-        counts[k * nbu:(k + 1) * nbu] = np.add.reduceat(valid[k], np.arange(0, n, 64))
+        c = np.add.reduceat(valid[k], np.arange(0, n, 64))
+        per_unit[k, :len(c)] = c
+    counts = per_unit.reshape(K, 8, nbu).transpose(1, 0, 2).reshape(-1)      # (eighth, offset, unit)
     assert np.array_equal(pre, np.concatenate([[0], np.cumsum(counts)]))
     assert cut[0] == 0 and cut[-1] == U and np.all(np.diff(cut) >= 0)
     total = int(counts.sum())
@@ -979,10 +983,10 @@ def test_hip_weight_gradient_plan_cuts_the_table_into_equal_pieces(cuda, hip_lib
     assert np.all(np.abs(per_piece - total / pieces) <= 64 + 1), (per_piece.min(), per_piece.max(), total / pieces)
     nseg = np.array([0 if cut[i] == cut[i + 1] else (cut[i + 1] - 1) // nbu - cut[i] // nbu + 1 for i in range(pieces)])
     assert np.array_equal(slab0, np.concatenate([[0], np.cumsum(nseg)]))
-    assert slab0[-1] <= pieces + K - 1
-    for k in range(K):
-        ids = [slab0[i] + (k - cut[i] // nbu) for i in range(pieces) if cut[i] < cut[i + 1] and cut[i] // nbu <= k <= (cut[i + 1] - 1) // nbu]
-        assert ids == list(range(runs[k, 0], runs[k, 0] + runs[k, 1])), k
+    assert slab0[-1] <= pieces + G - 1
+    for g in range(G):
+        ids = [slab0[i] + (g - cut[i] // nbu) for i in range(pieces) if cut[i] < cut[i + 1] and cut[i] // nbu <= g <= (cut[i + 1] - 1) // nbu]
+        assert ids == list(range(runs[g, 0], runs[g, 0] + runs[g, 1])), g
 
 
 @pytest.mark.gpu
