@@ -298,7 +298,7 @@ int sv_sparse_conv_wgrad_stage1(const float* X, int64_t n_src, const int32_t* nb
 int sv_sparse_conv_wgrad_reduce_batch(const int64_t* jobs_host, int n_jobs, void* stream);
 /* Weight gradient on EQUAL PIECES (the default of the trained path; replaces the role of spconv's indice_conv_backward filter gradient as the entries above do).
  * The chunked stage 1 above gives every (row chunk, offset) a workgroup: an offset's work follows its density, and the launch ends when the unluckiest CU
- * does (pairs per SIMD max / mean 1.4-1.6 on a LiDAR rulebook, tools/wgrad_trace.py).  Here a per-TABLE plan cuts the table's pairs, offset-major, into
+ * does (pairs per SIMD max / mean 1.4-1.6 on a LiDAR rulebook, tools/wgrad_trace.py).  Here a per-TABLE plan cuts the table's pairs, in (row eighth, offset, row) order, into
  * sv_wgrad_plan_pieces(Cin, Cout) pieces of equal pair count (up to one 64-row unit) -- as many as workgroups are resident -- and stage 1 runs one
  * workgroup per piece (one (Cin, Cout) slab per (row eighth, offset) a piece touches; the order of the cut is row eighth, offset, row, so that an XCD's
  * workgroups stay inside one eighth of the rows).  A plan is a function of (table, pieces) only: build it once per rulebook
