@@ -2266,7 +2266,7 @@ static WgradPlanPtrs wgrad_plan_ptrs(void* plan, int pieces, int K) {
 // rows; unit u of group g is rows [64 r, 64 r + 64), r = x * nbu8 + (u - g * nbu8).  Pieces are cut along this order and workgroup b takes piece
 // (b % 8) * (pieces / 8) + b / 8: the pieces of XCD x (workgroup b runs on XCD b % 8) lie in the x-th eighth of the order, i.e. (up to the drift of
 // the cuts) in the x-th eighth of the ROWS -- a row's X / dY go through one L2 for all 27 offsets instead of through eight.  (Offset-major over the
-// whole table, the first version, pulled 4.7x the algorithmic bytes: profiles/r04_d_traffic.json.)
+// whole table, the first version, pulled 4.7x the algorithmic bytes: set d of the round-4 profiles, in git history; now 2.2x, profiles/r04_e_traffic.json.)
 static int64_t wgrad_units_per_group(int64_t n_rows) {
   const int64_t nbu = (n_rows + WGE_UNIT - 1) / WGE_UNIT;
   return (nbu + WGE_EIGHTHS - 1) / WGE_EIGHTHS;
