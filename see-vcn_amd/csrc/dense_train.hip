@@ -314,7 +314,7 @@ extern "C" int sv_segment_sum(const float* x, int64_t ldx, int groups, int rows_
 __global__ __launch_bounds__(256) void k_act_backward(const float* __restrict__ dy, const float* __restrict__ y, int64_t n, int act, float slope, float* __restrict__ dz) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float g = dy[i], v = y[i];
-    dz[i] = act == SV_ACT_RELU ? (v > 0.f ? g : 0.f) : act == SV_ACT_LRELU ? (v >= 0.f ? g : g * slope) : g;
+    dz[i] = act == SV_ACT_RELU ? (v > 0.f ? g : 0.f) : act == SV_ACT_LRELU ? (v > 0.f ? g : g * slope) : g;     // torch: input > 0 takes the unit slope, 0 and -0 take `slope`
   }
 }
 

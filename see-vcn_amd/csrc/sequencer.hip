@@ -21,13 +21,20 @@ template <typename T>
 inline T* ptr_of(int64_t v) { return reinterpret_cast<T*>(static_cast<uintptr_t>(v)); }
 }   // namespace
 
-// Events for the two-stream form: recorded and waited for inside one call, reused by the next (a wait captures the record in front of it)
-static hipEvent_t g_ev[2] = {nullptr, nullptr};
-static int seq_events() {
-  for (auto& e : g_ev)
-    if (!e) SV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  return SV_OK;
-}
+// Events for the two-stream form live for ONE call (created on the caller's current device, destroyed before the call returns: destroying an event
+// that is still pending only defers its release): no state shared between devices or host threads.
+struct SeqEvents {
+  hipEvent_t fork = nullptr, join = nullptr;
+  int create() {
+    SV_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    SV_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    return SV_OK;
+  }
+  ~SeqEvents() {
+    if (fork) (void)hipEventDestroy(fork);
+    if (join) (void)hipEventDestroy(join);
+  }
+};
 
 static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_stream);
 
@@ -47,9 +54,17 @@ static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_strea
   SV_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "sv_run_ops: null list");
   hipStream_t st_main = sv_stream(stream), st_side = side_stream ? sv_stream(side_stream) : nullptr;
   bool side_used = false;
+  SeqEvents ev;
   if (st_side) {
-    if (int rc = seq_events()) return rc;
+    if (int rc = ev.create()) return rc;
   }
+  // side stream behind everything enqueued on the main stream so far; a failure here is a failure of the operation (the list stops, the join below still runs)
+  auto fork_side = [&]() -> int {
+    SV_HIP(hipEventRecord(ev.fork, st_main));
+    side_used = true;                                     // from here on the side stream may hold work of this call
+    SV_HIP(hipStreamWaitEvent(st_side, ev.fork, 0));
+    return SV_OK;
+  };
   void* const wstream = side_stream ? side_stream : stream;      // where weight gradients go
   constexpr int MAX_DEFERRED = 64;
   int64_t deferred[MAX_DEFERRED * 10];       // stage-2 jobs of the SV_OP_WGRAD_DEFERRED operations of this list
@@ -103,11 +118,7 @@ static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_strea
                                         ptr_of<float>(p[7]), ptr_of<float>(p[8]), ptr_of<float>(p[9]), stream);
         break;
       case SV_OP_WGRAD:
-        if (st_side) {
-          SV_HIP(hipEventRecord(g_ev[0], st_main));
-          SV_HIP(hipStreamWaitEvent(st_side, g_ev[0], 0));
-          side_used = true;
-        }
+        if (st_side && (rc = fork_side()) != SV_OK) break;
         if (p[5])
           rc = sv_sparse_conv_wgrad_planned(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
                                             (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<const void>(p[5]), ptr_of<void>(p[4]), wstream);
@@ -116,11 +127,7 @@ static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_strea
                                           (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<void>(p[4]), wstream);
         break;
       case SV_OP_WGRAD_DEFERRED:
-        if (st_side) {
-          SV_HIP(hipEventRecord(g_ev[0], st_main));
-          SV_HIP(hipStreamWaitEvent(st_side, g_ev[0], 0));
-          side_used = true;
-        }
+        if (st_side && (rc = fork_side()) != SV_OK) break;
         if (n_deferred == MAX_DEFERRED) {     // more than a list's worth: sum what is pending, go on
           rc = sv_sparse_conv_wgrad_reduce_batch(deferred, n_deferred, wstream);
           n_deferred = 0;
@@ -148,8 +155,15 @@ static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_strea
   int rc = fail;
   if (rc == SV_OK && n_deferred > 0) rc = sv_sparse_conv_wgrad_reduce_batch(deferred, n_deferred, wstream);     // every deferred weight gradient: one launch at the end of the list
   if (side_used) {                  // whatever happened above: the caller's stream comes back ordered behind the side stream
-    SV_HIP(hipEventRecord(g_ev[1], st_side));
-    SV_HIP(hipStreamWaitEvent(st_main, g_ev[1], 0));
+    hipError_t e = hipEventRecord(ev.join, st_side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st_main, ev.join, 0);
+    if (e != hipSuccess) {          // cannot order the streams by event: wait for the side stream on the host so that no buffer of this call is still in use on return
+      (void)hipStreamSynchronize(st_side);
+      if (rc == SV_OK) {
+        sv_set_error("sv_run_ops_two_streams: joining the side stream failed: %s", hipGetErrorString(e));
+        rc = SV_ERR_HIP;
+      }
+    }
   }
   return rc;
 }

@@ -569,6 +569,23 @@ static size_t plan_lds_bytes(PlanFusedArgs& a) {
   a.stable = (big <= 65535 && !force_atomic) ? 1 : 0;
   return (size_t)(a.stable ? 8 : 2) * PL_CLASSES * 4 + (size_t)a.max_tiles * 6;
 }
+static size_t plan_lds_bytes_for(const PlanFusedArgs& a) { return (size_t)(a.stable ? 8 : 2) * PL_CLASSES * 4 + (size_t)a.max_tiles * 6; }
+
+// The deterministic body needs 128 KB + tiles of dynamic LDS: above 48 KB a kernel's limit has to be raised, PER DEVICE (the attribute belongs to the
+// function's code object on the current device).  Returns false when this device cannot give the kernel that much (the caller then takes the body with
+// LDS atomics); `which` = 0 k_plan_region, 1 k_plan_region_batch.
+static bool plan_raise_lds(const void* fn, int which) {
+  constexpr int MAX_DEV = 64;
+  static signed char state[2][MAX_DEV] = {};                          // 0 unknown, 1 raised, -1 refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
+  if (state[which][dev] == 0) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    if (e != hipSuccess) (void)hipGetLastError();                       // not an error of the call: the atomic body runs instead
+    state[which][dev] = e == hipSuccess ? 1 : -1;
+  }
+  return state[which][dev] > 0;
+}
 
 __device__ __forceinline__ void plan_region_body(const PlanFusedArgs& a, const int r) {
   extern __shared__ int32_t s_dyn[];
@@ -919,11 +936,10 @@ extern "C" int sv_conv_plan_build_dealt(const int32_t* masks, int64_t n_rows, in
     if (a.d.tiles[r] > a.max_tiles) a.max_tiles = a.d.tiles[r];
   }
   a.max_tiles = (a.max_tiles + 1) & ~1;                                  // keeps the uint16 array 4-byte aligned
-  const size_t lds = plan_lds_bytes(a);
-  static bool raised = false;
-  if (lds > 48 * 1024 && !raised) {
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_region), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    raised = true;
+  size_t lds = plan_lds_bytes(a);
+  if (lds > 48 * 1024 && !plan_raise_lds(reinterpret_cast<const void*>(k_plan_region), 0)) {
+    a.stable = 0;                                                       // no large LDS on this device: the body with LDS atomics (32 KB + tiles)
+    lds = plan_lds_bytes_for(a);
   }
   hipLaunchKernelGGL(k_plan_region, dim3(PL_REGIONS), dim3(1024), lds, sv_stream(stream), a);
   SV_LAUNCH_CHECK();
@@ -934,16 +950,19 @@ extern "C" int sv_conv_plan_build_dealt(const int32_t* masks, int64_t n_rows, in
 // in one launch (groups of PL_BATCH_MAX tables)
 extern "C" int sv_conv_plan_build_dealt_batch(const int64_t* jobs_host, int n_jobs, void* stream) {
   SV_CHECK_ARG(n_jobs >= 0 && (jobs_host || n_jobs == 0), "sv_conv_plan_build_dealt_batch: bad arguments");
-  static bool raised = false;
   hipStream_t st = sv_stream(stream);
   PlanBatchArgs b;
   int nb = 0;
   size_t lds = 0;
   auto flush = [&]() -> int {
     if (nb == 0) return SV_OK;
-    if (lds > 48 * 1024 && !raised) {
-      SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_region_batch), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-      raised = true;
+    if (lds > 48 * 1024 && !plan_raise_lds(reinterpret_cast<const void*>(k_plan_region_batch), 1)) {
+      lds = 0;
+      for (int q = 0; q < nb; ++q) {
+        b.j[q].stable = 0;
+        const size_t need = plan_lds_bytes_for(b.j[q]);
+        if (need > lds) lds = need;
+      }
     }
     hipLaunchKernelGGL(k_plan_region_batch, dim3(PL_REGIONS * nb), dim3(1024), lds, st, b);
     nb = 0, lds = 0;

@@ -144,6 +144,10 @@ def segment_max(x, rows_per_group):
     return _SegmentMax.apply(x, int(rows_per_group))
 
 
+def _has_hooks(m):
+    return bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None) or getattr(m, "_forward_hooks_with_kwargs", None))
+
+
 def run_sequential(layers, x):
     """An nn.Sequential of Linear | Conv1d(kernel 1) | BatchNorm1d | ReLU | Dropout modules on (rows, C) CUDA fp32 features through this
     library's kernels -- linear() for the products (hand-written backward), the fused BatchNorm(+ReLU) kernels of spconv.norm for the norms (batch
@@ -153,8 +157,8 @@ def run_sequential(layers, x):
     import torch.nn as nn
     from .spconv import norm
     mods = list(layers)
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
-        return layers(x)
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2) or _has_hooks(layers) or any(_has_hooks(m) for m in mods):
+        return layers(x)                                              # hooks observe module calls: the fused walk below calls no module (spconv/chain.py does the same)
     i = 0
     while i < len(mods):
         m = mods[i]

@@ -1,5 +1,6 @@
 """Host wrappers + autograd Functions over the rulebook / sparse-conv entry points of libseevcn_hip.so."""
 import ctypes
+import math
 import os
 import weakref
 
@@ -368,9 +369,11 @@ def build_network_index(coords, batch_size, spatial_shape, specs, n0_dev=None, w
         caps, cap = [], cap0
         for l, sp in enumerate(strided):
             per_in = 1
-            for k, st in zip(sp.ksize, sp.stride):
-                per_in *= -(-k // st)
-            cap = max(min(cap * per_in, ncells[l + 1]), 1)           # an input reaches at most prod(ceil(k/s)) outputs; never more than the cells
+            for k, st, dl in zip(sp.ksize, sp.stride, sp.dilation):
+                # per axis an input reaches the outputs o with o * st = x + pad - j * dl, j < k: ceil(k / st) of them when dilation and stride are
+                # coprime (the residues j * dl mod st then cycle evenly), up to k when they share a factor (dilation 2, stride 2: every j fits)
+                per_in *= -(-k // st) if math.gcd(dl, st) == 1 else k
+            cap = max(min(cap * per_in, ncells[l + 1]), 1)           # never more than the cells
             caps.append(cap)
         works = [_lib.workspace.persistent(f"rb_index_{tuple(shapes[l + 1])}_{B}", lib.sv_index_persistent_bytes(ncells[l + 1]), dev) for l in range(L)]
         assert len({w.data_ptr() for w in works}) == L, "two levels of a chain on one grid would share their index"
@@ -391,7 +394,8 @@ def build_network_index(coords, batch_size, spatial_shape, specs, n0_dev=None, w
         else:
             vals = _lib.host_ints([n0_dev]) if n0_dev is not None else []
         n = [vals.pop(0) if n0_dev is not None else cap0] + vals
-        assert all(n[l + 1] <= caps[l] for l in range(L)), "site capacity exceeded: the bound prod(ceil(k/s)) per input does not hold?"
+        if any(n[l + 1] > caps[l] for l in range(L)):                  # not an assert: `python -O` must not turn a truncated site list into wrong tables
+            raise _lib.SeevcnHipError(f"build_network_index: a strided level emitted {n[1:]} output sites for capacities {caps}")
     except BaseException:
         if L:
             for w in works:                                            # phase 1 left its marks: a failed read must not leak them into the next call

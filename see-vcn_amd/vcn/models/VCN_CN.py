@@ -62,7 +62,7 @@ class VCN_CN(nn.Module):
         else:
             _lib.require_cuda(x)
             g2 = L.encode_train(self.encoder, pc.float().reshape(bs * n, 3), bs, n)
-            coarse = L.run_fc_train(self.shape_fc, g2).reshape(-1, self.number_coarse, 3)
+            coarse = L.run_fc_train(self.shape_fc, g2, tap="shape_fc").reshape(-1, self.number_coarse, 3)
         return {'coarse': cn_to_vc(restore_scale(coarse.contiguous(), boxes), boxes)}
 
     def train(self, mode=True):

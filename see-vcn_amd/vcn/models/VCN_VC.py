@@ -116,14 +116,18 @@ class VCN_VC(nn.Module):
             return D.linear(rows, m.weight.squeeze(-1), m.bias, act, L.LRELU_SLOPE, **kw)
 
         h = conv(pe[0], (pc_fview - pts_mean).reshape(bs * n, 3), D.ACT_LRELU)
+        L._tap("pose.act0", h)
         h = conv(pe[2], h, D.ACT_LRELU)
-        pose_feat = D.segment_max(conv(pe[4], h), n)                                     # AdaptiveMaxPool1d(1)
-        rel_pose = L.run_fc_train(self.pose_fc, pose_feat)
+        L._tap("pose.act1", h)
+        z = conv(pe[4], h)
+        pose_feat = D.segment_max(z, n)                                                  # AdaptiveMaxPool1d(1)
+        L._tap("pose.max", z, pose_feat)
+        rel_pose = L.run_fc_train(self.pose_fc, pose_feat, tap="pose_fc")
         centre = pts_mean + rel_pose[:, :3].unsqueeze(1)
         rot_mat = compute_rotation_matrix_from_ortho6d(rel_pose[:, 3:9])
         pc_cn = torch.matmul(pc_fview - centre, rot_mat.permute(0, 2, 1))
         g2 = L.encode_train(self.encoder, pc_cn.reshape(bs * n, 3), bs, n)                # (B, 1024)
-        t = L.run_fc_train(self.shape_fc, g2)
+        t = L.run_fc_train(self.shape_fc, g2, tap="shape_fc")
         coarse = t.reshape(-1, self.number_coarse, 3)
         coarse_vc = torch.matmul(coarse, rot_mat) + centre
         return {'coarse': rotate_points_along_z(coarse_vc.contiguous(), frustum_angle),

@@ -191,31 +191,57 @@ def run_fc(layers, x, hidden_act):
 
 
 # ---------------------------------------------------------------------------------------------------------------- training mode, own kernels
+TAPS = None   # tests set this to a dict: the training forward then leaves the tensors its discrete decisions are taken on (activation outputs, pool
+              # inputs / outputs) under the decision names of oracle/vcn_train.py, so that the float64 oracle can follow the device's branch inside its band
+
+
+def _tap(name, *tensors):
+    if TAPS is not None:
+        TAPS[name] = tuple(t.detach() for t in tensors) if len(tensors) > 1 else tensors[0].detach()
+
+
+def _bn_relu(bn, x):
+    """BatchNorm1d + ReLU: the fused kernels when the norm qualifies (spconv.norm.fusable), the module + torch.relu otherwise (a norm frozen in eval()
+    inside a training model, channel counts the kernels do not take)"""
+    from ...spconv import norm
+    if norm.fusable(bn, x):
+        return norm.batch_norm_relu(bn, x, True)
+    return torch.relu(bn(x))
+
+
 def encode_train(enc, pts_rows, batch, n):
     """FeatureEncoder.forward (VCN_VC.py:97-106) in TRAINING mode on channel-last rows (B n, 3) -> (B, 1024), differentiable: Conv1d(k=1) =
     dense_ops.linear (fp32 MFMA forward, hand-written backward), BatchNorm1d(batch statistics) + ReLU = the fused kernels of spconv.norm, max over
     the points = dense_ops.segment_max.  The conv over cat([global.expand, local]) is local W_l^T + (global W_g^T)[object] + b."""
     from ... import dense_ops as D
-    from ...spconv import norm
     c1, c2 = enc.mlp_conv1, enc.mlp_conv2
-    f = norm.batch_norm_relu(c1[1], D.linear(pts_rows, c1[0].weight.squeeze(-1), c1[0].bias), True)
+    f = _bn_relu(c1[1], D.linear(pts_rows, c1[0].weight.squeeze(-1), c1[0].bias))
+    _tap("enc.act1", f)
     local = D.linear(f, c1[3].weight.squeeze(-1), c1[3].bias)                             # (B n, 256)
     g1 = D.segment_max(local, n)                                                          # (B, 256)
+    _tap("enc.max1", local, g1)
     cg = g1.shape[1]
     w2 = c2[0].weight.squeeze(-1)
     gb = D.linear(g1, w2[:, :cg], None)                                                   # the global half: one row per object
-    f2 = norm.batch_norm_relu(c2[1], D.linear(local, w2[:, cg:], c2[0].bias, group_bias=gb, rows_per_group=n), True)
-    return D.segment_max(D.linear(f2, c2[3].weight.squeeze(-1), c2[3].bias), n)           # (B, 1024)
+    f2 = _bn_relu(c2[1], D.linear(local, w2[:, cg:], c2[0].bias, group_bias=gb, rows_per_group=n))
+    _tap("enc.act2", f2)
+    z = D.linear(f2, c2[3].weight.squeeze(-1), c2[3].bias)
+    g2 = D.segment_max(z, n)                                                              # (B, 1024)
+    _tap("enc.max2", z, g2)
+    return g2
 
 
-def run_fc_train(seq, x, hidden_act_slope=None):
+def run_fc_train(seq, x, tap=None):
     """An nn.Sequential of Linear [+ ReLU / LeakyReLU] modules on dense_ops.linear (activation fused into the layer in front of it)."""
     from ... import dense_ops as D
     mods = list(seq)
-    i = 0
+    i = j = 0
     while i < len(mods):
         nxt = mods[i + 1] if i + 1 < len(mods) else None
         act = D.ACT_RELU if isinstance(nxt, nn.ReLU) else D.ACT_LRELU if isinstance(nxt, nn.LeakyReLU) else D.ACT_NONE
         x = D.linear(x, mods[i].weight, mods[i].bias, act, nxt.negative_slope if act == D.ACT_LRELU else 0.0)
+        if act != D.ACT_NONE and tap is not None:
+            _tap(f"{tap}.act{j}", x)
+            j += 1
         i += 2 if act != D.ACT_NONE else 1
     return x

@@ -11,6 +11,18 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# Collection order = importance for the hot path, not the alphabet: the driver runs `pytest -x`, so whatever fails first hides everything
+# behind it.  The stages north_star demands bit-exact (voxel indices, rulebooks) and the headline kernels come first, the newest / widest-scope files last.
+ORDER = ["test_abi", "test_voxelize", "test_spconv", "test_vcn", "test_chamfer", "test_vcn_train", "test_config1", "test_configs", "test_pointnet2", "test_boxes",
+         "test_boundary", "test_head", "test_center_head", "test_pillars", "test_pvrcnn", "test_second_iou", "test_postprocess", "test_isolation", "test_io_nuscenes",
+         "test_collate", "test_dense_ops", "test_pipeline", "test_dist"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    rank = {name: i for i, name in enumerate(ORDER)}
+    items.sort(key=lambda it: rank.get(os.path.splitext(os.path.basename(str(it.fspath)))[0], len(ORDER)))       # stable: order inside a file is kept
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 

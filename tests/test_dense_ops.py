@@ -1,6 +1,5 @@
 """Training-side dense-layer kernels (csrc/dense_train.hip) and the autograd functions over them (seevcn_amd/dense_ops.py) against plain torch fp32
-ops of the same layers, and VCN_VC / VCN_CN in training mode on them against the same graph on torch modules (tolerances written per check)."""
-import copy
+ops of the same layers (tolerances written per check)."""
 
 import numpy as np
 import pytest
@@ -86,47 +85,9 @@ def test_hip_linear_function_matches_torch_autograd(cuda, hip_lib, M, K, N, act,
         _close(a_, b_, 5e-5, name)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", ["VCN_VC", "VCN_CN"])
-def test_hip_vcn_training_forward_backward_on_own_kernels_matches_torch_modules(cuda, hip_lib, name):
-    """VCN in TRAINING mode (batch-statistics BatchNorm): the forward on dense_ops / fused BatchNorm / segment max and its hand-written backward
-    against the reference's graph on torch modules with the same weights and inputs: outputs, every parameter gradient, running statistics.
-    Tolerance: 2e-3 of each tensor's largest entry (fp32 sums over 65 536 rows in different orders; the torch side may run TF32-free fp32 GEMMs)."""
-    import seevcn_amd.synth as synth
-    import seevcn_amd.vcn as V
-    import seevcn_amd.vcn.models.VCN_VC as vc_mod
-    from seeding import seeded_state_dict
-    clouds, boxes = synth.make_object_batch(8, seed=1000)
-    x, bx = torch.from_numpy(clouds).to(cuda), torch.from_numpy(boxes).to(cuda)
-    m1 = V.MODELS.build({"NAME": name})
-    m1.load_state_dict(seeded_state_dict(m1, seed=0))
-    m1 = m1.to(cuda).train()
-    m2 = copy.deepcopy(m1)
-    res = []
-    for m, on_torch in ((m1, False), (m2, True)):
-        saved, vc_mod.TRAIN_ON_TORCH = vc_mod.TRAIN_ON_TORCH, on_torch
-        try:
-            out = m({"input": x, "gt_boxes": bx})
-        finally:
-            vc_mod.TRAIN_ON_TORCH = saved
-        up = torch.randn(out["coarse"].shape, generator=torch.Generator().manual_seed(1)).to(cuda)
-        loss = (out["coarse"] * up).sum() + sum(v.sum() for k, v in out.items() if k != "coarse")
-        loss.backward()
-        res.append((out, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, {k: b.clone() for k, b in m.named_buffers()}))
-    (o1, g1, b1), (o2, g2, b2) = res
-    for k in o2:
-        _close(o1[k], o2[k], 2e-3, f"{name} {k}")
-    assert sorted(g1) == sorted(g2) and len(g1) >= 10
-    # a conv bias directly in front of a batch-statistics BatchNorm has an exactly zero gradient (the norm removes the mean): both sides hold
-    # rounding noise there, so the absolute floor is 1e-6 of the model's largest gradient entry
-    gmax = max(float(v.abs().max()) for v in g2.values())
-    for k in g2:
-        if k.endswith(("mlp_conv1.0.bias", "mlp_conv2.0.bias")):       # zero in exact arithmetic: noise on both sides, 1e-5 of the largest gradient at most
-            assert float(g1[k].abs().max()) <= 1e-5 * gmax and float(g2[k].abs().max()) <= 1e-5 * gmax, k
-            continue
-        _close(g1[k], g2[k], 2e-3, f"{name} grad {k}", atol=1e-6 * gmax)
-    for k in b2:
-        _close(b1[k].float(), b2[k].float(), 1e-4, f"{name} buffer {k}")
+# VCN_VC / VCN_CN in training mode on these kernels: tests/test_vcn_train.py (against the float64 oracle pinned to the reference's float64 modules; the
+# round-4 comparison with torch's fp32 modules on the GPU was a coin toss -- both fp32 sides flip ReLU branches within rounding distance of zero,
+# profiles/r05_vcn_train_diag.txt)
 
 
 def test_dense_ops_refuse_cpu(hip_lib):
