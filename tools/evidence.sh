@@ -3,8 +3,16 @@
 # One call that leaves everything profiles/ holds for a round under gpurun_out/: the default bench line, the rocprofv3 kernel stats of the
 # same command (whole process + steady steps), the PMC traffic passes, the side-mode bench lines with their steady kernel tables, and the
 # micro-benchmarks (per-layer sparse conv, FPS), the host-time split, the blocking-read traces and the launch sites of the PV-RCNN step.
+# FIRST the gate: the driver's own command (`pytest -m gpu -x -q`) at this tree, log kept as gpurun_out/<round>_gputest.log (copy it to profiles/);
+# a red gate stops the call -- numbers of a tree whose parity is not green are not evidence.  GATE=0 skips it (A/B reruns on a box that already ran it).
 TAG=$1
 cd $GRAFT_REPO_ROOT
+if [ "${GATE:-1}" != "0" ]; then
+  timeout 1500 python3 -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_out/${TAG%%_*}_gputest.log 2>&1
+  rc=$?
+  tail -3 gpurun_out/${TAG%%_*}_gputest.log
+  [ $rc -ne 0 ] && { echo "GATE RED (rc $rc): no evidence taken"; exit $rc; }
+fi
 timeout 900 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -c 600 gpurun_out/${TAG}_bench.json
 TOP=8 tools/profile.sh ${TAG}_main 20 2>&1 | head -10
