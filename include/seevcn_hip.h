@@ -253,6 +253,13 @@ int sv_conv_weight_fragments(const float* W, int64_t stride_k, int64_t stride_ci
  * stride_cout, K, C_in, C_out, frag_fwd pointer, frag_bwd pointer, first unit}; a layer has 2 * K * C_in * C_out / 4 units (float4, forward
  * then backward view), "first unit" is the running sum of the layers before it, total_units the sum over all layers. */
 int sv_conv_weight_fragments_batch(const void* descs_device, int n_layers, int64_t total_units, void* stream);
+/* Input transform of the NEXT sv_sparse_conv_gather_gemm_planned / sv_sparse_conv_wgrad* call of this host thread (consumed by it, whatever it
+ * returns): that call reads X through y = [relu](x * scale[c] + shift[c]), coef (2, C_in) = scale | shift (16-byte aligned) -- X is then the RAW
+ * output of the convolution below and coef the coefficients of its BatchNorm1d (sv_batchnorm_finalize_forward), i.e. the `norm_fn -> ReLU` tail of
+ * post_act_block (spconv_backbone.py:9-27) is applied as the rows are gathered and the normalised tensor is never written.  Same expression as the
+ * separate pass (fused multiply-add, then max): consumers see bit-identical values; absent neighbours contribute 0.  coef = NULL clears it.
+ * Entry points that cannot apply it (the plain k-major conv, non-MFMA weight-gradient shapes) fail with SV_ERR_ARG. */
+int sv_conv_next_input_norm(const float* coef, int relu);
 /* table_k_reversed: offset k reads table entry K-1-k (a submanifold table serving its own data gradient, no flipped copy). */
 int sv_sparse_conv_gather_gemm_planned(const float* X, int64_t n_src, const int32_t* table_rows, const int32_t* perm, const int32_t* masks_p,
                                        const int32_t* tile_of, int tiles_per_wave,
@@ -552,6 +559,12 @@ int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float*
  *                       (sv_sparse_conv_wgrad_reduce_batch): the gradients are complete when sv_run_ops returns, bitwise the values of SV_OP_WGRAD
  *   SV_OP_DGRAD_PLANNED_BN  sv_sparse_conv_dgrad_planned_bn: p = dZ, table_rows, perm, masks_p, tile_of, wfrag, dY, bn_x, bn_mean, bn_invstd, bn_gamma,
  *                       bn_beta, bn_partial; n = n_src, n_rows; i = tiles_per_wave, K, Kd, Nc, table_k_reversed, bn_relu
+ *   SV_OP_BN_FINALIZE   sv_batchnorm_finalize_forward: p = gamma, beta, running_mean, running_var, scratch, coef, save_mean, save_invstd,
+ *                       num_batches_tracked, x (0: partials in scratch); n = rows; i = channels, n_partials; f = momentum, eps
+ *   SV_OP_BN_APPLY      sv_batchnorm_apply: p = x, coef, y; n = rows; i = channels, relu
+ * Input transform: SV_OP_CONV_PLANNED with p12 = coef (2, Kd) and i6 = relu, SV_OP_WGRAD[_DEFERRED] with p6 = coef (2, Cin) and i4 = relu read their
+ * X through sv_conv_next_input_norm(coef, relu): X is then the RAW output of the convolution below, its BatchNorm (+ReLU) is applied as the rows are
+ * gathered, and the normalised activation tensor is never written.
  * Used by seevcn_amd/spconv/chain.py: the forward and the backward of a conv -> BatchNorm -> ReLU chain (VoxelBackBone8x, spconv_backbone.py:128-180)
  * as two calls inside one autograd node. */
 #define SV_OP_WORDS 32
@@ -562,6 +575,8 @@ int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float*
 #define SV_OP_WGRAD 6
 #define SV_OP_DGRAD_PLANNED_BN 7
 #define SV_OP_WGRAD_DEFERRED 8
+#define SV_OP_BN_FINALIZE 9
+#define SV_OP_BN_APPLY 10
 int sv_run_ops(const int64_t* ops, int n_ops, void* stream);
 /* The same list with its weight gradients (SV_OP_WGRAD, SV_OP_WGRAD_DEFERRED, the deferred reduction) on `side_stream`: each goes behind an event recorded on
  * `stream` after the operations in front of it; the other operations do not wait for it; `stream` waits for `side_stream` once, at the end, so that when
@@ -585,6 +600,14 @@ int sv_batchnorm_relu_forward(const float* x, int64_t n, int channels, const flo
 int sv_batchnorm_relu_forward_partial(const float* x, int64_t n, int channels, const float* gamma, const float* beta, float* running_mean,
                                       float* running_var, float momentum, float eps, int relu, void* scratch, int n_partials, float* y,
                                       float* save_mean, float* save_invstd, int64_t* num_batches_tracked, void* stream);
+/* the statistics of the training forward WITHOUT its elementwise pass: partials in scratch as above -> save_mean, save_invstd, running statistics and
+ * coef (2, channels) = scale | shift of y = x * scale + shift in the caller's buffer (16-byte aligned); y itself is made by the consumers as they read
+ * x (sv_conv_next_input_norm) or by sv_batchnorm_apply where a tensor is needed */
+int sv_batchnorm_finalize_forward(const float* x /* NULL: partials in scratch; else the statistics pass over x runs first */, int64_t n, int channels, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  float momentum, float eps, void* scratch, int n_partials, float* coef, float* save_mean, float* save_invstd,
+                                  int64_t* num_batches_tracked, void* stream);
+/* y = [relu](x * scale + shift), coef (2, channels) = scale | shift: the elementwise pass on its own */
+int sv_batchnorm_apply(const float* x, int64_t n, int channels, const float* coef, int relu, float* y, void* stream);
 int sv_batchnorm_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, int relu, void* scratch, float* dx, float* dgamma,
                                float* dbeta, void* stream);

@@ -165,6 +165,9 @@ SIGNATURES = {
     "sv_batchnorm_relu_forward": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_batchnorm_relu_backward": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_batchnorm_relu_backward_partial": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "sv_conv_next_input_norm": (c_i, [c_p, c_i]),
+    "sv_batchnorm_finalize_forward": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sv_batchnorm_apply": (c_i, [c_p, c_i64, c_i, c_p, c_i, c_p, c_p]),
     "sv_run_ops": (c_i, [c_p, c_i, c_p]),
     "sv_run_ops_two_streams": (c_i, [c_p, c_i, c_p, c_p]),
     "sv_anchor_decode": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p]),

@@ -228,6 +228,41 @@ extern "C" int sv_batchnorm_relu_forward_partial(const float* x, int64_t n, int 
   return SV_OK;
 }
 
+// The training-mode statistics WITHOUT the elementwise pass: from n_partials per-workgroup partial sums in `scratch` (as for
+// sv_batchnorm_relu_forward_partial) to save_mean / save_invstd, the running statistics, and coef (2, C) = scale | shift of y = x * scale + shift in the
+// CALLER's buffer (the shared scratch is overwritten by the next norm of the same width).  The consumers of y apply the coefficients as they read x
+// (sv_conv_next_input_norm), or sv_batchnorm_apply materialises y where a tensor is needed.  One launch; x != NULL: the producer left no partials, the
+// statistics pass over x (n, C) runs first (n_partials ignored).
+extern "C" int sv_batchnorm_finalize_forward(const float* x, int64_t n, int channels, const float* gamma, const float* beta, float* running_mean,
+                                             float* running_var, float momentum, float eps, void* scratch, int n_partials, float* coef, float* save_mean,
+                                             float* save_invstd, int64_t* num_batches_tracked, void* stream) {
+  if (int rc = bn_common_check("sv_batchnorm_finalize_forward", n, channels)) return rc;
+  SV_CHECK_ARG(scratch && coef && save_mean && save_invstd, "sv_batchnorm_finalize_forward: null pointer");
+  SV_CHECK_ARG(x || (n_partials >= 1 && n_partials <= BN_MAX_WGS), "sv_batchnorm_finalize_forward: x, or 1..%d partials (got %d)", BN_MAX_WGS, n_partials);
+  BnArgs a{};
+  a.x = x, a.gamma = gamma, a.beta = beta, a.running_mean = running_mean, a.running_var = running_var;
+  a.save_mean = save_mean, a.save_invstd = save_invstd, a.n = n, a.C = channels, a.momentum = momentum, a.eps = eps;
+  a.wgs = x ? bn_wgs(n, channels) : n_partials;
+  a.num_batches_tracked = num_batches_tracked;
+  bn_scratch(a, scratch);
+  a.coef = coef;                                           // k_bn_finalize<false> writes coef[c] and coef[C + c] only
+  if (x) hipLaunchKernelGGL(k_bn_reduce<false>, dim3(a.wgs), dim3(BN_THREADS), 0, sv_stream(stream), a);       // no producer-side partials: the statistics pass runs here
+  hipLaunchKernelGGL(k_bn_finalize<false>, dim3(channels), dim3(BN_THREADS), 0, sv_stream(stream), a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// y = [relu](x * scale + shift) with coef (2, C) = scale | shift: the elementwise pass of the forward on its own (the same kernel, the same expression)
+extern "C" int sv_batchnorm_apply(const float* x, int64_t n, int channels, const float* coef, int relu, float* y, void* stream) {
+  if (int rc = bn_common_check("sv_batchnorm_apply", n, channels)) return rc;
+  SV_CHECK_ARG(x && coef && y && (uintptr_t)coef % 16 == 0, "sv_batchnorm_apply: null or misaligned pointer");
+  BnArgs a{};
+  a.x = x, a.out = y, a.n = n, a.C = channels, a.relu = relu, a.coef = const_cast<float*>(coef);
+  hipLaunchKernelGGL(k_bn_apply_fwd, dim3(sv_grid_1d(n * (channels / 4), BN_THREADS)), dim3(BN_THREADS), 0, sv_stream(stream), a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 extern "C" int sv_batchnorm_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* gamma, const float* beta,
                                           const float* save_mean, const float* save_invstd, int relu, void* scratch, float* dx,
                                           float* dgamma, float* dbeta, void* stream) {

@@ -78,6 +78,7 @@ static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_strea
     int rc = SV_OK;
     switch ((int)o[0]) {
       case SV_OP_CONV_PLANNED:
+        if (p[12]) sv_conv_next_input_norm(ptr_of<const float>(p[12]), (int)i[6]);        // X = raw conv output of the layer below, its BatchNorm applied on load
         rc = sv_sparse_conv_gather_gemm_planned(ptr_of<const float>(p[0]), n[0], ptr_of<const int32_t>(p[1]), ptr_of<const int32_t>(p[2]),
                                                 ptr_of<const int32_t>(p[3]), ptr_of<const int32_t>(p[4]), (int)i[0], ptr_of<const float>(p[5]),
                                                 ptr_of<float>(p[6]), n[1], (int)i[1], (int)i[2], (int)i[3], ptr_of<const float>(p[7]),
@@ -117,8 +118,17 @@ static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_strea
                                         ptr_of<const float>(p[3]), ptr_of<const float>(p[4]), ptr_of<const float>(p[5]), (int)i[1], ptr_of<void>(p[6]),
                                         ptr_of<float>(p[7]), ptr_of<float>(p[8]), ptr_of<float>(p[9]), stream);
         break;
+      case SV_OP_BN_FINALIZE:
+        rc = sv_batchnorm_finalize_forward(ptr_of<const float>(p[9]), n[0], (int)i[0], ptr_of<const float>(p[0]), ptr_of<const float>(p[1]), ptr_of<float>(p[2]), ptr_of<float>(p[3]),
+                                           (float)as_double(f[0]), (float)as_double(f[1]), ptr_of<void>(p[4]), (int)i[1], ptr_of<float>(p[5]), ptr_of<float>(p[6]),
+                                           ptr_of<float>(p[7]), ptr_of<int64_t>(p[8]), stream);
+        break;
+      case SV_OP_BN_APPLY:
+        rc = sv_batchnorm_apply(ptr_of<const float>(p[0]), n[0], (int)i[0], ptr_of<const float>(p[1]), (int)i[1], ptr_of<float>(p[2]), stream);
+        break;
       case SV_OP_WGRAD:
         if (st_side && (rc = fork_side()) != SV_OK) break;
+        if (p[6]) sv_conv_next_input_norm(ptr_of<const float>(p[6]), (int)i[4]);
         if (p[5])
           rc = sv_sparse_conv_wgrad_planned(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
                                             (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<const void>(p[5]), ptr_of<void>(p[4]), wstream);
@@ -133,6 +143,7 @@ static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_strea
           n_deferred = 0;
           if (rc != SV_OK) break;
         }
+        if (p[6]) sv_conv_next_input_norm(ptr_of<const float>(p[6]), (int)i[4]);
         if (p[5])
           rc = sv_sparse_conv_wgrad_planned_stage1(ptr_of<const float>(p[0]), i[3], ptr_of<const int32_t>(p[1]), ptr_of<const float>(p[2]), ptr_of<float>(p[3]), n[0],
                                                    (int)i[0], (int)i[1], (int)i[2], n[1], n[2], n[3], ptr_of<const void>(p[5]), ptr_of<void>(p[4]),
@@ -153,6 +164,7 @@ static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_strea
     }
   }
   int rc = fail;
+  sv_conv_next_input_norm(nullptr, 0);                    // an operation that failed before it consumed its input transform must not leave it to a later call
   if (rc == SV_OK && n_deferred > 0) rc = sv_sparse_conv_wgrad_reduce_batch(deferred, n_deferred, wstream);     // every deferred weight gradient: one launch at the end of the list
   if (side_used) {                  // whatever happened above: the caller's stream comes back ordered behind the side stream
     hipError_t e = hipEventRecord(ev.join, st_side);

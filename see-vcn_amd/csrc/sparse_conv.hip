@@ -33,6 +33,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// Input transform of the NEXT call (sv_conv_next_input_norm): the convolution / weight gradient reads X through y = [relu](x * scale[c] + shift[c]) --
+// X is then the RAW output of the convolution below and (scale, shift) the coefficients of its BatchNorm (sv_batchnorm_finalize_forward), so that the
+// normalised activations are never written to memory: the BatchNorm's elementwise pass (one read + one write of every activation tensor) disappears
+// into the gathers that read the tensor anyway.  Same expression as k_bn_apply_fwd (bn_act, then fmaxf): the values a consumer sees are bit for bit
+// the ones the separate pass would have stored.  Absent neighbours contribute 0, not relu(shift).
+struct InNorm {
+  const float* coef = nullptr;   // (2, C_in): scale | shift
+  int relu = 0;
+};
+static thread_local InNorm g_next_in;
+extern "C" int sv_conv_next_input_norm(const float* coef, int relu) {
+  g_next_in.coef = coef, g_next_in.relu = relu ? 1 : 0;
+  return SV_OK;
+}
+static InNorm take_input_norm() {
+  const InNorm r = g_next_in;
+  g_next_in = InNorm{};
+  return r;
+}
+
 struct ConvArgs {
   const float* X;         // (n_src, Kd)
   const int32_t* nbr;     // (K, n_rows)
@@ -1142,14 +1162,26 @@ struct PlanView {
                             // 8 / 16 weight / row loads of a wave all at ONE address (one cache line per load instead of 16)
   unsigned long long* trace;   // measurement only (sv_debug_conv_trace): 8 words per wave, or null
   int prio;                 // SEEVCN_RS3_PRIO (A/B): 1 = s_setprio 3 for a pass's prologue, 2 = for its epilogue too; the main loop runs at 0
+  const float* in_coef;     // FIN instances: (2, Kd) scale | shift applied to every gathered X value (+ ReLU when in_relu); see InNorm
+  int in_relu;
 };
 
 // DBG: 0 production; 1 the measurement switches of PlanView::debug (+ trace); 2 per-wave trace only (the production loop + a few s_memtime per pass)
-template <int NT, int KQ, int RS_G, int DBG = 0>
+#ifndef SEEVCN_RS3_RA
+#define SEEVCN_RS3_RA 3
+#endif
+#ifndef SEEVCN_RS3_RB
+#define SEEVCN_RS3_RB 2
+#endif
+constexpr int RS3_RA = SEEVCN_RS3_RA;      // stages of the row ring (RS3_RA - 1 steps of gathers in flight)
+constexpr int RS3_RB = SEEVCN_RS3_RB;      // stages of the weight ring
+// FIN: the gathered rows go through pv.in_coef (BatchNorm + ReLU of the layer below applied on load) -- production instances only
+template <int NT, int KQ, int RS_G, int DBG = 0, bool FIN = false>
 __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs a, PlanView pv, const float* __restrict__ wfrag, uint32_t x_bytes,
                                                                         uint32_t w_bytes) {
   constexpr int Kd = KQ * 16;
   __shared__ int32_t s_idx_all[4][RS3_KMAX + 1][64];       // [k][lane]: source row of (tile lane>>4, row lane&15); [27][lane]: its output row
+  __shared__ __attribute__((aligned(16))) float s_coef_all[FIN ? 4 : 1][2][FIN ? Kd : 4];      // wave-private copies of (scale | shift): no workgroup barrier
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int li = lane & 15, kk = lane >> 4;
   const int region = blockIdx.x % PL_REGIONS, lw = (blockIdx.x / PL_REGIONS) * 4 + wid;
@@ -1157,6 +1189,13 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   unsigned long long t_pro = 0ull, t_loop = 0ull, t_mark = t_start;      // cycles in pass prologues / main loops, summed over the passes
   unsigned trace_work = 0;
   int32_t(*s_idx)[64] = s_idx_all[wid];
+  float(*s_coef)[FIN ? Kd : 4] = s_coef_all[FIN ? wid : 0];
+  float in_lo = 0.f;
+  if constexpr (FIN) {
+    for (int c = lane; c < Kd; c += 64) s_coef[0][c] = pv.in_coef[c], s_coef[1][c] = pv.in_coef[Kd + c];
+    in_lo = pv.in_relu ? 0.f : -__builtin_inff();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
   const int nt_total = pv.nc_total / 16, col_tile0 = blockIdx.y * NT;
   const i32x4 srd_x = make_srd(a.X, x_bytes), srd_w = make_srd(wfrag, w_bytes);
   const int32_t* my_tiles = pv.tile_of + ((int64_t)region * PL_REGION_WAVES + lw) * (pv.d.n_pass * RS_G);
@@ -1217,27 +1256,33 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   if (pv.prio) __builtin_amdgcn_s_setprio(0);
 
   if (active) {
-    // ring depth 3 = two steps of loads in flight.  Tried: 5 stages for the one-tile-per-wave instance (its registers allow it) -- slower,
+    // Operand rings.  Rows (A): RA stages = RA - 1 steps of gathers in flight (a gathered row comes from HBM / a remote L2 line: ~2 us under load).
+    // Weights (B): RB = 2 stages, ONE step ahead -- the 442 KB of fragments are shared by every wave of the launch and sit in L2, a step of four
+    // waves' MFMAs (~4 k cycles) covers that latency; the third B stage (16 VGPRs at NT = 4) is what kept the two-tile instances at the
+    // 128-register line with spills in every pass prologue, and is what the input transform's (FIN) coefficients now live in.
+    // (History: one ring of 3 stages for both operands until round 5.  Tried on it: 5 stages for the one-tile-per-wave instance -- slower,
     // 64->64 at 66 k rows 78 -> 85 us, 64->128 28 -> 39 us: the extra dummy loads of the tail and the longer prologue cost more than the
-    // lookahead buys (round 1 found the same on the narrow kernels); 4 stages for it in round 3 (128 VGPRs, no spill): 65.5 -> 67-68 us
-    constexpr int RING = 3;
-    f32x4 A[RING][RS_G], B[RING][NT];
+    // lookahead buys (round 1 found the same on the narrow kernels); 4 stages for it in round 3 (128 VGPRs, no spill): 65.5 -> 67-68 us.)
+    constexpr int RA = RS3_RA, RB = RS3_RB, UNR = (RA % RB == 0) ? RA : RA * RB;
+    static_assert(RA >= RB && RB >= 2, "the counted wait below is written for a weight ring no deeper than the row ring");
+    f32x4 A[RA][RS_G], B[RB][NT];
     // defined here so that their live ranges start inside the pass (the asm waits below read-modify them: left undefined, hipcc keeps all
-    // 18-24 stage registers alive across the whole pass loop, prologue and epilogue included, and spills 55 VGPRs at four waves per SIMD)
+    // stage registers alive across the whole pass loop, prologue and epilogue included, and spills 55 VGPRs at four waves per SIMD)
 #pragma unroll
-    for (int st = 0; st < RING; ++st) {
+    for (int st = 0; st < RA; ++st)
 #pragma unroll
       for (int g = 0; g < RS_G; ++g) A[st][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
+    for (int st = 0; st < RB; ++st)
+#pragma unroll
       for (int t = 0; t < NT; ++t) B[st][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    // load iterator (two steps ahead of the compute iterator)
+    // Row-load iterator (RA - 1 steps ahead of the compute iterator).  Per offset: rowoff[g] = byte offset of the lane's gathered row (+ its
+    // 4-channel column), or an out-of-range value when the row has no neighbour there / the list has ended.  Per 16-channel step the loads then
+    // need NO vector arithmetic: rows at rowoff + (scalar) 64 * q, weights at one constant per-lane offset + (scalar) fragment base of
+    // (offset, q) + (immediate) 1 KiB * column tile.  (The first version recomputed every load's offset each step: 74 scalar + 25 vector
+    // instructions per step next to its 32 MFMAs.)
     unsigned long long la = active;
     int kl = __ffsll((long long)la) - 1, ql = 0;
-    // Per offset: rowoff[g] = byte offset of the lane's gathered row (+ its 4-channel column), or an out-of-range value when the row has no
-    // neighbour there / the list has ended.  Per 16-channel step the loads then need NO vector arithmetic: rows at rowoff + (scalar) 64 * q,
-    // weights at one constant per-lane offset + (scalar) fragment base of (offset, q) + (immediate) 1 KiB * column tile.  (The first version
-    // recomputed every load's offset each step: 74 scalar + 25 vector instructions per step next to its 32 MFMAs.)
     constexpr uint32_t OOB = 0xfffffff0u;
     // the weight loads add immediates of up to 3 KiB to their vector offset: an out-of-range value that cannot wrap around 2^32 with them
     // (the fragment buffer is a few MB)
@@ -1264,28 +1309,41 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     // running scalar offsets: sa = 64 * q (rows), sw = fragment base of (offset, q) (weights)
     constexpr uint32_t WSTEP = 1024u;                                // one (offset, q, column tile) fragment
     const uint32_t wq = (uint32_t)nt_total * WSTEP;                   // q -> q + 1
-    uint32_t sa = 0u, sw = (uint32_t)((kl < 0 ? 0 : kl) * KQ * nt_total + col_tile0) * WSTEP;
-    auto issue = [&](f32x4 (&As)[RS_G], f32x4 (&Bs)[NT]) {       // exactly NLOAD loads, always
+    uint32_t sa = 0u;
+    auto issue_a = [&](f32x4 (&As)[RS_G]) {                          // exactly RS_G loads, always
 #pragma unroll
       for (int g = 0; g < RS_G; ++g) As[g] = buf_load_b128_s<0>(srd_x, rowoff[g], sa);
-      if constexpr (NT >= 1) Bs[0] = buf_load_b128_s<0>(srd_w, wvoff, sw);
-      if constexpr (NT >= 2) Bs[1] = buf_load_b128_s<1024>(srd_w, wvoff, sw);
-      if constexpr (NT >= 3) Bs[2] = buf_load_b128_s<2048>(srd_w, wvoff, sw);
-      if constexpr (NT >= 4) Bs[3] = buf_load_b128_s<3072>(srd_w, wvoff, sw);
       if (kl >= 0) {
-        sa += 64u, sw += wq;
+        sa += 64u;
         if (++ql == KQ) {
           ql = 0, sa = 0u;
           la &= la - 1;
           kl = la ? __ffsll((long long)la) - 1 : -1;
-          if (kl >= 0) {
-            sw = (uint32_t)(kl * KQ * nt_total + col_tile0) * WSTEP;
-            read_j();
-          } else {                                                 // the list has ended: every further load is an out-of-range dummy
-            wvoff = WOOB;
+          if (kl >= 0) read_j();
+          else {                                                   // the list has ended: every further load is an out-of-range dummy
 #pragma unroll
             for (int g = 0; g < RS_G; ++g) rowoff[g] = OOB;
           }
+        }
+      }
+    };
+    // weight-load iterator (one step ahead)
+    unsigned long long lb = active;
+    int kb = __ffsll((long long)lb) - 1, qb = 0;
+    uint32_t sw = (uint32_t)((kb < 0 ? 0 : kb) * KQ * nt_total + col_tile0) * WSTEP;
+    auto issue_b = [&](f32x4 (&Bs)[NT]) {                            // exactly NT loads, always
+      if constexpr (NT >= 1) Bs[0] = buf_load_b128_s<0>(srd_w, wvoff, sw);
+      if constexpr (NT >= 2) Bs[1] = buf_load_b128_s<1024>(srd_w, wvoff, sw);
+      if constexpr (NT >= 3) Bs[2] = buf_load_b128_s<2048>(srd_w, wvoff, sw);
+      if constexpr (NT >= 4) Bs[3] = buf_load_b128_s<3072>(srd_w, wvoff, sw);
+      if (kb >= 0) {
+        sw += wq;
+        if (++qb == KQ) {
+          qb = 0;
+          lb &= lb - 1;
+          kb = lb ? __ffsll((long long)lb) - 1 : -1;
+          if (kb >= 0) sw = (uint32_t)(kb * KQ * nt_total + col_tile0) * WSTEP;
+          else wvoff = WOOB;
         }
       }
     };
@@ -1294,24 +1352,43 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     int kc = __ffsll((long long)ca) - 1, qc = 0;
     unsigned mc = (unsigned)__builtin_amdgcn_readlane((int)maskreg, kc);
     auto compute = [&](f32x4 (&As)[RS_G], f32x4 (&Bs)[NT]) {
-      // the stage's loads are the oldest NLOAD in flight: everything issued later (2 steps) may stay outstanding
-#define RS3_WAIT(N, ...) asm volatile("s_waitcnt vmcnt(" #N ")" : __VA_ARGS__)
+      // Issue order inside a step: weights of step s + 1, then rows of step s + RA - 1.  The younger of this step's operands is its weight stage
+      // (issued one step ago, in front of that step's row loads): behind it in the queue are one step's row loads and one whole step,
+      // NWAIT = RS_G + (RS_G + NT) loads that may stay outstanding; loads return in order, so the row stage (older) has arrived as well.
+      // (RA == RB, the measurement build SEEVCN_RS3_RB=3: both of a step's stages were issued RA - 1 steps ago, whole steps only behind them.)
+      constexpr int NWAIT = RA > RB ? RS_G + (RB - 1) * (RS_G + NT) : (RA - 1) * (RS_G + NT);
+#define RS3_WAIT(...) asm volatile("s_waitcnt vmcnt(%[nw])" : __VA_ARGS__ : [nw] "n"(NWAIT))
 #define V(x) "+v"(x)
-      if constexpr (RS_G == 4 && NT == 4) RS3_WAIT(16, V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3]));
-      else if constexpr (RS_G == 4 && NT == 2) RS3_WAIT(12, V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]), V(Bs[1]));
-      else if constexpr (RS_G == 4 && NT == 1) RS3_WAIT(10, V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]));
-      else if constexpr (RS_G == 3 && NT == 4) RS3_WAIT(14, V(As[0]), V(As[1]), V(As[2]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3]));
-      else if constexpr (RS_G == 3 && NT == 2) RS3_WAIT(10, V(As[0]), V(As[1]), V(As[2]), V(Bs[0]), V(Bs[1]));
-      else if constexpr (RS_G == 3 && NT == 1) RS3_WAIT(8, V(As[0]), V(As[1]), V(As[2]), V(Bs[0]));
-      else if constexpr (RS_G == 2 && NT == 4) RS3_WAIT(12, V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3]));
-      else if constexpr (RS_G == 2 && NT == 2) RS3_WAIT(8, V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1]));
-      else if constexpr (RS_G == 1 && NT == 4) RS3_WAIT(10, V(As[0]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3]));
+      if constexpr (RS_G == 4 && NT == 4) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
+      else if constexpr (RS_G == 4 && NT == 2) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]), V(Bs[1])); }
+      else if constexpr (RS_G == 4 && NT == 1) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0])); }
+      else if constexpr (RS_G == 3 && NT == 4) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
+      else if constexpr (RS_G == 3 && NT == 2) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(Bs[0]), V(Bs[1])); }
+      else if constexpr (RS_G == 3 && NT == 1) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(Bs[0])); }
+      else if constexpr (RS_G == 2 && NT == 4) { RS3_WAIT(V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
+      else if constexpr (RS_G == 2 && NT == 2) { RS3_WAIT(V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1])); }
+      else if constexpr (RS_G == 1 && NT == 4) { RS3_WAIT(V(As[0]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
       else {
         static_assert(RS_G == 2 && NT == 1, "no counted wait for this (tiles per wave, column tiles) pair");
-        RS3_WAIT(6, V(As[0]), V(As[1]), V(Bs[0]));
+        RS3_WAIT(V(As[0]), V(As[1]), V(Bs[0]));
       }
 #undef V
 #undef RS3_WAIT
+      if constexpr (FIN) {
+        // channels of the lane's four values in this step: 16 qc + 4 kk + {0..3}
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(&s_coef[0][qc * 16 + kk * 4]), sh = *reinterpret_cast<const f32x4*>(&s_coef[1][qc * 16 + kk * 4]);
+#pragma unroll
+        for (int g = 0; g < RS_G; ++g)
+          if ((mc >> g) & 1u) {
+            // a row WITHOUT a neighbour at this offset was an out-of-range load (zeros), which the transform would turn into relu(shift): its
+            // values are cleared again.  The validity is re-read from the index block every step (one LDS word) instead of living in a register
+            // across the offset's steps.
+            const int32_t absent = s_idx[pv.k_flip ? a.K - 1 - kc : kc][g * 16 + li] >> 31;          // all-ones: no neighbour
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              As[g][i] = __uint_as_float(__float_as_uint(fmaxf(__fmaf_rn(As[g][i], sc[i], sh[i]), in_lo)) & ~(uint32_t)absent);
+          }
+      }
       // per tile: 4 passes over the NT column tiles, so that consecutive MFMAs never share an accumulator (a dependent
       // v_mfma_f32_16x16x4_f32 issues 47 cycles after its producer, an independent one after 32)
 #pragma unroll
@@ -1333,13 +1410,18 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
         if (kc >= 0) mc = (unsigned)__builtin_amdgcn_readlane((int)maskreg, kc);
       }
     };
+    // the steps in front of the first compute, in the loop's own issue order (virtual steps -(RA - 1) .. -1)
 #pragma unroll
-    for (int st = 0; st < RING - 1; ++st) issue(A[st], B[st]);
+    for (int s0 = -(RA - 1); s0 < 0; ++s0) {
+      if (s0 + RB - 1 >= 0) issue_b(B[(s0 + RB - 1) % RB]);
+      issue_a(A[(s0 + RA - 1) % RA]);
+    }
     for (bool more = true; more;) {
 #pragma unroll
-      for (int st = 0; st < RING; ++st) {
-        issue(A[(st + RING - 1) % RING], B[(st + RING - 1) % RING]);
-        compute(A[st], B[st]);
+      for (int u = 0; u < UNR; ++u) {
+        issue_b(B[(u + RB - 1) % RB]);
+        issue_a(A[(u + RA - 1) % RA]);
+        compute(A[u % RA], B[u % RB]);
         if (kc < 0) {
           more = false;
           break;
@@ -1493,6 +1575,15 @@ static void launch_rs3_g(const ConvArgs& a, const PlanView& pv, const float* wfr
     }
     return;
   }
+  if (pv.in_coef) {                    // BatchNorm (+ ReLU) of the layer below applied on load
+    if constexpr (NT == 4) {
+      if (pv.d.G == 1) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 1, 0, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+      else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2, 0, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+    } else {
+      hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 4, 0, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+    }
+    return;
+  }
   if constexpr (NT == 4) {
     if (pv.d.G == 1) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 1>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
     else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 2>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
@@ -1524,6 +1615,7 @@ struct BnBwdView {            // the BatchNorm whose output gradient a data-grad
 static int conv_planned(const float* X, int64_t n_src, const int32_t* table_rows, const int32_t* perm, const int32_t* masks_p, const int32_t* tile_of,
                         int tiles_per_wave, const float* wfrag, float* Y, int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale,
                         const float* shift, const float* residual, int relu, int table_k_reversed, float* bn_partial, const BnBwdView* bnb, void* stream) {
+  const InNorm in = take_input_norm();
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Kd > 0 && Nc > 0, "sparse_conv (planned): bad sizes");
   SV_CHECK_ARG(!bn_partial || (!bias && !scale && !residual && !relu), "sparse_conv (planned): BatchNorm partial sums are made by the plain epilogue only");
   if (n_rows == 0) return SV_OK;
@@ -1543,6 +1635,8 @@ static int conv_planned(const float* X, int64_t n_src, const int32_t* table_rows
   static const int prio = getenv("SEEVCN_RS3_PRIO") ? atoi(getenv("SEEVCN_RS3_PRIO")) : 0;
   pv.prio = prio;
   pv.trace = g_conv_trace;
+  pv.in_coef = in.coef, pv.in_relu = in.relu;
+  SV_CHECK_ARG(!in.coef || (!pv.debug && !pv.trace && (uintptr_t)in.coef % 16 == 0), "sparse_conv (planned): an input transform needs a production instance and 16-byte aligned coefficients");
   const int nc_blk = Nc > 64 ? 64 : Nc;
   const dim3 grid((unsigned)(PL_REGIONS * PL_REGION_WAVES / 4), (unsigned)(Nc / nc_blk));
   const uint32_t xb = (uint32_t)((uint64_t)n_src * Kd * 4), wb = (uint32_t)((uint64_t)K * Nc * Kd * 4);
@@ -1651,6 +1745,7 @@ __global__ __launch_bounds__(256) void k_spconv_small_cin(ConvArgs a) {
 extern "C" int sv_sparse_conv_gather_gemm(const float* X, int64_t n_src, const int32_t* nbr, const float* Wt, float* Y,
                                           int64_t n_rows, int K, int Kd, int Nc, const float* bias, const float* scale, const float* shift,
                                           const float* residual, int relu, void* stream) {
+  SV_CHECK_ARG(!take_input_norm().coef, "sparse_conv: the plain entry takes no input transform (sv_conv_next_input_norm is for the planned kernel and the weight gradients)");
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Kd > 0 && Nc > 0, "sparse_conv: bad sizes");
   if (n_rows == 0) return SV_OK;
   SV_CHECK_ARG(X && nbr && Wt && Y, "sparse_conv: null pointer");
@@ -1710,6 +1805,35 @@ struct WgradArgs {
   int xcd_order;         // workgroup -> (chunk, offset, tile group) decoded per XCD (k_spconv_wgrad)
   int64_t n_src;         // rows of X, or <= 0 when the caller does not know (then no 32-bit offsets)
   unsigned long long* trace;   // measurement only (sv_debug_wgrad_trace, instance DBG = 16): 8 words per wave, or null
+  const float* in_coef;  // (2, Cin) scale | shift: X is read through y = [relu](x * scale + shift) (InNorm), or null
+  int in_relu;
+};
+
+// The lane's CT input channels are the same in every step (c_base + CT li + c): their coefficients sit in registers, the transform is CT fused
+// multiply-adds + CT max per operand load.  Pairs are compacted, so every loaded row is a real neighbour (no validity select); the ring's dummy and
+// tail loads are zeroed AFTER the transform or meet a zeroed dY operand.
+template <int CT>
+struct WgIn {
+  float sc[CT], sh[CT], lo;
+  bool on;
+  __device__ __forceinline__ void init(const float* coef, int relu, int Cin, int c0, bool x_in) {
+    on = coef != nullptr;
+    lo = relu ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      sc[c] = (on && x_in) ? coef[c0 + c] : 1.f;
+      sh[c] = (on && x_in) ? coef[Cin + c0 + c] : 0.f;
+    }
+  }
+  template <typename XV>
+  __device__ __forceinline__ void apply(XV& xs) const {
+    if (!on) return;                                         // wave-uniform
+    if constexpr (CT == 1) xs = fmaxf(__fmaf_rn(xs, sc[0], sh[0]), lo);
+    else {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) xs[c] = fmaxf(__fmaf_rn(xs[c], sc[c], sh[c]), lo);
+    }
+  }
 };
 
 template <int N> struct WgVec;
@@ -1797,6 +1921,8 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad(WgradA
   const float* dYc = a.dY + r_begin * a.Cout;                // this chunk's rows (uniform)
   const uint32_t xconst = (uint32_t)(x_in ? c_base + CT * li : 0) * 4u, yconst = (uint32_t)(n_base + NTL * li) * 4u;
   const uint32_t xrow = (uint32_t)a.Cin * 4u, yrow = (uint32_t)a.Cout * 4u;
+  WgIn<CT> win;
+  win.init(a.in_coef, a.in_relu, a.Cin, c_base + CT * li, x_in);
   auto issue = [&](int p, int cnt, XV& xs, YV& ys) {
     if constexpr (DBG & 1) {
       xs = XV{} + 1.f, ys = YV{} + 1.f;                        // measurement: what the kernel costs without its operand loads
@@ -1815,6 +1941,7 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad(WgradA
   auto consume = [&](int p0, int cnt, XV& xs, YV& ys) {
     asm volatile("s_waitcnt vmcnt(6)" : "+v"(xs), "+v"(ys));
     if (p0 >= cnt) return;                                   // wave-uniform: a dummy step of the ring's tail
+    win.apply(xs);
     if constexpr (OFF32) {
       // ONE block of MFMAs (two would get two sets of accumulators); the tail mask is applied in place, and only in a list's last step
       if (p0 + 4 > cnt || !(CT > 1 || c_base + 16 <= a.Cin)) {                       // wave-uniform
@@ -2113,6 +2240,7 @@ struct WgradReduceJob {
 
 static int wgrad_run(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K,
                                     int Cin, int Cout, void* scratch, void* stream, WgradOut out, WgradReduceJob* defer = nullptr) {
+  const InNorm in = take_input_norm();
   SV_CHECK_ARG(n_rows >= 0 && K > 0 && Cin > 0 && Cout > 0 && dW, "sparse_conv_wgrad: bad arguments");
   hipStream_t st = sv_stream(stream);
   const int64_t slab = (int64_t)K * Cin * Cout;
@@ -2132,6 +2260,8 @@ static int wgrad_run(const float* X, int64_t n_src, const int32_t* nbr, const fl
   const int xcd_order = xcd_env >= 0 ? xcd_env : (Cin <= 32 ? 1 : 0);
   const bool reduce4 = slab % 4 == 0 && Cout % 4 == 0 && (uintptr_t)dW % 16 == 0 && (uintptr_t)scratch % 16 == 0;
   WgradArgs a{X, nbr, dY, reinterpret_cast<float*>(scratch), n_rows, K, Cin, Cout, w.nchunks, w.chunk_rows, xcd_order, n_src};
+  a.in_coef = in.coef, a.in_relu = in.relu;
+  SV_CHECK_ARG(!in.coef || w.mfma, "sparse_conv_wgrad: an input transform needs an MFMA tile shape (C_in %d, C_out %d)", Cin, Cout);
   const int nslabs = a.nchunks;
   if (w.mfma) {
     if (w.tiles_c == 4) launch_wgrad<4, 4>(a, st);
@@ -2619,6 +2749,8 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad_eq(Wgr
   const uint32_t xconst = (uint32_t)(x_in ? c_base + CT * li : 0) * 4u, yconst = (uint32_t)(n_base + NTL * li) * 4u;
   const uint32_t xrow = (uint32_t)a.Cin * 4u, yrow = (uint32_t)a.Cout * 4u;
   f32x4 acc[CT][NTL];
+  WgIn<CT> win;
+  win.init(a.in_coef, a.in_relu, a.Cin, c_base + CT * li, x_in);
   auto issue = [&](int p, XV& xs, YV& ys) {
     const int2 jr = plist[p];                                // byte offsets; entries past the wave's share are other pairs or the padding (row 0)
     wg_gload_s(xs, (uint32_t)jr.x + xconst, a.X);
@@ -2627,6 +2759,7 @@ __global__ __launch_bounds__(256, SEEVCN_WGRAD_WAVES) void k_spconv_wgrad_eq(Wgr
   auto consume = [&](int p0, int pend, XV& xs, YV& ys) {
     asm volatile("s_waitcnt vmcnt(6)" : "+v"(xs), "+v"(ys));
     if (p0 >= pend) return;                                  // wave-uniform: a dummy step of the ring's tail
+    win.apply(xs);
     if (p0 + 4 > pend || !(CT > 1 || c_base + 16 <= a.Cin)) {                      // wave-uniform: the tail mask only in a share's last step
       const bool ok = p0 + kk < pend;
       if (!(ok && x_in)) xs = XV{};
@@ -2803,6 +2936,7 @@ extern "C" size_t sv_sparse_conv_wgrad_planned_bytes(int K, int Cin, int Cout) {
 
 static int wgrad_planned_run(const float* X, int64_t n_src, const int32_t* nbr, const float* dY, float* dW, int64_t n_rows, int K, int Cin, int Cout,
                              const void* plan, void* partial, void* stream, WgradOut out, WgradReduceJob* defer) {
+  const InNorm in = take_input_norm();
   SV_CHECK_ARG(X && nbr && dY && dW && plan && partial, "sparse_conv_wgrad_planned: null pointer");
   SV_CHECK_ARG(sv_wgrad_planned_applies(n_src, n_rows, K, Cin, Cout), "sparse_conv_wgrad_planned: not for this layer (ask sv_wgrad_planned_applies first)");
   SV_CHECK_ARG((uintptr_t)dW % 16 == 0 && (uintptr_t)partial % 16 == 0, "sparse_conv_wgrad_planned: 16-byte alignment");
@@ -2812,6 +2946,7 @@ static int wgrad_planned_run(const float* X, int64_t n_src, const int32_t* nbr, 
   hipStream_t st = sv_stream(stream);
   static const int prio = getenv("SEEVCN_WGRAD_PRIO") ? atoi(getenv("SEEVCN_WGRAD_PRIO")) : 1;
   WgradArgs a{X, nbr, dY, static_cast<float*>(partial), n_rows, K, Cin, Cout, 0, 0, prio, n_src};
+  a.in_coef = in.coef, a.in_relu = in.relu;
   const WgradPlanView pl{p.cut, p.slab0, p.pre, pieces, (int)wgrad_units_per_group(n_rows)};
   if (w.tiles_c == 4) launch_wgrad_eq<4, 4>(a, pl, st);
   else if (w.tiles_c == 2 && w.tiles_n == 4) launch_wgrad_eq<2, 4>(a, pl, st);

@@ -31,7 +31,12 @@ DEFER_WGRAD_REDUCE = os.environ.get("SEEVCN_WGRAD_DEFER", "1") != "0"
 # input side's stream already shares the GPU, 4.07-4.19 -> 4.3-4.4 ms (three streams fragment the one-resident-round launches).  Off by default.
 WGRAD_STREAM = os.environ.get("SEEVCN_WGRAD_STREAM", "0") == "1"
 _wgrad_stream = {}
-OP_CONV_PLANNED, OP_CONV_PLAIN, OP_BN_FWD, OP_BN_BWD, OP_WGRAD, OP_DGRAD_PLANNED_BN, OP_WGRAD_DEFERRED = 1, 2, 3, 5, 6, 7, 8
+# 1 (default): the BatchNorm + ReLU behind a conv is NOT applied in a pass of its own -- the block keeps the raw conv output and the norm's (scale, shift), and the
+# next block's convolution and weight gradient apply them as they gather the rows (sv_conv_next_input_norm): one read + one write of every activation
+# tensor and one launch per block less; the values a consumer sees are bit for bit those of the separate pass.  Tensors that leave the chain (taps) are
+# made when somebody reads them (LazyTap), the last block's in the list.  0: every block writes its normalised output (A/B runs, tests).
+BN_FOLD = os.environ.get("SEEVCN_BN_FOLD", "1") != "0"
+OP_CONV_PLANNED, OP_CONV_PLAIN, OP_BN_FWD, OP_BN_BWD, OP_WGRAD, OP_DGRAD_PLANNED_BN, OP_WGRAD_DEFERRED, OP_BN_FINALIZE, OP_BN_APPLY = 1, 2, 3, 5, 6, 7, 8, 9, 10
 WORDS = 32
 
 
@@ -140,6 +145,36 @@ def applicable(blocks, x):
     return True
 
 
+class _TapApply(torch.autograd.Function):
+    """The normalised output of a chain block made on demand from its raw conv output: y = [relu](x * scale + shift) (sv_batchnorm_apply: the forward's
+    own elementwise pass).  For autograd it is the identity: the chain's backward runs that block's BatchNorm backward itself, with whatever gradient
+    arrives here as the gradient w.r.t. y."""
+
+    @staticmethod
+    def forward(ctx, raw, coef, relu):
+        y = torch.empty_like(raw)
+        _lib.check(_lib.load().sv_batchnorm_apply(_lib.ptr(raw), raw.shape[0], raw.shape[1], _lib.ptr(coef), int(relu), _lib.ptr(y), _lib.stream()), "sv_batchnorm_apply")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None
+
+
+def fold_plan(blocks, rulebooks):
+    """-> (fold_in, materialize): fold_in[k]: block k reads block k-1's RAW conv output through that block's BatchNorm coefficients (its conv runs on a
+    plan and its weight gradient on an MFMA tile shape: the kernels that carry the transform); materialize[k]: block k writes its normalised output in
+    the list (the last block, and a block whose successor cannot fold)."""
+    L = len(blocks)
+    fold_in = [False] * L
+    if BN_FOLD:
+        for k in range(1, L):
+            b, rb = blocks[k], rulebooks[k]
+            fold_in[k] = rb.plan_addrs("fwd", b.cin, b.cout) is not None and b.cin % 16 == 0 and b.cout % 16 == 0
+    materialize = [k == L - 1 or not fold_in[k + 1] for k in range(L)]
+    return fold_in, materialize
+
+
 class SparseChainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, blocks, rulebooks, *params):
@@ -147,20 +182,23 @@ class SparseChainFunction(torch.autograd.Function):
         dev = features.device
         ctx.set_materialize_grads(False)                                              # a tap nobody differentiates arrives as None, not as zeros
         features = features.contiguous().float()
-        # one allocation for every activation: per block [conv output | block output | batch mean | batch invstd]
+        fold_in, materialize = fold_plan(blocks, rulebooks)
+        # one allocation for every activation: per block [conv output | block output (when it is written at all) | batch mean | batch invstd | scale | shift]
         offs, total = [], 0
-        for b, rb in zip(blocks, rulebooks):
+        for k, (b, rb) in enumerate(zip(blocks, rulebooks)):
             n = rb.n_out * b.cout
-            offs.append((total, total + n, total + 2 * n, total + 2 * n + b.cout))
-            total += 2 * n + 2 * b.cout
+            ny = n if materialize[k] else 0
+            offs.append((total, total + n, total + n + ny, total + n + ny + b.cout, total + n + ny + 2 * b.cout))
+            total += n + ny + 4 * b.cout
         arena = torch.empty((total,), dtype=torch.float32, device=dev)
         base = arena.data_ptr()
         n_part = lib.sv_conv_planned_partials()
         rows, x_ptr, n_src, keep = [], features.data_ptr(), features.shape[0], []
         frags = []
+        in_coef = None                                                                # (address, relu) of the transform the next conv applies on load
         for k, (b, rb) in enumerate(zip(blocks, rulebooks)):
             w, gamma, beta = params[3 * k:3 * k + 3]
-            o_conv, o_y, o_mean, o_istd = (base + 4 * v for v in offs[k])
+            o_conv, o_y, o_mean, o_istd, o_coef = (base + 4 * v for v in offs[k])
             wk = b.conv.weight_kio_nograd()
             plan = rb.plan_addrs("fwd", b.cin, b.cout)
             scratch = norm._scratch(b.cout, dev).data_ptr()
@@ -170,32 +208,55 @@ class SparseChainFunction(torch.autograd.Function):
                 ff, fb = Fsp.fragment_cache.get(wk)
                 frags.append(fb)
                 partial = scratch + 16 * b.cout if norm.STATS_IN_CONV else 0
-                rows.append(_row(OP_CONV_PLANNED, i=(g, b.K, b.cin, b.cout, 0, int(bool(rev))), n=(n_src, rb.n_out),
-                                 p=(x_ptr, a_rows, a_perm, a_masks_p, a_tiles, ff.data_ptr(), o_conv, None, None, None, None, partial or None)))
+                rows.append(_row(OP_CONV_PLANNED, i=(g, b.K, b.cin, b.cout, 0, int(bool(rev)), in_coef[1] if in_coef else 0), n=(n_src, rb.n_out),
+                                 p=(x_ptr, a_rows, a_perm, a_masks_p, a_tiles, ff.data_ptr(), o_conv, None, None, None, None, partial or None,
+                                    in_coef[0] if in_coef else None)))
             else:
+                assert in_coef is None
                 frags.append(None)
                 wt = wk.detach().permute(0, 2, 1).contiguous()                       # (K, C_out, C_in): the 3-channel input layer only
                 keep.append(wt)
                 rows.append(_row(OP_CONV_PLAIN, i=(b.K, b.cin, b.cout, 0), n=(n_src, rb.n_out), p=(x_ptr, rb.addr("nbr_out"), wt.data_ptr(), o_conv)))
-            rows.append(_row(OP_BN_FWD, i=(b.cout, 1, int(b.relu), n_part if partial else 0), n=(rb.n_out,), f=b.mom_eps,
-                             p=(o_conv, gamma.data_ptr(), beta.data_ptr(), b.bn.running_mean.data_ptr(), b.bn.running_var.data_ptr(), scratch, o_y, o_mean,
-                                o_istd, b.bn.num_batches_tracked.data_ptr())))
-            x_ptr, n_src = o_y, rb.n_out
+            if BN_FOLD:
+                rows.append(_row(OP_BN_FINALIZE, i=(b.cout, n_part if partial else 0), n=(rb.n_out,), f=b.mom_eps,
+                                 p=(gamma.data_ptr(), beta.data_ptr(), b.bn.running_mean.data_ptr(), b.bn.running_var.data_ptr(), scratch, o_coef, o_mean, o_istd,
+                                    b.bn.num_batches_tracked.data_ptr(), None if partial else o_conv)))
+                if materialize[k]:
+                    rows.append(_row(OP_BN_APPLY, i=(b.cout, int(b.relu)), n=(rb.n_out,), p=(o_conv, o_coef, o_y)))
+            else:
+                rows.append(_row(OP_BN_FWD, i=(b.cout, 1, int(b.relu), n_part if partial else 0), n=(rb.n_out,), f=b.mom_eps,
+                                 p=(o_conv, gamma.data_ptr(), beta.data_ptr(), b.bn.running_mean.data_ptr(), b.bn.running_var.data_ptr(), scratch, o_y, o_mean,
+                                    o_istd, b.bn.num_batches_tracked.data_ptr())))
+            if k + 1 < len(blocks) and fold_in[k + 1]:
+                x_ptr, in_coef = o_conv, (o_coef, int(b.relu))
+            else:
+                x_ptr, in_coef = o_y, None
+            n_src = rb.n_out
         _run(rows, "sv_run_ops (chain forward)")
-        ctx.blocks, ctx.rulebooks, ctx.offs, ctx.frags = blocks, rulebooks, offs, frags
+        ctx.blocks, ctx.rulebooks, ctx.offs, ctx.frags, ctx.fold_in = blocks, rulebooks, offs, frags, fold_in
         ctx.save_for_backward(features, arena, *params)
-        outs = tuple(arena[offs[k][1]:offs[k][2]].view(rulebooks[k].n_out, b.cout) for k, b in enumerate(blocks) if b.tap)
-        return outs
+        # a tap whose normalised output is written in the list is that tensor; the others hand out [raw conv output, coefficients] (see run_chain)
+        outs = []
+        for k, b in enumerate(blocks):
+            if b.tap:
+                n, c = rulebooks[k].n_out, b.cout
+                if materialize[k]:
+                    outs.append(arena[offs[k][1]:offs[k][2]].view(n, c))
+                else:
+                    outs.append(arena[offs[k][0]:offs[k][1]].view(n, c))
+        coefs = [arena[offs[k][4]:offs[k][4] + 2 * b.cout] for k, b in enumerate(blocks) if b.tap and not materialize[k]]
+        ctx.mark_non_differentiable(*coefs)
+        return tuple(outs) + tuple(coefs)
 
     @staticmethod
     def backward(ctx, *grads):
         lib = _lib.load()
         features, arena, *params = ctx.saved_tensors
-        blocks, rulebooks, offs, frags = ctx.blocks, ctx.rulebooks, ctx.offs, ctx.frags
+        blocks, rulebooks, offs, frags, fold_in = ctx.blocks, ctx.rulebooks, ctx.offs, ctx.frags, ctx.fold_in
         dev = arena.device
         L = len(blocks)
         ext, gi = [None] * L, 0                                                       # gradient that reaches a block's output from outside the chain
-        for k, b in enumerate(blocks):
+        for k, b in enumerate(blocks):                                                # (behind the taps' gradients come the Nones of the coefficient outputs)
             if b.tap:
                 ext[k] = None if grads[gi] is None else grads[gi].contiguous().float()
                 gi += 1
@@ -230,14 +291,16 @@ class SparseChainFunction(torch.autograd.Function):
             b, rb = blocks[k], rulebooks[k]
             w, gamma, beta = params[3 * k:3 * k + 3]
             o_dconv, o_dx, o_dg, o_db = (base + 4 * v for v in boffs[k])
-            a_conv, a_y, a_mean, a_istd = (abase + 4 * v for v in offs[k])
-            x_in = features.data_ptr() if k == 0 else abase + 4 * offs[k - 1][1]
+            a_conv, a_y, a_mean, a_istd, _ = (abase + 4 * v for v in offs[k])
+            # the layer's input: the features, the block below's normalised output, or (folded) its raw conv output + the coefficients of its BatchNorm
+            x_in = features.data_ptr() if k == 0 else abase + 4 * offs[k - 1][0 if fold_in[k] else 1]
+            x_coef = (abase + 4 * offs[k - 1][4], int(blocks[k - 1].relu)) if fold_in[k] else (None, 0)
             scratch = norm._scratch(b.cout, dev)
             rows.append(_row(OP_BN_BWD, i=(b.cout, int(b.relu), n_part_bwd), n=(rb.n_out,),
                              p=(a_conv, dy_ptr, gamma.data_ptr(), beta.data_ptr(), a_mean, a_istd, scratch.data_ptr(), o_dconv, o_dg, o_db)))
             n_part_bwd = 0
-            rows.append(_row(OP_WGRAD_DEFERRED if DEFER_WGRAD_REDUCE else OP_WGRAD, i=(b.K, b.cin, b.cout, rb.n_in), n=(rb.n_out, b.cin, 1, b.K * b.cin),
-                             p=(x_in, rb.addr("nbr_out"), o_dconv, wbase + 4 * woffs[k], wscratch.data_ptr() + poffs[k], wplans[k] or None)))
+            rows.append(_row(OP_WGRAD_DEFERRED if DEFER_WGRAD_REDUCE else OP_WGRAD, i=(b.K, b.cin, b.cout, rb.n_in, x_coef[1]), n=(rb.n_out, b.cin, 1, b.K * b.cin),
+                             p=(x_in, rb.addr("nbr_out"), o_dconv, wbase + 4 * woffs[k], wscratch.data_ptr() + poffs[k], wplans[k] or None, x_coef[0])))
             if k > 0:
                 a_rows, a_perm, a_masks_p, a_tiles, g, rev = rb.plan_addrs("bwd", b.cout, b.cin)
                 res = ext[k - 1]
@@ -245,7 +308,7 @@ class SparseChainFunction(torch.autograd.Function):
                     # the gradient this launch writes is the whole gradient of block k-1's output: its epilogue also makes the two sums of that
                     # block's BatchNorm backward (the rows' x comes from the arena), and the BatchNorm op below starts at the combine
                     lo = blocks[k - 1]
-                    p_conv, _, p_mean, p_istd = (abase + 4 * v for v in offs[k - 1])
+                    p_conv, _, p_mean, p_istd, _ = (abase + 4 * v for v in offs[k - 1])
                     g_lo, b_lo = params[3 * (k - 1) + 1], params[3 * (k - 1) + 2]
                     partial = norm._scratch(lo.cout, dev).data_ptr() + 16 * lo.cout
                     rows.append(_row(OP_DGRAD_PLANNED_BN, i=(g, b.K, b.cout, b.cin, int(bool(rev)), int(lo.relu)), n=(rb.n_out, rb.n_in),
@@ -269,6 +332,28 @@ class SparseChainFunction(torch.autograd.Function):
         return tuple(out)
 
 
+class LazyTap:
+    """Mixin state of a tap whose normalised features are made when somebody reads them (BN_FOLD): PV-RCNN's set abstraction reads
+    multi_scale_3d_features, SECOND / the benchmarked step read none of x_conv1..4 -- their elementwise passes never run."""
+
+
+def _lazy_tensor(raw, coef, relu, indices, shape, batch_size, grid, indice_dict):
+    from .core import SparseConvTensor
+
+    class _Lazy(SparseConvTensor, LazyTap):
+        @property
+        def features(self):
+            if self._features is None:
+                self._features = _TapApply.apply(raw, coef, relu)
+            return self._features
+
+        @features.setter
+        def features(self, value):
+            self._features = value
+
+    return _Lazy(None, indices, shape, batch_size, grid, indice_dict)
+
+
 def run_chain(blocks, x):
     """x: SparseConvTensor at the chain's input with every rulebook prebuilt.  -> list of SparseConvTensor, one per tap, in order."""
     from .core import SparseConvTensor
@@ -277,5 +362,14 @@ def run_chain(blocks, x):
     for b in blocks:
         params += [b.conv.weight, b.bn.weight, b.bn.bias]
     outs = SparseChainFunction.apply(x.features, blocks, rulebooks, *params)
-    taps = [rb for b, rb in zip(blocks, rulebooks) if b.tap]
-    return [SparseConvTensor(f, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.indice_dict) for f, rb in zip(outs, taps)]
+    taps = [(b, rb) for b, rb in zip(blocks, rulebooks) if b.tap]
+    _, materialize = fold_plan(blocks, rulebooks)
+    tap_mat = [materialize[k] for k, b in enumerate(blocks) if b.tap]
+    coefs = list(outs[len(taps):])
+    res = []
+    for f, (b, rb), mat in zip(outs[:len(taps)], taps, tap_mat):
+        if mat:
+            res.append(SparseConvTensor(f, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.indice_dict))
+        else:
+            res.append(_lazy_tensor(f, coefs.pop(0), b.relu, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.indice_dict))
+    return res

@@ -623,7 +623,9 @@ def test_hip_backbone_chain_equals_the_module_path(cuda, hip_lib):
     (SparseSequential: one node per block): the same kernels with the same arguments, so outputs, running statistics and every gradient are
     bit-identical; a gradient that enters at a multi-scale tap (x_conv3, as PV-RCNN's set abstraction sends it) is carried as well.
     Both in the DEFAULT configuration (BatchNorm statistics summed in the conv epilogues, in the order of the plan's tiles -- the two networks
-    build their own rulebooks and plans, and a table has exactly one plan) and with the statistics made by their own reduction pass."""
+    build their own rulebooks and plans, and a table has exactly one plan) and with the statistics made by their own reduction pass; and with the
+    chain's BatchNorm + ReLU applied by the consumers as they gather (chain.BN_FOLD, the default: no normalised tensor is written between the blocks,
+    x_conv3 is made when it is read) as well as with every block writing its output -- the module path always writes them: bit-identical either way."""
     import copy
     import seevcn_amd.synth as synth
     from seevcn_amd.pcdet.models import backbones_3d
@@ -634,29 +636,33 @@ def test_hip_backbone_chain_equals_the_module_path(cuda, hip_lib):
     f, c, _ = voxel_ops.voxelize_dynamic(torch.from_numpy(pts).to(cuda), g["point_cloud_range"], g["voxel_size"], g["grid_size"], 2)
     torch.manual_seed(0)
     net1 = backbones_3d.__all__['VoxelBackBone8x']({}, 3, g['grid_size']).to(cuda).train()
-    for stats_in_conv in (True, False):
+    for stats_in_conv, fold in ((True, True), (False, True), (True, False)):
         net2 = copy.deepcopy(net1)
         net3 = copy.deepcopy(net1)
         res = []
         for net, off in ((net2, False), (net3, True)):
             saved, chain.CHAIN_OFF = chain.CHAIN_OFF, off
             saved_stats, norm.STATS_IN_CONV = norm.STATS_IN_CONV, stats_in_conv
+            saved_fold, chain.BN_FOLD = chain.BN_FOLD, fold
             try:
                 assert (net._chain_blocks() is not None)
                 bd = net({'batch_size': 2, 'voxel_features': f.clone(), 'voxel_coords': c.clone()})
-                out, x3 = bd['encoded_spconv_tensor'].features, bd['multi_scale_3d_features']['x_conv3'].features
+                x3t = bd['multi_scale_3d_features']['x_conv3']
+                assert isinstance(x3t, chain.LazyTap) == (fold and not off)
+                out, x3 = bd['encoded_spconv_tensor'].features, x3t.features
                 assert (type(out.grad_fn).__name__ == "SparseChainFunctionBackward") == (not off)
                 (out.square().sum() + (x3 * 0.5).sum()).backward()
             finally:
                 chain.CHAIN_OFF = saved
                 norm.STATS_IN_CONV = saved_stats
+                chain.BN_FOLD = saved_fold
             res.append((out.detach(), x3.detach(), [p.grad.clone() for p in net.parameters()], [b.clone() for b in net.buffers()]))
         a, b = res
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), stats_in_conv
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (stats_in_conv, fold)
         for (n1, _), g1, g2 in zip(net1.named_parameters(), a[2], b[2]):
-            assert torch.equal(g1, g2), (n1, stats_in_conv)
+            assert torch.equal(g1, g2), (n1, stats_in_conv, fold)
         for (n1, _), b1, b2 in zip(net1.named_buffers(), a[3], b[3]):
-            assert torch.equal(b1, b2), (n1, stats_in_conv)
+            assert torch.equal(b1, b2), (n1, stats_in_conv, fold)
 
 
 @pytest.mark.gpu
