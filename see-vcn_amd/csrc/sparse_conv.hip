@@ -1176,12 +1176,19 @@ struct PlanView {
 constexpr int RS3_RA = SEEVCN_RS3_RA;      // stages of the row ring (RS3_RA - 1 steps of gathers in flight)
 constexpr int RS3_RB = SEEVCN_RS3_RB;      // stages of the weight ring
 // FIN: the gathered rows go through pv.in_coef (BatchNorm + ReLU of the layer below applied on load) -- production instances only
-template <int NT, int KQ, int RS_G, int DBG = 0, bool FIN = false>
+// DYN (one tile per pass, production instances): the four waves of a workgroup take the workgroup's tiles -- the union of the four waves' slots in
+// the plan, heaviest level first -- one at a time from a counter in LDS instead of each walking its own slots.  A wave's length is then the
+// workgroup's work / 4 up to one light tile, whatever the tiles cost one by one (dealt statically, waves of the 139 k-row layer ran 14 .. 37
+// (tile, offset) steps around a mean of 21.7, and a long wave alone on its SIMD cannot fill the matrix pipe: it waits for its own gathers).  Which
+// wave computes a tile does not change the tile's values; the BatchNorm column sums are kept PER LIST POSITION in LDS and combined in list order, so
+// the workgroup's partial sums -- and with them the training step -- stay bit-reproducible.
+constexpr int RS3_DYN_COLS = 1024;         // floats of one kind (sum / sum of squares) in the per-position array: positions x 16 NT columns
+template <int NT, int KQ, int RS_G, int DBG = 0, bool FIN = false, bool DYN = false>
 __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs a, PlanView pv, const float* __restrict__ wfrag, uint32_t x_bytes,
                                                                         uint32_t w_bytes) {
   constexpr int Kd = KQ * 16;
   __shared__ int32_t s_idx_all[4][RS3_KMAX + 1][64];       // [k][lane]: source row of (tile lane>>4, row lane&15); [27][lane]: its output row
-  __shared__ __attribute__((aligned(16))) float s_coef_all[FIN ? 4 : 1][2][FIN ? Kd : 4];      // wave-private copies of (scale | shift): no workgroup barrier
+  __shared__ __attribute__((aligned(16))) float s_coef[2][FIN ? Kd : 4];      // (scale | shift) of the input transform
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int li = lane & 15, kk = lane >> 4;
   const int region = blockIdx.x % PL_REGIONS, lw = (blockIdx.x / PL_REGIONS) * 4 + wid;
@@ -1189,30 +1196,52 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   unsigned long long t_pro = 0ull, t_loop = 0ull, t_mark = t_start;      // cycles in pass prologues / main loops, summed over the passes
   unsigned trace_work = 0;
   int32_t(*s_idx)[64] = s_idx_all[wid];
-  float(*s_coef)[FIN ? Kd : 4] = s_coef_all[FIN ? wid : 0];
   float in_lo = 0.f;
   if constexpr (FIN) {
-    for (int c = lane; c < Kd; c += 64) s_coef[0][c] = pv.in_coef[c], s_coef[1][c] = pv.in_coef[Kd + c];
+    for (int c = threadIdx.x; c < 2 * Kd; c += 256) s_coef[c / Kd][c % Kd] = pv.in_coef[c];
     in_lo = pv.in_relu ? 0.f : -__builtin_inff();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
   const int nt_total = pv.nc_total / 16, col_tile0 = blockIdx.y * NT;
   const i32x4 srd_x = make_srd(a.X, x_bytes), srd_w = make_srd(wfrag, w_bytes);
   const int32_t* my_tiles = pv.tile_of + ((int64_t)region * PL_REGION_WAVES + lw) * (pv.d.n_pass * RS_G);
+  static_assert(!DYN || (RS_G == 1 && DBG == 0), "the dynamic list hands out single tiles to production instances");
+  __shared__ int s_next;                                                               // DYN: next position of the workgroup's list
+  __shared__ float s_bnpos[DYN ? 2 : 1][DYN ? RS3_DYN_COLS : 1];                       // DYN: column sums / sums of squares of the tile at every list position
+  const int dyn_slots = pv.d.n_pass * pv.d.G, dyn_n = 4 * dyn_slots;                   // the plan's slots per wave (laid out for pv.d.G tiles per pass)
+  const int32_t* wg_tiles = pv.tile_of + ((int64_t)region * PL_REGION_WAVES + (blockIdx.x / PL_REGIONS) * 4) * dyn_slots;
+  if constexpr (DYN) {
+    if (threadIdx.x == 0) s_next = 0;
+    for (int e = threadIdx.x; e < 2 * RS3_DYN_COLS; e += 256) s_bnpos[e / RS3_DYN_COLS][e % RS3_DYN_COLS] = 0.f;
+  }
+  if constexpr (DYN || FIN) __syncthreads();               // the only workgroup barrier in front of the epilogue
+  int dyn_pos = 0;
 
   // BatchNorm statistics: lane c < 16 NT sums column c of every tile the wave stores, read back from the staging tile row by row (fixed order).
   // Two registers carried across the pass loop; the first version summed straight from the accumulators (column 16 t + li in lane (li, kk):
   // 2 NT registers), which hipcc spilled around the main loop at four waves per SIMD.
   float bn0 = 0.f, bn1 = 0.f;
 #pragma nounroll
-  for (int pass = 0; pass < pv.d.n_pass; ++pass) {
-  if (my_tiles[pass * RS_G] < 0) break;                    // slots are filled front to back: an empty first slot ends the wave's list
+  for (int pass = 0; DYN || pass < pv.d.n_pass; ++pass) {
+  int32_t dyn_tile = -1;
+  if constexpr (DYN) {
+    // position i of the list = slot i / 4 of wave i % 4: the deal fills slot levels heaviest first
+    int i = 0;
+    if (lane == 0) i = atomicAdd(&s_next, 1);
+    i = __builtin_amdgcn_readfirstlane(i);
+    if (i >= dyn_n) break;
+    dyn_pos = i;
+    dyn_tile = wg_tiles[(i & 3) * dyn_slots + (i >> 2)];
+    if (dyn_tile < 0) continue;                            // a wave whose slots ended early: other waves' deeper levels may still hold tiles
+  } else {
+    if (my_tiles[pass * RS_G] < 0) break;                  // slots are filled front to back: an empty first slot ends the wave's list
+  }
   if (pv.prio) __builtin_amdgcn_s_setprio(3);
+  if constexpr (DYN) bn0 = 0.f, bn1 = 0.f;                 // this tile's column sums only (kept per list position)
   // the wave's rows of the regrouped table -> LDS; per-offset tile masks in lane k of maskreg
   unsigned maskreg = 0;
   {
     const int g = lane >> 4;
-    const int32_t t = g < RS_G ? my_tiles[pass * RS_G + g] : -1;
+    const int32_t t = DYN ? (g < 1 ? dyn_tile : -1) : (g < RS_G ? my_tiles[pass * RS_G + g] : -1);
     i32x4 e[PL_ROW / 4];
     const int64_t p = (int64_t)t * 16 + li;
     const int32_t row = t >= 0 ? pv.perm[p] : -1;
@@ -1486,6 +1515,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
             bn0 += v, bn1 += v * v;
           }
         }
+        if constexpr (DYN) s_bnpos[0][dyn_pos * (NT * 16) + lane_e] = bn0, s_bnpos[1][dyn_pos * (NT * 16) + lane_e] = bn1;
       }
       constexpr int C4N = NT * 4;                                     // 16-byte pieces per row
 #pragma unroll
@@ -1517,6 +1547,15 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   if (pv.bn_partial) {
     // BatchNorm statistics of this launch's output: lane c holds column c of its wave -> the workgroup (4 waves, fixed order) -> one partial
     // per workgroup and column, combined by k_bn_finalize in a fixed order
+    if constexpr (DYN) {
+      __syncthreads();                                     // every wave has left the list: all positions are final (untouched ones hold zeros)
+      for (int e = threadIdx.x; e < 2 * NT * 16; e += 256) {
+        const int which = e / (NT * 16), c = e % (NT * 16);
+        float v = 0.f;
+        for (int pos = 0; pos < dyn_n; ++pos) v += s_bnpos[which][pos * (NT * 16) + c];      // list order: the same sum whichever wave took which tile
+        pv.bn_partial[((size_t)blockIdx.x * 2 + which) * pv.nc_total + col_tile0 * 16 + c] = v;
+      }
+    } else {
     __shared__ float s_bn[4][2][64];
     if (NT == 4 || lane < NT * 16) s_bn[wid][0][lane] = bn0, s_bn[wid][1][lane] = bn1;
     __syncthreads();
@@ -1524,6 +1563,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       const int which = e / (NT * 16), c = e % (NT * 16);
       const float v = (s_bn[0][which][c] + s_bn[1][which][c]) + (s_bn[2][which][c] + s_bn[3][which][c]);
       pv.bn_partial[((size_t)blockIdx.x * 2 + which) * pv.nc_total + col_tile0 * 16 + c] = v;
+    }
     }
   }
   if (DBG && pv.trace && lane == 0) {
@@ -1574,6 +1614,18 @@ static void launch_rs3_g(const ConvArgs& a, const PlanView& pv, const float* wfr
       hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 4, 2>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
     }
     return;
+  }
+  if constexpr (NT == 4) {
+    // SEEVCN_RS3_DYN=1 (A/B, off by default): the workgroup-local dynamic list (one tile per pass) for the 64-column kernels whenever the workgroup's
+    // list fits the per-position sums.  Measured (round 5, same box, profiles/r05_dyn_ab.txt): 64 -> 64 at 139 k rows 114.9 -> 119.9 us, the other layers
+    // +-1 %, the step 4.05 ms either way -- equal wave lengths buy nothing here: a one-tile pass has half the MFMA work in flight per gather latency
+    // (1024 pipe cycles against 2048 with two tiles), and the 66 k-row layers have one tile per wave whoever takes it.
+    static const int dyn_env = getenv("SEEVCN_RS3_DYN") ? atoi(getenv("SEEVCN_RS3_DYN")) : 0;
+    if (dyn_env && 4 * pv.d.n_pass * pv.d.G * NT * 16 <= RS3_DYN_COLS) {
+      if (pv.in_coef) hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 1, 0, true, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+      else hipLaunchKernelGGL((k_spconv_rs3<NT, KQ, 1, 0, false, true>), grid, dim3(256), 0, st, a, pv, wfrag, xb, wb);
+      return;
+    }
   }
   if (pv.in_coef) {                    // BatchNorm (+ ReLU) of the layer below applied on load
     if constexpr (NT == 4) {
