@@ -56,24 +56,39 @@ def build_model(device, seed=0):
 
 
 class _MeanSquare(torch.autograd.Function):
-    """mean(x^2) with a one-kernel forward (dot) and a one-kernel backward (scale) -- same value and gradient as
-    x.square().mean(), without autograd's pow/mul/expand chain over the 577 MB BEV tensor."""
+    """mean(x^2) over the dense BEV tensor: same value and gradient as x.square().mean().  The forward reads the tensor once and, while it does,
+    writes the loss's own gradient (2 / n) x (sv_mean_square: one read + one write, fixed-order sums); the backward hands that tensor on, scaled by
+    the upstream gradient on the device only when it is not 1 (sv_scale_by_device_scalar).  Round 4 ran a row-norm reduction forward (145 us for the
+    577 MB tensor) and an elementwise product backward (210 us); SEEVCN_BENCH_LOSS=torch keeps that pair for A/B runs."""
 
     @staticmethod
     def forward(ctx, x):
-        ctx.save_for_backward(x)
-        flat = x.reshape(-1)
-        n = flat.numel()
-        if n % 1024 == 0 and os.environ.get("SEEVCN_BENCH_DOT") != "1":
-            # row norms of a (n / 1024, 1024) view, squared and summed: 111 us for the 577 MB BEV tensor (5.2 TB/s); rocBLAS' dot takes
-            # 216 us, vector_norm over the whole tensor 150 us (measured on MI355X)
-            return torch.linalg.vector_norm(flat.view(-1, 1024), dim=1).square().sum() / n
-        return torch.dot(flat, flat) / n
+        from seevcn_amd import _lib
+        n = x.numel()
+        if os.environ.get("SEEVCN_BENCH_LOSS") == "torch" or n % 4 or not x.is_contiguous():
+            ctx.fused = False
+            ctx.save_for_backward(x)
+            flat = x.reshape(-1)
+            if n % 1024 == 0:
+                return torch.linalg.vector_norm(flat.view(-1, 1024), dim=1).square().sum() / n
+            return torch.dot(flat, flat) / n
+        lib = _lib.load()
+        ctx.fused = True
+        grad = torch.empty_like(x)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        scratch = _lib.workspace.scratch("bench_mean_square", lib.sv_mean_square_scratch_bytes(), x.device)
+        _lib.check(lib.sv_mean_square(_lib.ptr(x), n, 1.0 / n, 2.0 / n, _lib.ptr(grad), _lib.ptr(out), _lib.ptr(scratch), _lib.stream()), "sv_mean_square")
+        ctx.save_for_backward(grad)
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        return x * (g * (2.0 / x.numel()))
+        from seevcn_amd import _lib
+        (t,) = ctx.saved_tensors
+        if not ctx.fused:
+            return t * (g * (2.0 / t.numel()))
+        _lib.check(_lib.load().sv_scale_by_device_scalar(_lib.ptr(t), t.numel(), _lib.ptr(g.contiguous().float()), _lib.stream()), "sv_scale_by_device_scalar")
+        return t
 
 
 def loss_fn(bd):
@@ -123,10 +138,11 @@ class Prefetch:
     """The input side of batch N + 1 (SceneStep.front: stage A, voxelisation, rulebooks, plans -- no weights involved) on a side stream while batch N
     trains on the main stream: the role of the reference's offline completion (SEE_VCN.py:85-115) and its dataloader workers
     (tools/train_utils/train_utils.py:22-29 fetches the next batch while the GPU works).  Every step still does one front and one compute.
-    SEEVCN_BENCH_PREFETCH_DEPTH=2 (A/B): two stages -- front_b(N + 1) (voxelise + index, the one blocking read) first, then front_a(N + 2) (stage A of the
-    batch after next, no read), so that the read no longer waits for stage A's kernels.  Measured (tools/step_hosttime.py): the host then needs
-    3.1 ms per step instead of 4.1, and the step takes the same 4.13-4.21 ms either way -- with the one-read input side the step is bound by the
-    GPU (trained side alone: 3.26 ms; the input side's 2.0 ms of side-stream kernels cost the resident conv launches ~0.9 ms), not by the host."""
+    SEEVCN_BENCH_PREFETCH_DEPTH=2 (the default since round 5; 1 = one stage, A/B): two stages -- front_b(N + 1) (voxelise + index, the one blocking read)
+    first, then front_a(N + 2) (stage A of the batch after next, no read), so that the read no longer waits for stage A's kernels.  Round 4 measured
+    (tools/step_hosttime.py) 3.1 ms of host time per step instead of 4.1 and the same 4.13-4.21 ms step either way: the step was bound by the GPU
+    (trained side alone 3.26 ms).  With round 5's shorter trained side (3.04 ms alone) the one-stage order's host thread (3.9 ms) is the longer chain and
+    the two-stage order wins by 0.03-0.09 ms."""
 
     def __init__(self, model, inputs, threaded=False):
         from concurrent.futures import ThreadPoolExecutor
@@ -137,7 +153,7 @@ class Prefetch:
         self.pool = ThreadPoolExecutor(max_workers=1) if threaded else None
         if threaded:
             sys.setswitchinterval(float(os.environ.get("SEEVCN_BENCH_SWITCH_S", "2e-5")))   # default 5 ms: two launch-bound threads would take turns in 5 ms slices
-        self.depth = int(os.environ.get("SEEVCN_BENCH_PREFETCH_DEPTH", "1"))
+        self.depth = int(os.environ.get("SEEVCN_BENCH_PREFETCH_DEPTH", "2"))          # round 5: 2 is the default (same box, three alternations: 4.06 / 4.01 / 3.99 at depth 1, 3.97 / 3.98 / 3.97 at depth 2)
         self.pending = None
         self.pasted = None                 # front_a's output waiting for its front_b (depth 2)
         self.first = True
@@ -274,45 +290,61 @@ def measure_dominant_kernel(model, inputs, reps=5):
 
 
 def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
-    """Live HIP-event timing of every sv_sparse_conv_gather_gemm_planned launch (forward and data-gradient) of `reps` full steps, grouped
-    by kernel instance k_spconv_rs3<NT, KQ, G> (NT = min(C_out, 64) / 16 column tiles per wave, KQ = C_in / 16).  Returns the instance group
-    with the largest total time: (name, avg launch ms, algorithmic flop per launch = 2*pairs*Cin*Cout averaged over its launches, algorithmic
-    bytes per launch, launches per step, ms per step).  Pairs are counted from the rulebook table actually used (outside the timed events)."""
-    from seevcn_amd.spconv import functional as F
-    records = []
-    orig = F.gather_gemm_planned
-
-    def timed(x, plan, wfrag, n_rows, K, kd, nc, *args, **kw):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        out = orig(x, plan, wfrag, n_rows, K, kd, nc, *args, **kw)
-        e.record()
-        records.append((int(kd), int(nc), int(K), int(x.shape[0]), int(n_rows), plan[0].source, s, e))
-        return out
-
+    """Live HIP-event timing of every planned sparse-conv launch (forward and data gradient) of `reps` extra, untimed steps ON THE LAUNCH-LIST PATH the
+    timed steps run: the step's own forward / backward lists go through sv_run_ops_timed (events around every operation on the list's stream), so the
+    launches timed are the instances the step really uses (input-transform instances in the forward, plain ones in the data gradient).  Grouped by
+    kernel instance k_spconv_rs3<NT, KQ, G> (NT = min(C_out, 64) / 16 column tiles per wave, KQ = C_in / 16).  Returns the instance group with the
+    largest total time: (name, avg launch ms, algorithmic flop per launch = 2*pairs*Cin*Cout averaged over its launches, algorithmic bytes per launch,
+    launches per step, ms per step).  Pairs are counted from the rulebook table each launch used (outside the timed events)."""
+    import ctypes
+    from seevcn_amd import _lib
     from seevcn_amd.spconv import chain
-    # the events bracket single launches, so these (untimed, extra) steps go through the per-module path: the same kernel launches with the
-    # same arguments as the launch list of the timed steps, issued one call at a time
-    F.gather_gemm_planned = timed
-    chain_was, chain.CHAIN_OFF = chain.CHAIN_OFF, True
+    lists, dicts = [], []
+    orig_run, orig_chain = chain._run, chain.run_chain
+
+    def timed_run(rows, what):
+        arr = np.array(rows, dtype=np.int64)
+        ms = (ctypes.c_float * len(rows))()
+        _lib.check(_lib.load().sv_run_ops_timed(arr.ctypes.data, len(rows), _lib.stream(), ctypes.cast(ms, ctypes.c_void_p)), what)
+        lists.append((arr, list(ms)))
+
+    def spy_chain(blocks, x):
+        dicts.append(x.indice_dict)
+        return orig_chain(blocks, x)
+
+    chain._run, chain.run_chain = timed_run, spy_chain
     try:
         for _ in range(reps):
             run_step(model, opt, params, inputs, world)
         torch.cuda.synchronize()
     finally:
-        F.gather_gemm_planned = orig
-        chain.CHAIN_OFF = chain_was
-    groups, pair_cache = {}, {}
-    for kd, nc, K, n_src, n_rows, nbr, s, e in records:
-        key = nbr.data_ptr()
-        if key not in pair_cache:
-            pair_cache[key] = int((nbr >= 0).sum().item())
-        pairs = pair_cache[key]
-        g = groups.setdefault((min(nc, 64) // 16, kd // 16), [0.0, 0.0, 0.0, 0])
-        g[0] += s.elapsed_time(e)
-        g[1] += 2.0 * pairs * kd * nc
-        g[2] += 4.0 * (n_src * kd + n_rows * nc) + 4.0 * K * kd * nc + 8.0 * pairs    # SURVEY 8(d): features in+out, weights, rulebook pairs
-        g[3] += 1
+        chain._run, chain.run_chain = orig_run, orig_chain
+    if not lists:
+        raise RuntimeError("the step did not run through the launch-list chain: nothing to time")
+    # table address -> pairs of its rulebook (both directions of a layer share the pairs)
+    pairs_of = {}
+    for d in dicts:
+        for rb in d.values():
+            pairs = None
+            for direction in ("fwd", "bwd"):
+                for tp in ([rb._plans.get("fwd")] if direction == "fwd" or rb.subm else [rb._plans.get("bwd")]):
+                    if tp is not None and tp.addr("rows") not in pairs_of:
+                        if pairs is None:
+                            pairs = int((rb.nbr_out >= 0).sum().item())
+                        pairs_of[tp.addr("rows")] = pairs
+    groups = {}
+    for arr, ms in lists:
+        for row, t in zip(arr, ms):
+            if int(row[0]) != chain.OP_CONV_PLANNED:
+                continue
+            K, kd, nc = int(row[2]), int(row[3]), int(row[4])
+            n_src, n_rows, table = int(row[9]), int(row[10]), int(row[18])
+            pairs = pairs_of[table]
+            g = groups.setdefault((min(nc, 64) // 16, kd // 16), [0.0, 0.0, 0.0, 0])
+            g[0] += t
+            g[1] += 2.0 * pairs * kd * nc
+            g[2] += 4.0 * (n_src * kd + n_rows * nc) + 4.0 * K * kd * nc + 8.0 * pairs    # SURVEY 8(d): features in+out, weights, rulebook pairs
+            g[3] += 1
     (nt, kq), (ms, flop, byt, n) = max(groups.items(), key=lambda kv: kv[1][0])
     return f"k_spconv_rs3<{nt}, {kq}, ", ms / n, flop / n, byt / n, n // reps, ms / reps
 

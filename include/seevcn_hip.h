@@ -77,6 +77,13 @@ int sv_mean_vfe(const float* voxels, const int32_t* num_points, int64_t num_voxe
 #define SV_ACT_LRELU 2
 
 int sv_fill_f32(float* dst, int64_t n, float value, void* stream);
+/* *out = mul * sum(x^2) and, y != NULL, y = scale * x in ONE pass over x (n % 4 == 0, 16-byte aligned): a mean-square loss over a dense tensor that
+ * leaves its own gradient behind while it reads the tensor (mul = 1 / n, scale = 2 / n) -- bench.py's stand-in for the loss behind HeightCompression
+ * (the reference's BEV backbone + head, base_bev_backbone.py / anchor_head_single.py, are not in the headline step).  Deterministic (fixed grid,
+ * fixed-order sums); scratch: sv_mean_square_scratch_bytes().  sv_scale_by_device_scalar: x *= *g, skipped on the device when *g == 1. */
+size_t sv_mean_square_scratch_bytes(void);
+int sv_mean_square(const float* x, int64_t n, float mul, float scale, float* y, float* out, void* scratch, void* stream);
+int sv_scale_by_device_scalar(float* x, int64_t n, const float* g, void* stream);
 
 /* C[M,N] = act(A[M,K] @ W[N,K]^T + bias[N] + group_bias[row / rows_per_group][N])  on the fp32 MFMA
  * (v_mfma_f32_32x32x2_f32: exact fp32).  Replaces the Conv1d(k=1)(+BN folded)(+ReLU/LeakyReLU) layers of
@@ -578,6 +585,9 @@ int sv_three_interpolate_grad_batch(int batch, int c, int n, int m, const float*
 #define SV_OP_BN_FINALIZE 9
 #define SV_OP_BN_APPLY 10
 int sv_run_ops(const int64_t* ops, int n_ops, void* stream);
+/* measurement form: events around every operation on `stream`, the call waits for the stream and writes each operation's elapsed milliseconds to
+ * ms[0 .. n_ops) (bench.py's roofline block times the conv launches of the step's own launch lists with it) */
+int sv_run_ops_timed(const int64_t* ops, int n_ops, void* stream, float* ms);
 /* The same list with its weight gradients (SV_OP_WGRAD, SV_OP_WGRAD_DEFERRED, the deferred reduction) on `side_stream`: each goes behind an event recorded on
  * `stream` after the operations in front of it; the other operations do not wait for it; `stream` waits for `side_stream` once, at the end, so that when
  * the call returns everything is ordered on `stream` as after sv_run_ops.  A weight gradient only feeds the optimiser: the backward chain need not stop

@@ -29,6 +29,9 @@ SIGNATURES = {
     "sv_voxelize_dynamic": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "sv_mean_vfe": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p, c_p]),
     "sv_fill_f32": (c_i, [c_p, c_i64, c_f, c_p]),
+    "sv_mean_square_scratch_bytes": (ctypes.c_size_t, []),
+    "sv_mean_square": (c_i, [c_p, c_i64, c_f, c_f, c_p, c_p, c_p, c_p]),
+    "sv_scale_by_device_scalar": (c_i, [c_p, c_i64, c_p, c_p]),
     "sv_gemm_bias_act": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "sv_gemm_splitk_splits": (c_i, [c_i, c_i, c_i]),
     "sv_gemm_splitk_scratch_bytes": (c_sz, [c_i, c_i, c_i]),
@@ -169,6 +172,7 @@ SIGNATURES = {
     "sv_batchnorm_finalize_forward": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sv_batchnorm_apply": (c_i, [c_p, c_i64, c_i, c_p, c_i, c_p, c_p]),
     "sv_run_ops": (c_i, [c_p, c_i, c_p]),
+    "sv_run_ops_timed": (c_i, [c_p, c_i, c_p, c_p]),
     "sv_run_ops_two_streams": (c_i, [c_p, c_i, c_p, c_p]),
     "sv_anchor_decode": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p]),
     "sv_assign_targets_axis_aligned": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

@@ -190,3 +190,68 @@ extern "C" int sv_dense_to_sparse(const float* dense, const int32_t* coords, int
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// sum(x^2) and y = scale * x in ONE pass over x (n floats, n % 4 == 0): the forward of a mean-square loss over a dense BEV tensor that leaves the
+// loss's gradient (2 / n) x behind as it reads x -- one read + one write of the tensor instead of a reduction pass in the forward and a
+// read + write pass in the backward (bench.py's stand-in for the BEV backbone: 577 MB at the KITTI geometry, 16 scenes).  Deterministic: a fixed
+// grid of MS_WGS workgroups, each a fixed-order tree, partials combined in order by sv_mean_square's second launch.
+// ------------------------------------------------------------------------------------------------
+constexpr int MS_WGS = 2048, MS_THREADS = 256;
+__global__ __launch_bounds__(MS_THREADS) void k_square_sum_scale(const float4* __restrict__ x, int64_t n4, float scale, float4* __restrict__ y, float* __restrict__ partial) {
+  __shared__ float s_red[MS_THREADS];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * MS_THREADS + threadIdx.x; i < n4; i += (int64_t)MS_WGS * MS_THREADS) {
+    const float4 v = x[i];
+    acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    if (y) y[i] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+  }
+  s_red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = MS_THREADS / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0];
+}
+__global__ __launch_bounds__(MS_THREADS) void k_square_sum_finish(const float* __restrict__ partial, float mul, float* __restrict__ out) {
+  __shared__ double s_red[MS_THREADS];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < MS_WGS; i += MS_THREADS) acc += (double)partial[i];
+  s_red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = MS_THREADS / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = (float)(s_red[0] * (double)mul);
+}
+extern "C" size_t sv_mean_square_scratch_bytes(void) { return MS_WGS * sizeof(float); }
+// *out = mul * sum(x^2); y (nullable) = scale * x.  mean(x^2) and its gradient: mul = 1 / n, scale = 2 / n.
+extern "C" int sv_mean_square(const float* x, int64_t n, float mul, float scale, float* y, float* out, void* scratch, void* stream) {
+  SV_CHECK_ARG(n > 0 && n % 4 == 0 && x && out && scratch, "sv_mean_square: n must be a positive multiple of 4, pointers non-null");
+  SV_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0, "sv_mean_square: 16-byte alignment");
+  hipStream_t st = sv_stream(stream);
+  hipLaunchKernelGGL(k_square_sum_scale, dim3(MS_WGS), dim3(MS_THREADS), 0, st, reinterpret_cast<const float4*>(x), n / 4, scale, reinterpret_cast<float4*>(y),
+                     reinterpret_cast<float*>(scratch));
+  hipLaunchKernelGGL(k_square_sum_finish, dim3(1), dim3(MS_THREADS), 0, st, reinterpret_cast<const float*>(scratch), mul, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+// x *= *g unless *g == 1 (a device scalar: the upstream gradient of a loss is 1 in a plain backward, and then nothing is touched)
+__global__ __launch_bounds__(MS_THREADS) void k_scale_unless_one(float4* __restrict__ x, int64_t n4, const float* __restrict__ g) {
+  const float s = *g;
+  if (s == 1.f) return;
+  for (int64_t i = (int64_t)blockIdx.x * MS_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * MS_THREADS) {
+    float4 v = x[i];
+    v.x *= s, v.y *= s, v.z *= s, v.w *= s;
+    x[i] = v;
+  }
+}
+extern "C" int sv_scale_by_device_scalar(float* x, int64_t n, const float* g, void* stream) {
+  SV_CHECK_ARG(n > 0 && n % 4 == 0 && x && g && (uintptr_t)x % 16 == 0, "sv_scale_by_device_scalar: bad arguments");
+  hipLaunchKernelGGL(k_scale_unless_one, dim3(MS_WGS), dim3(MS_THREADS), 0, sv_stream(stream), reinterpret_cast<float4*>(x), n / 4, g);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -683,6 +683,7 @@ extern "C" int sv_rulebook_pair_counts(const int32_t* nbr, int64_t n_out, int K,
 // ===========================================================================================================================================
 constexpr int CH_BLOCK = 256;          // chunks per workgroup of the count / emit passes (256 KiB of cells, 64 KiB of bitmap)
 constexpr int CH_MAX_LEVELS = 8;
+constexpr int CH_EMIT_SPLIT = 4;       // workgroups that share the emit of one block's non-empty chunks
 static_assert(CH_BLOCK == RB_THREADS, "k_chain_emit scans one chunk count per thread");
 static bool small_kernel_host(const ConvGeom& g) { return g.ksize[0] <= 3 && g.ksize[1] <= 3 && g.ksize[2] <= 3; }
 
@@ -740,6 +741,9 @@ __global__ __launch_bounds__(RB_THREADS) void k_chain_count(SvIndexView ix, int6
 // block b: rank base = sum of the blocks before it; the sites of its non-empty chunks -> sites[rank] (ascending key).  The next level's marks are a
 // launch of their own (k_chain_mark_list with the count on the device): fused in here they were bound by the few blocks that hold most of a
 // LiDAR scene's sites (186 us for level 1 of the bench batch).
+// grid = (blocks, CH_EMIT_SPLIT): the same imbalance bounded this kernel too (a LiDAR scene's sites sit in a few z-slices: a quarter of the blocks
+// hold nine tenths of them, 38 us standalone / 66 us inside the step per level), so workgroup (b, y) emits the y-th share of block b's non-empty
+// chunks; the scans in front are repeated per share (256 chunk counts) and the shares of an empty block leave after them.
 __global__ __launch_bounds__(RB_THREADS) void k_chain_emit(SvIndexView ix, int64_t nchunks, const int32_t* __restrict__ block_sums, int4* __restrict__ sites,
                                                            int64_t capacity, int32_t* __restrict__ num_out, ConvGeom gout /* shape of THIS level in out_shape */) {
   __shared__ int s_red[RB_THREADS / SV_WAVE], s_wtot[RB_THREADS / SV_WAVE], s_wne[RB_THREADS / SV_WAVE];
@@ -772,20 +776,22 @@ __global__ __launch_bounds__(RB_THREADS) void k_chain_emit(SvIndexView ix, int64
   }
   s_cbase[tid] = base + wbase + incl - cnt;
   if (cnt > 0) s_list[nebase + __popcll(ne & ((1ull << lane) - 1ull))] = (uint16_t)tid;
-  if (b == (int)gridDim.x - 1 && tid == 0) *num_out = base + total;
+  if (b == (int)gridDim.x - 1 && blockIdx.y == 0 && tid == 0) *num_out = base + total;
   __syncthreads();
+  // this workgroup's share of the block's non-empty chunks
+  const int q_lo = (int)((int64_t)n_ne * blockIdx.y / gridDim.y), q_hi = (int)((int64_t)n_ne * (blockIdx.y + 1) / gridDim.y);
   // emit: 32 lanes per non-empty chunk, a lane walks the set bits of its word.  The word's first key is decoded with divisions once; its 32
   // cells follow by carries (x-fastest key).  EM_B words are requested before the first is used.
   const int X = gout.out_shape[2], Y = gout.out_shape[1], Z = gout.out_shape[0];
   const bool narrow = ix.ncells < ((int64_t)1 << 31);
   constexpr int EM_B = 4, GROUPS = RB_THREADS / 32;
-  for (int q0 = sub; q0 < n_ne; q0 += GROUPS * EM_B) {
+  for (int q0 = q_lo + sub; q0 < q_hi; q0 += GROUPS * EM_B) {
     uint2 wd[EM_B];
     int jj[EM_B];
 #pragma unroll
     for (int u = 0; u < EM_B; ++u) {
       const int q = q0 + GROUPS * u;
-      jj[u] = q < n_ne ? (int)s_list[q] : -1;
+      jj[u] = q < q_hi ? (int)s_list[q] : -1;
       wd[u] = jj[u] >= 0 ? ix.words[((int64_t)b * CH_BLOCK + jj[u]) * SV_CHUNK_WORDS + lane32] : make_uint2(0u, 0u);
     }
 #pragma unroll
@@ -866,7 +872,8 @@ extern "C" int sv_rulebook_chain_count(const int32_t* coords0, int64_t n0, const
     const int blocks = (int)((nchunks + CH_BLOCK - 1) / CH_BLOCK);
     int4* s4 = reinterpret_cast<int4*>(sites[l]);
     hipLaunchKernelGGL(k_chain_count, dim3(blocks), dim3(RB_THREADS), 0, st, ix[l], nchunks, sums);
-    hipLaunchKernelGGL(k_chain_emit, dim3(blocks), dim3(RB_THREADS), 0, st, ix[l], nchunks, sums, s4, caps[l], num_out + l, g[l]);
+    static const int emit_split = getenv("SEEVCN_EMIT_SPLIT") ? atoi(getenv("SEEVCN_EMIT_SPLIT")) : CH_EMIT_SPLIT;       // A/B: 1 = one workgroup per block
+    hipLaunchKernelGGL(k_chain_emit, dim3(blocks, emit_split < 1 ? 1 : emit_split), dim3(RB_THREADS), 0, st, ix[l], nchunks, sums, s4, caps[l], num_out + l, g[l]);
     if (l + 1 < n_levels) {
       // the next level's marks from the sites just written; their number is num_out[l] on the device, the grid is sized for the capacity
       const dim3 grid(sv_grid_1d(caps[l], RB_THREADS, 2048));

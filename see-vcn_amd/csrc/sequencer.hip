@@ -36,9 +36,17 @@ struct SeqEvents {
   }
 };
 
-static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_stream);
+static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_stream, float* ms = nullptr);
 
 extern "C" int sv_run_ops(const int64_t* ops, int n_ops, void* stream) { return run_ops(ops, n_ops, stream, nullptr); }
+
+// Measurement form: the same list, with a HIP event recorded on `stream` in front of every operation and behind the last; the call then WAITS for the
+// stream and writes the elapsed time of every operation to ms[0 .. n_ops) (an operation of several launches -- BatchNorm backward -- as one span; the
+// deferred slab reduction at the end of the list belongs to no operation).  bench.py times the conv launches of the step's own launch lists with it.
+extern "C" int sv_run_ops_timed(const int64_t* ops, int n_ops, void* stream, float* ms) {
+  SV_CHECK_ARG(ms || n_ops == 0, "sv_run_ops_timed: null output");
+  return run_ops(ops, n_ops, stream, nullptr, ms);
+}
 
 // The same list with its weight gradients (SV_OP_WGRAD, SV_OP_WGRAD_DEFERRED and the deferred reduction) on `side_stream`: each goes behind an event
 // recorded on `stream` after the operations in front of it, the other operations do not wait for it, and `stream` waits for `side_stream` once, at the
@@ -50,8 +58,21 @@ extern "C" int sv_run_ops_two_streams(const int64_t* ops, int n_ops, void* strea
   return run_ops(ops, n_ops, stream, side_stream);
 }
 
-static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_stream) {
+static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_stream, float* ms) {
   SV_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "sv_run_ops: null list");
+  struct Stamps {                    // measurement form only
+    hipEvent_t* ev = nullptr;
+    int n = 0;
+    ~Stamps() {
+      for (int q = 0; q < n; ++q) (void)hipEventDestroy(ev[q]);
+      delete[] ev;
+    }
+  } stamps;
+  if (ms) {
+    stamps.ev = new hipEvent_t[n_ops + 1];
+    for (; stamps.n <= n_ops; ++stamps.n) SV_HIP(hipEventCreate(&stamps.ev[stamps.n]));
+    SV_HIP(hipEventRecord(stamps.ev[0], sv_stream(stream)));
+  }
   hipStream_t st_main = sv_stream(stream), st_side = side_stream ? sv_stream(side_stream) : nullptr;
   bool side_used = false;
   SeqEvents ev;
@@ -162,10 +183,15 @@ static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_strea
       fail = rc;
       break;
     }
+    if (ms) SV_HIP(hipEventRecord(stamps.ev[k + 1], st_main));
   }
   int rc = fail;
   sv_conv_next_input_norm(nullptr, 0);                    // an operation that failed before it consumed its input transform must not leave it to a later call
   if (rc == SV_OK && n_deferred > 0) rc = sv_sparse_conv_wgrad_reduce_batch(deferred, n_deferred, wstream);     // every deferred weight gradient: one launch at the end of the list
+  if (ms && rc == SV_OK) {
+    SV_HIP(hipStreamSynchronize(st_main));
+    for (int k = 0; k < n_ops; ++k) SV_HIP(hipEventElapsedTime(&ms[k], stamps.ev[k], stamps.ev[k + 1]));
+  }
   if (side_used) {                  // whatever happened above: the caller's stream comes back ordered behind the side stream
     hipError_t e = hipEventRecord(ev.join, st_side);
     if (e == hipSuccess) e = hipStreamWaitEvent(st_main, ev.join, 0);

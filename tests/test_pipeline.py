@@ -111,3 +111,21 @@ def test_hip_bench_vcn_gemm_counts_computed_rows(cuda, hip_lib):
         assert got[True][0] == got[False][0]      # same rows computed either way; the host-read forward passes exact shapes
     finally:
         bench.SCENES_PER_GPU, bench.OBJECTS_PER_GPU = saved
+
+
+@pytest.mark.gpu
+def test_hip_bench_loss_matches_torch_value_and_gradient(cuda, hip_lib):
+    """bench.py's fused mean-square loss (sv_mean_square: one pass that also writes the gradient) == x.square().mean() under autograd, also with an
+    upstream gradient other than 1; twice: bitwise equal (fixed grid, fixed-order sums)."""
+    import bench
+    x = torch.randn(4, 8, 50, 44, generator=torch.Generator().manual_seed(5)).to(cuda).requires_grad_(True)
+    outs = []
+    for scale in (1.0, 3.0):
+        x.grad = None
+        loss = bench._MeanSquare.apply(x)
+        (loss * scale).backward()
+        ref = x.detach().double().square().mean()
+        assert abs(float(loss) - float(ref)) <= 1e-6 * float(ref)
+        assert torch.allclose(x.grad, (x.detach() * (2.0 * scale / x.numel())), rtol=1e-6, atol=0)
+        outs.append(float(loss))
+    assert outs[0] == outs[1]
