@@ -1259,17 +1259,26 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       s_idx[k][lane] = e[k >> 2][k & 3];            // table order (entries >= K are -1 in the table); a reversed table is read at K-1-k in the loop
     s_idx[RS3_KMAX][lane] = row;                           // output row (-1: padding)
     if (pv.k_flip) m = __brev(m) >> (32 - a.K);
+    unsigned mall = m;                                                      // FIN: offsets EVERY row of the tile has (a padding row has none: its tile always clears)
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) m |= __shfl_xor(m, off, 16);      // OR over the tile's 16 rows
+    if constexpr (FIN) {
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) mall &= __shfl_xor(mall, off, 16);
+    }
     unsigned mk = 0;
 #pragma unroll
     for (int t2 = 0; t2 < RS_G; ++t2) {
       const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)m, 16 * t2);
       mk |= ((tm >> (lane & 31)) & 1u) << t2;
+      if constexpr (FIN) {                                                  // bit 8 + t2: tile t2 has a neighbour in every row at this offset
+        const unsigned ta = (unsigned)__builtin_amdgcn_readlane((int)mall, 16 * t2);
+        mk |= ((ta >> (lane & 31)) & 1u) << (8 + t2);
+      }
     }
     maskreg = lane < a.K ? mk : 0u;
   }
-  const unsigned long long active = __ballot(maskreg != 0);
+  const unsigned long long active = __ballot((maskreg & 0xffu) != 0);
   if constexpr (DBG != 0) {
     if (pv.trace) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -1385,6 +1394,16 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       // (issued one step ago, in front of that step's row loads): behind it in the queue are one step's row loads and one whole step,
       // NWAIT = RS_G + (RS_G + NT) loads that may stay outstanding; loads return in order, so the row stage (older) has arrived as well.
       // (RA == RB, the measurement build SEEVCN_RS3_RB=3: both of a step's stages were issued RA - 1 steps ago, whole steps only behind them.)
+      // FIN: the step's coefficients (channels 16 qc + 4 kk + {0..3} of the lane's four values) and the rows' validity are LDS reads that do not
+      // depend on the operands: requested here, in front of the wait, their latency hides behind it (behind it they sat on every step's critical
+      // path: the two-tile forward at 139 k rows ran 127 us against 115 without the transform)
+      f32x4 fin_sc, fin_sh;
+      int32_t fin_absent[RS_G];
+      if constexpr (FIN) {
+        fin_sc = *reinterpret_cast<const f32x4*>(&s_coef[0][qc * 16 + kk * 4]), fin_sh = *reinterpret_cast<const f32x4*>(&s_coef[1][qc * 16 + kk * 4]);
+#pragma unroll
+        for (int g = 0; g < RS_G; ++g) fin_absent[g] = s_idx[pv.k_flip ? a.K - 1 - kc : kc][g * 16 + li] >> 31;     // all-ones: no neighbour
+      }
       constexpr int NWAIT = RA > RB ? RS_G + (RB - 1) * (RS_G + NT) : (RA - 1) * (RS_G + NT);
 #define RS3_WAIT(...) asm volatile("s_waitcnt vmcnt(%[nw])" : __VA_ARGS__ : [nw] "n"(NWAIT))
 #define V(x) "+v"(x)
@@ -1403,34 +1422,29 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       }
 #undef V
 #undef RS3_WAIT
-      if constexpr (FIN) {
-        // channels of the lane's four values in this step: 16 qc + 4 kk + {0..3}
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(&s_coef[0][qc * 16 + kk * 4]), sh = *reinterpret_cast<const f32x4*>(&s_coef[1][qc * 16 + kk * 4]);
-#pragma unroll
-        for (int g = 0; g < RS_G; ++g)
-          if ((mc >> g) & 1u) {
-            // a row WITHOUT a neighbour at this offset was an out-of-range load (zeros), which the transform would turn into relu(shift): its
-            // values are cleared again.  The validity is re-read from the index block every step (one LDS word) instead of living in a register
-            // across the offset's steps.
-            const int32_t absent = s_idx[pv.k_flip ? a.K - 1 - kc : kc][g * 16 + li] >> 31;          // all-ones: no neighbour
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              As[g][i] = __uint_as_float(__float_as_uint(fmaxf(__fmaf_rn(As[g][i], sc[i], sh[i]), in_lo)) & ~(uint32_t)absent);
-          }
-      }
       // per tile: 4 passes over the NT column tiles, so that consecutive MFMAs never share an accumulator (a dependent
-      // v_mfma_f32_16x16x4_f32 issues 47 cycles after its producer, an independent one after 32)
+      // v_mfma_f32_16x16x4_f32 issues 47 cycles after its producer, an independent one after 32).
+      // FIN: the transform of a tile's k-th operand register (fused multiply-add, max, and -- unless every row of the tile has this neighbour -- the
+      // clearing of the rows without one) is written BEHIND the first MFMA of the register before it: the wave issues it while the matrix pipe works
+      // on that MFMA instead of in front of the step's whole MFMA block (12-15 % on every forward launch when it sat there).
+      auto fin1 = [&](int g, int i) {
+        float v = fmaxf(__fmaf_rn(As[g][i], fin_sc[i], fin_sh[i]), in_lo);
+        if (!((mc >> (8 + g)) & 1u)) v = __uint_as_float(__float_as_uint(v) & ~(uint32_t)fin_absent[g]);       // wave-uniform test
+        As[g][i] = v;
+      };
 #pragma unroll
       for (int g = 0; g < RS_G; ++g)
         if (((mc >> g) & 1u) && !(DBG == 1 && (pv.debug & 4))) {
+          if constexpr (FIN) fin1(g, 0);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g].x, Bs[t].x, acc[g][t], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) {
+            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g][i], Bs[0][i], acc[g][0], 0, 0, 0);
+            if constexpr (FIN) {
+              if (i + 1 < 4) fin1(g, i + 1);
+            }
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g].y, Bs[t].y, acc[g][t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g].z, Bs[t].z, acc[g][t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g].w, Bs[t].w, acc[g][t], 0, 0, 0);
+            for (int t = 1; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g][i], Bs[t][i], acc[g][t], 0, 0, 0);
+          }
         }
       if (++qc == KQ) {
         qc = 0;

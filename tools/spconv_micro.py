@@ -82,6 +82,16 @@ def main():
             c, shape = rb.out_indices, rb.out_shape
             continue
         tf = td = tw = float("nan")
+        # FIN=1: forward and weight gradient read x through an input transform (sv_conv_next_input_norm: BatchNorm + ReLU of the layer below on load),
+        # as the chain's launches do since round 5
+        fin = os.environ.get("FIN") == "1" and cin % 16 == 0
+        coef = torch.cat([torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1])
+        lib = Fsp._lib.load()
+
+        def with_in(fn):
+            if not fin:
+                return fn
+            return lambda: (lib.sv_conv_next_input_norm(coef.data_ptr(), 1), fn())
         pf = rb.plan("fwd", cin, cout)
         pb = rb.plan("bwd", cout, cin)
         tplan = float("nan")
@@ -92,7 +102,7 @@ def main():
                 tf = timeit(lambda: Fsp.gather_gemm(x, rb.nbr_out, wt, rb.n_out))
             else:
                 ff = Fsp.fragment_cache.get(w)[0]
-                tf = timeit(lambda: Fsp.gather_gemm_planned(x, pf, ff, rb.n_out, K, cin, cout))
+                tf = timeit(with_in(lambda: Fsp.gather_gemm_planned(x, pf, ff, rb.n_out, K, cin, cout)))
         if mode in ("all", "bwd"):
             if pb is None:
                 td = timeit(lambda: Fsp.gather_gemm(dy, rb.table_for_backward_data(), w, rb.n_in))
@@ -101,7 +111,7 @@ def main():
                 td = timeit(lambda: Fsp.gather_gemm_planned(dy, pb, fb, rb.n_in, K, cout, cin))
         if mode in ("all", "wgrad"):
             wp = rb.wgrad_plan(cin, cout)                   # equal-pieces plan of the table (None with SEEVCN_WGRAD_PLANNED=0: the chunked kernel)
-            tw = timeit(lambda: Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout, plan=wp))
+            tw = timeit(with_in(lambda: Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout, plan=wp)))
         fl = 2.0 * pairs * cin * cout
         print(f"{name:8s} {cin:3d}->{cout:3d} N_in={rb.n_in:7d} N_out={rb.n_out:7d} pairs={pairs:8d} rulebook {tb:7.1f} us plan {tplan:6.1f} us | "
               f"fwd {tf:7.1f} us ({fl / tf / 1e6:6.2f} TF) | bwd-data {td:7.1f} us ({fl / td / 1e6:6.2f} TF) | wgrad {tw:7.1f} us ({fl / tw / 1e6:6.2f} TF)")
