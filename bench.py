@@ -313,12 +313,13 @@ def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
         return orig_chain(blocks, x)
 
     chain._run, chain.run_chain = timed_run, spy_chain
+    stream_was, chain.WGRAD_STREAM = chain.WGRAD_STREAM, False      # the events bracket single launches: these extra steps keep the weight gradients on the list's stream
     try:
         for _ in range(reps):
             run_step(model, opt, params, inputs, world)
         torch.cuda.synchronize()
     finally:
-        chain._run, chain.run_chain = orig_run, orig_chain
+        chain._run, chain.run_chain, chain.WGRAD_STREAM = orig_run, orig_chain, stream_was
     if not lists:
         raise RuntimeError("the step did not run through the launch-list chain: nothing to time")
     # table address -> pairs of its rulebook (both directions of a layer share the pairs)

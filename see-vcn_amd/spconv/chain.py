@@ -25,11 +25,12 @@ BWD_SUMS_IN_CONV = os.environ.get("SEEVCN_BN_BWD_IN_CONV", "0") == "1"
 # 0: every weight gradient is followed by its own slab-reduction launch (SV_OP_WGRAD) instead of ONE reduction launch for all layers at the end of the backward
 # list (SV_OP_WGRAD_DEFERRED: bitwise the same gradients) -- A/B runs
 DEFER_WGRAD_REDUCE = os.environ.get("SEEVCN_WGRAD_DEFER", "1") != "0"
-# 1: the weight gradients of the backward list on a stream of their own (sv_run_ops_two_streams), each behind the BatchNorm backward that makes its operand;
-# the main chain (data gradient -> next BatchNorm backward -> ...) does not wait for them until the end of the list.  Measured, same box: the trained side
-# alone 3.16 -> 3.06 ms (the matrix-core work fills the bandwidth-bound BatchNorm launches and the data gradients' tails); the pipelined step, where the
-# input side's stream already shares the GPU, 4.07-4.19 -> 4.3-4.4 ms (three streams fragment the one-resident-round launches).  Off by default.
-WGRAD_STREAM = os.environ.get("SEEVCN_WGRAD_STREAM", "0") == "1"
+# 1 (default since round 5): the weight gradients of the backward list on a stream of their own (sv_run_ops_two_streams), each behind the BatchNorm backward that
+# makes its operand; the main chain (data gradient -> next BatchNorm backward -> ...) does not wait for them until the end of the list.  Their matrix-core work
+# fills the bandwidth-bound BatchNorm launches and the prologues / tails of the data-gradient launches.  Round 4 measured the trained side alone 3.16 -> 3.06 ms
+# but the pipelined step 4.07-4.19 -> 4.3-4.4 ms (a third stream on a GPU the one-stage input side kept busy) and left it off; with round 5's two-stage
+# prefetch and shorter forward the same switch takes the step from 3.92 to 3.73 ms (same box, two alternations: profiles/r05_wstream_ab.txt).  0: one stream.
+WGRAD_STREAM = os.environ.get("SEEVCN_WGRAD_STREAM", "1") != "0"
 _wgrad_stream = {}
 # 1 (default): the BatchNorm + ReLU behind a conv is NOT applied in a pass of its own -- the block keeps the raw conv output and the norm's (scale, shift), and the
 # next block's convolution and weight gradient apply them as they gather the rows (sv_conv_next_input_norm): one read + one write of every activation
