@@ -714,6 +714,14 @@ int sv_project_lidar_to_image_nuscenes(const float* points, int64_t n_points, in
                                        uint8_t* fov, void* stream);
 /* get_pts_in_mask (datasets/shared_utils.py:36-106): per instance the FOV points with mask[v,u] set.  Give either masks
  * (I,img_h,img_w) uint8 or rects (I,4) int32 [x0,y0,x1,y1] (use_bbox, :56-60).  Lists as in sv_crop_points_in_boxes. */
+/* COCO polygons -> binary instance masks on the device: `dataset.annToMask(instance)` of get_pts_in_mask (shared_utils.py:66), i.e. pycocotools'
+ * rleFrPoly + rleMerge(union) + rleDecode (cocoapi common/maskApi.c) with the same boundary arithmetic; the run-length code is replaced by a parity
+ * scan (a pixel is inside iff an odd number of run boundaries lies at or before its column-major index).  xy: flat (x, y) doubles of all polygons;
+ * poly_off (n_polygons + 1) first vertex of each; poly_inst (n_polygons) the instance each belongs to; masks (n_instances, img_h, img_w) uint8, written
+ * whole; scratch: sv_polygon_masks_scratch_bytes.  max_vertices = the longest polygon (<= 4096); img_w <= 8192. */
+size_t sv_polygon_masks_scratch_bytes(int n_polygons, int img_h, int img_w);
+int sv_polygons_to_masks(const double* xy, const int32_t* poly_off, const int32_t* poly_inst, int n_polygons, int max_vertices, int n_instances, int img_h,
+                         int img_w, void* scratch, uint8_t* masks, void* stream);
 int sv_points_in_masks(const int32_t* uv, const uint8_t* fov, int64_t n_points, const uint8_t* masks, const int32_t* rects,
                        int n_instances, int img_w, int img_h, int64_t cap, int32_t* out_index, int32_t* out_count, void* stream);
 /* isolate_det_pts (SEE_VCN.py:144-181) and db_scan(..., return_largest_cluster=True) (shared_utils.py:395-409), one workgroup

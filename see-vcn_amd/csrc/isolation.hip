@@ -455,6 +455,170 @@ extern "C" int sv_points_in_masks(const int32_t* uv, const uint8_t* fov, int64_t
   return SV_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// COCO polygons -> binary instance masks: the `dataset.annToMask(instance)` of get_pts_in_mask (see/surface_completion/datasets/shared_utils.py:66),
+// i.e. pycocotools' rleFrPoly + rleMerge(union) + rleDecode (cocoapi common/maskApi.c), without the run-length detour:
+//   * every polygon edge is walked at 5x the pixel scale, one step per unit of its longer axis (same integer / double arithmetic as rleFrPoly: the
+//     vertices (int)(5 v + .5), the minor coordinate (int)(start + slope * t + .5));
+//   * wherever the walk's x changes, the down-sampled (column, row) boundary point -- when its column lands on a pixel centre -- is a run boundary of
+//     the column-major run-length code, key = column * h + row.  rleFrPoly sorts the keys and turns differences into runs, dropping zero-length
+//     runs: a pixel is inside iff an ODD number of keys is <= its column-major index.  Here every key TOGGLES one bit of a per-polygon bit array
+//     (atomic xor: equal keys cancel like the zero-length runs), and the mask is the running parity down the columns, carried from column to column;
+//   * the polygons of an instance OR into its mask (rleMerge, intersect = 0).
+// One workgroup per polygon: polygons of a few hundred vertices, a few thousand boundary points, h x w parity steps.
+// ------------------------------------------------------------------------------------------------
+constexpr int PM_THREADS = 256, PM_MAXV = 4096, PM_MAXW = 8192;
+__device__ __forceinline__ void pm_point(const int* sx, const int* sy, const int* start, int k, int p, int& u, int& v) {
+  int lo = 0, hi = k - 1;                                   // last edge whose first point is <= p
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (start[mid] <= p) lo = mid;
+    else hi = mid - 1;
+  }
+  const int j = lo, d = p - start[j];
+  int xs = sx[j], xe = sx[j + 1], ys = sy[j], ye = sy[j + 1];
+  const int dx = abs(xe - xs), dy = abs(ys - ye);
+  const bool flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+  if (flip) {
+    int t = xs; xs = xe; xe = t;
+    t = ys; ys = ye; ye = t;
+  }
+  if (dx >= dy) {
+    const int t = flip ? dx - d : d;
+    u = t + xs;
+    if (dx == 0) v = ys;                                      // a repeated vertex: one point (its slope is 0 / 0 in the C code and never used by a key)
+    else {
+      const double s = (double)(ye - ys) / (double)dx;
+      v = (int)((double)ys + s * (double)t + .5);
+    }
+  } else {
+    const int t = flip ? dy - d : d;
+    const double s = (double)(xe - xs) / (double)dy;
+    v = t + ys;
+    u = (int)((double)xs + s * (double)t + .5);
+  }
+}
+
+__global__ __launch_bounds__(PM_THREADS) void k_polygon_masks(const double* __restrict__ xy, const int32_t* __restrict__ poly_off, const int32_t* __restrict__ poly_inst,
+                                                            int h, int w, int64_t words, uint32_t* __restrict__ scratch, uint8_t* __restrict__ masks) {
+  __shared__ int s_x[PM_MAXV + 1], s_y[PM_MAXV + 1], s_start[PM_MAXV + 1];
+  __shared__ uint8_t s_col[PM_MAXW];
+  __shared__ int s_scan[PM_THREADS];
+  const int poly = blockIdx.x, tid = threadIdx.x;
+  const int v0 = poly_off[poly], k = poly_off[poly + 1] - v0;
+  uint32_t* T = scratch + (int64_t)poly * words;
+  for (int64_t i = tid; i < words; i += PM_THREADS) T[i] = 0u;
+  if (k < 1) return;                                        // uniform
+  for (int j = tid; j < k; j += PM_THREADS) {
+    s_x[j] = (int)(5.0 * xy[2 * (int64_t)(v0 + j)] + .5);
+    s_y[j] = (int)(5.0 * xy[2 * (int64_t)(v0 + j) + 1] + .5);
+  }
+  __syncthreads();
+  if (tid == 0) s_x[k] = s_x[0], s_y[k] = s_y[0];
+  __syncthreads();
+  // points per edge -> exclusive prefix (block scan, PM_MAXV / PM_THREADS edges per thread)
+  constexpr int PER = PM_MAXV / PM_THREADS;
+  int cnt[PER], mine = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int j = tid * PER + q;
+    cnt[q] = j < k ? max(abs(s_x[j] - s_x[j + 1]), abs(s_y[j] - s_y[j + 1])) + 1 : 0;
+    mine += cnt[q];
+  }
+  s_scan[tid] = mine;
+  __syncthreads();
+  for (int off = 1; off < PM_THREADS; off <<= 1) {
+    const int t = tid >= off ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += t;
+    __syncthreads();
+  }
+  int run = s_scan[tid] - mine;
+  const int m = s_scan[PM_THREADS - 1];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int j = tid * PER + q;
+    if (j < k) s_start[j] = run;
+    run += cnt[q];
+  }
+  __threadfence();                                          // the zeroed words are in place before any toggle of another wave
+  __syncthreads();
+  for (int p = 1 + tid; p < m; p += PM_THREADS) {
+    int u, v, up, vp;
+    pm_point(s_x, s_y, s_start, k, p, u, v);
+    pm_point(s_x, s_y, s_start, k, p - 1, up, vp);
+    if (u == up) continue;
+    double xd = (double)(u < up ? u : u - 1);
+    xd = (xd + .5) / 5.0 - .5;
+    if (floor(xd) != xd || xd < 0 || xd > (double)(w - 1)) continue;
+    double yd = (double)(v < vp ? v : vp);
+    yd = (yd + .5) / 5.0 - .5;
+    if (yd < 0) yd = 0;
+    else if (yd > (double)h) yd = (double)h;
+    yd = ceil(yd);
+    const int64_t key = (int64_t)(int)xd * h + (int)yd;
+    if (key < (int64_t)h * w) atomicXor(&T[key >> 5], 1u << (key & 31));
+  }
+  __threadfence();
+  __syncthreads();
+  // parity of every column's toggles, then the parity carried into each column
+  auto bit = [&](int64_t idx) { return (T[idx >> 5] >> (idx & 31)) & 1u; };
+  for (int x = tid; x < w; x += PM_THREADS) {
+    const int64_t a = (int64_t)x * h, b = a + h;            // bits [a, b)
+    unsigned par = 0;
+    for (int64_t wd = a >> 5; wd <= (b - 1) >> 5; ++wd) {
+      uint32_t bits = T[wd];
+      const int64_t lo = wd << 5;
+      if (lo < a) bits &= ~0u << (a - lo);
+      if (lo + 32 > b) bits &= ~0u >> (lo + 32 - b);
+      par ^= __popc(bits) & 1u;
+    }
+    s_col[x] = (uint8_t)par;
+  }
+  __syncthreads();
+  if (tid == 0) {                                           // exclusive running parity over the columns (w <= PM_MAXW)
+    unsigned c = 0;
+    for (int x = 0; x < w; ++x) {
+      const unsigned t = s_col[x];
+      s_col[x] = (uint8_t)c;
+      c ^= t;
+    }
+  }
+  __syncthreads();
+  uint8_t* M = masks + (int64_t)poly_inst[poly] * h * w;
+  for (int x = tid; x < w; x += PM_THREADS) {
+    unsigned state = s_col[x];
+    int64_t idx = (int64_t)x * h;
+    for (int y = 0; y < h; ++y, ++idx) {
+      state ^= bit(idx);
+      if (state) M[(int64_t)y * w + x] = 1;                 // the parts of an instance only ever write ones: their union, whatever the order
+    }
+  }
+}
+
+extern "C" size_t sv_polygon_masks_scratch_bytes(int n_polygons, int img_h, int img_w) {
+  return (size_t)n_polygons * (((size_t)img_h * img_w + 31) / 32 + 1) * sizeof(uint32_t);
+}
+// xy: the polygons' vertices, flat doubles (x, y pairs); poly_off (n_polygons + 1): first vertex of each polygon; poly_inst (n_polygons): the instance a
+// polygon belongs to; masks (n_instances, img_h, img_w) uint8, written whole (zeros outside the polygons).  All pointers on the device.
+extern "C" int sv_polygons_to_masks(const double* xy, const int32_t* poly_off, const int32_t* poly_inst, int n_polygons, int max_vertices, int n_instances,
+                                    int img_h, int img_w, void* scratch, uint8_t* masks, void* stream) {
+  SV_CHECK_ARG(n_polygons >= 0 && n_instances >= 0 && img_h > 0 && img_w > 0, "sv_polygons_to_masks: bad sizes");
+  SV_CHECK_ARG(img_w <= PM_MAXW && max_vertices <= PM_MAXV, "sv_polygons_to_masks: images up to %d columns, polygons up to %d vertices", PM_MAXW, PM_MAXV);
+  SV_CHECK_ARG((int64_t)img_h * img_w < ((int64_t)1 << 31), "sv_polygons_to_masks: image too large");
+  if (n_instances == 0) return SV_OK;
+  SV_CHECK_ARG(masks, "sv_polygons_to_masks: null masks");
+  hipStream_t st = sv_stream(stream);
+  SV_HIP(hipMemsetAsync(masks, 0, (size_t)n_instances * img_h * img_w, st));
+  if (n_polygons == 0) return SV_OK;
+  SV_CHECK_ARG(xy && poly_off && poly_inst && scratch, "sv_polygons_to_masks: null pointer");
+  const int64_t words = ((int64_t)img_h * img_w + 31) / 32 + 1;
+  hipLaunchKernelGGL(k_polygon_masks, dim3(n_polygons), dim3(PM_THREADS), 0, st, xy, poly_off, poly_inst, img_h, img_w, words,
+                     static_cast<uint32_t*>(scratch), masks);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 extern "C" int64_t sv_isolate_cluster_scratch_bytes(int n_instances, int64_t max_points) {
   if (max_points <= ISO_LDS_N) return 0;
   return (int64_t)n_instances * 6 * max_points * 4;

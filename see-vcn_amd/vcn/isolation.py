@@ -209,10 +209,89 @@ def points_in_masks_device(uv, fov, masks=None, rects=None, cap=None):
     return index, count
 
 
+def _rle_counts(counts):
+    """the compressed 'counts' string of a COCO RLE dict -> run lengths (pycocotools rleFrString: 5 payload bits per character, bit 5 = more,
+    bit 4 of the last character = sign; from the third run on a value is a difference to the run two before)"""
+    if isinstance(counts, (list, tuple)):
+        return [int(c) for c in counts]
+    if isinstance(counts, bytes):
+        counts = counts.decode("ascii")
+    out, p = [], 0
+    while p < len(counts):
+        x, k, more = 0, 0, True
+        while more:
+            c = ord(counts[p]) - 48
+            x |= (c & 0x1f) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(out) > 2:
+            x += out[-2]
+        out.append(x)
+    return out
+
+
+def _rle_to_mask(seg):
+    h, w = seg["size"]
+    flat = np.zeros(h * w, np.uint8)
+    pos, val = 0, 0
+    for c in _rle_counts(seg["counts"]):
+        if val:
+            flat[pos:pos + c] = 1
+        pos += c
+        val ^= 1
+    return np.ascontiguousarray(flat.reshape(w, h).T)                 # the runs are column-major
+
+
+def instance_masks_device(instances, img_h, img_w, device='cuda'):
+    """The binary masks of COCO annotations, (I, img_h, img_w) uint8 on the device: `dataset.annToMask(instance)` of the reference
+    (shared_utils.py:66 -> pycocotools annToRLE / frPyObjects / decode).  Polygon segmentations are rasterised by sv_polygons_to_masks (the
+    boundary arithmetic of cocoapi's rleFrPoly, union of an instance's parts); RLE dicts are decoded on the host and copied; an instance that
+    already carries 'bin_mask' keeps it."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    n = len(instances)
+    masks = torch.empty((n, img_h, img_w), dtype=torch.uint8, device=dev)
+    xy, off, inst_of, host = [], [0], [], {}
+    for i, inst in enumerate(instances):
+        seg = inst.get('bin_mask')
+        if seg is not None:
+            host[i] = np.asarray(seg, np.uint8)
+        elif isinstance(inst['segmentation'], dict):
+            host[i] = _rle_to_mask(inst['segmentation'])
+        else:
+            for poly in inst['segmentation']:
+                if len(poly) < 2:
+                    continue
+                xy.extend(float(t) for t in poly[:2 * (len(poly) // 2)])
+                off.append(len(xy) // 2)
+                inst_of.append(i)
+    n_poly = len(inst_of)
+    if n_poly:
+        xy_t = torch.tensor(xy, dtype=torch.float64, device=dev)
+        off_t = torch.tensor(off, dtype=torch.int32, device=dev)
+        inst_t = torch.tensor(inst_of, dtype=torch.int32, device=dev)
+        max_v = max(b - a for a, b in zip(off[:-1], off[1:]))
+        scratch = torch.empty((lib.sv_polygon_masks_scratch_bytes(n_poly, img_h, img_w),), dtype=torch.uint8, device=dev)
+    else:
+        xy_t = off_t = inst_t = scratch = None
+        max_v = 0
+    _lib.check(lib.sv_polygons_to_masks(_lib.ptr(xy_t), _lib.ptr(off_t), _lib.ptr(inst_t), n_poly, max_v, n, img_h, img_w, _lib.ptr(scratch),
+                                        _lib.ptr(masks), _lib.stream()), "sv_polygons_to_masks")
+    for i, m in host.items():
+        assert m.shape == (img_h, img_w), f"instance {i}: mask {m.shape} on a {(img_h, img_w)} image"
+        masks[i].copy_(torch.from_numpy(np.ascontiguousarray(m)))
+    return masks
+
+
 def get_pts_in_mask(dataset, instances, imgfov, shrink_percentage=0, use_bbox=False, append_mask_info=False):
-    """shared_utils.py:36-106.  `dataset` is only used for annToMask when an instance has no 'bin_mask' yet; shrinking masks
-    needs shapely and is not supported (shrink_percentage must be 0)."""
-    assert shrink_percentage == 0, "mask shrinking (shapely) is outside this build's scope"
+    """shared_utils.py:36-106.  Instances may carry COCO polygons / RLE dicts under 'segmentation' (rasterised on the device: instance_masks_device,
+    the role of `dataset.annToMask`; the image size comes from dataset.imgs when the COCO object is given, else from imgfov['img_shape']) or a ready
+    'bin_mask'.  Shrinking the polygons first (shrink_percentage != 0: shapely's Polygon.buffer, i.e. GEOS, shared_utils.py:295-330) is not part of
+    this build: neither library is available to pin an implementation against."""
+    assert shrink_percentage == 0, "mask shrinking (shapely / GEOS polygon buffering) is outside this build's scope"
     pts, uv, fov = imgfov["_device"]
     kept = [dict(inst) for inst in instances if inst['segmentation']]
     out = {"img_uv": [], "cam_xyz": [], "lidar_xyz": [], "img_labels": []}
@@ -228,10 +307,15 @@ def get_pts_in_mask(dataset, instances, imgfov, shrink_percentage=0, use_bbox=Fa
             rects.append([max(int(bbox[0]), 0), max(int(bbox[1]), 0), min(int(bbox[2]), img_w), min(int(bbox[3]), img_h)])
         index, count = points_in_masks_device(uv, fov, rects=torch.tensor(rects, dtype=torch.int32, device=uv.device))
     else:
-        for inst in kept:
-            if 'bin_mask' not in inst:
-                inst['bin_mask'] = dataset.annToMask(inst)
-        masks = torch.from_numpy(np.ascontiguousarray(np.stack([inst['bin_mask'] for inst in kept]).astype(np.uint8))).to(uv.device)
+        if all('bin_mask' in inst for inst in kept):
+            masks = torch.from_numpy(np.ascontiguousarray(np.stack([inst['bin_mask'] for inst in kept]).astype(np.uint8))).to(uv.device)
+        else:
+            img = getattr(dataset, 'imgs', {}).get(kept[0].get('image_id')) if dataset is not None else None
+            img_h, img_w = (img['height'], img['width']) if img else imgfov["img_shape"]
+            masks = instance_masks_device(kept, int(img_h), int(img_w), uv.device)
+            masks_h = masks.cpu().numpy()
+            for g, inst in enumerate(kept):                           # the reference keeps the binary mask with the label (shared_utils.py:69)
+                inst.setdefault('bin_mask', masks_h[g])
         index, count = points_in_masks_device(uv, fov, masks=masks)
     count_h = count.cpu().numpy()
     index_h = index.cpu().numpy()

@@ -258,3 +258,96 @@ def test_isolation_refuses_cpu(hip_lib):
     from seevcn_amd.vcn import isolation as I
     with pytest.raises((RuntimeError, AssertionError, ValueError)):
         I.crop_boxes_device(torch.zeros((10, 3)), [I.OrientedBox([0, 0, 0], np.eye(3), [1, 1, 1])])
+
+
+# ------------------------------------------------------------------------------------------ polygons -> masks (annToMask)
+def _random_polygons(rng, h, w, n):
+    """star-shaped and arbitrary polygons with fractional vertices, some leaving the image"""
+    out = []
+    for i in range(n):
+        k = int(rng.integers(3, 40))
+        if i % 2:
+            c = rng.uniform([0, 0], [w, h])
+            ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+            r = rng.uniform(2, 0.6 * min(h, w), k)
+            pts = np.stack([c[0] + r * np.cos(ang), c[1] + r * np.sin(ang)], 1)
+        else:
+            pts = rng.uniform([-5, -5], [w + 5, h + 5], (k, 2))
+        if i % 3 == 0:
+            pts = np.round(pts)                                                  # integer vertices: boundaries exactly on pixel corners
+        out.append([float(t) for t in pts.reshape(-1)])
+    return out
+
+
+def test_oracle_polygon_mask_known_answers():
+    """oracle/coco_mask.py (a restatement of pycocotools' rleFrPoly / decode, PARITY UNPINNED: the library is absent) against answers derived by hand
+    from the algorithm: an integer rectangle (x0, y0)-(x1, y1) covers the pixels [x0, x1) x [y0, y1); a polygon along the image border covers the
+    whole image (its runs end on the border, equal run boundaries cancel); an empty / degenerate polygon covers nothing."""
+    from oracle import coco_mask as cm
+    m = cm.ann_to_mask({"segmentation": [[1, 1, 4, 1, 4, 3, 1, 3]]}, 5, 6)
+    want = np.zeros((5, 6), np.uint8)
+    want[1:3, 1:4] = 1
+    assert np.array_equal(m, want)
+    assert cm.rle_from_polygon([1, 1, 4, 1, 4, 3, 1, 3], 5, 6) == [6, 2, 3, 2, 3, 2, 12]      # runs worked out by hand in the test's history (column-major)
+    assert np.array_equal(cm.ann_to_mask({"segmentation": [[0, 0, 6, 0, 6, 5, 0, 5]]}, 5, 6), np.ones((5, 6), np.uint8))
+    assert cm.ann_to_mask({"segmentation": [[2, 2, 2, 2, 2, 2]]}, 5, 6).sum() == 0
+    # two parts of one annotation: their union; an uncompressed RLE dict: its runs, column-major
+    two = cm.ann_to_mask({"segmentation": [[0, 0, 2, 0, 2, 2, 0, 2], [3, 3, 6, 3, 6, 5, 3, 5]]}, 5, 6)
+    want = np.zeros((5, 6), np.uint8)
+    want[0:2, 0:2] = 1
+    want[3:5, 3:6] = 1
+    assert np.array_equal(two, want)
+    assert np.array_equal(cm.ann_to_mask({"segmentation": {"size": [5, 6], "counts": [6, 2, 3, 2, 3, 2, 12]}}, 5, 6), cm.ann_to_mask({"segmentation": [[1, 1, 4, 1, 4, 3, 1, 3]]}, 5, 6))
+
+
+@pytest.mark.gpu
+def test_hip_polygon_masks_bitexact_vs_oracle(cuda, hip_lib):
+    """sv_polygons_to_masks (boundary walk + parity scan) == the oracle's run-length route, pixel for pixel: the hand-derived cases, 60 random polygons
+    (integer and fractional vertices, concave, self-intersecting, partly outside) on a 93 x 131 image, multi-part instances, and a KITTI-sized image."""
+    from oracle import coco_mask as cm
+    from seevcn_amd.vcn import isolation as I
+    inst = [{"segmentation": [[1, 1, 4, 1, 4, 3, 1, 3]]}, {"segmentation": [[0, 0, 6, 0, 6, 5, 0, 5]]}, {"segmentation": [[2, 2, 2, 2, 2, 2]]},
+            {"segmentation": [[0, 0, 2, 0, 2, 2, 0, 2], [3, 3, 6, 3, 6, 5, 3, 5]]}, {"segmentation": {"size": [5, 6], "counts": [6, 2, 3, 2, 3, 2, 12]}}]
+    got = I.instance_masks_device(inst, 5, 6, cuda).cpu().numpy()
+    for g, a in zip(got, inst):
+        assert np.array_equal(g, cm.ann_to_mask(a, 5, 6)), a
+    rng = np.random.default_rng(11)
+    h, w = 93, 131
+    polys = _random_polygons(rng, h, w, 60)
+    inst = [{"segmentation": [p]} for p in polys[:40]] + [{"segmentation": polys[40 + 4 * i:44 + 4 * i]} for i in range(5)]
+    got = I.instance_masks_device(inst, h, w, cuda).cpu().numpy()
+    for i, (g, a) in enumerate(zip(got, inst)):
+        want = cm.ann_to_mask(a, h, w)
+        assert np.array_equal(g, want), (i, int((g != want).sum()))
+    assert 0 < got.mean() < 1
+    h, w = 375, 1242
+    polys = _random_polygons(np.random.default_rng(12), h, w, 6)
+    got = I.instance_masks_device([{"segmentation": [p]} for p in polys], h, w, cuda).cpu().numpy()
+    for g, p in zip(got, polys):
+        assert np.array_equal(g, cm.ann_to_mask({"segmentation": [p]}, h, w))
+
+
+@pytest.mark.gpu
+def test_hip_get_pts_in_mask_takes_coco_polygons(inputs, golden, cuda, hip_lib):
+    """get_pts_in_mask with instances that carry ONLY polygons (as the reference's detections do before annToMask, shared_utils.py:62-69): the masks
+    are rasterised on the device, the selected points equal those of the same masks handed in as 'bin_mask' (made by the oracle), and every label
+    comes back with its binary mask like the reference's."""
+    from oracle import coco_mask as cm
+    from seevcn_amd.vcn import isolation as I
+    calib = I.Calibration(inputs['calib'])
+    imgfov = I.map_pointcloud_to_image(inputs['points'], calib, IMG_SHAPE, min_dist=1.0)
+    rng = np.random.default_rng(3)
+    polys = []
+    for inst in inputs['instances'][:6]:
+        x0, y0, bw, bh = inst['bbox']
+        k = 12
+        ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+        pts = np.stack([x0 + bw / 2 + 0.7 * bw * np.cos(ang), y0 + bh / 2 + 0.7 * bh * np.sin(ang)], 1)
+        polys.append([float(t) for t in pts.reshape(-1)])
+    only_poly = [{"segmentation": [p], "bbox": i["bbox"], "category_id": 1, "box_id": i["box_id"]} for p, i in zip(polys, inputs['instances'])]
+    with_mask = [dict(a, bin_mask=cm.ann_to_mask(a, *IMG_SHAPE)) for a in only_poly]
+    a = I.get_pts_in_mask(None, only_poly, imgfov)
+    b = I.get_pts_in_mask(None, with_mask, imgfov)
+    assert len(a["lidar_xyz"]) == len(b["lidar_xyz"]) > 0
+    for la, lb, ia, ib in zip(a["lidar_xyz"], b["lidar_xyz"], a["img_labels"], b["img_labels"]):
+        assert np.array_equal(la, lb) and np.array_equal(ia["bin_mask"], ib["bin_mask"])
