@@ -157,6 +157,22 @@ class Prefetch:
         self.pending = None
         self.pasted = None                 # front_a's output waiting for its front_b (depth 2)
         self.first = True
+        self._prime_allocator()
+
+    def _prime_allocator(self):
+        """Setup, not a step: spare blocks in the caching allocator's pools of both streams.  Buffers that cross from the input side's stream to the trained
+        side's (the 450 MB index arena, voxel features, ...) go back to their pool only when the consumer's events have completed; until the pool holds a
+        block or two more than the pipeline's depth a request finds none free and falls through to hipMalloc -- a 5-15 ms stall inside a step, tens of
+        them while the pool fills (tools/alloc_trace.py).  A training run fills the pool in its first hundred steps; a 20-step measurement would spend
+        them there.  SEEVCN_BENCH_PRIME=0: off (A/B)."""
+        if os.environ.get("SEEVCN_BENCH_PRIME", "1") == "0":
+            return
+        sizes_mb = [512, 512, 256, 256, 128, 128, 64, 64, 64, 32, 32, 32, 16, 16, 16, 16]
+        for stream in (self.side, torch.cuda.current_stream()):
+            with torch.cuda.stream(stream):
+                blocks = [torch.empty((mb << 20,), dtype=torch.uint8, device="cuda") for mb in sizes_mb]
+                del blocks
+        torch.cuda.synchronize()
 
     def _front(self):
         torch.cuda.set_device(self.device)
@@ -231,6 +247,13 @@ def run_step_prefetched(model, opt, params, pre, world, interleave=True):
     main stream could run dry; then the read, then the tables and plans of batch N + 1.  interleave False (A/B): the whole trained side first,
     then the input side."""
     from seevcn_amd import _lib
+    # Back-pressure: the host reads only the input side's stream, so nothing ties it to the TRAINED side's -- when that stream is the slower one
+    # the host and the input side run ahead of it by a step every dozen steps, each with a live 450 MB index arena and its voxel tensors (round 5:
+    # 20 extra arenas = 9 GB hipMalloc'ed over 200 steps, tools/alloc_trace.py).  A step therefore first waits for the trained side of the step
+    # before last (an event that has usually long completed): at most two trained steps are ever queued.
+    inflight = pre.__dict__.setdefault("_done_events", [])
+    if len(inflight) >= int(os.environ.get("SEEVCN_BENCH_MAX_INFLIGHT", "2")):
+        inflight.pop(0).synchronize()
     bd = pre.take()
     out = []
     gen = _compute_gen(model, opt, params, bd, world, out)
@@ -257,6 +280,7 @@ def run_step_prefetched(model, opt, params, pre, world, interleave=True):
         _lib.set_sync_hook(prev)
     for _ in gen:                                             # a front without a read (nothing to do) leaves the pieces here
         pass
+    inflight.append(main.record_event())
     return out[0]
 
 
@@ -567,9 +591,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    import gc
+    gc0 = [dict(g) for g in gc.get_stats()]
+    dev_allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    stamps = []                        # host clock after every step's enqueue (a pipelined step ends in a blocking read: stamps follow the steps): one
+    for _ in range(args.steps):        # perf_counter call per step, reported as the slowest / median step interval so that a transient shows in the line
         step()
+        stamps.append(time.perf_counter())
     if pre is not None:
         pre.wait_issued()              # K steps = K computes + K fronts: the last front issued belongs to the timed region
     torch.cuda.synchronize()
@@ -588,6 +617,11 @@ def main():
     ident = gather_rank_identities(device, world)            # collective: every rank, before rank 0 goes off measuring alone
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
+        gaps = np.diff(np.array([t0] + stamps)) * 1e3
+        dev_allocs = torch.cuda.memory_stats().get("num_device_alloc", 0) - dev_allocs0
+        gc1 = gc.get_stats()
+        gc_runs = [b["collections"] - a["collections"] for a, b in zip(gc0, gc1)]
+        gc_freed = sum(b["collected"] - a["collected"] for a, b in zip(gc0, gc1))
         scenes = SCENES_PER_GPU * world * args.steps
         in_range = int(((pts_np[:, 1] >= 0) & (pts_np[:, 1] < 70.4) & (np.abs(pts_np[:, 2]) < 40) & (pts_np[:, 3] >= -3) & (pts_np[:, 3] < 1)).sum())
         out = {
@@ -602,6 +636,9 @@ def main():
                        "geometry": "KITTI [0,-40,-3,70.4,40,1] @ [0.05,0.05,0.1] -> sparse [41,1600,1408]", "parallelism": f"dp{world}",
                        "input_side": "in line" if pre is None else "side stream, one batch ahead (every step = 1 front + 1 compute)"},
             "completed_objects_per_sec": round(OBJECTS_PER_GPU * world * args.steps / elapsed, 1), "device_spinup_s": args.spinup,
+            "step_interval_ms": {"median": round(float(np.median(gaps)), 3), "max": round(float(gaps.max()), 3), "first_10": [round(float(g), 2) for g in gaps[:10]],
+                                 "slow_steps": int((gaps > 2 * np.median(gaps)).sum()),
+                                 "python_gc_runs_by_generation": gc_runs, "python_gc_objects_freed": gc_freed, "hipMalloc_calls_in_timed_steps": int(dev_allocs)},
             "ranks": ident, "backend": (backend if world > 1 else None),
         }
         if not args.no_kernel_rooflines:

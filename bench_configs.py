@@ -59,8 +59,8 @@ def build(config, rank, device, scenes=None):
         def step():
             with torch.no_grad():
                 coarse = vcn({"input": x})["coarse"]
-                surface, _ = sampling.get_partial_mesh_batch_device(x, coarse, k=30)
-                clustered, _ = sampling.get_largest_cluster_batch_device(surface, eps=0.4, min_points=2, total_pts=coarse.shape[1])
+                surface, n_sel = sampling.get_partial_mesh_batch_device(x, coarse, k=30)
+                clustered, _ = sampling.get_largest_cluster_batch_device(surface, eps=0.4, min_points=2, total_pts=coarse.shape[1], period=n_sel)
             return clustered
         return step, n_obj, "objects/sec", "completed objects/sec (VCN_VC fwd + surface select + largest cluster)", {
             "workload": f"BASELINE configs[1]: VCN surface completion only, {n_obj} objects x 1024 pts per GPU, inference", "objects_per_gpu": n_obj}

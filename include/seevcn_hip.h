@@ -668,6 +668,11 @@ int sv_vcn_surface_select(const float* partial, const float* complete, int batch
  * noise (the reference raises there); out rows of that object are left untouched. */
 int sv_vcn_largest_cluster(const float* points, int batch, int n, double eps, int min_points, int total_pts, float* out,
                            int32_t* n_cluster, void* stream);
+/* the same with a hint (device int32 per object): the cloud of object b repeats its first period[b] rows cyclically -- what sv_vcn_surface_select returns
+ * (np.tile(selected)[:surface_pts], sampling.py:37-39, n_selected as the period).  The pair tests then run over the first period[b] rows only (copies hang
+ * under their originals: distance 0); the hint is verified on the device, a cloud that does not repeat takes the all-pairs path.  Same output. */
+int sv_vcn_largest_cluster_periodic(const float* points, int batch, int n, const int32_t* period, double eps, int min_points, int total_pts, float* out,
+                                    int32_t* n_cluster, void* stream);
 /* Exact duplicates among n rows [b,x,y,z] (float32, 16-byte aligned): every copy of a row but the first gets b = -1 in place.  The unsorted form of np.unique(np.vstack(instances), axis=0) (SEE_VCN.py:115) for consumers that need the set only; no host
  * sync.  scratch: sv_dedup_rows_scratch_bytes(n) bytes, any content. */
 size_t sv_dedup_rows_scratch_bytes(int64_t n);

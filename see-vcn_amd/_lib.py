@@ -137,6 +137,7 @@ SIGNATURES = {
     "sv_vcn_surface_select_scratch_bytes": (c_sz, [c_i]),
     "sv_vcn_surface_select": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_vcn_largest_cluster": (c_i, [c_p, c_i, c_i, c_d, c_i, c_i, c_p, c_p, c_p]),
+    "sv_vcn_largest_cluster_periodic": (c_i, [c_p, c_i, c_i, c_p, c_d, c_i, c_i, c_p, c_p, c_p]),
     "sv_dedup_rows_scratch_bytes": (c_sz, [c_i64]),
     "sv_dedup_rows": (c_i, [c_p, c_i64, c_p, c_p]),
     "sv_points_near_set": (c_i, [c_p, c_i64, c_p, c_i64, c_i, c_d, c_p, c_p]),

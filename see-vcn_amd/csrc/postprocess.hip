@@ -341,6 +341,8 @@ struct ClusterArgs {
   int* n_cluster;       // (B)
   int n, total, min_points;
   double eps2;
+  const int* period;    // optional (B): the cloud of object b repeats its first period[b] rows cyclically (np.tile(...)[:n], what the surface selection
+                        // returns); a HINT: verified on the device, a cloud that does not repeat takes the all-pairs path
 };
 
 __device__ __forceinline__ int uf_find(volatile int* parent, int x) {
@@ -369,15 +371,37 @@ __global__ __launch_bounds__(PP_THREADS) void k_largest_cluster(ClusterArgs a) {
   if (tid == 0) s_best = 0ull, s_nmember = 0;
   __syncthreads();
 
-  if (tid < a.n) {
+  // Periodic clouds.  The surface selection tiles its U selected points to n rows (sampling.py:37-39: np.tile(sel, ...)[:surface_pts], U ~ 150-400 of
+  // 1024), so row i equals row i - U: a copy is at distance 0 < eps from its original -- same component, both core -- and every other test between
+  // copies repeats a test between originals.  The pair tests then run over the first U rows only (U^2 / 2 instead of n^2 / 2 float64 distances: 117 ->
+  // ~10 us for 64 objects), the copies hang themselves under their originals; roots (smallest index of a component), core flags and member counts come
+  // out as with all pairs.
+  int U = a.n;
+  if (a.period) {
+    const int u = a.period[b];
+    if (u >= 1 && u < a.n) {
+      bool same = true;
+      if (tid >= u && tid < a.n)
+        same = __float_as_uint(s_x[tid * 3]) == __float_as_uint(s_x[(tid - u) * 3]) && __float_as_uint(s_x[tid * 3 + 1]) == __float_as_uint(s_x[(tid - u) * 3 + 1]) &&
+               __float_as_uint(s_x[tid * 3 + 2]) == __float_as_uint(s_x[(tid - u) * 3 + 2]);
+      if (__syncthreads_and(same ? 1 : 0)) U = u;
+    }
+  }
+  if (tid >= U && tid < a.n) {                // a copy: joins its original (the smaller index stays the root), both are core
+    s_parent[tid] = tid % U;
+    s_core[tid] = 1, s_core[tid % U] = 1;
+  }
+  __syncthreads();
+
+  if (tid < U) {
     const double x = s_x[tid * 3], y = s_x[tid * 3 + 1], z = s_x[tid * 3 + 2];
     bool has_nbr = false;
-    const int half = a.n / 2;
+    const int half = U / 2;
     int my_parent = tid;
 #pragma unroll 4
-    for (int s = 1; s <= half; ++s) {         // every unordered pair once (twice for s == n/2 when n is even: harmless)
+    for (int s = 1; s <= half; ++s) {         // every unordered pair once (twice for s == U/2 when U is even: harmless)
       int j = tid + s;
-      if (j >= a.n) j -= a.n;
+      if (j >= U) j -= U;
       // parent[j] is fetched with the coordinates so the common "already merged" test needs no dependent LDS round trip;
       // a stale value only sends us down the full union path, which re-reads
       const float jx = s_x[j * 3], jy = s_x[j * 3 + 1], jz = s_x[j * 3 + 2];
@@ -584,15 +608,26 @@ extern "C" int sv_vcn_surface_select(const float* partial, const float* complete
   return SV_OK;
 }
 
+static int largest_cluster_run(const float* points, int batch, int n, const int32_t* period, double eps, int min_points, int total_pts, float* out,
+                               int32_t* n_cluster, void* stream);
 extern "C" int sv_vcn_largest_cluster(const float* points, int batch, int n, double eps, int min_points, int total_pts, float* out,
                                       int32_t* n_cluster, void* stream) {
+  return largest_cluster_run(points, batch, n, nullptr, eps, min_points, total_pts, out, n_cluster, stream);
+}
+// the same with a hint: object b's cloud repeats its first period[b] rows (device int32, the surface selection's n_selected); see k_largest_cluster
+extern "C" int sv_vcn_largest_cluster_periodic(const float* points, int batch, int n, const int32_t* period, double eps, int min_points, int total_pts,
+                                               float* out, int32_t* n_cluster, void* stream) {
+  return largest_cluster_run(points, batch, n, period, eps, min_points, total_pts, out, n_cluster, stream);
+}
+static int largest_cluster_run(const float* points, int batch, int n, const int32_t* period, double eps, int min_points, int total_pts, float* out,
+                               int32_t* n_cluster, void* stream) {
   SV_CHECK_ARG(batch >= 0 && n >= 1 && n <= PP_MAXN, "sv_vcn_largest_cluster: 1 <= n <= %d (got %d)", PP_MAXN, n);
   SV_CHECK_ARG(min_points >= 0 && min_points <= 2,
                "sv_vcn_largest_cluster: min_points <= 2 only (border-point order of open3d's BFS is not reproduced); got %d", min_points);
   SV_CHECK_ARG(total_pts >= 1 && eps > 0, "sv_vcn_largest_cluster: total_pts >= 1, eps > 0");
   if (batch == 0) return SV_OK;
   SV_CHECK_ARG(points && out && n_cluster, "sv_vcn_largest_cluster: null pointer");
-  ClusterArgs a{points, out, n_cluster, n, total_pts, min_points, eps * eps};
+  ClusterArgs a{points, out, n_cluster, n, total_pts, min_points, eps * eps, period};
   hipLaunchKernelGGL(k_largest_cluster, dim3(batch), dim3(PP_THREADS), 0, sv_stream(stream), a);
   SV_LAUNCH_CHECK();
   return SV_OK;

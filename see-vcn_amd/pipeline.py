@@ -47,9 +47,9 @@ class SceneStep(nn.Module):
             bcol = object_scene.view(-1, 1, 1).expand(-1, coarse.shape[1], 1)
             return torch.cat([points, torch.cat([bcol, coarse], dim=2).view(-1, 4)], dim=0)
         # VCN.inference's post-processing (models/VCN.py:89-93) and the scene merge (SEE_VCN.py:115,247-265), all on the GPU
-        surface, _ = get_partial_mesh_batch_device(objects, coarse, k=self.sel_k)
+        surface, n_sel = get_partial_mesh_batch_device(objects, coarse, k=self.sel_k)
         # the empty-cluster check rides on the voxeliser's read below instead of blocking here (one host <-> device round trip less per step)
-        clustered, _ = get_largest_cluster_batch_device(surface, eps=self.cluster_eps, min_points=2, total_pts=coarse.shape[1], defer_check=True)
+        clustered, _ = get_largest_cluster_batch_device(surface, eps=self.cluster_eps, min_points=2, total_pts=coarse.shape[1], defer_check=True, period=n_sel)
         return complete_scene_batch_device(points, clustered, object_scene, 0.1, compact=False)   # replaced points: scene id -1, dropped by the VFE
 
     def front_a(self, points, objects, object_scene):

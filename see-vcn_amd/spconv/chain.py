@@ -16,6 +16,7 @@ import torch
 from .. import _lib
 from . import functional as Fsp
 from . import norm
+from .core import SparseConvTensor
 
 CHAIN_OFF = os.environ.get("SEEVCN_CHAIN", "1") == "0"          # 0: every block through its own modules (A/B runs, tests)
 # 1: a BatchNorm backward takes its two per-channel sums from the epilogue of the data-gradient launch above it (sv_sparse_conv_dgrad_planned_bn)
@@ -333,31 +334,29 @@ class SparseChainFunction(torch.autograd.Function):
         return tuple(out)
 
 
-class LazyTap:
-    """Mixin state of a tap whose normalised features are made when somebody reads them (BN_FOLD): PV-RCNN's set abstraction reads
-    multi_scale_3d_features, SECOND / the benchmarked step read none of x_conv1..4 -- their elementwise passes never run."""
+class LazyTap(SparseConvTensor):
+    """A tap whose normalised features are made when somebody reads them (BN_FOLD): PV-RCNN's set abstraction reads multi_scale_3d_features, SECOND /
+    the benchmarked step read none of x_conv1..4 -- their elementwise passes never run.  (One class for all taps: a class made per call is a
+    reference cycle that only the cyclic collector frees, and it kept the tap's tensors alive with it -- sporadic allocator growth in the step.)"""
 
+    def __init__(self, raw, coef, relu, indices, spatial_shape, batch_size, grid=None, indice_dict=None):
+        super().__init__(None, indices, spatial_shape, batch_size, grid, indice_dict)
+        self._raw, self._coef, self._relu = raw, coef, relu
 
-def _lazy_tensor(raw, coef, relu, indices, shape, batch_size, grid, indice_dict):
-    from .core import SparseConvTensor
+    @property
+    def features(self):
+        if self._features is None:
+            self._features = _TapApply.apply(self._raw, self._coef, self._relu)
+            self._raw = self._coef = None
+        return self._features
 
-    class _Lazy(SparseConvTensor, LazyTap):
-        @property
-        def features(self):
-            if self._features is None:
-                self._features = _TapApply.apply(raw, coef, relu)
-            return self._features
-
-        @features.setter
-        def features(self, value):
-            self._features = value
-
-    return _Lazy(None, indices, shape, batch_size, grid, indice_dict)
+    @features.setter
+    def features(self, value):
+        self._features = value
 
 
 def run_chain(blocks, x):
     """x: SparseConvTensor at the chain's input with every rulebook prebuilt.  -> list of SparseConvTensor, one per tap, in order."""
-    from .core import SparseConvTensor
     rulebooks = [x.indice_dict[b.conv.indice_key] for b in blocks]
     params = []
     for b in blocks:
@@ -372,5 +371,5 @@ def run_chain(blocks, x):
         if mat:
             res.append(SparseConvTensor(f, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.indice_dict))
         else:
-            res.append(_lazy_tensor(f, coefs.pop(0), b.relu, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.indice_dict))
+            res.append(LazyTap(f, coefs.pop(0), b.relu, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.indice_dict))
     return res

@@ -95,7 +95,7 @@ class TablePlan(_ArenaViews):
         """from_parts with every piece given as an (offset, count, shape) slice of `arena`; `owner`.`table_name` is the k-major table."""
         self = cls.__new__(cls)
         self.n_rows, self.K = int(n_rows), int(K)
-        self._owner, self._table_name = owner, table_name
+        self._owner, self._table_name = weakref.ref(owner), table_name
         self._tiles = {}
         self._tiles_lazy = {int(g): tile_of}
         self._set_lazy(arena, arena_ptr, {"rows": rows, "masks": masks, "perm": perm, "masks_p": masks_p})
@@ -104,7 +104,12 @@ class TablePlan(_ArenaViews):
     @property
     def source(self):
         src = self.__dict__.get("_source")
-        return src if src is not None else getattr(self._owner, self._table_name)
+        if src is not None:
+            return src
+        owner = self._owner()                      # a WEAK reference: the rulebook holds its plans, a strong one back made a cycle that kept the whole
+        if owner is None:                          # index arena of a batch (~450 MB) alive until the cyclic collector ran
+            raise RuntimeError("the rulebook of this plan is gone")
+        return getattr(owner, self._table_name)
 
     def tiles_addr(self, g):
         lz = self.__dict__.get("_tiles_lazy")

@@ -75,6 +75,6 @@ class VCN:
             if self.norm_with_gt:
                 in_dict['gt_boxes'] = torch.from_numpy(gt).float().to(self.device)
             output = self.model(in_dict)['coarse']
-        surface, _ = get_partial_mesh_batch_device(in_pc, output, k=k)
-        clustered, _ = get_largest_cluster_batch_device(surface, eps=eps, min_points=2, total_pts=output.shape[1])
+        surface, n_sel = get_partial_mesh_batch_device(in_pc, output, k=k)
+        clustered, _ = get_largest_cluster_batch_device(surface, eps=eps, min_points=2, total_pts=output.shape[1], period=n_sel)
         return {'input': in_pc, 'surface': surface, 'clustered': clustered, 'coarse': output.detach()}

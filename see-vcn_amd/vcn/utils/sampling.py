@@ -47,10 +47,12 @@ def _no_cluster(smallest):
         raise ValueError("attempt to get argmax of an empty sequence")
 
 
-def get_largest_cluster_batch_device(pc, eps=0.4, min_points=1, total_pts=1024, defer_check=False):
+def get_largest_cluster_batch_device(pc, eps=0.4, min_points=1, total_pts=1024, defer_check=False, period=None):
     """(B,n,3) CUDA tensor -> (B,total_pts,3) float32 tensor, cluster sizes (B) int32.  Raises ValueError (like the reference's
     np.argmax over an empty bincount) if some object has no cluster at all -- at once, or with defer_check at the caller's next blocking
-    read on this stream (_lib.defer_check: the pipeline's voxel count follows within the same step)."""
+    read on this stream (_lib.defer_check: the pipeline's voxel count follows within the same step).  period (B) int32 CUDA tensor, optional:
+    object b's cloud repeats its first period[b] rows (get_partial_mesh_batch_device's second return value) -- a hint that is verified on the
+    device and only shortens the pair tests (same output)."""
     lib = _lib.load()
     _lib.require_cuda(pc)
     x = _as_device_f32(pc)
@@ -58,8 +60,13 @@ def get_largest_cluster_batch_device(pc, eps=0.4, min_points=1, total_pts=1024, 
     B = x.shape[0]
     out = torch.zeros((B, total_pts, 3), dtype=torch.float32, device=x.device)
     cnt = torch.empty((B,), dtype=torch.int32, device=x.device)
-    _lib.check(lib.sv_vcn_largest_cluster(_lib.ptr(x), B, x.shape[1], float(eps), int(min_points), int(total_pts), _lib.ptr(out), _lib.ptr(cnt),
-                                          _lib.stream()), "sv_vcn_largest_cluster")
+    if period is not None:
+        assert period.dtype == torch.int32 and period.shape == (B,) and period.is_cuda
+        _lib.check(lib.sv_vcn_largest_cluster_periodic(_lib.ptr(x), B, x.shape[1], _lib.ptr(period.contiguous()), float(eps), int(min_points), int(total_pts),
+                                                       _lib.ptr(out), _lib.ptr(cnt), _lib.stream()), "sv_vcn_largest_cluster_periodic")
+    else:
+        _lib.check(lib.sv_vcn_largest_cluster(_lib.ptr(x), B, x.shape[1], float(eps), int(min_points), int(total_pts), _lib.ptr(out), _lib.ptr(cnt),
+                                              _lib.stream()), "sv_vcn_largest_cluster")
     if B:
         if defer_check:
             _lib.defer_check(cnt.min(), _no_cluster)

@@ -94,6 +94,36 @@ def test_hip_largest_cluster_bitexact_vs_oracle(golden_dir, cuda, hip_lib):
 
 
 @pytest.mark.gpu
+def test_hip_largest_cluster_period_hint_changes_nothing(golden_dir, cuda, hip_lib):
+    """The periodic fast path (sv_vcn_largest_cluster_periodic: pair tests over the first period[b] rows, copies under their originals) against the
+    all-pairs kernel and the oracle: the surface selection's own output with its n_selected as the period (the pipeline's call), synthetic tiled clouds
+    whose period leaves a partial last copy (rows without a copy), and WRONG hints (a cloud that does not repeat, a period of 1 / n / beyond n), which
+    must fall back to all pairs -- bit-identical clouds and sizes everywhere."""
+    from seevcn_amd.vcn.utils import sampling as S
+    g = np.load(os.path.join(golden_dir, "vcn_post.npz"))
+    partial, coarse = make_pairs()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    surface, nsel = S.get_partial_mesh_batch_device(dev(partial), dev(coarse), k=30)
+    assert int(nsel.max()) < surface.shape[1]                                       # the selection really tiles
+    cases = [(surface, nsel, 0.4, 2), (surface, nsel, 0.05, 2), (surface, nsel, 0.3, 1)]
+    rng = np.random.default_rng(4)
+    for U in (1, 2, 333, 600, 1023):                                                # 600, 1023: rows U .. n - U have no copy
+        base = rng.normal(size=(5, U, 3)).astype(np.float32) * 0.5
+        tiled = np.tile(base, (1, -(-1024 // U), 1))[:, :1024]
+        cases.append((dev(tiled), torch.full((5,), U, dtype=torch.int32, device=cuda), 0.25, 2))
+    plain = dev(coarse)
+    for wrong in (1, 7, 512, plain.shape[1], plain.shape[1] + 5, 0, -3):                  # hints that do not hold (or are no hints): all-pairs path
+        cases.append((plain, torch.full((plain.shape[0],), wrong, dtype=torch.int32, device=cuda), 0.15, 2))
+    for pcs, period, eps, mp in cases:
+        want, wcnt = S.get_largest_cluster_batch_device(pcs, eps=eps, min_points=mp, total_pts=1024)
+        got, gcnt = S.get_largest_cluster_batch_device(pcs, eps=eps, min_points=mp, total_pts=1024, period=period)
+        assert torch.equal(got, want) and torch.equal(gcnt, wcnt), (eps, mp, period[:3].tolist())
+    o, size = opp.largest_cluster(surface[0].cpu().numpy(), eps=0.4, min_points=2, total_pts=1024)
+    got, gcnt = S.get_largest_cluster_batch_device(surface[:1], eps=0.4, min_points=2, total_pts=1024, period=nsel[:1])
+    assert int(gcnt[0]) == size and np.array_equal(got[0].cpu().numpy().astype(np.float64), o)
+
+
+@pytest.mark.gpu
 def test_hip_scene_merge_vs_oracle(golden_dir, cuda, hip_lib):
     import seevcn_amd.synth as synth
     from seevcn_amd.vcn import scene_merge as M
