@@ -34,11 +34,20 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
 // ------------------------------------------------------------------------------------------------
 // C[M,N] = act(A[M,K] * W[N,K]^T + bias[N] + group_bias[row / rows_per_group][N])
 //   EPI_STORE: write C;  EPI_MAX: column max over each group of rows_per_group rows -> gmax[group][N]
-// 128x128 tile, BK=32, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles, double-buffered LDS with
-// 36-float row pitch (conflict-free ds_read_b128), register-staged global loads.
+// 128x128 tile, K tile BK (16), 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles, double-buffered LDS with
+// a BK + 4-float row pitch, register-staged global loads.
 // K order inside an 8-group is permuted identically for A and W (lane half h takes k = 8q+4h+t).
 // ------------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 32, LDP = 36;
+// K tile of the LDS stages and workgroups per CU.  Round 5: 16 / 3 (40 KB of LDS, 124 VGPRs: three to four workgroups per CU) instead of 32 / 2
+// (74 KB, 156 VGPRs: two) -- stage A 0.759 -> 0.74 ms, same box (tools/build_variant.sh ... vcn); twice the barriers, half again the waves to cover them.
+#ifndef SEEVCN_GEMM_BK
+#define SEEVCN_GEMM_BK 16
+#endif
+#ifndef SEEVCN_GEMM_WGS
+#define SEEVCN_GEMM_WGS 3
+#endif
+constexpr int BM = 128, BN = 128, BK = SEEVCN_GEMM_BK, LDP = BK + 4;     // K tile of the LDS stages (callers keep K % 32 == 0)
+constexpr int GEMM_ROW_THREADS = BK / 4, GEMM_ROWS_PER_PASS = 256 / GEMM_ROW_THREADS, GEMM_PASSES = BM / GEMM_ROWS_PER_PASS;
 
 struct GemmArgs {
   const float* A; int lda;
@@ -56,7 +65,7 @@ struct GemmArgs {
 };
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmArgs g) {
+__global__ __launch_bounds__(256, SEEVCN_GEMM_WGS) void k_gemm_f32(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[2][BM * LDP];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDP];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -75,13 +84,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmArgs g) {
   }
   if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
   const int m0 = (lin / (int)gridDim.x) * BM, n0 = (lin % (int)gridDim.x) * BN;
-  const int lr = tid >> 3, lc = (tid & 7) * 4;  // staging: row lr (+32*i), k offset lc
+  const int lr = tid / GEMM_ROW_THREADS, lc = (tid % GEMM_ROW_THREADS) * 4;  // staging: row lr (+GEMM_ROWS_PER_PASS*i), k offset lc
 
-  float4 ra[4], rb[4];
+  float4 ra[GEMM_PASSES], rb[GEMM_PASSES];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = lr + 32 * i;
+    for (int i = 0; i < GEMM_PASSES; ++i) {
+      const int r = lr + GEMM_ROWS_PER_PASS * i;
       const int m = m0 + r, n = n0 + r;
       ra[i] = (m < g.M) ? *reinterpret_cast<const float4*>(g.A + (int64_t)m * g.lda + k0 + lc) : make_float4(0, 0, 0, 0);
       rb[i] = (n < g.N) ? *reinterpret_cast<const float4*>(g.W + (int64_t)n * g.ldw + k0 + lc) : make_float4(0, 0, 0, 0);
@@ -89,8 +98,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmArgs g) {
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = lr + 32 * i;
+    for (int i = 0; i < GEMM_PASSES; ++i) {
+      const int r = lr + GEMM_ROWS_PER_PASS * i;
       *reinterpret_cast<float4*>(&As[buf][r * LDP + lc]) = ra[i];
       *reinterpret_cast<float4*>(&Bs[buf][r * LDP + lc]) = rb[i];
     }
