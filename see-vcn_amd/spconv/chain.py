@@ -19,10 +19,13 @@ from . import norm
 from .core import SparseConvTensor
 
 CHAIN_OFF = os.environ.get("SEEVCN_CHAIN", "1") == "0"          # 0: every block through its own modules (A/B runs, tests)
-# 1: a BatchNorm backward takes its two per-channel sums from the epilogue of the data-gradient launch above it (sv_sparse_conv_dgrad_planned_bn)
-# instead of reducing them in a pass of its own.  Built, tested, and OFF by default: same-box A/B 5.13-5.26 ms without, 5.26-5.56 ms with -- the
-# 11 saved reduce launches (12 us each) are paid back by the epilogues' 16 extra row reads per tile (conv launches +3.4 .. +8.6 us each).
-BWD_SUMS_IN_CONV = os.environ.get("SEEVCN_BN_BWD_IN_CONV", "0") == "1"
+# 1 (default since round 5): a BatchNorm backward takes its two per-channel sums from the epilogue of the data-gradient launch above it
+# (sv_sparse_conv_dgrad_planned_bn) instead of reducing them in a pass of its own.  Round 3 built it and measured 5.13-5.26 ms without, 5.26-5.56 ms with
+# (the 11 saved reduce launches were paid back by the epilogues' 16 extra row reads per tile on a chain that was waiting for its weight gradients anyway);
+# with the weight gradients on their own stream the data-gradient chain IS the critical path and the saved launches count: 3.70 -> 3.63 ms (same box, two
+# alternations).  The sums are added in plan order instead of row order: gradients equal the separate pass to 1e-5 of each tensor's largest entry, and
+# are reproducible run to run (one plan per table, fixed partial slots); 0 restores bit-identity with the per-module path.
+BWD_SUMS_IN_CONV = os.environ.get("SEEVCN_BN_BWD_IN_CONV", "1") != "0"
 # 0: every weight gradient is followed by its own slab-reduction launch (SV_OP_WGRAD) instead of ONE reduction launch for all layers at the end of the backward
 # list (SV_OP_WGRAD_DEFERRED: bitwise the same gradients) -- A/B runs
 DEFER_WGRAD_REDUCE = os.environ.get("SEEVCN_WGRAD_DEFER", "1") != "0"

@@ -644,6 +644,7 @@ def test_hip_backbone_chain_equals_the_module_path(cuda, hip_lib):
             saved, chain.CHAIN_OFF = chain.CHAIN_OFF, off
             saved_stats, norm.STATS_IN_CONV = norm.STATS_IN_CONV, stats_in_conv
             saved_fold, chain.BN_FOLD = chain.BN_FOLD, fold
+            saved_bwd, chain.BWD_SUMS_IN_CONV = chain.BWD_SUMS_IN_CONV, False      # bit-identity: the BatchNorm backward sums in passes of their own, like the modules
             try:
                 assert (net._chain_blocks() is not None)
                 bd = net({'batch_size': 2, 'voxel_features': f.clone(), 'voxel_coords': c.clone()})
@@ -656,6 +657,7 @@ def test_hip_backbone_chain_equals_the_module_path(cuda, hip_lib):
                 chain.CHAIN_OFF = saved
                 norm.STATS_IN_CONV = saved_stats
                 chain.BN_FOLD = saved_fold
+                chain.BWD_SUMS_IN_CONV = saved_bwd
             res.append((out.detach(), x3.detach(), [p.grad.clone() for p in net.parameters()], [b.clone() for b in net.buffers()]))
         a, b = res
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (stats_in_conv, fold)
