@@ -65,7 +65,10 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_reduce(BnArgs a) {
 
 // per-channel statistics from the workgroup partials: one workgroup per channel, fp64 tree in a fixed order
 // (tried: one workgroup per 8 channels with every thread walking each 32nd partial row of one channel -- coalesced 32-byte pieces instead of one
-// 128-byte line per thread and row -- 12.5 / 9.9 us instead of 5.7 / 5.0: eight workgroups with 32 dependent loads per thread lose to 64 x 4)
+// 128-byte line per thread and row -- 12.5 / 9.9 us instead of 5.7 / 5.0: eight workgroups with 32 dependent loads per thread lose to 64 x 4;
+// round 5: ONE wave per channel, its <= 16 partial pairs per lane requested up front and the lane sums met by shuffles instead of the eight-barrier LDS
+// tree -- the step went 3.64 -> 3.78 ms (profiles/r05_fin_ab.txt): 32 load instructions of 64 different lines each through one wave's address unit take
+// longer than the four waves' shorter queues.  Measured with SEEVCN_DEBUG_SKIP_FINALIZE: the 12 forward launches cost the step 0.08 ms in all.)
 template <bool BWD>
 __global__ __launch_bounds__(BN_THREADS) void k_bn_finalize(BnArgs a) {
   __shared__ double s0[BN_THREADS], s1[BN_THREADS];

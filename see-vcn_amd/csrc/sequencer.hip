@@ -139,11 +139,17 @@ static int run_ops(const int64_t* ops, int n_ops, void* stream, void* side_strea
                                         ptr_of<const float>(p[3]), ptr_of<const float>(p[4]), ptr_of<const float>(p[5]), (int)i[1], ptr_of<void>(p[6]),
                                         ptr_of<float>(p[7]), ptr_of<float>(p[8]), ptr_of<float>(p[9]), stream);
         break;
-      case SV_OP_BN_FINALIZE:
+      case SV_OP_BN_FINALIZE: {
+        // MEASUREMENT ONLY (results are stale after the first calls): SEEVCN_DEBUG_SKIP_FINALIZE=n skips the launch from the n-th call on -- what the step would
+        // gain if the statistics' combine cost the chain nothing
+        static const int skip_after = getenv("SEEVCN_DEBUG_SKIP_FINALIZE") ? atoi(getenv("SEEVCN_DEBUG_SKIP_FINALIZE")) : 0;
+        static int calls = 0;
+        if (skip_after > 0 && ++calls > skip_after && !p[9]) break;
         rc = sv_batchnorm_finalize_forward(ptr_of<const float>(p[9]), n[0], (int)i[0], ptr_of<const float>(p[0]), ptr_of<const float>(p[1]), ptr_of<float>(p[2]), ptr_of<float>(p[3]),
                                            (float)as_double(f[0]), (float)as_double(f[1]), ptr_of<void>(p[4]), (int)i[1], ptr_of<float>(p[5]), ptr_of<float>(p[6]),
                                            ptr_of<float>(p[7]), ptr_of<int64_t>(p[8]), stream);
         break;
+      }
       case SV_OP_BN_APPLY:
         rc = sv_batchnorm_apply(ptr_of<const float>(p[0]), n[0], (int)i[0], ptr_of<const float>(p[1]), (int)i[1], ptr_of<float>(p[2]), stream);
         break;
