@@ -360,7 +360,7 @@ def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
     groups = {}
     for arr, ms in lists:
         for row, t in zip(arr, ms):
-            if int(row[0]) != chain.OP_CONV_PLANNED:
+            if int(row[0]) not in (chain.OP_CONV_PLANNED, chain.OP_DGRAD_PLANNED_BN):     # the same kernel; the second form's epilogue also makes a BatchNorm's backward sums
                 continue
             K, kd, nc = int(row[2]), int(row[3]), int(row[4])
             n_src, n_rows, table = int(row[9]), int(row[10]), int(row[18])
