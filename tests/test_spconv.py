@@ -1094,3 +1094,83 @@ def test_hip_backward_list_with_weight_gradients_on_a_second_stream_is_bitwise_t
         res.append({k: p.grad.clone() for k, p in net.named_parameters()})
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,kind", [(16, 16, "subm"), (16, 32, "strided"), (32, 32, "subm"), (32, 64, "strided"), (64, 64, "subm"), (64, 64, "strided"),
+                                           (64, 128, "down"), (128, 64, "subm")])
+def test_hip_input_norm_on_load_is_bit_identical_to_the_separate_pass(cuda, hip_lib, cin, cout, kind):
+    """sv_conv_next_input_norm: the planned conv (forward table and the data-gradient table) and the weight gradients (equal pieces and chunked) read X
+    through y = [relu](x * scale + shift) -- against the same kernels on the tensor sv_batchnorm_apply writes: bit-identical, with ReLU and without,
+    scales of both signs and a zero scale (an absent neighbour must contribute 0, not relu(shift)); sv_batchnorm_finalize_forward + sv_batchnorm_apply
+    against sv_batchnorm_relu_forward (same statistics kernel, same expression); the transform is consumed by ONE call and refused by the plain entry."""
+    import seevcn_amd.synth as synth
+    from seevcn_amd import _lib
+    from seevcn_amd.pcdet.ops import voxel_ops
+    from seevcn_amd.spconv import functional as Fsp
+    from seevcn_amd.spconv import norm
+    lib = hip_lib
+    pts, _ = synth.make_scene_batch(2, seed=2003, n_az=100)
+    g = dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.1, 0.1, 0.2], grid_size=[704, 800, 20])
+    _, coords, _ = voxel_ops.voxelize_dynamic(torch.from_numpy(pts).to(cuda), g["point_cloud_range"], g["voxel_size"], g["grid_size"], 2)
+    shape = [21, 800, 704]
+    if kind == "subm":
+        rb = Fsp.build_subm_rulebook(coords, 2, shape, [3, 3, 3])
+    elif kind == "strided":
+        rb = Fsp.build_sparse_rulebook(coords, 2, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    else:
+        rb = Fsp.build_sparse_rulebook(coords, 2, shape, [3, 1, 1], [2, 1, 1], [0, 0, 0])
+    K = rb.nbr_out.shape[0]
+    gen = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn(rb.n_in, cin, generator=gen).to(cuda)
+    w = (torch.randn(K, cin, cout, generator=gen) * 0.1).to(cuda)
+    dy = torch.randn(rb.n_out, cout, generator=gen).to(cuda)
+    scale = torch.randn(cin, generator=gen)
+    scale[0] = 0.0                                                                   # gamma == 0: every row's value is relu(shift), an absent neighbour's still 0
+    coef = torch.cat([scale, torch.randn(cin, generator=gen) * 0.5]).to(cuda)
+    ff, fb = Fsp.fragment_cache.get(w)
+    pf = rb.plan("fwd", cin, cout)
+    assert pf is not None
+    for relu in (1, 0):
+        y = torch.empty_like(x)
+        _lib.check(lib.sv_batchnorm_apply(_lib.ptr(x), x.shape[0], cin, _lib.ptr(coef), relu, _lib.ptr(y), _lib.stream()), "sv_batchnorm_apply")
+        ref = x * coef[:cin] + coef[cin:]
+        assert torch.allclose(y, torch.relu(ref) if relu else ref, rtol=1e-6, atol=1e-6)
+        want = Fsp.gather_gemm_planned(y, pf, ff, rb.n_out, K, cin, cout)
+        lib.sv_conv_next_input_norm(coef.data_ptr(), relu)
+        got = Fsp.gather_gemm_planned(x, pf, ff, rb.n_out, K, cin, cout)
+        assert torch.equal(got, want), (relu, "forward")
+        again = Fsp.gather_gemm_planned(y, pf, ff, rb.n_out, K, cin, cout)                # the transform was consumed: this call reads y as it is
+        assert torch.equal(again, want)
+        wp = rb.wgrad_plan(cin, cout)
+        for plan in ((wp, None) if wp is not None else (None,)):
+            want_w = Fsp.wgrad(y, rb.nbr_out, dy, K, cin, cout, plan=plan)
+            lib.sv_conv_next_input_norm(coef.data_ptr(), relu)
+            got_w = Fsp.wgrad(x, rb.nbr_out, dy, K, cin, cout, plan=plan)
+            assert torch.equal(got_w, want_w), (relu, "weight gradient", plan is not None)
+    # the data-gradient direction reads gradients, never activations -- but the kernel is the same: the input-major table with a transform on its operand
+    pb = rb.plan("bwd", cout, cin)
+    if pb is not None:
+        coef_o = torch.cat([torch.randn(cout, generator=gen), torch.randn(cout, generator=gen)]).to(cuda)
+        yo = torch.empty_like(dy)
+        _lib.check(lib.sv_batchnorm_apply(_lib.ptr(dy), dy.shape[0], cout, _lib.ptr(coef_o), 1, _lib.ptr(yo), _lib.stream()), "sv_batchnorm_apply")
+        want = Fsp.gather_gemm_planned(yo, pb, fb, rb.n_in, K, cout, cin)
+        lib.sv_conv_next_input_norm(coef_o.data_ptr(), 1)
+        assert torch.equal(Fsp.gather_gemm_planned(dy, pb, fb, rb.n_in, K, cout, cin), want)
+    # finalize + apply == the one-call forward (statistics from x itself), running statistics included
+    bn_a, bn_b = torch.nn.BatchNorm1d(cin, eps=1e-3, momentum=0.01).to(cuda).train(), torch.nn.BatchNorm1d(cin, eps=1e-3, momentum=0.01).to(cuda).train()
+    with torch.no_grad():
+        bn_a.weight.uniform_(-1.5, 1.5), bn_a.bias.uniform_(-0.5, 0.5)
+        bn_b.load_state_dict(bn_a.state_dict())
+    want_y, want_mean, want_istd = norm.bn_forward_raw(x, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var, 0.01, 1e-3, True, True, bn_a.num_batches_tracked)
+    coef2, mean, istd, y2 = torch.empty(2 * cin, device=cuda), torch.empty(cin, device=cuda), torch.empty(cin, device=cuda), torch.empty_like(x)
+    _lib.check(lib.sv_batchnorm_finalize_forward(_lib.ptr(x), x.shape[0], cin, _lib.ptr(bn_b.weight), _lib.ptr(bn_b.bias), _lib.ptr(bn_b.running_mean), _lib.ptr(bn_b.running_var),
+                                                 0.01, 1e-3, _lib.ptr(norm._scratch(cin, cuda)), 0, _lib.ptr(coef2), _lib.ptr(mean), _lib.ptr(istd),
+                                                 _lib.ptr(bn_b.num_batches_tracked), _lib.stream()), "sv_batchnorm_finalize_forward")
+    _lib.check(lib.sv_batchnorm_apply(_lib.ptr(x), x.shape[0], cin, _lib.ptr(coef2), 1, _lib.ptr(y2), _lib.stream()), "sv_batchnorm_apply")
+    assert torch.equal(y2, want_y) and torch.equal(mean, want_mean) and torch.equal(istd, want_istd)
+    assert torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var) and int(bn_b.num_batches_tracked) == 1
+    # the plain k-major entry cannot apply a transform: it must say so instead of ignoring it
+    lib.sv_conv_next_input_norm(coef.data_ptr(), 1)
+    with pytest.raises(_lib.SeevcnHipError, match="input transform"):
+        Fsp.gather_gemm(x, rb.nbr_out, w.permute(0, 2, 1).contiguous(), rb.n_out)
