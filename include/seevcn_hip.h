@@ -373,6 +373,17 @@ int sv_stack_farthest_point_sampling_multi(const float* xyz, const int32_t* xyz_
 size_t sv_fps_multi_error_offset(int batch);
 int sv_stack_farthest_point_sampling_multi_async(const float* xyz, const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int batch, int max_n,
                                                  int m, float* temp, void* multi_scratch, int32_t* idx, int write_through, void* stream);
+/* The same samples from ONE workgroup per scene that skips what a pick cannot change (seevcn extension; csrc/fps_bucket.hip): the scene's points are
+ * put in Morton-cell order (64 consecutive points = one bucket with a bounding box and its largest running distance), a round re-computes only the
+ * buckets whose box is nearer to the new pick than that maximum -- an exact test, IEEE rounding being monotone -- and reduces the arg-max over the
+ * per-bucket maxima.  Index-exact with sv_farthest_point_sampling / sv_stack_farthest_point_sampling including the tie rule; nothing to poll, nothing
+ * to read back.  Layouts: starts / counts given: stacked scenes, idx (batch, m) GLOBAL rows; both NULL: `batch` scenes of fixed_n (= max_n) points, idx
+ * scene-local.  sv_fps_bucket_applies: 2048 <= max_n <= 24576 and m > 1 (SEEVCN_FPS_BUCKET=0: never; SEEVCN_FPS_BUCKET_MIN overrides the lower bound);
+ * scratch: sv_fps_bucket_scratch_bytes(batch, max_n) bytes, any content. */
+int sv_fps_bucket_applies(int batch, int max_n, int m);
+size_t sv_fps_bucket_scratch_bytes(int batch, int max_n);
+int sv_farthest_point_sampling_bucketed(const float* xyz, const int32_t* xyz_batch_start, const int32_t* xyz_batch_cnt, int batch, int fixed_n, int max_n,
+                                        int m, void* scratch, int32_t* idx, void* stream);
 /* ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx) (src/ball_query.cpp:31-47,
  * kernel ball_query_gpu.cu:16-66): idx (M,nsample) scene-local indices of the first nsample points with d^2 < r^2 in index
  * order, padded with the first hit; idx[m][0] = -1 for an empty ball. */

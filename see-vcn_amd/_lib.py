@@ -106,6 +106,9 @@ SIGNATURES = {
     "sv_stack_farthest_point_sampling_multi": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_fps_multi_error_offset": (c_sz, [c_i]),
     "sv_stack_farthest_point_sampling_multi_async": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
+    "sv_fps_bucket_applies": (c_i, [c_i, c_i, c_i]),
+    "sv_fps_bucket_scratch_bytes": (c_sz, [c_i, c_i]),
+    "sv_farthest_point_sampling_bucketed": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_ball_query_stack": (c_i, [c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sv_ball_query_hash_scratch_bytes": (c_sz, [c_i64]),
     "sv_ball_query_stack_hashed": (c_i, [c_i, c_i, c_i64, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

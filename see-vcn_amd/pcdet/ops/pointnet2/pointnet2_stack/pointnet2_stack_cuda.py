@@ -93,17 +93,31 @@ def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt,
     return 1
 
 
+def fps_bucketed(points, starts, cnt, batch, fixed_n, max_n, m, idx):
+    """One workgroup per scene on spatial buckets (csrc/fps_bucket.hip) where it applies -> True; False: the caller takes the exhaustive kernels.
+    Same indices either way."""
+    lib = _lib.load()
+    if not lib.sv_fps_bucket_applies(int(batch), int(max_n), int(m)):
+        return False
+    scratch = torch.empty((int(lib.sv_fps_bucket_scratch_bytes(int(batch), int(max_n))),), dtype=torch.uint8, device=points.device)
+    _lib.check(lib.sv_farthest_point_sampling_bucketed(_lib.ptr(points), _lib.ptr(starts), _lib.ptr(cnt), int(batch), int(fixed_n), int(max_n), int(m),
+                                                       _lib.ptr(scratch), _lib.ptr(idx), _lib.stream()), "sv_farthest_point_sampling_bucketed")
+    return True
+
+
 def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     lib = _lib.load()
     _lib.require_cuda(points, idx)
+    if fps_bucketed(points, None, None, b, n, n, m, idx):
+        return 1
     rc = lib.sv_farthest_point_sampling(_lib.ptr(points), int(b), int(n), int(m), _lib.ptr(temp), _lib.ptr(idx), _lib.stream())
     _lib.check(rc, "sv_farthest_point_sampling")
     return 1
 
 
-def stack_farthest_point_sampling(points, xyz_batch_cnt, npoint, max_n=None):
+def stack_farthest_point_sampling(points, xyz_batch_cnt, npoint, max_n=None, bucketed=True):
     """All ragged scenes in one launch -> (batch, npoint) int32 GLOBAL row indices (seevcn extension; replaces the
-    per-scene loop of voxel_set_abstraction.py:250-256)."""
+    per-scene loop of voxel_set_abstraction.py:250-256).  bucketed=False: the exhaustive kernels only (tests, A/B runs)."""
     lib = _lib.load()
     _lib.require_cuda(points)
     starts, cnt = _starts(xyz_batch_cnt)
@@ -111,6 +125,8 @@ def stack_farthest_point_sampling(points, xyz_batch_cnt, npoint, max_n=None):
     if max_n is None:
         max_n = int(cnt.max().item())
     idx = torch.empty((batch, npoint), dtype=torch.int32, device=points.device)
+    if bucketed and fps_bucketed(points, starts, cnt, batch, 0, max_n, npoint, idx):
+        return idx
     temp = torch.empty((points.shape[0],), dtype=torch.float32, device=points.device) if max_n > 24576 else None
     # several workgroups per scene where that applies (sv_stack_farthest_point_sampling_multi decides; same indices either way)
     nbytes = int(lib.sv_fps_multi_scratch_bytes(batch))
@@ -130,6 +146,8 @@ class FpsHandle:
         self.idx, self.err, self.stream, self._rerun = idx, err, stream, rerun
 
     def result(self):
+        if self.err is None:                   # sampled by the one-workgroup bucket kernel: nothing that could have gone missing
+            return self.idx
         with torch.cuda.stream(self.stream):
             bad = int(self.err.item())
             if bad:
@@ -149,6 +167,8 @@ def stack_farthest_point_sampling_async(points, xyz_batch_cnt, npoint, max_n):
     starts, cnt = _starts(xyz_batch_cnt)
     batch = cnt.shape[0]
     idx = torch.empty((batch, npoint), dtype=torch.int32, device=points.device)
+    if fps_bucketed(points, starts, cnt, batch, 0, max_n, npoint, idx):
+        return FpsHandle(idx, None, torch.cuda.current_stream(), None)
     temp = torch.empty((points.shape[0],), dtype=torch.float32, device=points.device) if max_n > 24576 else None
     nbytes = int(lib.sv_fps_multi_scratch_bytes(batch))
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=points.device)

@@ -11,6 +11,8 @@ def fps(data, number):
     x = data.detach().float().contiguous()
     B, N, _ = x.shape
     idx = torch.empty((B, number), dtype=torch.int32, device=x.device)
-    temp = torch.empty((B, N), dtype=torch.float32, device=x.device)
-    _lib.check(lib.sv_farthest_point_sampling(_lib.ptr(x), B, N, int(number), _lib.ptr(temp), _lib.ptr(idx), _lib.stream()), "sv_farthest_point_sampling")
+    from ...pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda import fps_bucketed
+    if not fps_bucketed(x, None, None, B, N, N, int(number), idx):
+        temp = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        _lib.check(lib.sv_farthest_point_sampling(_lib.ptr(x), B, N, int(number), _lib.ptr(temp), _lib.ptr(idx), _lib.stream()), "sv_farthest_point_sampling")
     return torch.gather(data, 1, idx.long().unsqueeze(-1).expand(-1, -1, data.shape[2])).contiguous()

@@ -92,12 +92,73 @@ def test_hip_stack_fps_several_workgroups_per_scene_index_exact(cuda, hip_lib, c
     xyz = rng.normal(size=(sum(counts), 3)).astype(np.float32) * 20
     xyz[counts[0] // 2:counts[0]] = xyz[:counts[0] - counts[0] // 2]          # duplicates inside scene 0
     for _ in range(2):                                                         # twice: stale records of the first call must not match
-        idx = pu.stack_farthest_point_sample(torch.from_numpy(xyz).to(cuda), torch.tensor(counts, dtype=torch.int32, device=cuda), m).cpu().numpy()
+        idx = pu.stack_farthest_point_sample(torch.from_numpy(xyz).to(cuda), torch.tensor(counts, dtype=torch.int32, device=cuda), m, None, False).cpu().numpy()
         s = 0
         for b, c in enumerate(counts):
             ref = op2.farthest_point_sampling(xyz[s:s + c], m) + s
             assert np.array_equal(idx[b], ref), (b, np.nonzero(idx[b] != ref)[0][:5])
             s += c
+
+
+def _fps_cloud(kind, n, rng):
+    if kind == "gauss":
+        return (rng.normal(size=(n, 3)) * 20).astype(np.float32)
+    if kind == "sweep":                                   # lidar-like: rings on a ground plane + a few boxes, 70 x 80 x 4 m
+        r = rng.uniform(2, 50, n) ** 1.0
+        a = rng.uniform(-np.pi, np.pi, n)
+        z = np.where(rng.random(n) < 0.8, rng.normal(-1.6, 0.03, n), rng.uniform(-1.6, 2.0, n))
+        return np.stack([r * np.cos(a), r * np.sin(a), z], 1).astype(np.float32)
+    if kind == "lattice":                                 # integer lattice: masses of exactly equal distances
+        g = rng.integers(0, 12, size=(n, 3))
+        return g.astype(np.float32)
+    if kind == "dupes":                                   # 97 distinct points, each many times: m > distinct ends in all-zero distances
+        base = (rng.normal(size=(97, 3)) * 5).astype(np.float32)
+        return base[rng.integers(0, 97, n)]
+    raise ValueError(kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,counts,m", [("gauss", [2048], 256), ("gauss", [17000, 5000], 700), ("sweep", [17000, 17011], 1024), ("sweep", [24576], 300),
+                                           ("lattice", [4096, 3000], 600), ("dupes", [2500], 300), ("gauss", [3000, 0, 1, 70, 9000], 128)])
+def test_hip_fps_on_buckets_index_exact(cuda, hip_lib, kind, counts, m):
+    """csrc/fps_bucket.hip (Morton-cell order, buckets skipped when their box is farther than their largest running distance) against the
+    oracle: same picks in the same order -- ties (lattice, duplicates, more picks than distinct points), ragged batches with an empty scene, a
+    one-point scene and a scene smaller than a bucket, the largest scene the path takes."""
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as ps
+    rng = np.random.default_rng(len(counts) * 1000 + m)
+    xyz = np.concatenate([_fps_cloud(kind, c, rng) for c in counts]) if sum(counts) else np.zeros((0, 3), np.float32)
+    assert hip_lib.sv_fps_bucket_applies(len(counts), max(counts), m)
+    idx = ps.stack_farthest_point_sampling(torch.from_numpy(xyz).to(cuda), torch.tensor(counts, dtype=torch.int32, device=cuda), m, max(counts)).cpu().numpy()
+    s = 0
+    for b, c in enumerate(counts):
+        if c:
+            ref = op2.farthest_point_sampling(xyz[s:s + c], m) + s
+            assert np.array_equal(idx[b], ref), (b, np.nonzero(idx[b] != ref)[0][:5], idx[b][:8], ref[:8])
+        s += c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sweep", "gauss"])
+def test_hip_fps_on_buckets_equals_the_exhaustive_kernels_at_full_size(cuda, hip_lib, kind):
+    """4 scenes x ~17k points -> 4096 keypoints (the PV-RCNN sampling, source-nuscenes/pvrcnn.yaml:111) and the fixed-size layout (64 x 16384 -> 1024):
+    the bucket path and the exhaustive kernels pick the same rows."""
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as ps
+    from seevcn_amd.pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as PB
+    from seevcn_amd import _lib
+    rng = np.random.default_rng(17)
+    counts = [17000, 16411, 17000, 20480]
+    xyz = torch.from_numpy(np.concatenate([_fps_cloud(kind, c, rng) for c in counts])).to(cuda)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=cuda)
+    a = ps.stack_farthest_point_sampling(xyz, cnt, 4096, max(counts))
+    b = ps.stack_farthest_point_sampling(xyz, cnt, 4096, max(counts), bucketed=False)
+    assert torch.equal(a, b)
+    h = ps.stack_farthest_point_sampling_async(xyz, cnt, 4096, max(counts))
+    assert h.err is None and torch.equal(h.result(), b)
+    fixed = torch.from_numpy(np.stack([_fps_cloud(kind, 16384, rng) for _ in range(8)])).to(cuda)
+    got = PB.farthest_point_sample(fixed, 1024)
+    want = torch.empty_like(got)
+    _lib.check(hip_lib.sv_farthest_point_sampling(_lib.ptr(fixed), 8, 16384, 1024, None, _lib.ptr(want), _lib.stream()), "sv_farthest_point_sampling")
+    assert torch.equal(got, want)
 
 
 @pytest.mark.gpu
