@@ -1,8 +1,10 @@
 import copy
+import os
 
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.init import kaiming_normal_
 
 from .... import _lib
@@ -36,6 +38,63 @@ class SeparateHead(nn.Module):
 
     def forward(self, x):
         return {name: self.__getattr__(name)(x) for name in self.sep_head_dict}
+
+
+# All branches of all heads as three convolutions instead of 6 x 6 x 2 (seevcn: same parameters, same state_dict, same sums in another order).  One
+# 180 x 180 nuScenes map, forward + backward on one MI355X (tools/head_conv_probe.py, profiles/r05_head_conv_probe.txt): first layers 36 x (64 -> 64)
+# 5.04 ms -> one 64 -> 2304 convolution 2.57; 36 BatchNorm + ReLU 4.19 -> one over 2304 channels 0.84; second layers 36 x (64 -> k) 5.05 -> one
+# block-diagonal 2304 -> 108 convolution 2.89 (MIOpen's grouped form: 3.85) -- the small maps never filled the GPU and every launch cost its latency.
+MERGE_BRANCHES = os.environ.get("SEEVCN_CENTERHEAD_MERGED", "1") != "0"
+
+
+def _plain(m):
+    return not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
+
+
+def merged_branches(heads, x):
+    """[head(x) for head in heads] with every branch's first conv + BatchNorm + ReLU run as ONE convolution / ONE BatchNorm over the concatenated
+    channels and every last conv as ONE block-diagonal convolution.  Returns None when the branches are not all `conv-BN-ReLU, conv` of one width
+    on plain modules (the caller then runs them one by one, as center_head.py:43-45 does)."""
+    branches = [(hi, name, getattr(head, name)) for hi, head in enumerate(heads) for name in head.sep_head_dict]
+    if len(branches) < 2 or not x.is_cuda:
+        return None
+    c = x.shape[1]
+    for _, _, fc in branches:
+        if len(fc) != 2 or not isinstance(fc[0], nn.Sequential) or len(fc[0]) != 3:
+            return None
+        conv1, bn, act, conv2 = fc[0][0], fc[0][1], fc[0][2], fc[1]
+        ok = (isinstance(conv1, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU) and isinstance(conv2, nn.Conv2d)
+              and conv1.in_channels == c and conv1.out_channels == c and conv2.in_channels == c and conv2.bias is not None
+              and all(m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 for m in (conv1, conv2))
+              and (conv1.bias is None) == (branches[0][2][0][0].bias is None)
+              and bn.affine and bn.track_running_stats and bn.momentum == branches[0][2][0][1].momentum and bn.eps == branches[0][2][0][1].eps
+              and bn.training == branches[0][2][0][1].training and all(_plain(m) for m in (fc, fc[0], conv1, bn, act, conv2)))
+        if not ok:
+            return None
+    nb = len(branches)
+    conv1s, bns, conv2s = [b[2][0][0] for b in branches], [b[2][0][1] for b in branches], [b[2][1] for b in branches]
+    # first layers: (nb c, c, 3, 3)
+    y = F.conv2d(x, torch.cat([m.weight for m in conv1s], 0), None if conv1s[0].bias is None else torch.cat([m.bias for m in conv1s], 0), padding=1)
+    bn0 = bns[0]
+    gamma, beta = torch.cat([m.weight for m in bns], 0), torch.cat([m.bias for m in bns], 0)
+    mean, var = torch.cat([m.running_mean for m in bns], 0), torch.cat([m.running_var for m in bns], 0)
+    y = F.relu(F.batch_norm(y, mean, var, gamma, beta, bn0.training, bn0.momentum, bn0.eps))
+    if bn0.training:
+        with torch.no_grad():                                    # the running statistics back into the modules that own them
+            torch._foreach_copy_([m.running_mean for m in bns], list(mean.split(c)))
+            torch._foreach_copy_([m.running_var for m in bns], list(var.split(c)))
+            torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+    # last layers: branch b reads channels [b c, (b + 1) c) only -- a (nb kmax, nb c, 3, 3) weight that is zero off the diagonal blocks
+    kmax = max(m.out_channels for m in conv2s)
+    wp = torch.stack([F.pad(m.weight, (0, 0, 0, 0, 0, 0, 0, kmax - m.out_channels)) for m in conv2s], 0)          # (nb, kmax, c, 3, 3)
+    eye = torch.eye(nb, device=x.device, dtype=x.dtype)
+    wd = (wp[:, :, None] * eye[:, None, :, None, None, None]).reshape(nb * kmax, nb * c, 3, 3)
+    bp = torch.cat([F.pad(m.bias, (0, kmax - m.out_channels)) for m in conv2s], 0)
+    z = F.conv2d(y, wd, bp, padding=1)
+    out = [dict() for _ in heads]
+    for b, (hi, name, _) in enumerate(branches):
+        out[hi][name] = z[:, b * kmax:b * kmax + conv2s[b].out_channels]
+    return out
 
 
 class CenterHead(nn.Module):
@@ -170,7 +229,9 @@ class CenterHead(nn.Module):
 
     def forward(self, data_dict):
         x = self.shared_conv(data_dict['spatial_features_2d'])
-        pred_dicts = [head(x) for head in self.heads_list]
+        pred_dicts = merged_branches(self.heads_list, x) if MERGE_BRANCHES else None
+        if pred_dicts is None:
+            pred_dicts = [head(x) for head in self.heads_list]
         if self.training:
             self.forward_ret_dict['target_dicts'] = self.assign_targets(data_dict['gt_boxes'], feature_map_size=data_dict['spatial_features_2d'].size()[2:])
         self.forward_ret_dict['pred_dicts'] = pred_dicts

@@ -97,3 +97,62 @@ def test_hip_center_head_losses_and_decode_match_reference_golden(golden_dir, cu
             d = np.abs(pb - gb[i]).max(1) + np.abs(ps - gs[i]) + (pl != gl[i]) * 1e3
             hit += d.min() < 2e-3
         assert hit >= 0.99 * len(gb), (hit, len(gb))
+
+
+@pytest.mark.gpu
+def test_hip_center_head_merged_branches_equal_the_separate_ones(cuda, hip_lib):
+    """merged_branches (one 64 -> 36 x 64 convolution, one BatchNorm, one block-diagonal last convolution) against the 36 branch modules run one by
+    one on the same weights: every prediction map, every parameter gradient and the BatchNorm running statistics -- the same sums in another
+    order, held to 1e-4 of each tensor's scale; eval mode too; a head with a hook stands the merged form down."""
+    import copy
+    from seevcn_amd.pcdet.models.dense_heads import center_head as ch
+    inp = make_inputs()
+    feat = torch.from_numpy(inp['feat']).to(cuda)
+    a = _head().to(cuda).train()
+    with torch.no_grad():
+        for m in a.modules():                                   # non-trivial BatchNorm parameters and statistics
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5), m.bias.uniform_(-0.3, 0.3), m.running_mean.uniform_(-0.2, 0.2), m.running_var.uniform_(0.5, 2.0)
+    b = copy.deepcopy(a)
+
+    def run(head, merged, train):
+        head.train(train)
+        saved, ch.MERGE_BRANCHES = ch.MERGE_BRANCHES, merged
+        try:
+            x = head.shared_conv(feat)
+            preds = ch.merged_branches(head.heads_list, x) if merged else [h(x) for h in head.heads_list]
+        finally:
+            ch.MERGE_BRANCHES = saved
+        assert preds is not None
+        return preds
+
+    pa, pb = run(a, True, True), run(b, False, True)
+    gen = torch.Generator().manual_seed(3)
+    loss_a = loss_b = 0.0
+    for da, db in zip(pa, pb):
+        assert list(da) == list(db)
+        for k in da:
+            assert da[k].shape == db[k].shape
+            scale = float(db[k].abs().max())
+            assert float((da[k] - db[k]).abs().max()) <= 1e-4 * scale, (k, float((da[k] - db[k]).abs().max()), scale)
+            w = torch.randn(da[k].shape, generator=gen).to(cuda)
+            loss_a = loss_a + (da[k] * w).sum()
+            loss_b = loss_b + (db[k] * w).sum()
+    loss_a.backward(), loss_b.backward()
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None, n
+            continue
+        # a conv bias in front of a batch-statistics BatchNorm has gradient 0: what is left of it is rounding noise on either side (absolute floor)
+        scale = float(q.grad.abs().max())
+        assert float((p.grad - q.grad).abs().max()) <= 2e-4 * scale + 2e-4, (n, float((p.grad - q.grad).abs().max()), scale)
+    for (n, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.allclose(u.float(), v.float(), rtol=1e-5, atol=1e-6), n
+    assert int(a.heads_list[3].dim[0][1].num_batches_tracked) == 1
+    with torch.no_grad():
+        for da, db in zip(run(a, True, False), run(b, False, False)):
+            for k in da:
+                assert float((da[k] - db[k]).abs().max()) <= 1e-4 * float(db[k].abs().max()), k
+    handle = a.heads_list[2].rot[1].register_forward_hook(lambda *args: None)
+    assert ch.merged_branches(a.heads_list, a.shared_conv(feat)) is None
+    handle.remove()
