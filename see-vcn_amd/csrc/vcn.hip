@@ -10,6 +10,8 @@
 // weights keep PyTorch's (C_out, C_in) layout, so both GEMM operands are K-contiguous.
 #include <math.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -44,10 +46,10 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
 #define SEEVCN_GEMM_BK 16
 #endif
 #ifndef SEEVCN_GEMM_WGS
-#define SEEVCN_GEMM_WGS 3
+#define SEEVCN_GEMM_WGS 4
 #endif
 constexpr int BM = 128, BN = 128, BK = SEEVCN_GEMM_BK, LDP = BK + 4;     // K tile of the LDS stages (callers keep K % 32 == 0)
-constexpr int GEMM_ROW_THREADS = BK / 4, GEMM_ROWS_PER_PASS = 256 / GEMM_ROW_THREADS, GEMM_PASSES = BM / GEMM_ROWS_PER_PASS;
+constexpr int GEMM_ROW_THREADS = BK / 4, GEMM_ROWS_PER_PASS = 256 / GEMM_ROW_THREADS;
 
 struct GemmArgs {
   const float* A; int lda;
@@ -62,54 +64,46 @@ struct GemmArgs {
   int act; float slope;
   const int32_t* m_dev;     // optional: the true number of rows lives on the device (<= M, which then sizes the grid and the buffers)
   int k_chunk;              // EPI_PARTIAL: K range of a split (a multiple of BK); workgroup z takes [z * k_chunk, min(K, (z + 1) * k_chunk))
+  int n_tiles;              // column tiles of the launch (the grid is 1-D over row-block-major tiles when tile_mode != 0)
+  int tile_mode;            // 0: 128 x 128 tiles on a (N tiles, M tiles[, splits]) grid; 1: 64 x 128; 2: 64 x 64; -1: chosen by the kernel from *m_dev
 };
 
-template <int EPI>
-__global__ __launch_bounds__(256, SEEVCN_GEMM_WGS) void k_gemm_f32(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDP];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDP];
+// The tile body: 4 waves (2 x 2), each (32 MT) x (32 NT) of a (64 MT) x (64 NT) tile.  MT = NT = 2 is the 128 x 128 tile; the smaller ones exist for
+// products with few rows: VCN's distinct rows are ~15 k of a 65 536-row capacity, i.e. 115 row blocks of 128 -- 460 / 230 / 115 workgroups for
+// N = 512 / 256 / 128 on 256 CUs that hold three each (0.41 / 0.20 / 0.05 of the fp32 MFMA peak, tools/vcn_gemm_trace.py).  Every output element sums
+// its K products in the same order whatever the tile shape: the results are bit-identical.
+template <int EPI, int MT, int NT>
+__device__ __forceinline__ void gemm_tile(GemmArgs& g, int m0, int n0, float (*As)[BM * LDP], float (*Bs)[BN * LDP]) {
+  constexpr int TM = 64 * MT, TN = 64 * NT, PA = TM / GEMM_ROWS_PER_PASS, PB = TN / GEMM_ROWS_PER_PASS;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of the
-  // (row-block major) tile list: the N-tiles that share an A row-block then hit the same L2 instead of 8 different ones.
-  int lin = blockIdx.y * gridDim.x + blockIdx.x;
-  int total = gridDim.x * gridDim.y;
-  if (g.m_dev) {
-    // rows counted on the device (VCN's distinct rows: no host read): the launch is sized for the capacity, the tiles past the count leave at
-    // once, and the XCD-aware order is made over the real tiles -- the first `total` workgroup ids, dealt to the XCDs round-robin like any launch
-    const int m_real = min(*g.m_dev, g.M);
-    g.M = m_real;
-    total = (int)gridDim.x * ((m_real + BM - 1) / BM);
-    if (lin >= total) return;
-  }
-  if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
-  const int m0 = (lin / (int)gridDim.x) * BM, n0 = (lin % (int)gridDim.x) * BN;
   const int lr = tid / GEMM_ROW_THREADS, lc = (tid % GEMM_ROW_THREADS) * 4;  // staging: row lr (+GEMM_ROWS_PER_PASS*i), k offset lc
 
-  float4 ra[GEMM_PASSES], rb[GEMM_PASSES];
+  float4 ra[PA], rb[PB];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < GEMM_PASSES; ++i) {
-      const int r = lr + GEMM_ROWS_PER_PASS * i;
-      const int m = m0 + r, n = n0 + r;
+    for (int i = 0; i < PA; ++i) {
+      const int m = m0 + lr + GEMM_ROWS_PER_PASS * i;
       ra[i] = (m < g.M) ? *reinterpret_cast<const float4*>(g.A + (int64_t)m * g.lda + k0 + lc) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int n = n0 + lr + GEMM_ROWS_PER_PASS * i;
       rb[i] = (n < g.N) ? *reinterpret_cast<const float4*>(g.W + (int64_t)n * g.ldw + k0 + lc) : make_float4(0, 0, 0, 0);
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < GEMM_PASSES; ++i) {
-      const int r = lr + GEMM_ROWS_PER_PASS * i;
-      *reinterpret_cast<float4*>(&As[buf][r * LDP + lc]) = ra[i];
-      *reinterpret_cast<float4*>(&Bs[buf][r * LDP + lc]) = rb[i];
-    }
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<float4*>(&As[buf][(lr + GEMM_ROWS_PER_PASS * i) * LDP + lc]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) *reinterpret_cast<float4*>(&Bs[buf][(lr + GEMM_ROWS_PER_PASS * i) * LDP + lc]) = rb[i];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -118,36 +112,35 @@ __global__ __launch_bounds__(256, SEEVCN_GEMM_WGS) void k_gemm_f32(GemmArgs g) {
   gload(k_begin);
   lstore(0);
   __syncthreads();
-  const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), kh = 4 * (lane >> 5);
+  const int arow = wm * 32 * MT + (lane & 31), brow = wn * 32 * NT + (lane & 31), kh = 4 * (lane >> 5);
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload(k_begin + (kt + 1) * BK);
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
-      float4 a[2], b[2];
+      float4 a[MT], b[NT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const float4*>(&As[buf][(arow + 32 * i) * LDP + kg * 8 + kh]);
-        b[i] = *reinterpret_cast<const float4*>(&Bs[buf][(brow + 32 * i) * LDP + kg * 8 + kh]);
-      }
-      // the four accumulators in turn: consecutive MFMAs never share one (written tile by tile, hipcc alternated two of them: every MFMA waited
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(&As[buf][(arow + 32 * i) * LDP + kg * 8 + kh]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[buf][(brow + 32 * j) * LDP + kg * 8 + kh]);
+      // the accumulators in turn: consecutive MFMAs never share one (written tile by tile, hipcc alternated two of them: every MFMA waited
       // for the one before the last)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
@@ -155,18 +148,97 @@ __global__ __launch_bounds__(256, SEEVCN_GEMM_WGS) void k_gemm_f32(GemmArgs g) {
 
   // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int h = lane >> 5;
+  if constexpr ((EPI & EPI_PARTIAL) == 0) {
+    // the common tile -- every row and column inside the matrix, every row of ONE group (rows of a group are contiguous) -- without the per-element
+    // tests, group look-ups and exec-mask branches of the general form below (64 outputs per lane: they were a third of a K = 256 tile's time).
+    // Same expression per element, (acc + bias) + group bias -> activation: bit-identical.
+    bool fast = m0 + TM <= g.M && n0 + TN <= g.N;
+    int g0 = 0, g1 = 0, split = TM;                             // rows [0, split) of the tile belong to g0, [split, TM) to g1
+    if (fast && (g.group_bias || (EPI & EPI_MAX))) {
+      const int last = m0 + TM - 1;
+      g0 = g.row_group ? g.row_group[m0] : m0 / g.rows_per_group;
+      g1 = g.row_group ? g.row_group[last] : last / g.rows_per_group;
+      if (g1 != g0) {
+        // two groups (an object's rows end inside the tile: every other 128-row tile of a batch of ~230-row objects): where does the second
+        // start?  Groups are non-decreasing, so the tile holds exactly two iff the first row that is not g0's is g1's.
+        if (g.row_group) {
+          const bool da = g.row_group[m0 + lane] != g0, db = TM > 64 ? g.row_group[m0 + (TM > 64 ? 64 : 0) + lane] != g0 : false;
+          const unsigned long long ba = __ballot(da), bb = __ballot(db);
+          split = ba ? __builtin_ctzll(ba) : 64 + (bb ? __builtin_ctzll(bb) : 63);
+          fast = g.row_group[m0 + split] == g1;
+        } else {
+          split = (g0 + 1) * g.rows_per_group - m0;
+          fast = g1 == g0 + 1;
+        }
+      }
+    }
+    if (fast) {
+      const bool two = g1 != g0;                                // uniform
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * 32 * NT + j * 32 + (lane & 31);
+        const float bv = g.bias ? g.bias[col] : 0.f;
+        const float gv0 = g.group_bias ? g.group_bias[(int64_t)g0 * g.N + col] : 0.f;
+        float* out = (EPI & EPI_STORE) ? g.C + (int64_t)(m0 + wm * 32 * MT + 4 * h) * g.ldc + col : nullptr;
+        if (!two) {
+          float cmax = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[i][j][r] + bv;
+              if (g.group_bias) v += gv0;
+              v = apply_act(v, g.act, g.slope);
+              if (EPI & EPI_STORE) out[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc] = v;
+              if (EPI & EPI_MAX) cmax = fmaxf(cmax, v);
+            }
+          }
+          if (EPI & EPI_MAX) {
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+            if (h == 0) atomic_max_f32(&g.gmax[(int64_t)g0 * g.N + col], cmax);
+          }
+        } else {
+          const float gv1 = g.group_bias ? g.group_bias[(int64_t)g1 * g.N + col] : 0.f;
+          const int rel0 = wm * 32 * MT + 4 * h;                // tile-relative row of (i = 0, r = 0)
+          float cmax0 = -INFINITY, cmax1 = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool second = rel0 + i * 32 + (r & 3) + 8 * (r >> 2) >= split;
+              float v = acc[i][j][r] + bv;
+              if (g.group_bias) v += second ? gv1 : gv0;
+              v = apply_act(v, g.act, g.slope);
+              if (EPI & EPI_STORE) out[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc] = v;
+              if (EPI & EPI_MAX) {
+                cmax0 = fmaxf(cmax0, second ? -INFINITY : v);
+                cmax1 = fmaxf(cmax1, second ? v : -INFINITY);
+              }
+            }
+          }
+          if (EPI & EPI_MAX) {
+            cmax0 = fmaxf(cmax0, __shfl_xor(cmax0, 32, 64));
+            cmax1 = fmaxf(cmax1, __shfl_xor(cmax1, 32, 64));
+            if (h == 0 && cmax0 > -INFINITY) atomic_max_f32(&g.gmax[(int64_t)g0 * g.N + col], cmax0);
+            if (h == 0 && cmax1 > -INFINITY) atomic_max_f32(&g.gmax[(int64_t)g1 * g.N + col], cmax1);
+          }
+        }
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * 32 * NT + j * 32 + (lane & 31);
     const bool cok = col < g.N;
     const float bv = (cok && g.bias) ? g.bias[col] : 0.f;
     float cmax = -INFINITY;
     int cgroup = -1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int row = m0 + wm * 32 * MT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (!cok || row >= g.M) continue;
         if constexpr ((EPI & EPI_PARTIAL) != 0) {
           g.C[((int64_t)blockIdx.z * g.M + row) * g.ldc + col] = acc[i][j][r];
@@ -200,6 +272,47 @@ __global__ __launch_bounds__(256, SEEVCN_GEMM_WGS) void k_gemm_f32(GemmArgs g) {
         }
       }
     }
+  }
+}
+
+// tile shape for (rows, N): the largest tile that still gives the chip >= GEMM_FILL workgroups (256 CUs x 3 resident), 128 x 128 when none does not
+constexpr int GEMM_FILL = 600;
+__host__ __device__ inline int gemm_tile_mode(int rows, int N) {
+  const int t128 = ((rows + 127) / 128) * ((N + 127) / 128);
+  if (t128 >= GEMM_FILL) return 0;
+  if (2 * t128 >= GEMM_FILL || N <= 64) return 1;              // 64 x 128
+  return 2;                                                     // 64 x 64
+}
+__host__ __device__ inline int gemm_tiles(int rows, int N, int mode) {
+  return mode == 0 ? ((rows + 127) / 128) * ((N + 127) / 128) : mode == 1 ? ((rows + 63) / 64) * ((N + 127) / 128) : ((rows + 63) / 64) * ((N + 63) / 64);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, SEEVCN_GEMM_WGS) void k_gemm_f32(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDP];
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of the
+  // (row-block major) tile list: the N-tiles that share an A row-block then hit the same L2 instead of 8 different ones.
+  int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  int mode = g.tile_mode;
+  if (g.m_dev) {
+    // rows counted on the device (VCN's distinct rows: no host read): the launch is sized for the capacity (and for the finest tiling), the tile
+    // shape is chosen here from the real count, the workgroups past the last real tile leave at once, and the XCD-aware order is made over the real
+    // tiles -- the first `total` workgroup ids, dealt to the XCDs round-robin like any launch
+    g.M = min(*g.m_dev, g.M);
+    if (mode < 0) mode = gemm_tile_mode(g.M, g.N);
+  }
+  const int n_tiles = (EPI & EPI_PARTIAL) ? (int)gridDim.x : mode <= 1 ? (g.N + 127) / 128 : (g.N + 63) / 64;
+  const int total = (EPI & EPI_PARTIAL) ? (int)(gridDim.x * gridDim.y) : gemm_tiles(g.M, g.N, mode);
+  if (lin >= total) return;
+  if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+  const int mt = lin / n_tiles, nt = lin % n_tiles;
+  if constexpr ((EPI & EPI_PARTIAL) != 0) {
+    gemm_tile<EPI, 2, 2>(g, mt * 128, nt * 128, As, Bs);
+  } else {
+    if (mode == 0) gemm_tile<EPI, 2, 2>(g, mt * 128, nt * 128, As, Bs);
+    else if (mode == 1) gemm_tile<EPI, 1, 2>(g, mt * 64, nt * 128, As, Bs);
+    else gemm_tile<EPI, 1, 1>(g, mt * 64, nt * 64, As, Bs);
   }
 }
 
@@ -327,8 +440,13 @@ static int gemm_launch(const float* A, int lda, const float* W, int ldw, const f
   SV_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "gemm_bias_act: A/W must be 16-byte aligned");
   SV_CHECK_ARG(rows_per_group >= 1, "gemm_bias_act: rows_per_group must be >= 1");
   SV_CHECK_ARG(act >= 0 && act <= 2, "gemm_bias_act: unknown activation %d", act);
-  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, row_group, C, ldc, group_max, M, N, K, act, slope, m_dev, 0};
-  dim3 grid(sv_div_up(N, BN), sv_div_up(M, BM));
+  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, row_group, C, ldc, group_max, M, N, K, act, slope, m_dev, 0, 0, 0};
+  // tile shape: from M when the host knows it; with the row count on the device the kernel chooses (mode -1) and the 1-D grid covers the finest
+  // tiling of the capacity.  SEEVCN_GEMM_TILES=0: 128 x 128 always (A/B runs)
+  static const bool big_only = getenv("SEEVCN_GEMM_TILES") && atoi(getenv("SEEVCN_GEMM_TILES")) == 0;
+  g.tile_mode = big_only ? 0 : (m_dev ? -1 : gemm_tile_mode(M, N));
+  const int wgs = g.tile_mode < 0 ? std::max(std::max(gemm_tiles(M, N, 0), gemm_tiles(M, N, 1)), gemm_tiles(M, N, 2)) : gemm_tiles(M, N, g.tile_mode);
+  dim3 grid(wgs);
   hipStream_t st = sv_stream(stream);
   if (M <= 64 && C && !group_max && !group_bias && !row_group && !m_dev) {
     hipLaunchKernelGGL(k_gemm_small_m, dim3(sv_div_up(N, 16)), dim3(256), 0, st, g);
@@ -362,7 +480,7 @@ extern "C" int sv_gemm_bias_act_splitk(const float* A, int lda, const float* W, 
   SV_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "gemm_bias_act_splitk: A/W must be 16-byte aligned");
   SV_CHECK_ARG(rows_per_group >= 1 && act >= 0 && act <= 2 && ldc >= N, "gemm_bias_act_splitk: bad arguments");
   const int chunk = sv_div_up(sv_div_up(K, splits), BK) * BK;
-  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, nullptr, reinterpret_cast<float*>(scratch), N, nullptr, M, N, K, act, slope, nullptr, chunk};
+  GemmArgs g{A, lda, W, ldw, bias, group_bias, rows_per_group, nullptr, reinterpret_cast<float*>(scratch), N, nullptr, M, N, K, act, slope, nullptr, chunk, 0, 0};
   hipStream_t st = sv_stream(stream);
   hipLaunchKernelGGL(k_gemm_f32<EPI_PARTIAL>, dim3(sv_div_up(N, BN), sv_div_up(M, BM), splits), dim3(256), 0, st, g);
   g.C = C, g.ldc = ldc;
