@@ -190,13 +190,14 @@ class VCN_VC(nn.Module):
         pts = centred.view(bs * n, 3)
         h = L.pointwise3(pts, w0, b0, L.ACT_LRELU, sel=sel, m_dev=u_dev, tag="pose_h0")
         h = L.gemm(h, w1, b1, L.ACT_LRELU, row_group=rg if u_dev is not None else None, m_dev=u_dev, tag="pose_h1")
-        pose_feat = L.neg_inf((bs, w2.shape[0]), dev)
+        pool = L.NegInfPool(bs * (w2.shape[0] + p["enc"]["w1b"].shape[0] + p["enc"]["w2b"].shape[0]), dev)
+        pose_feat = pool.take((bs, w2.shape[0]))
         L.gemm(h, w2, b2, L.ACT_NONE, rows_per_group=n, store=False, group_max=pose_feat, row_group=rg, m_dev=u_dev)
         rel_pose = L.run_fc(p["pose_fc"], pose_feat, L.ACT_LRELU)                     # (B, 9)   :194
         pc_cn = torch.empty_like(x)
         _lib.check(lib.sv_vcn_vc_pose(_lib.ptr(fview), bs, n, _lib.ptr(rel_pose), _lib.ptr(state), _lib.ptr(pc_cn), st), "sv_vcn_vc_pose")
         pts = pc_cn.view(bs * n, 3)
-        feat = L.encode(p["enc"], pts, bs, n, row_group=rg, sel=sel, m_dev=u_dev)      # (B, 1024) :203
+        feat = L.encode(p["enc"], pts, bs, n, row_group=rg, sel=sel, m_dev=u_dev, pool=pool)      # (B, 1024) :203
         coarse_cn = L.run_fc(p["shape_fc"], feat, L.ACT_RELU)                         # (B, 3072) :204
         nc = self.number_coarse
         coarse = torch.empty((bs, nc, 3), dtype=torch.float32, device=dev)

@@ -154,6 +154,21 @@ def neg_inf(shape, device):
     return t
 
 
+class NegInfPool:
+    """The -inf start values of a forward's column-max outputs from ONE allocation and ONE fill launch (three 5 us launches in VCN_VC's forward
+    otherwise); take() hands out consecutive (rows, cols) views."""
+
+    def __init__(self, numel, device):
+        self.buf, self.used = neg_inf((int(numel),), device), 0
+
+    def take(self, shape):
+        n = int(shape[0]) * int(shape[1])
+        assert self.used + n <= self.buf.numel()
+        out = self.buf[self.used:self.used + n].view(shape)
+        self.used += n
+        return out
+
+
 def prepare_encoder(enc):
     """Weights of FeatureEncoder in execution form. mlp_conv2[0] is split into its global (first 256 inputs)
     and local halves: the global half multiplies a per-object constant, so it becomes a per-object bias."""
@@ -166,16 +181,16 @@ def prepare_encoder(enc):
                 b2a=b2a, w2b=w2b, b2b=b2b)
 
 
-def encode(p, pts, batch, n, row_group=None, sel=None, m_dev=None):
+def encode(p, pts, batch, n, row_group=None, sel=None, m_dev=None, pool=None):
     """FeatureEncoder.forward (VCN_VC.py:97-106) on channel-last activations. pts: (B*n, 3); with row_group only the distinct rows
     pts[sel] are run (row_group = their objects; m_dev: their number on the device, sel / row_group at capacity) -> (B, 1024)."""
     dev = pts.device
     f1 = pointwise3(pts, p["w1a"], p["b1a"], ACT_RELU, sel=sel, m_dev=m_dev, tag="enc_f1")         # conv 3->128 + BN + ReLU
-    g1 = neg_inf((batch, p["w1b"].shape[0]), dev)
+    g1 = pool.take((batch, p["w1b"].shape[0])) if pool is not None else neg_inf((batch, p["w1b"].shape[0]), dev)
     local = gemm(f1, p["w1b"], p["b1b"], ACT_NONE, rows_per_group=n, group_max=g1, row_group=row_group, m_dev=m_dev, tag="enc_local")  # conv 128->256, max over n
     gb = gemm(g1, p["w2a_g"], None, ACT_NONE)                                        # global half of conv 512->512
     f2 = gemm(local, p["w2a_l"], p["b2a"], ACT_RELU, group_bias=gb, rows_per_group=n, row_group=row_group, m_dev=m_dev, tag="enc_f2")  # + BN + ReLU
-    g2 = neg_inf((batch, p["w2b"].shape[0]), dev)
+    g2 = pool.take((batch, p["w2b"].shape[0])) if pool is not None else neg_inf((batch, p["w2b"].shape[0]), dev)
     gemm(f2, p["w2b"], p["b2b"], ACT_NONE, rows_per_group=n, store=False, group_max=g2, row_group=row_group, m_dev=m_dev)  # conv 512->1024, max over n
     return g2
 
