@@ -41,9 +41,9 @@ class SeparateHead(nn.Module):
 
 
 # All branches of all heads as three convolutions instead of 6 x 6 x 2 (seevcn: same parameters, same state_dict, same sums in another order).  One
-# 180 x 180 nuScenes map, forward + backward on one MI355X (tools/head_conv_probe.py, profiles/r05_head_conv_probe.txt): first layers 36 x (64 -> 64)
-# 5.04 ms -> one 64 -> 2304 convolution 2.57; 36 BatchNorm + ReLU 4.19 -> one over 2304 channels 0.84; second layers 36 x (64 -> k) 5.05 -> one
-# block-diagonal 2304 -> 108 convolution 2.89 (MIOpen's grouped form: 3.85) -- the small maps never filled the GPU and every launch cost its latency.
+# 180 x 180 nuScenes map: 1 997 -> 1 455 launches per CenterPoint train step, step 23.6 -> 23.2 ms; GPU time is unchanged (the block-diagonal last
+# convolution does 36x the needed arithmetic, which eats what the fewer BatchNorm / transpose / weight-gradient launches save -- in isolation the
+# merged form looks 2x faster only because a chain of small launches on an idle GPU is latency; profiles/r05_head_conv_probe.txt).
 MERGE_BRANCHES = os.environ.get("SEEVCN_CENTERHEAD_MERGED", "1") != "0"
 
 
