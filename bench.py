@@ -527,6 +527,9 @@ def main():
                     "two launch-bound Python threads take turns on the GIL)")
     ap.add_argument("--spinup", type=float, default=0.0, help="seconds of untimed device spin-up (dense GEMMs) before the warm-up steps (A/B switch: a GPU "
                     "that idled may start below its sustained clocks; measured here: no effect, default off)")
+    ap.add_argument("--roofline-only", type=int, default=0, metavar="REPS", help="no timed steps: warm up, then REPS passes of the launch-list timing the "
+                    "`roofline` block is made of (one stream, weight gradients in line) and print that block -- the command tools/evidence.sh puts under "
+                    "rocprofv3 --kernel-trace --stats, so that profiles/ holds the trace of exactly the launches the line's roofline times")
     ap.add_argument("--config", default="main", choices=("main", "stageA", "second", "pvrcnn", "centerpoint"),
                     help="main (default): the headline step; the others are side modes over the other BASELINE configs (bench_configs.py)")
     args = ap.parse_args()
@@ -572,6 +575,18 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, fused=True)     # one multi-tensor kernel instead of ~70 small launches
     inputs = (points, objects, scene)
+
+    if args.roofline_only:
+        for _ in range(max(args.warmup, 3)):
+            run_step(model, opt, params, inputs, world)
+        torch.cuda.synchronize()
+        name, c_ms, c_flop, c_bytes, c_launches, c_step_ms = measure_spconv_kernel(model, opt, params, inputs, 1, reps=args.roofline_only)
+        if rank == 0:
+            c_ach = c_flop / (c_ms * 1e-3) / 1e12
+            print(json.dumps({"roofline_only": True, "reps": args.roofline_only, "kernel": f"{name}G>", "avg_launch_ms": round(c_ms, 4), "launches_per_step": c_launches,
+                              "achieved": round(c_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(c_ach / PEAK_F32_MFMA_TFLOPS, 4),
+                              "algorithmic_flop_per_launch": round(c_flop)}))
+        return
 
     device_spinup(args.spinup, device)
     # SEEVCN_BENCH_MAIN_PRIORITY (A/B): the trained side on a stream of its own with this priority instead of the default stream (priority 0)

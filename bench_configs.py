@@ -43,6 +43,10 @@ def _train_step(net, batch, opt, params, world, allreduce):
 
 def build(config, rank, device, scenes=None):
     """-> (step() callable, units per step on this rank, unit name, metric name, config dict)"""
+    # SEEVCN_MIOPEN_FIND=1: torch.backends.cudnn.benchmark -- MIOpen then times its applicable solvers for every new convolution shape (in the warm-up
+    # steps) instead of taking the heuristic pick of immediate mode.  A runtime switch of the library the dense 2-D part stays on, not a code path here.
+    if os.environ.get("SEEVCN_MIOPEN_FIND") is not None:
+        torch.backends.cudnn.benchmark = os.environ["SEEVCN_MIOPEN_FIND"] == "1"
     import seevcn_amd.synth as synth
     from seevcn_amd.pcdet import model_cfgs as C
     if config == "stageA":

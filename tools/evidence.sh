@@ -19,6 +19,7 @@ fi
 timeout 900 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -c 600 gpurun_out/${TAG}_bench.json
 TOP=8 tools/profile.sh ${TAG}_main 20 2>&1 | head -10
+tools/roofline_pass.sh ${TAG} 2>&1 | tail -8
 tools/traffic.sh ${TAG} 2>&1 | tail -6
 tools/mfma_busy.sh ${TAG} 2>&1 | tail -8
 : > gpurun_out/${TAG}_side_modes.jsonl
@@ -33,6 +34,8 @@ tail -3 gpurun_out/${TAG}_spconv_micro.txt
 # farthest point sampling: bucket statistics (library variant built with -DFB_STATS: tools/build_variant.sh fbstats "-DFB_STATS" fps_bucket) and the
 # dependent-issue rate the rounds are made of
 [ -f see-vcn_amd/lib/variants/libseevcn_hip_fbstats.so ] && SEEVCN_LIB=see-vcn_amd/lib/variants/libseevcn_hip_fbstats.so timeout 200 python3 tools/fps_stats.py > gpurun_out/${TAG}_fps_stats.txt 2>&1
+timeout 200 python3 tools/vcn_gemm_trace.py > gpurun_out/${TAG}_vcn_gemm_trace.txt 2>&1
+timeout 300 python3 tools/vcn_gemm_micro.py > gpurun_out/${TAG}_vcn_gemm_micro.txt 2>&1
 (cd tools/ubench && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/valu_clock valu_clock.hip 2>/dev/null && /tmp/valu_clock | head -10) > gpurun_out/${TAG}_valu_clock.txt 2>&1
 timeout 300 python3 tools/host_time.py > gpurun_out/${TAG}_host_time.txt 2>&1
 for c in main pvrcnn centerpoint second; do timeout 300 python3 tools/sync_trace.py $c > gpurun_out/${TAG}_sync_trace_$c.txt 2>&1; done
