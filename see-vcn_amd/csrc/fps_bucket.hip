@@ -18,8 +18,6 @@
 // Rounds: 1.9 us (16 workgroups per scene exchanging records through L2, k_fps_multi) -> see profiles/r05_*_fps_micro.txt.
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "common.h"
 
 namespace {
@@ -77,15 +75,6 @@ __device__ __forceinline__ float fb_max16_nonneg(float f) {
       : "+v"(v));
   return __int_as_float(__builtin_amdgcn_readlane(v, 0));
 }
-
-// v[lane I] = s.  v_writelane: no `lane == i` mask (48 of those, hoisted out of the loop, were 96 scalar registers and their spills); s_nop: the
-// scalar comes from a v_readlane
-template <int I>
-__device__ __forceinline__ void fb_writelane(float& v, float s) {
-  asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(I));
-}
-
-__device__ __forceinline__ void fb_pin(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
 
 // A wave's register file of one quantity: P values per lane, addressed by a WAVE-UNIFORM slot number that is only known at run time (the slot of a
 // flagged bucket).  Held as ONE LLVM vector value, so that `v[s]` is the hardware's indexed register access (s_set_gpr_idx_on / v_mov /
@@ -311,6 +300,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_fps_bucket(const float* __restri
         const float d2 = fb_min(d, pt.get(s));
         pt.set(s, d2);
         const float mx = fb_wave_max_nonneg(d2);
+        // bmax[lane s] = mx: one v_writelane (lane select in m0), no `lane == s` mask; s_nop: the scalar comes from the v_readlane just above
         asm volatile("s_nop 3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(bmax) : "s"(mx), "s"(s) : "m0");
       } while (mask != 0ull);
       FB_STAMP(1)

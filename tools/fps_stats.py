@@ -23,6 +23,8 @@ def main():
     fn = raw.sv_fps_bucket_stats
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
     out = (ctypes.c_ulonglong * 24)()
+    print("# segment cycles come from s_memtime stamps, each waiting for every outstanding LDS / scalar-memory return of its wave: the instrumented round is\n"
+          "# ~1.7x the production one (0.66 us = 1 580 cycles) and a segment that ends in an LDS write (publish) carries that wait -- a ranking, not a budget")
     for kind in ("sweep", "gauss"):
         for counts, m in (([17000] * 4, 4096), ([5000] * 4, 2048)):
             xyz = torch.from_numpy(np.concatenate([cloud(kind, c, rng) for c in counts])).to(dev)
