@@ -738,6 +738,14 @@ int sv_project_lidar_to_image_nuscenes(const float* points, int64_t n_points, in
 size_t sv_polygon_masks_scratch_bytes(int n_polygons, int img_h, int img_w);
 int sv_polygons_to_masks(const double* xy, const int32_t* poly_off, const int32_t* poly_inst, int n_polygons, int max_vertices, int n_instances, int img_h,
                          int img_w, void* scratch, uint8_t* masks, void* stream);
+/* The same with every polygon's boundary moved inwards first (the reference's shrink_instance_masks, shared_utils.py:295-330: Polygon.buffer(-d) with
+ * d = SHRINK_MASK_PERCENTAGE % of the half diagonal of the polygon's bounding box, then annToMask): a pixel of the polygon's mask is kept when its
+ * centre lies at least shrink[p] from every edge of polygon p.  This is the region GEOS's negative buffer describes, sampled at the pixel centres --
+ * NOT its vertex list (arcs cut into 16 chords per quadrant, vertices truncated to int, rasterised again): masks agree except in a band of about one
+ * pixel along the shrunken boundary (shapely is not available here: unpinned).  shrink NULL = no shrinking; kept (n_polygons int32, nullable): pixels
+ * each polygon wrote, 0 = its shrunken part is empty (the caller then falls back like shared_utils.py:325-326). */
+int sv_polygons_to_masks_shrunk(const double* xy, const int32_t* poly_off, const int32_t* poly_inst, const double* shrink, int n_polygons, int max_vertices,
+                                int n_instances, int img_h, int img_w, void* scratch, uint8_t* masks, int32_t* kept, void* stream);
 int sv_points_in_masks(const int32_t* uv, const uint8_t* fov, int64_t n_points, const uint8_t* masks, const int32_t* rects,
                        int n_instances, int img_w, int img_h, int64_t cap, int32_t* out_index, int32_t* out_count, void* stream);
 /* isolate_det_pts (SEE_VCN.py:144-181) and db_scan(..., return_largest_cluster=True) (shared_utils.py:395-409), one workgroup

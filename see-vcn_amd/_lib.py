@@ -153,6 +153,7 @@ SIGNATURES = {
     "sv_project_lidar_to_image_nuscenes": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p]),
     "sv_polygon_masks_scratch_bytes": (c_sz, [c_i, c_i, c_i]),
     "sv_polygons_to_masks": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "sv_polygons_to_masks_shrunk": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "sv_points_in_masks": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i, c_i, c_i, c_i64, c_p, c_p, c_p]),
     "sv_isolate_cluster_scratch_bytes": (c_i64, [c_i, c_i64]),
     "sv_isolate_largest_cluster": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i64, c_d, c_d, c_d, c_d, c_d, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),

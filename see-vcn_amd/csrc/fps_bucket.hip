@@ -300,8 +300,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_fps_bucket(const float* __restri
         const float d2 = fb_min(d, pt.get(s));
         pt.set(s, d2);
         const float mx = fb_wave_max_nonneg(d2);
-        // bmax[lane s] = mx: one v_writelane (lane select in m0), no `lane == s` mask; s_nop: the scalar comes from the v_readlane just above
-        asm volatile("s_nop 3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(bmax) : "s"(mx), "s"(s) : "m0");
+        bmax = lane == s ? mx : bmax;
       } while (mask != 0ull);
       FB_STAMP(1)
       // 2. the wave's candidate from the bucket maxima

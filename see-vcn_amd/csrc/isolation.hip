@@ -499,8 +499,11 @@ __device__ __forceinline__ void pm_point(const int* sx, const int* sy, const int
   }
 }
 
+// shrink (nullable): per polygon, the distance its boundary moves inwards (shared_utils.py:295-330 shrinks by Polygon.buffer(-d)): a pixel of the
+// polygon is then kept only if it lies at least d from every edge.  kept (nullable): pixels written per polygon (0 = the shrunken part is empty).
 __global__ __launch_bounds__(PM_THREADS) void k_polygon_masks(const double* __restrict__ xy, const int32_t* __restrict__ poly_off, const int32_t* __restrict__ poly_inst,
-                                                            int h, int w, int64_t words, uint32_t* __restrict__ scratch, uint8_t* __restrict__ masks) {
+                                                            int h, int w, int64_t words, uint32_t* __restrict__ scratch, uint8_t* __restrict__ masks,
+                                                            const double* __restrict__ shrink, int32_t* __restrict__ kept) {
   __shared__ int s_x[PM_MAXV + 1], s_y[PM_MAXV + 1], s_start[PM_MAXV + 1];
   __shared__ uint8_t s_col[PM_MAXW];
   __shared__ int s_scan[PM_THREADS];
@@ -586,13 +589,43 @@ __global__ __launch_bounds__(PM_THREADS) void k_polygon_masks(const double* __re
   }
   __syncthreads();
   uint8_t* M = masks + (int64_t)poly_inst[poly] * h * w;
+  const double d = shrink ? shrink[poly] : 0.0, d2 = d * d;
+  const double* V = xy + 2 * (int64_t)v0;
+  int written = 0;
   for (int x = tid; x < w; x += PM_THREADS) {
     unsigned state = s_col[x];
     int64_t idx = (int64_t)x * h;
     for (int y = 0; y < h; ++y, ++idx) {
       state ^= bit(idx);
-      if (state) M[(int64_t)y * w + x] = 1;                 // the parts of an instance only ever write ones: their union, whatever the order
+      if (!state) continue;
+      if (d > 0.0) {
+        // squared distance of the pixel (its centre is the integer point: rleFrPoly samples column x at x) to the nearest edge, original vertices
+        const double px = (double)x, py = (double)y;
+        bool far = true;
+        for (int j = 0; j < k && far; ++j) {
+          const int jn = j + 1 < k ? j + 1 : 0;
+          const double ax = V[2 * j], ay = V[2 * j + 1], ex = V[2 * jn] - ax, ey = V[2 * jn + 1] - ay;
+          const double len2 = ex * ex + ey * ey;
+          double t = len2 > 0.0 ? ((px - ax) * ex + (py - ay) * ey) / len2 : 0.0;
+          t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+          const double qx = ax + t * ex - px, qy = ay + t * ey - py;
+          far = qx * qx + qy * qy >= d2;
+        }
+        if (!far) continue;
+      }
+      M[(int64_t)y * w + x] = 1;                            // the parts of an instance only ever write ones: their union, whatever the order
+      ++written;
     }
+  }
+  if (kept) {
+    __syncthreads();
+    s_scan[tid] = written;
+    __syncthreads();
+    for (int off = PM_THREADS / 2; off > 0; off >>= 1) {
+      if (tid < off) s_scan[tid] += s_scan[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) kept[poly] = s_scan[0];
   }
 }
 
@@ -601,8 +634,9 @@ extern "C" size_t sv_polygon_masks_scratch_bytes(int n_polygons, int img_h, int 
 }
 // xy: the polygons' vertices, flat doubles (x, y pairs); poly_off (n_polygons + 1): first vertex of each polygon; poly_inst (n_polygons): the instance a
 // polygon belongs to; masks (n_instances, img_h, img_w) uint8, written whole (zeros outside the polygons).  All pointers on the device.
-extern "C" int sv_polygons_to_masks(const double* xy, const int32_t* poly_off, const int32_t* poly_inst, int n_polygons, int max_vertices, int n_instances,
-                                    int img_h, int img_w, void* scratch, uint8_t* masks, void* stream) {
+// shrink (n_polygons doubles or NULL): inward distance per polygon; kept (n_polygons int32 or NULL): pixels each polygon wrote
+extern "C" int sv_polygons_to_masks_shrunk(const double* xy, const int32_t* poly_off, const int32_t* poly_inst, const double* shrink, int n_polygons,
+                                           int max_vertices, int n_instances, int img_h, int img_w, void* scratch, uint8_t* masks, int32_t* kept, void* stream) {
   SV_CHECK_ARG(n_polygons >= 0 && n_instances >= 0 && img_h > 0 && img_w > 0, "sv_polygons_to_masks: bad sizes");
   SV_CHECK_ARG(img_w <= PM_MAXW && max_vertices <= PM_MAXV, "sv_polygons_to_masks: images up to %d columns, polygons up to %d vertices", PM_MAXW, PM_MAXV);
   SV_CHECK_ARG((int64_t)img_h * img_w < ((int64_t)1 << 31), "sv_polygons_to_masks: image too large");
@@ -614,9 +648,14 @@ extern "C" int sv_polygons_to_masks(const double* xy, const int32_t* poly_off, c
   SV_CHECK_ARG(xy && poly_off && poly_inst && scratch, "sv_polygons_to_masks: null pointer");
   const int64_t words = ((int64_t)img_h * img_w + 31) / 32 + 1;
   hipLaunchKernelGGL(k_polygon_masks, dim3(n_polygons), dim3(PM_THREADS), 0, st, xy, poly_off, poly_inst, img_h, img_w, words,
-                     static_cast<uint32_t*>(scratch), masks);
+                     static_cast<uint32_t*>(scratch), masks, shrink, kept);
   SV_LAUNCH_CHECK();
   return SV_OK;
+}
+
+extern "C" int sv_polygons_to_masks(const double* xy, const int32_t* poly_off, const int32_t* poly_inst, int n_polygons, int max_vertices, int n_instances,
+                                    int img_h, int img_w, void* scratch, uint8_t* masks, void* stream) {
+  return sv_polygons_to_masks_shrunk(xy, poly_off, poly_inst, nullptr, n_polygons, max_vertices, n_instances, img_h, img_w, scratch, masks, nullptr, stream);
 }
 
 extern "C" int64_t sv_isolate_cluster_scratch_bytes(int n_instances, int64_t max_points) {

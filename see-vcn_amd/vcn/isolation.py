@@ -10,8 +10,9 @@ datasets/kitti/kitti_utils.py:15-114, datasets/kitti/kitti_objects.py:153-176).
   populate_gtboxes / isolate_gt_pts   oriented-box crops of the ground-truth boxes
   merge_multi_camera_detections   stacks instances seen by two cameras
 
-2-D segmentation (polygon -> mask rasterisation by pycocotools, mask shrinking by shapely) is out of scope: instances
-carry a binary mask under 'bin_mask' (what the reference stores after annToMask, shared_utils.py:67-69) or a 'bbox'.
+The 2-D segmentation network is out of scope; its output is taken as the reference takes it: instances carry COCO polygons / RLE
+dicts under 'segmentation' (rasterised on the device like dataset.annToMask, optionally shrunk first like shrink_instance_masks), a ready binary
+mask under 'bin_mask' (what the reference stores after annToMask, shared_utils.py:67-69) or a 'bbox'.
 Everything runs through libseevcn_hip.so; there is no CPU fallback.  Results come back as numpy arrays like the reference's,
 the *_device variants keep index lists on the GPU.
 """
@@ -245,16 +246,22 @@ def _rle_to_mask(seg):
     return np.ascontiguousarray(flat.reshape(w, h).T)                 # the runs are column-major
 
 
-def instance_masks_device(instances, img_h, img_w, device='cuda'):
+def instance_masks_device(instances, img_h, img_w, device='cuda', shrink_percentage=0):
     """The binary masks of COCO annotations, (I, img_h, img_w) uint8 on the device: `dataset.annToMask(instance)` of the reference
     (shared_utils.py:66 -> pycocotools annToRLE / frPyObjects / decode).  Polygon segmentations are rasterised by sv_polygons_to_masks (the
     boundary arithmetic of cocoapi's rleFrPoly, union of an instance's parts); RLE dicts are decoded on the host and copied; an instance that
-    already carries 'bin_mask' keeps it."""
+    already carries 'bin_mask' keeps it.
+
+    shrink_percentage != 0 (shrink_instance_masks, shared_utils.py:310-330; polygon instances only, like the reference): every part's boundary moves
+    inwards by d = half diagonal of its bounding box x percentage / 100 before the mask is made -- here as "the pixels of the part at least d from
+    its edges" (sv_polygons_to_masks_shrunk), which is the region shapely's buffer(-d) describes sampled at the pixel centres, not its vertex list:
+    equal masks except in a band of about one pixel along the shrunken boundary (oracle/coco_mask.py; shapely is not available to pin against).  An
+    instance with a part that shrinks to nothing keeps its unshrunken mask, as the reference returns the original polygons then."""
     lib = _lib.load()
     dev = torch.device(device)
     n = len(instances)
     masks = torch.empty((n, img_h, img_w), dtype=torch.uint8, device=dev)
-    xy, off, inst_of, host = [], [0], [], {}
+    xy, off, inst_of, host, dist = [], [0], [], {}, []
     for i, inst in enumerate(instances):
         seg = inst.get('bin_mask')
         if seg is not None:
@@ -265,9 +272,12 @@ def instance_masks_device(instances, img_h, img_w, device='cuda'):
             for poly in inst['segmentation']:
                 if len(poly) < 2:
                     continue
-                xy.extend(float(t) for t in poly[:2 * (len(poly) // 2)])
+                part = [float(t) for t in poly[:2 * (len(poly) // 2)]]
+                xy.extend(part)
                 off.append(len(xy) // 2)
                 inst_of.append(i)
+                xs, ys = part[0::2], part[1::2]
+                dist.append(0.5 * float(np.hypot(max(xs) - min(xs), max(ys) - min(ys))) * (shrink_percentage / 100.0))
     n_poly = len(inst_of)
     if n_poly:
         xy_t = torch.tensor(xy, dtype=torch.float64, device=dev)
@@ -278,8 +288,18 @@ def instance_masks_device(instances, img_h, img_w, device='cuda'):
     else:
         xy_t = off_t = inst_t = scratch = None
         max_v = 0
-    _lib.check(lib.sv_polygons_to_masks(_lib.ptr(xy_t), _lib.ptr(off_t), _lib.ptr(inst_t), n_poly, max_v, n, img_h, img_w, _lib.ptr(scratch),
-                                        _lib.ptr(masks), _lib.stream()), "sv_polygons_to_masks")
+    if shrink_percentage and n_poly:
+        dist_t = torch.tensor(dist, dtype=torch.float64, device=dev)
+        kept = torch.empty((n_poly,), dtype=torch.int32, device=dev)
+        _lib.check(lib.sv_polygons_to_masks_shrunk(_lib.ptr(xy_t), _lib.ptr(off_t), _lib.ptr(inst_t), _lib.ptr(dist_t), n_poly, max_v, n, img_h, img_w,
+                                                   _lib.ptr(scratch), _lib.ptr(masks), _lib.ptr(kept), _lib.stream()), "sv_polygons_to_masks_shrunk")
+        empty = sorted({inst_of[p] for p in np.nonzero(kept.cpu().numpy() == 0)[0]})
+        if empty:                                                 # shared_utils.py:325-326: such an instance keeps its original polygons
+            redo = instance_masks_device([{'segmentation': instances[i]['segmentation']} for i in empty], img_h, img_w, dev, 0)
+            masks[torch.tensor(empty, device=dev)] = redo
+    else:
+        _lib.check(lib.sv_polygons_to_masks(_lib.ptr(xy_t), _lib.ptr(off_t), _lib.ptr(inst_t), n_poly, max_v, n, img_h, img_w, _lib.ptr(scratch),
+                                            _lib.ptr(masks), _lib.stream()), "sv_polygons_to_masks")
     for i, m in host.items():
         assert m.shape == (img_h, img_w), f"instance {i}: mask {m.shape} on a {(img_h, img_w)} image"
         masks[i].copy_(torch.from_numpy(np.ascontiguousarray(m)))
@@ -289,9 +309,9 @@ def instance_masks_device(instances, img_h, img_w, device='cuda'):
 def get_pts_in_mask(dataset, instances, imgfov, shrink_percentage=0, use_bbox=False, append_mask_info=False):
     """shared_utils.py:36-106.  Instances may carry COCO polygons / RLE dicts under 'segmentation' (rasterised on the device: instance_masks_device,
     the role of `dataset.annToMask`; the image size comes from dataset.imgs when the COCO object is given, else from imgfov['img_shape']) or a ready
-    'bin_mask'.  Shrinking the polygons first (shrink_percentage != 0: shapely's Polygon.buffer, i.e. GEOS, shared_utils.py:295-330) is not part of
-    this build: neither library is available to pin an implementation against."""
-    assert shrink_percentage == 0, "mask shrinking (shapely / GEOS polygon buffering) is outside this build's scope"
+    'bin_mask'.  shrink_percentage != 0 (SHRINK_MASK_PERCENTAGE of the reference's cfgs; shapely's Polygon.buffer(-d) in shared_utils.py:295-330)
+    moves the polygons' boundaries inwards before the masks are made -- see instance_masks_device for what exactly is computed and where it
+    can differ from GEOS's output (a band of about one pixel).  Like the reference, shrinking applies to polygon segmentations."""
     pts, uv, fov = imgfov["_device"]
     kept = [dict(inst) for inst in instances if inst['segmentation']]
     out = {"img_uv": [], "cam_xyz": [], "lidar_xyz": [], "img_labels": []}
@@ -307,12 +327,14 @@ def get_pts_in_mask(dataset, instances, imgfov, shrink_percentage=0, use_bbox=Fa
             rects.append([max(int(bbox[0]), 0), max(int(bbox[1]), 0), min(int(bbox[2]), img_w), min(int(bbox[3]), img_h)])
         index, count = points_in_masks_device(uv, fov, rects=torch.tensor(rects, dtype=torch.int32, device=uv.device))
     else:
-        if all('bin_mask' in inst for inst in kept):
+        if all('bin_mask' in inst for inst in kept) and not shrink_percentage:
             masks = torch.from_numpy(np.ascontiguousarray(np.stack([inst['bin_mask'] for inst in kept]).astype(np.uint8))).to(uv.device)
         else:
             img = getattr(dataset, 'imgs', {}).get(kept[0].get('image_id')) if dataset is not None else None
             img_h, img_w = (img['height'], img['width']) if img else imgfov["img_shape"]
-            masks = instance_masks_device(kept, int(img_h), int(img_w), uv.device)
+            if shrink_percentage:                                   # the reference shrinks instance['segmentation'] and rasterises again
+                kept = [{k: v for k, v in inst.items() if k != 'bin_mask' or not isinstance(inst['segmentation'], list)} for inst in kept]
+            masks = instance_masks_device(kept, int(img_h), int(img_w), uv.device, shrink_percentage)
             masks_h = masks.cpu().numpy()
             for g, inst in enumerate(kept):                           # the reference keeps the binary mask with the label (shared_utils.py:69)
                 inst.setdefault('bin_mask', masks_h[g])

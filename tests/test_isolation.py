@@ -351,3 +351,74 @@ def test_hip_get_pts_in_mask_takes_coco_polygons(inputs, golden, cuda, hip_lib):
     assert len(a["lidar_xyz"]) == len(b["lidar_xyz"]) > 0
     for la, lb, ia, ib in zip(a["lidar_xyz"], b["lidar_xyz"], a["img_labels"], b["img_labels"]):
         assert np.array_equal(la, lb) and np.array_equal(ia["bin_mask"], ib["bin_mask"])
+
+
+def test_oracle_shrunken_mask_known_answers():
+    """oracle/coco_mask.ann_to_mask_shrunk (the region of shapely's buffer(-d) sampled at the pixel centres -- PARITY UNPINNED and known to differ from
+    GEOS's rasterised vertex list in a band of about one pixel): an integer rectangle shrinks to the pixels at least d from its four edges; the
+    distance follows shared_utils.py:295-306 (percentage of the bounding box's half diagonal); a part that shrinks to nothing leaves the instance
+    unshrunken (shared_utils.py:325-326); percentage 0 and RLE dicts are untouched."""
+    from oracle import coco_mask as cm
+    rect = [10, 20, 50, 20, 50, 50, 10, 50]
+    assert abs(cm.shrink_distance(rect, 10) - 0.5 * np.hypot(40, 30) * 0.1) < 1e-12           # 2.5
+    m = cm.ann_to_mask_shrunk({"segmentation": [rect]}, 64, 64, 10)
+    want = np.zeros((64, 64), np.uint8)
+    want[23:48, 13:48] = 1                                     # pixel centres x in [12.5, 47.5], y in [22.5, 47.5]
+    assert np.array_equal(m, want)
+    assert np.array_equal(cm.ann_to_mask_shrunk({"segmentation": [rect]}, 64, 64, 0), cm.ann_to_mask({"segmentation": [rect]}, 64, 64))
+    sliver = [5, 5, 60, 5, 60, 7, 5, 7]                        # half diagonal 27.5: 10 % = 2.75 > its half height
+    two = {"segmentation": [rect, sliver]}
+    assert np.array_equal(cm.ann_to_mask_shrunk(two, 64, 64, 10), cm.ann_to_mask(two, 64, 64))
+    # an L shape: the reflex corner's circle of radius d is cut out
+    ell = [0, 0, 40, 0, 40, 20, 20, 20, 20, 40, 0, 40]
+    m = cm.ann_to_mask_shrunk({"segmentation": [ell]}, 48, 48, 15)
+    d = cm.shrink_distance(ell, 15)
+    assert abs(d - 0.5 * np.hypot(40, 40) * 0.15) < 1e-12                                  # 4.24
+    assert m[15, 15] == 1 and m[10, 30] == 1 and m[30, 10] == 1                             # >= d from every edge
+    assert m[18, 18] == 0                                                                   # 2.83 from the reflex corner (20, 20): inside its circle
+    assert m[10, 37] == 0 and m[3, 10] == 0                                                 # 3 from the edge x = 40 / y = 0
+    assert m.sum() < cm.ann_to_mask({"segmentation": [ell]}, 48, 48).sum()
+
+
+@pytest.mark.gpu
+def test_hip_shrunken_masks_equal_the_oracle_and_get_pts_in_mask_uses_them(inputs, cuda, hip_lib):
+    """sv_polygons_to_masks_shrunk == oracle/coco_mask.ann_to_mask_shrunk pixel for pixel: the hand cases (rectangle, L shape, a part that shrinks
+    away -> unshrunken instance), 40 random polygons and multi-part instances at 3 % and 10 %; get_pts_in_mask(shrink_percentage=3) selects the
+    points of those masks (SHRINK_MASK_PERCENTAGE of the reference's cfgs) and strictly fewer than without shrinking."""
+    from oracle import coco_mask as cm
+    from seevcn_amd.vcn import isolation as I
+    rect, sliver, ell = [10, 20, 50, 20, 50, 50, 10, 50], [5, 5, 60, 5, 60, 7, 5, 7], [0, 0, 40, 0, 40, 20, 20, 20, 20, 40, 0, 40]
+    inst = [{"segmentation": [rect]}, {"segmentation": [ell]}, {"segmentation": [rect, sliver]}, {"segmentation": [sliver]},
+            {"segmentation": {"size": [64, 64], "counts": [100, 50, 64 * 64 - 150]}}]
+    for pct in (10, 3):
+        got = I.instance_masks_device(inst, 64, 64, cuda, pct).cpu().numpy()
+        for g, a in zip(got, inst):
+            assert np.array_equal(g, cm.ann_to_mask_shrunk(a, 64, 64, pct)), (pct, a)
+    rng = np.random.default_rng(21)
+    h, w = 93, 131
+    polys = _random_polygons(rng, h, w, 52)
+    inst = [{"segmentation": [p]} for p in polys[:40]] + [{"segmentation": polys[40 + 4 * i:44 + 4 * i]} for i in range(3)]
+    for pct in (3, 10):
+        got = I.instance_masks_device(inst, h, w, cuda, pct).cpu().numpy()
+        plain = I.instance_masks_device(inst, h, w, cuda).cpu().numpy()
+        for i, (g, a) in enumerate(zip(got, inst)):
+            want = cm.ann_to_mask_shrunk(a, h, w, pct)
+            assert np.array_equal(g, want), (pct, i, int((g != want).sum()))
+        assert got.sum() < plain.sum() and ((got == 1) <= (plain == 1)).all()
+    calib = I.Calibration(inputs['calib'])
+    imgfov = I.map_pointcloud_to_image(inputs['points'], calib, IMG_SHAPE, min_dist=1.0)
+    polys = []
+    for it in inputs['instances'][:6]:
+        x0, y0, bw, bh = it['bbox']
+        ang = np.sort(rng.uniform(0, 2 * np.pi, 12))
+        pts = np.stack([x0 + bw / 2 + 0.7 * bw * np.cos(ang), y0 + bh / 2 + 0.7 * bh * np.sin(ang)], 1)
+        polys.append([float(t) for t in pts.reshape(-1)])
+    only_poly = [{"segmentation": [p], "bbox": i["bbox"], "category_id": 1, "box_id": i["box_id"]} for p, i in zip(polys, inputs['instances'])]
+    shrunk = I.get_pts_in_mask(None, only_poly, imgfov, shrink_percentage=3)
+    with_mask = [dict(a, bin_mask=cm.ann_to_mask_shrunk(a, *IMG_SHAPE, 3)) for a in only_poly]
+    ref = I.get_pts_in_mask(None, [{k: v for k, v in a.items()} for a in with_mask], imgfov)
+    full = I.get_pts_in_mask(None, only_poly, imgfov)
+    assert len(shrunk["lidar_xyz"]) == len(ref["lidar_xyz"]) > 0
+    for la, lb in zip(shrunk["lidar_xyz"], ref["lidar_xyz"]):
+        assert np.array_equal(la, lb)
+    assert sum(len(x) for x in shrunk["lidar_xyz"]) < sum(len(x) for x in full["lidar_xyz"])
