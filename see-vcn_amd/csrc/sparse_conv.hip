@@ -1133,10 +1133,42 @@ __device__ __forceinline__ f32x4 buf_load_b128(i32x4 srd, uint32_t voff) {
 }
 // address = base + soff (SGPR) + voff (VGPR) + IMM; the range check looks at voff + IMM only, so an out-of-range voff still returns zeros
 // without a memory access whatever soff is
+// cache-policy bits of the operand loads (measurement switches: tools/build_variant.sh x "-DSEEVCN_RS3_ROW_POLICY=1"): 0 plain (default), 1 nt
+// (streaming), 2 sc1, 3 sc0 sc1
+#ifndef SEEVCN_RS3_ROW_POLICY
+#define SEEVCN_RS3_ROW_POLICY 0
+#endif
+#ifndef SEEVCN_RS3_W_POLICY
+#define SEEVCN_RS3_W_POLICY 0
+#endif
+#if SEEVCN_RS3_ROW_POLICY == 1
+#define SEEVCN_RS3_ROW_BITS " nt"
+#elif SEEVCN_RS3_ROW_POLICY == 2
+#define SEEVCN_RS3_ROW_BITS " sc1"
+#elif SEEVCN_RS3_ROW_POLICY == 3
+#define SEEVCN_RS3_ROW_BITS " sc0 sc1"
+#else
+#define SEEVCN_RS3_ROW_BITS ""
+#endif
+#if SEEVCN_RS3_W_POLICY == 1
+#define SEEVCN_RS3_W_BITS " nt"
+#elif SEEVCN_RS3_W_POLICY == 2
+#define SEEVCN_RS3_W_BITS " sc1"
+#elif SEEVCN_RS3_W_POLICY == 3
+#define SEEVCN_RS3_W_BITS " sc0 sc1"
+#else
+#define SEEVCN_RS3_W_BITS ""
+#endif
 template <int IMM>
 __device__ __forceinline__ f32x4 buf_load_b128_s(i32x4 srd, uint32_t voff, uint32_t soff) {
   f32x4 v;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(srd), "s"(soff), "i"(IMM) : "memory");
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" SEEVCN_RS3_ROW_BITS : "=v"(v) : "v"(voff), "s"(srd), "s"(soff), "i"(IMM) : "memory");
+  return v;
+}
+template <int IMM>
+__device__ __forceinline__ f32x4 buf_load_b128_w(i32x4 srd, uint32_t voff, uint32_t soff) {
+  f32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" SEEVCN_RS3_W_BITS : "=v"(v) : "v"(voff), "s"(srd), "s"(soff), "i"(IMM) : "memory");
   return v;
 }
 
@@ -1370,10 +1402,10 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     int kb = __ffsll((long long)lb) - 1, qb = 0;
     uint32_t sw = (uint32_t)((kb < 0 ? 0 : kb) * KQ * nt_total + col_tile0) * WSTEP;
     auto issue_b = [&](f32x4 (&Bs)[NT]) {                            // exactly NT loads, always
-      if constexpr (NT >= 1) Bs[0] = buf_load_b128_s<0>(srd_w, wvoff, sw);
-      if constexpr (NT >= 2) Bs[1] = buf_load_b128_s<1024>(srd_w, wvoff, sw);
-      if constexpr (NT >= 3) Bs[2] = buf_load_b128_s<2048>(srd_w, wvoff, sw);
-      if constexpr (NT >= 4) Bs[3] = buf_load_b128_s<3072>(srd_w, wvoff, sw);
+      if constexpr (NT >= 1) Bs[0] = buf_load_b128_w<0>(srd_w, wvoff, sw);
+      if constexpr (NT >= 2) Bs[1] = buf_load_b128_w<1024>(srd_w, wvoff, sw);
+      if constexpr (NT >= 3) Bs[2] = buf_load_b128_w<2048>(srd_w, wvoff, sw);
+      if constexpr (NT >= 4) Bs[3] = buf_load_b128_w<3072>(srd_w, wvoff, sw);
       if (kb >= 0) {
         sw += wq;
         if (++qb == KQ) {
