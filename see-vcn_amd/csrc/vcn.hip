@@ -335,12 +335,15 @@ extern "C" int sv_fill_f32(float* dst, int64_t n, float value, void* stream) {
 // waves share K in interleaved 16-wide steps (16x16x4 MFMA, one 16-byte load per operand and 16 k), partial sums meet in LDS in a fixed order.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs g) {
-  __shared__ float s_red[4][4][4][64];                      // [wave][row tile][reg][lane]
+// NW waves share K (4, or 16 from K = 512 on: a wave then has at most SM_U steps and requests everything it will ever read in one go -- with 4 waves
+// a 1024-long K is four dependent rounds of load latency, 10.6 us for a layer whose 4 MB of weights stream in 1.3)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_gemm_small_m(GemmArgs g) {
+  __shared__ float s_red[NW][4][4][64];                     // [wave][row tile][reg][lane]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int li = lane & 15, kk = lane >> 4;
   const int n0 = blockIdx.x * 16;
-  // K % 32 == 0 (checked by the launcher): the four waves take the 16-wide k-steps round-robin
+  // K % 16 == 0 (checked by the launcher): the waves take the 16-wide k-steps round-robin
   f32x4v acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
@@ -354,15 +357,15 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs g) {
   }
   // lane (li, kk) holds k = k0 + 4*kk + s in MFMA s, for A and W alike.  SM_U k-steps of a wave are requested together: one step at a time the
   // kernel was a chain of load latencies (13-16 us for a 4 MB weight matrix = 0.3 TB/s on 64 workgroups)
-  constexpr int SM_U = 4;
+  constexpr int SM_U = 4, KS = 16 * NW;                       // KS: k covered by one step of all waves
   int k0 = wid * 16;
-  for (; k0 + 64 * (SM_U - 1) < g.K; k0 += 64 * SM_U) {
+  for (; k0 + KS * (SM_U - 1) < g.K; k0 += KS * SM_U) {
     f32x4v b[SM_U], a[SM_U][4];
 #pragma unroll
     for (int u = 0; u < SM_U; ++u) {
-      b[u] = *reinterpret_cast<const f32x4v*>(wrow + k0 + 64 * u);
+      b[u] = *reinterpret_cast<const f32x4v*>(wrow + k0 + KS * u);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) a[u][t] = *reinterpret_cast<const f32x4v*>(arow[t] + k0 + 64 * u);
+      for (int t = 0; t < 4; ++t) a[u][t] = *reinterpret_cast<const f32x4v*>(arow[t] + k0 + KS * u);
     }
 #pragma unroll
     for (int u = 0; u < SM_U; ++u)
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs g) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t][s], b[u][s], acc[t], 0, 0, 0);
   }
-  for (; k0 < g.K; k0 += 64) {
+  for (; k0 < g.K; k0 += KS) {
     const f32x4v b = *reinterpret_cast<const f32x4v*>(wrow + k0);
     f32x4v a[4];
 #pragma unroll
@@ -388,14 +391,17 @@ __global__ __launch_bounds__(256) void k_gemm_small_m(GemmArgs g) {
   __syncthreads();
   // D layout (16x16): col = lane & 15, row = 4 * (lane >> 4) + reg.  Thread (wid = row tile, lane) finishes 4 outputs.
   const int col = n0 + li;
-  if (col >= g.N) return;
+  if (col >= g.N || wid >= 4) return;
   const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = wid * 16 + 4 * kk + r;
     if (row >= g.M) continue;
-    float v = ((s_red[0][wid][r][lane] + s_red[1][wid][r][lane]) + (s_red[2][wid][r][lane] + s_red[3][wid][r][lane])) + bv;
-    g.C[(int64_t)row * g.ldc + col] = apply_act(v, g.act, g.slope);
+    float v = 0.f;                                            // partials of groups of four waves, pairwise, in wave order: a fixed order
+#pragma unroll
+    for (int q = 0; q < NW; q += 4)
+      v += (s_red[q][wid][r][lane] + s_red[q + 1][wid][r][lane]) + (s_red[q + 2][wid][r][lane] + s_red[q + 3][wid][r][lane]);
+    g.C[(int64_t)row * g.ldc + col] = apply_act(v + bv, g.act, g.slope);
   }
 }
 
@@ -449,7 +455,9 @@ static int gemm_launch(const float* A, int lda, const float* W, int ldw, const f
   dim3 grid(wgs);
   hipStream_t st = sv_stream(stream);
   if (M <= 64 && C && !group_max && !group_bias && !row_group && !m_dev) {
-    hipLaunchKernelGGL(k_gemm_small_m, dim3(sv_div_up(N, 16)), dim3(256), 0, st, g);
+    static const int small_waves = getenv("SEEVCN_GEMM_SMALL_WAVES") ? atoi(getenv("SEEVCN_GEMM_SMALL_WAVES")) : 0;      // 4 / 16: A/B runs
+    if (small_waves == 16 || (small_waves != 4 && K >= 512)) hipLaunchKernelGGL(k_gemm_small_m<16>, dim3(sv_div_up(N, 16)), dim3(1024), 0, st, g);
+    else hipLaunchKernelGGL(k_gemm_small_m<4>, dim3(sv_div_up(N, 16)), dim3(256), 0, st, g);
     SV_LAUNCH_CHECK();
     return SV_OK;
   }
