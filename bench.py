@@ -672,7 +672,7 @@ def main():
         dist.destroy_process_group()
 
 
-def side_modes_brief(device, warmup=3, steps=5):
+def side_modes_brief(device, warmup=6, steps=15):
     """{config: ms_per_step, ...} of bench_configs' detector train steps (second = BASELINE configs[2], pvrcnn = [3], centerpoint = [4]) and
     stage A alone ([1]); N = 1 only, warm-up includes MIOpen's solver search."""
     import gc
