@@ -358,8 +358,34 @@ def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
                             pairs = int((rb.nbr_out >= 0).sum().item())
                         pairs_of[tp.addr("rows")] = pairs
     groups = {}
+    nbr_pairs = {}
+    for d in dicts:
+        for rb in d.values():
+            nbr_pairs[rb.addr("nbr_out")] = rb
+    wg = [0.0, 0.0, 0.0, 0]          # the equal-pieces weight gradient of the 64 -> 64 layers (k_spconv_wgrad_eq<4, 4>): ms, flop, SURVEY 8(d) bytes, launches
+    all_flop = 0.0                   # every conv / data-gradient / weight-gradient operation of the lists: 2 * pairs * C_in * C_out each
     for arr, ms in lists:
         for row, t in zip(arr, ms):
+            if int(row[0]) in (chain.OP_WGRAD, chain.OP_WGRAD_DEFERRED):
+                K, cin, cout, n_in, n_out = int(row[1]), int(row[2]), int(row[3]), int(row[4]), int(row[9])
+                rb = nbr_pairs.get(int(row[18]))
+                if rb is None:
+                    continue
+                tp = rb._plans.get("fwd")
+                key = tp.addr("rows") if tp is not None else None
+                if key in pairs_of:
+                    pairs = pairs_of[key]
+                else:
+                    pairs = int((rb.nbr_out >= 0).sum().item())
+                all_flop += 2.0 * pairs * cin * cout
+                if int(row[22]) and cin == 64 and cout == 64:                              # p[5]: an equal-pieces plan -> k_spconv_wgrad_eq<4, 4>
+                    wg[0] += t
+                    wg[1] += 2.0 * pairs * cin * cout
+                    wg[2] += 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * pairs
+                    wg[3] += 1
+                continue
+            if int(row[0]) == chain.OP_CONV_PLAIN:
+                continue
             if int(row[0]) not in (chain.OP_CONV_PLANNED, chain.OP_DGRAD_PLANNED_BN):     # the same kernel; the second form's epilogue also makes a BatchNorm's backward sums
                 continue
             K, kd, nc = int(row[2]), int(row[3]), int(row[4])
@@ -370,7 +396,10 @@ def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
             g[1] += 2.0 * pairs * kd * nc
             g[2] += 4.0 * (n_src * kd + n_rows * nc) + 4.0 * K * kd * nc + 8.0 * pairs    # features in+out, weights, rulebook pairs
             g[3] += 1
+            all_flop += 2.0 * pairs * kd * nc
     (nt, kq), (ms, flop, byt, n) = max(groups.items(), key=lambda kv: kv[1][0])
+    measure_spconv_kernel.extra = {"wgrad": (wg[0] / max(wg[3], 1), wg[1] / max(wg[3], 1), wg[2] / max(wg[3], 1), wg[3] // reps) if wg[3] else None,
+                                   "planned_flop_per_step": all_flop / reps}
     return f"k_spconv_rs3<{nt}, {kq}, ", ms / n, flop / n, byt / n, n // reps, ms / reps
 
 
@@ -756,6 +785,21 @@ def kernel_rooflines(out, model, opt, params, inputs):
                        "launches_per_step": c_launches, "avg_launch_ms": round(c_ms, 4), "ms_per_step": round(c_step_ms, 3),
                        "algorithmic_flop_per_launch": round(c_flop), "algorithmic_bytes_per_launch": round(c_bytes),
                        "algorithmic_GBps": round(c_bytes / (c_ms * 1e-3) / 1e9, 1)}
+    extra = getattr(measure_spconv_kernel, "extra", {})
+    if extra.get("wgrad"):
+        w_ms, w_flop, w_bytes, w_n = extra["wgrad"]
+        w_ach = w_flop / (w_ms * 1e-3) / 1e12
+        out["roofline_wgrad"] = {"bound": "mfma", "kernel": "k_spconv_wgrad_eq<4, 4> (sv_sparse_conv_wgrad_planned_stage1, v_mfma_f32_16x16x4_f32; 64 -> 64 layers)",
+                                 "achieved": round(w_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(w_ach / PEAK_F32_MFMA_TFLOPS, 4),
+                                 "traffic": None, "launches_per_step": w_n, "avg_launch_ms": round(w_ms, 4),
+                                 "algorithmic_flop_per_launch": round(w_flop), "algorithmic_bytes_per_launch": round(w_bytes),
+                                 "note": "event-timed on the list's own stream with the weight gradients in line (in the pipelined step they run on a second stream beside the data gradients)"}
+    if extra.get("planned_flop_per_step"):
+        # whole step against the matrix peak: every planned conv / data gradient / weight gradient's 2 * pairs * C_in * C_out over the driver-timed step
+        fl = extra["planned_flop_per_step"]
+        out["mfma_frac_step"] = {"sparse_conv_flop_per_step": round(fl), "ms_per_step": out["ms_per_step"],
+                                 "achieved": round(fl / (out["ms_per_step"] * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(fl / (out["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
     # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the newest committed PMC pass over this
     # same command (tools/traffic.sh -> profiles/*_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, x2 on reads for gfx950)
     import glob
@@ -767,6 +811,11 @@ def kernel_rooflines(out, model, opt, params, inputs):
             n_disp = sum(v["dispatches"] for v in hit)
             out["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in hit) / n_disp)
             out["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
+        hitw = [v for k, v in kernels.items() if "k_spconv_wgrad_eq<4, 4" in k]
+        if hitw and "roofline_wgrad" in out:
+            n_disp = sum(v["dispatches"] for v in hitw)
+            out["roofline_wgrad"]["traffic"] = round(sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in hitw) / n_disp)
+            out["roofline_wgrad"]["traffic_source"] = os.path.relpath(tf, ROOT)
     out["roofline_vcn_gemm"] = vcn_roof
 
 

@@ -509,6 +509,54 @@ static PlanDims plan_dims(int64_t n_rows, int G) {
   return d;
 }
 
+// The deal of a region's sorted tiles (descending cost) to its waves; called by every thread of the plan workgroup behind a barrier.
+// SEEVCN_PL_LPT = 0: quads to the 32 CU bins in plain snake order (rounds 1-5).
+// SEEVCN_PL_LPT = 1 (round 6): every round of 32 quads goes to the bins in order of the load they already hold -- the lightest bin takes the round's
+// costliest quad (longest-processing-time dealing under "one quad per bin and round", which the slot layout needs).  The costs are skewed (a few
+// 27-offset tiles, many of 5-9): snake order gives the bin of rank b the ranks b, 63 - b, 64 + b, ... whatever they cost, and the busiest CU carried
+// 1.14x (139 k rows), 1.26x (66 k rows), 1.41x (strided 64 -> 64) the mean of the launch (per-wave stamps, profiles/r06_conv_trace_raw.txt; an
+// emulation of the plan on the same tables reproduces 1.138 / 1.251 / 1.395 and gives 1.08 / 1.115 / 1.29 for this rule).  One wave does it: bins in
+// lanes 0..31, a round = 32 readlanes to rank the loads + the slot writes.  Deterministic (ties by bin index): a table still has one plan.
+#ifndef SEEVCN_PL_LPT
+#define SEEVCN_PL_LPT 1
+#endif
+template <typename CostOf>
+__device__ __forceinline__ void plan_deal_quads(const uint16_t* s_sorted, CostOf cost_of, int nt, int tile0, int slots, int32_t* __restrict__ out) {
+  const int tid = threadIdx.x;
+  const int nq = (nt + PL_QUAD - 1) / PL_QUAD;
+  auto put = [&](int qd, int j, int bin) {
+    const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;       // inside a bin the rounds walk its workgroups in snake order
+#pragma unroll
+    for (int part = 0; part < PL_QUAD; ++part) {
+      const int p = qd * PL_QUAD + part;
+      if (p < nt) out[(int64_t)((bin + PL_BINS * wg) * 4 + part) * slots + j / PL_WAVES_PER_SIMD] = tile0 + s_sorted[p];
+    }
+  };
+  if constexpr (SEEVCN_PL_LPT == 0) {
+    for (int qd = tid; qd < nq; qd += 1024) {
+      const int j = qd / PL_BINS, pos = qd % PL_BINS;                 // round of the bin, position in the round
+      put(qd, j, (j & 1) ? PL_BINS - 1 - pos : pos);
+    }
+  } else {
+    if (tid >= 64) return;
+    const int lane = tid;
+    int load = 0;                                                     // lanes 0..31: (tile, offset) steps the bin's waves hold so far
+    for (int j = 0; j * PL_BINS < nq; ++j) {
+      int rank = 0;
+#pragma unroll
+      for (int o = 0; o < PL_BINS; ++o) {
+        const int lo = __builtin_amdgcn_readlane(load, o);
+        rank += (lo < load || (lo == load && o < lane)) ? 1 : 0;
+      }
+      const int qd = j * PL_BINS + rank;                             // the bin with the rank-th lightest load takes the round's rank-th costliest quad
+      if (lane < PL_BINS && qd < nq) {
+        put(qd, j, lane);
+        load += cost_of(s_sorted[qd * PL_QUAD]);                      // the quad's first tile is its costliest
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ masks_p, PlanDims d, int32_t* __restrict__ tile_of) {
   __shared__ uint8_t s_cost[PL_MAX_REGION_TILES];
   __shared__ uint16_t s_sorted[PL_MAX_REGION_TILES];     // tiles of the region in descending cost order
@@ -546,17 +594,7 @@ __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ 
   __syncthreads();
   // quads of 4 consecutive tiles of the sorted list, dealt to the 32 CU bins in snake order (0 .. 31, 31 .. 0, ...); inside a bin the rounds
   // walk the four workgroups in snake order too.  One thread per quad.
-  const int nq = (nt + PL_QUAD - 1) / PL_QUAD;
-  for (int qd = tid; qd < nq; qd += 1024) {
-    const int j = qd / PL_BINS, pos = qd % PL_BINS;                 // round of the bin, position in the round
-    const int bin = (j & 1) ? PL_BINS - 1 - pos : pos;
-    const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;
-#pragma unroll
-    for (int part = 0; part < PL_QUAD; ++part) {
-      const int p = qd * PL_QUAD + part;
-      if (p < nt) out[(int64_t)((bin + PL_BINS * wg) * 4 + part) * slots + j / PL_WAVES_PER_SIMD] = d.tile0[r] + s_sorted[p];
-    }
-  }
+  plan_deal_quads(s_sorted, [&](int t) { return (int)s_cost[t]; }, nt, d.tile0[r], slots, out);
 }
 
 // The whole plan of a table in ONE launch: the 8 regions are independent (own classes, own positions, own tiles, own waves), so one
@@ -720,17 +758,7 @@ __device__ __forceinline__ void plan_region_body(const PlanFusedArgs& a, const i
     if (live) s_sorted[s_cstart[c] + off + rank] = (uint16_t)t;
   }
   __syncthreads();
-  const int nq = (nt + PL_QUAD - 1) / PL_QUAD;
-  for (int qd = tid; qd < nq; qd += 1024) {
-    const int j = qd / PL_BINS, pos = qd % PL_BINS;
-    const int bin = (j & 1) ? PL_BINS - 1 - pos : pos;
-    const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;
-#pragma unroll
-    for (int part = 0; part < PL_QUAD; ++part) {
-      const int p = qd * PL_QUAD + part;
-      if (p < nt) out[(int64_t)((bin + PL_BINS * wg) * 4 + part) * slots + j / PL_WAVES_PER_SIMD] = a.d.tile0[r] + s_sorted[p];
-    }
-  }
+  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, out);
 }
 
 // The same plan with a DETERMINISTIC order: inside a class the rows keep their table order, inside a cost bucket the tiles theirs, so a table has
@@ -882,17 +910,7 @@ __device__ __forceinline__ void plan_region_body_stable(const PlanFusedArgs& a, 
     if (live) s_sorted[s_cstart[c] + off + rank] = (uint16_t)t;
   }
   __syncthreads();
-  const int nq = (nt + PL_QUAD - 1) / PL_QUAD;
-  for (int qd = tid; qd < nq; qd += 1024) {
-    const int j = qd / PL_BINS, pos = qd % PL_BINS;
-    const int bin = (j & 1) ? PL_BINS - 1 - pos : pos;
-    const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;
-#pragma unroll
-    for (int part = 0; part < PL_QUAD; ++part) {
-      const int p = qd * PL_QUAD + part;
-      if (p < nt) out[(int64_t)((bin + PL_BINS * wg) * 4 + part) * slots + j / PL_WAVES_PER_SIMD] = a.d.tile0[r] + s_sorted[p];
-    }
-  }
+  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, out);
 }
 
 __device__ __forceinline__ void plan_region_dispatch(const PlanFusedArgs& a, const int r) {
@@ -1205,6 +1223,12 @@ struct PlanView {
 #ifndef SEEVCN_RS3_RB
 #define SEEVCN_RS3_RB 2
 #endif
+#ifndef SEEVCN_RS3_DEEP
+#define SEEVCN_RS3_DEEP 0             // 1: four row and four weight stages for the one-tile 64-column instances (A/B builds; slower: see DEEP below)
+#endif
+#ifndef SEEVCN_RS3_OFFSET_LOOP
+#define SEEVCN_RS3_OFFSET_LOOP 1      // 0: the step-by-step iterators for every instance (A/B builds)
+#endif
 constexpr int RS3_RA = SEEVCN_RS3_RA;      // stages of the row ring (RS3_RA - 1 steps of gathers in flight)
 constexpr int RS3_RB = SEEVCN_RS3_RB;      // stages of the weight ring
 // FIN: the gathered rows go through pv.in_coef (BatchNorm + ReLU of the layer below applied on load) -- production instances only
@@ -1267,7 +1291,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   } else {
     if (my_tiles[pass * RS_G] < 0) break;                  // slots are filled front to back: an empty first slot ends the wave's list
   }
-  if (pv.prio) __builtin_amdgcn_s_setprio(3);
+  if (pv.prio & 3) __builtin_amdgcn_s_setprio(3);
   if constexpr (DYN) bn0 = 0.f, bn1 = 0.f;                 // this tile's column sums only (kept per list position)
   // the wave's rows of the regrouped table -> LDS; per-offset tile masks in lane k of maskreg
   unsigned maskreg = 0;
@@ -1323,7 +1347,21 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
   for (int g = 0; g < RS_G; ++g)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (pv.prio) __builtin_amdgcn_s_setprio(0);
+  if (pv.prio & 3) __builtin_amdgcn_s_setprio(0);
+  if (pv.prio & 4) {
+    // Longest wave first: the wave's priority for its main loop follows its own (tile, offset) step count.  A SIMD's waves share one matrix pipe;
+    // a wave left alone on it cannot fill it (it waits for its own gathers), so the launch ends sooner when the long waves are served first and the
+    // short ones fill the gaps than when all run at the same rate and the long one finishes alone.
+    int steps = 0;
+#pragma unroll
+    for (int t2 = 0; t2 < RS_G; ++t2) steps += __popcll(__ballot((maskreg >> t2) & 1u));
+    const int unit = (pv.prio >> 4) > 0 ? (pv.prio >> 4) : 7 * RS_G;          // steps per priority level
+    const int lvl = steps / unit;
+    if (lvl >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+    else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  }
 
   if (active) {
     // Operand rings.  Rows (A): RA stages = RA - 1 steps of gathers in flight (a gathered row comes from HBM / a remote L2 line: ~2 us under load).
@@ -1333,7 +1371,13 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     // (History: one ring of 3 stages for both operands until round 5.  Tried on it: 5 stages for the one-tile-per-wave instance -- slower,
     // 64->64 at 66 k rows 78 -> 85 us, 64->128 28 -> 39 us: the extra dummy loads of the tail and the longer prologue cost more than the
     // lookahead buys (round 1 found the same on the narrow kernels); 4 stages for it in round 3 (128 VGPRs, no spill): 65.5 -> 67-68 us.)
-    constexpr int RA = RS3_RA, RB = RS3_RB, UNR = (RA % RB == 0) ? RA : RA * RB;
+    // DEEP (round 6): the one-tile instances of the 64-column kernels keep FOUR stages of both operands (three steps of loads in flight): such a
+    // launch ends with its densest tiles, each a wave alone on its SIMD walking 27 offsets x KQ steps, and a step of a lone wave lasts as long as
+    // its youngest operand's latency -- the weights', requested ONE step ahead (tools/conv_trace.py: ~1100-1260 cycles per step against 512 of
+    // MFMAs; four stages x (1 + 4) quads = 80 VGPRs where two tiles would need 96 + 32 accumulators).  Four stages and KQ % 4 == 0 also make the
+    // stage of a step its q: one offset per trip.
+    constexpr bool DEEP = (SEEVCN_RS3_DEEP != 0) && (SEEVCN_RS3_OFFSET_LOOP != 0) && RS_G == 1 && NT == 4 && KQ % 4 == 0 && RS3_RA == 3 && RS3_RB == 2;
+    constexpr int RA = DEEP ? 4 : RS3_RA, RB = DEEP ? 4 : RS3_RB, UNR = (RA % RB == 0) ? RA : RA * RB;
     static_assert(RA >= RB && RB >= 2, "the counted wait below is written for a weight ring no deeper than the row ring");
     f32x4 A[RA][RS_G], B[RB][NT];
     // defined here so that their live ranges start inside the pass (the asm waits below read-modify them: left undefined, hipcc keeps all
@@ -1346,6 +1390,165 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     for (int st = 0; st < RB; ++st)
 #pragma unroll
       for (int t = 0; t < NT; ++t) B[st][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr uint32_t OOB = 0xfffffff0u;
+    // the weight loads add immediates of up to 3 KiB to their vector offset: an out-of-range value that cannot wrap around 2^32 with them
+    // (the fragment buffer is a few MB)
+    constexpr uint32_t WOOB = 0x80000000u;
+    constexpr uint32_t WSTEP = 1024u;                                // one (offset, q, column tile) fragment
+    const uint32_t wq = (uint32_t)nt_total * WSTEP;                   // q -> q + 1
+    const uint32_t wlane = (uint32_t)lane * 16u;
+    auto math = [&](f32x4 (&As)[RS_G], f32x4 (&Bs)[NT], const int qc, const unsigned mc, const int32_t (&fin_absent)[RS_G]) {
+      // Issue order inside a step: weights of step s + 1, then rows of step s + RA - 1.  The younger of this step's operands is its weight stage
+      // (issued one step ago, in front of that step's row loads): behind it in the queue are one step's row loads and one whole step,
+      // NWAIT = RS_G + (RS_G + NT) loads that may stay outstanding; loads return in order, so the row stage (older) has arrived as well.
+      // (RA == RB, the measurement build SEEVCN_RS3_RB=3: both of a step's stages were issued RA - 1 steps ago, whole steps only behind them.)
+      // FIN: the step's coefficients (channels 16 qc + 4 kk + {0..3} of the lane's four values) and the rows' validity are LDS reads that do not
+      // depend on the operands: requested here, in front of the wait, their latency hides behind it (behind it they sat on every step's critical
+      // path: the two-tile forward at 139 k rows ran 127 us against 115 without the transform)
+      f32x4 fin_sc, fin_sh;
+      if constexpr (FIN) fin_sc = *reinterpret_cast<const f32x4*>(&s_coef[0][qc * 16 + kk * 4]), fin_sh = *reinterpret_cast<const f32x4*>(&s_coef[1][qc * 16 + kk * 4]);
+      constexpr int NWAIT = RA > RB ? RS_G + (RB - 1) * (RS_G + NT) : (RA - 1) * (RS_G + NT);
+#define RS3_WAIT(...) asm volatile("s_waitcnt vmcnt(%[nw])" : __VA_ARGS__ : [nw] "n"(NWAIT))
+#define V(x) "+v"(x)
+      if constexpr (RS_G == 4 && NT == 4) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
+      else if constexpr (RS_G == 4 && NT == 2) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]), V(Bs[1])); }
+      else if constexpr (RS_G == 4 && NT == 1) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0])); }
+      else if constexpr (RS_G == 3 && NT == 4) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
+      else if constexpr (RS_G == 3 && NT == 2) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(Bs[0]), V(Bs[1])); }
+      else if constexpr (RS_G == 3 && NT == 1) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(Bs[0])); }
+      else if constexpr (RS_G == 2 && NT == 4) { RS3_WAIT(V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
+      else if constexpr (RS_G == 2 && NT == 2) { RS3_WAIT(V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1])); }
+      else if constexpr (RS_G == 1 && NT == 4) { RS3_WAIT(V(As[0]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
+      else {
+        static_assert(RS_G == 2 && NT == 1, "no counted wait for this (tiles per wave, column tiles) pair");
+        RS3_WAIT(V(As[0]), V(As[1]), V(Bs[0]));
+      }
+#undef V
+#undef RS3_WAIT
+      // per tile: 4 passes over the NT column tiles, so that consecutive MFMAs never share an accumulator (a dependent
+      // v_mfma_f32_16x16x4_f32 issues 47 cycles after its producer, an independent one after 32).
+      // FIN: the transform of a tile's k-th operand register (fused multiply-add, max, and -- unless every row of the tile has this neighbour -- the
+      // clearing of the rows without one) is written BEHIND the first MFMA of the register before it: the wave issues it while the matrix pipe works
+      // on that MFMA instead of in front of the step's whole MFMA block (12-15 % on every forward launch when it sat there).
+      auto fin1 = [&](int g, int i) {
+        float v = fmaxf(__fmaf_rn(As[g][i], fin_sc[i], fin_sh[i]), in_lo);
+        if (!((mc >> (8 + g)) & 1u)) v = __uint_as_float(__float_as_uint(v) & ~(uint32_t)fin_absent[g]);       // wave-uniform test
+        As[g][i] = v;
+      };
+#pragma unroll
+      for (int g = 0; g < RS_G; ++g)
+        if (((mc >> g) & 1u) && !(DBG == 1 && (pv.debug & 4))) {
+          if constexpr (FIN) fin1(g, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g][i], Bs[0][i], acc[g][0], 0, 0, 0);
+            if constexpr (FIN) {
+              if (i + 1 < 4) fin1(g, i + 1);
+            }
+#pragma unroll
+            for (int t = 1; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g][i], Bs[t][i], acc[g][t], 0, 0, 0);
+          }
+        }
+    };
+    if constexpr ((SEEVCN_RS3_OFFSET_LOOP != 0) && KQ >= 2 && ((RA == 3 && RB == 2) || DEEP)) {
+      // The loop by OFFSET (round 6).  The first form below keeps three iterators (row loads, weight loads, compute) that each test "was this
+      // the offset's last 16-channel step" in EVERY step: ~30 scalar instructions and 6-8 taken branches between two MFMA blocks (hipcc keeps
+      // a step's MFMAs together, the bookkeeping is not interleaved with them).  With four waves on a SIMD the others' MFMAs cover that; a wave
+      // left ALONE does not: per-wave stamps (tools/conv_trace.py, profiles/r06_conv_trace_raw.txt) show every 64 -> 64 launch of <= 74 k rows
+      // ending with its 27-offset tiles, each walking 108 steps at ~1080 cycles where its 16 MFMAs need 512 -- the launch lasts as long as
+      // that wave (144 k cycles where the busiest SIMD needs 113 k, the mean one 89 k).  Here an iteration is one offset: its KQ steps are
+      // unrolled with compile-time q, the rows of step s + 2 and the weights of step s + 1 are "this offset's q + 2 / q + 1 or the next
+      // offset's q + 2 - KQ / 0" decided at compile time, and the list advances ONCE per offset (next offset, its gathered-row offsets from
+      // LDS, its weight base, its tile mask).  Three offsets per trip make the ring stages compile-time too (KQ steps per offset, 3 row stages).
+      // Same loads in the same order, same counted wait, same MFMA order: bit-identical results.
+      unsigned long long rest = active;                              // offsets behind k_n
+      int k_c = __ffsll((long long)rest) - 1;
+      rest &= rest - 1;
+      int k_n = rest ? __ffsll((long long)rest) - 1 : -1;
+      rest &= rest - 1;
+      auto rows_of = [&](int k, uint32_t (&ro)[RS_G]) {              // k >= 0: byte offset of the lane's gathered row (+ its 4-channel column), OOB without a neighbour
+#pragma unroll
+        for (int g = 0; g < RS_G; ++g) {
+          const int32_t j = s_idx[pv.k_flip ? a.K - 1 - k : k][g * 16 + li];
+          ro[g] = j >= 0 ? (uint32_t)(j * (Kd * 4) + kk * 16) : OOB;
+          if constexpr (DBG == 1) {
+            if (pv.debug & 1) ro[g] = OOB;
+            else if ((pv.debug & 16) && j >= 0) ro[g] = 0u;
+          }
+        }
+      };
+      auto wbase = [&](int k) { return (uint32_t)(k * KQ * nt_total + col_tile0) * WSTEP; };
+      uint32_t ro_c[RS_G], ro_n[RS_G], ro_t[RS_G];
+      rows_of(k_c, ro_c);
+#pragma unroll
+      for (int g = 0; g < RS_G; ++g) ro_n[g] = OOB;
+      if (k_n >= 0) rows_of(k_n, ro_n);
+      uint32_t wv_c = wlane;
+      if constexpr (DBG == 1) {
+        if (pv.debug & 2) wv_c = WOOB;
+        else if (pv.debug & 8) wv_c = 0u;
+      }
+      uint32_t wv_n = k_n >= 0 ? wv_c : WOOB;                         // past the list's end: out-of-range dummies (exactly NT + RS_G loads per step, always)
+      uint32_t sw_c = wbase(k_c), sw_n = k_n >= 0 ? wbase(k_n) : 0u;
+      unsigned mc = (unsigned)__builtin_amdgcn_readlane((int)maskreg, k_c);
+      auto load_a = [&](f32x4 (&As)[RS_G], const uint32_t (&ro)[RS_G], uint32_t sa) {
+#pragma unroll
+        for (int g = 0; g < RS_G; ++g) As[g] = buf_load_b128_s<0>(srd_x, ro[g], sa);
+      };
+      auto load_b = [&](f32x4 (&Bs)[NT], uint32_t wv, uint32_t sw) {
+        if constexpr (NT >= 1) Bs[0] = buf_load_b128_w<0>(srd_w, wv, sw);
+        if constexpr (NT >= 2) Bs[1] = buf_load_b128_w<1024>(srd_w, wv, sw);
+        if constexpr (NT >= 3) Bs[2] = buf_load_b128_w<2048>(srd_w, wv, sw);
+        if constexpr (NT >= 4) Bs[3] = buf_load_b128_w<3072>(srd_w, wv, sw);
+      };
+      constexpr int LA = RA - 1, LB = RB - 1;                         // steps of row / weight loads in flight
+      static_assert(LA <= KQ && LB <= LA, "a step's loads reach at most into the next offset");
+      constexpr int TRIP_STEPS = (KQ % RA == 0 && KQ % RB == 0) ? KQ : ((KQ * RA) % RB == 0 ? KQ * RA : KQ * RA * RB);
+      constexpr int NTRIP = TRIP_STEPS / KQ;                          // offsets per trip: the ring stages of a step are compile-time
+      // ring fill, in the loop's own issue order (virtual steps -LA .. -1: weights of step v + LB, then rows of step v + LA; all in the first offset)
+#pragma unroll
+      for (int v = -LA; v < 0; ++v) {
+        if (v + LB >= 0) load_b(B[(v + LB) % RB], wv_c, sw_c + (uint32_t)(v + LB) * wq);
+        load_a(A[(v + LA) % RA], ro_c, 64u * (uint32_t)(v + LA));
+      }
+      for (bool more = true; more;) {
+#pragma unroll
+        for (int u = 0; u < NTRIP; ++u) {
+          int32_t absent[RS_G];
+#pragma unroll
+          for (int g = 0; g < RS_G; ++g) absent[g] = FIN ? (ro_c[g] == OOB ? -1 : 0) : 0;     // all-ones: the row has no neighbour at this offset
+          int k_t = -1;
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            const int st = u * KQ + q;                               // step inside the trip (compile-time after unrolling)
+            if (q + LB < KQ) load_b(B[(st + LB) % RB], wv_c, sw_c + (uint32_t)(q + LB) * wq);
+            else load_b(B[(st + LB) % RB], wv_n, sw_n + (uint32_t)(q + LB - KQ) * wq);
+            if (q + LA < KQ) load_a(A[(st + LA) % RA], ro_c, 64u * (uint32_t)(q + LA));
+            else load_a(A[(st + LA) % RA], ro_n, 64u * (uint32_t)(q + LA - KQ));
+            if (q == KQ - 1) {
+              // the offset behind the next one: its rows' offsets are requested from LDS here, in front of this step's MFMAs, and first used
+              // KQ - LA steps into the next offset
+              k_t = rest ? __ffsll((long long)rest) - 1 : -1;
+              rest &= rest - 1;
+#pragma unroll
+              for (int g = 0; g < RS_G; ++g) ro_t[g] = OOB;
+              if (k_t >= 0) rows_of(k_t, ro_t);
+            }
+            math(A[st % RA], B[st % RB], q, mc, absent);
+          }
+          k_c = k_n, k_n = k_t;
+          if (k_c < 0) {
+            more = false;
+            break;
+          }
+#pragma unroll
+          for (int g = 0; g < RS_G; ++g) ro_c[g] = ro_n[g], ro_n[g] = ro_t[g];
+          sw_c = sw_n, sw_n = k_n >= 0 ? wbase(k_n) : 0u;
+          wv_n = k_n >= 0 ? wv_c : WOOB;
+          mc = (unsigned)__builtin_amdgcn_readlane((int)maskreg, k_c);
+        }
+      }
+    } else {
     // Row-load iterator (RA - 1 steps ahead of the compute iterator).  Per offset: rowoff[g] = byte offset of the lane's gathered row (+ its
     // 4-channel column), or an out-of-range value when the row has no neighbour there / the list has ended.  Per 16-channel step the loads then
     // need NO vector arithmetic: rows at rowoff + (scalar) 64 * q, weights at one constant per-lane offset + (scalar) fragment base of
@@ -1353,12 +1556,7 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     // instructions per step next to its 32 MFMAs.)
     unsigned long long la = active;
     int kl = __ffsll((long long)la) - 1, ql = 0;
-    constexpr uint32_t OOB = 0xfffffff0u;
-    // the weight loads add immediates of up to 3 KiB to their vector offset: an out-of-range value that cannot wrap around 2^32 with them
-    // (the fragment buffer is a few MB)
-    constexpr uint32_t WOOB = 0x80000000u;
     uint32_t rowoff[RS_G];
-    const uint32_t wlane = (uint32_t)lane * 16u;
     uint32_t wvoff = wlane;                                          // OOB once the list has ended (dummy loads)
     auto read_j = [&]() {
 #pragma unroll
@@ -1377,8 +1575,6 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
       else if (pv.debug & 8) wvoff = 0u;
     }
     // running scalar offsets: sa = 64 * q (rows), sw = fragment base of (offset, q) (weights)
-    constexpr uint32_t WSTEP = 1024u;                                // one (offset, q, column tile) fragment
-    const uint32_t wq = (uint32_t)nt_total * WSTEP;                   // q -> q + 1
     uint32_t sa = 0u;
     auto issue_a = [&](f32x4 (&As)[RS_G]) {                          // exactly RS_G loads, always
 #pragma unroll
@@ -1422,62 +1618,14 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
     int kc = __ffsll((long long)ca) - 1, qc = 0;
     unsigned mc = (unsigned)__builtin_amdgcn_readlane((int)maskreg, kc);
     auto compute = [&](f32x4 (&As)[RS_G], f32x4 (&Bs)[NT]) {
-      // Issue order inside a step: weights of step s + 1, then rows of step s + RA - 1.  The younger of this step's operands is its weight stage
-      // (issued one step ago, in front of that step's row loads): behind it in the queue are one step's row loads and one whole step,
-      // NWAIT = RS_G + (RS_G + NT) loads that may stay outstanding; loads return in order, so the row stage (older) has arrived as well.
-      // (RA == RB, the measurement build SEEVCN_RS3_RB=3: both of a step's stages were issued RA - 1 steps ago, whole steps only behind them.)
-      // FIN: the step's coefficients (channels 16 qc + 4 kk + {0..3} of the lane's four values) and the rows' validity are LDS reads that do not
-      // depend on the operands: requested here, in front of the wait, their latency hides behind it (behind it they sat on every step's critical
-      // path: the two-tile forward at 139 k rows ran 127 us against 115 without the transform)
-      f32x4 fin_sc, fin_sh;
       int32_t fin_absent[RS_G];
+#pragma unroll
+      for (int g = 0; g < RS_G; ++g) fin_absent[g] = 0;
       if constexpr (FIN) {
-        fin_sc = *reinterpret_cast<const f32x4*>(&s_coef[0][qc * 16 + kk * 4]), fin_sh = *reinterpret_cast<const f32x4*>(&s_coef[1][qc * 16 + kk * 4]);
 #pragma unroll
         for (int g = 0; g < RS_G; ++g) fin_absent[g] = s_idx[pv.k_flip ? a.K - 1 - kc : kc][g * 16 + li] >> 31;     // all-ones: no neighbour
       }
-      constexpr int NWAIT = RA > RB ? RS_G + (RB - 1) * (RS_G + NT) : (RA - 1) * (RS_G + NT);
-#define RS3_WAIT(...) asm volatile("s_waitcnt vmcnt(%[nw])" : __VA_ARGS__ : [nw] "n"(NWAIT))
-#define V(x) "+v"(x)
-      if constexpr (RS_G == 4 && NT == 4) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
-      else if constexpr (RS_G == 4 && NT == 2) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0]), V(Bs[1])); }
-      else if constexpr (RS_G == 4 && NT == 1) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(As[3]), V(Bs[0])); }
-      else if constexpr (RS_G == 3 && NT == 4) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
-      else if constexpr (RS_G == 3 && NT == 2) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(Bs[0]), V(Bs[1])); }
-      else if constexpr (RS_G == 3 && NT == 1) { RS3_WAIT(V(As[0]), V(As[1]), V(As[2]), V(Bs[0])); }
-      else if constexpr (RS_G == 2 && NT == 4) { RS3_WAIT(V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
-      else if constexpr (RS_G == 2 && NT == 2) { RS3_WAIT(V(As[0]), V(As[1]), V(Bs[0]), V(Bs[1])); }
-      else if constexpr (RS_G == 1 && NT == 4) { RS3_WAIT(V(As[0]), V(Bs[0]), V(Bs[1]), V(Bs[2]), V(Bs[3])); }
-      else {
-        static_assert(RS_G == 2 && NT == 1, "no counted wait for this (tiles per wave, column tiles) pair");
-        RS3_WAIT(V(As[0]), V(As[1]), V(Bs[0]));
-      }
-#undef V
-#undef RS3_WAIT
-      // per tile: 4 passes over the NT column tiles, so that consecutive MFMAs never share an accumulator (a dependent
-      // v_mfma_f32_16x16x4_f32 issues 47 cycles after its producer, an independent one after 32).
-      // FIN: the transform of a tile's k-th operand register (fused multiply-add, max, and -- unless every row of the tile has this neighbour -- the
-      // clearing of the rows without one) is written BEHIND the first MFMA of the register before it: the wave issues it while the matrix pipe works
-      // on that MFMA instead of in front of the step's whole MFMA block (12-15 % on every forward launch when it sat there).
-      auto fin1 = [&](int g, int i) {
-        float v = fmaxf(__fmaf_rn(As[g][i], fin_sc[i], fin_sh[i]), in_lo);
-        if (!((mc >> (8 + g)) & 1u)) v = __uint_as_float(__float_as_uint(v) & ~(uint32_t)fin_absent[g]);       // wave-uniform test
-        As[g][i] = v;
-      };
-#pragma unroll
-      for (int g = 0; g < RS_G; ++g)
-        if (((mc >> g) & 1u) && !(DBG == 1 && (pv.debug & 4))) {
-          if constexpr (FIN) fin1(g, 0);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g][i], Bs[0][i], acc[g][0], 0, 0, 0);
-            if constexpr (FIN) {
-              if (i + 1 < 4) fin1(g, i + 1);
-            }
-#pragma unroll
-            for (int t = 1; t < NT; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[g][i], Bs[t][i], acc[g][t], 0, 0, 0);
-          }
-        }
+      math(As, Bs, qc, mc, fin_absent);
       if (++qc == KQ) {
         qc = 0;
         ca &= ca - 1;
@@ -1503,9 +1651,10 @@ __global__ __launch_bounds__(256, PL_WAVES_PER_SIMD) void k_spconv_rs3(ConvArgs 
         }
       }
     }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // retire the dummy loads before the registers are reused
   }
-  if (pv.prio == 2) __builtin_amdgcn_s_setprio(3);
+  if ((pv.prio & 3) == 2) __builtin_amdgcn_s_setprio(3);
   if (DBG && pv.trace) {
     const unsigned long long t = __builtin_amdgcn_s_memtime();
     t_loop += t - t_mark, t_mark = t;

@@ -55,6 +55,8 @@ def main():
     lib.sv_debug_conv_trace(None)
     t = buf.cpu().numpy()
     t = t[t[:, 3] != 0]
+    if os.environ.get("DUMP"):                 # raw per-wave records for offline analysis: start, prologue cycles, loop cycles, end, HW_ID, XCC_ID, steps, (block << 8) | wave
+        np.save(os.path.join(os.environ["DUMP"], f"conv_trace_{want}.npy"), t)
     xcc_id = (t[:, 5] & 0xf).astype(np.int64)
     hw = t[:, 4].astype(np.int64)
     # s_memtime counts shader cycles and is NOT comparable between CUs on this part (tools/wgrad_trace.py found offsets of millions of ticks inside one
