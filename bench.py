@@ -58,7 +58,8 @@ def build_model(device, seed=0):
 class _MeanSquare(torch.autograd.Function):
     """mean(x^2) over the dense BEV tensor: same value and gradient as x.square().mean().  The forward reads the tensor once and, while it does,
     writes the loss's own gradient (2 / n) x (sv_mean_square: one read + one write, fixed-order sums); the backward hands that tensor on, scaled by
-    the upstream gradient on the device only when it is not 1 (sv_scale_by_device_scalar).  Round 4 ran a row-norm reduction forward (145 us for the
+    the upstream gradient on the device only when it is not 1 (sv_scale_by_device_scalar; in place, so ONE backward per forward).  The gradient tensor
+    (577 MB here) lives from the forward to the backward -- the step's memory holds it beside the dense tensor, as a framework's saved activation would.  Round 4 ran a row-norm reduction forward (145 us for the
     577 MB tensor) and an elementwise product backward (210 us); SEEVCN_BENCH_LOSS=torch keeps that pair for A/B runs."""
 
     @staticmethod
@@ -87,6 +88,9 @@ class _MeanSquare(torch.autograd.Function):
         (t,) = ctx.saved_tensors
         if not ctx.fused:
             return t * (g * (2.0 / t.numel()))
+        if getattr(ctx, "consumed", False):                        # the gradient tensor is scaled IN PLACE below: a second backward would scale it twice
+            raise RuntimeError("bench._MeanSquare: backward ran twice on one forward (retain_graph is not supported by the fused stand-in loss)")
+        ctx.consumed = True
         _lib.check(_lib.load().sv_scale_by_device_scalar(_lib.ptr(t), t.numel(), _lib.ptr(g.contiguous().float()), _lib.stream()), "sv_scale_by_device_scalar")
         return t
 

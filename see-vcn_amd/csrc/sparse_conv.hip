@@ -521,7 +521,8 @@ static PlanDims plan_dims(int64_t n_rows, int G) {
 #define SEEVCN_PL_LPT 1
 #endif
 template <typename CostOf>
-__device__ __forceinline__ void plan_deal_quads(const uint16_t* s_sorted, CostOf cost_of, int nt, int tile0, int slots, int32_t* __restrict__ out) {
+__device__ __forceinline__ void plan_deal_quads(const uint16_t* s_sorted, CostOf cost_of, int nt, int tile0, int slots, int32_t* __restrict__ out, uint8_t* s_bin) {
+  // s_bin: one byte of LDS per quad (the caller's: a table that is dead by now) -- the quad's cost, then its bin
   const int tid = threadIdx.x;
   const int nq = (nt + PL_QUAD - 1) / PL_QUAD;
   auto put = [&](int qd, int j, int bin) {
@@ -538,22 +539,24 @@ __device__ __forceinline__ void plan_deal_quads(const uint16_t* s_sorted, CostOf
       put(qd, j, (j & 1) ? PL_BINS - 1 - pos : pos);
     }
   } else {
-    if (tid >= 64) return;
-    const int lane = tid;
-    int load = 0;                                                     // lanes 0..31: (tile, offset) steps the bin's waves hold so far
-    for (int j = 0; j * PL_BINS < nq; ++j) {
-      int rank = 0;
+    for (int qd = tid; qd < nq; qd += 1024) s_bin[qd] = (uint8_t)cost_of(s_sorted[qd * PL_QUAD]);      // the quad's first tile is its costliest
+    __syncthreads();
+    if (tid < 64) {                                                   // the serial part: one wave, nothing but the ranking and two LDS bytes per round
+      const int lane = tid;
+      int key = lane;                                                 // (load << 5) | bin: unique, so a bin's rank is the number of smaller keys
+      for (int j = 0; j * PL_BINS < nq; ++j) {
+        int rank = 0;
 #pragma unroll
-      for (int o = 0; o < PL_BINS; ++o) {
-        const int lo = __builtin_amdgcn_readlane(load, o);
-        rank += (lo < load || (lo == load && o < lane)) ? 1 : 0;
-      }
-      const int qd = j * PL_BINS + rank;                             // the bin with the rank-th lightest load takes the round's rank-th costliest quad
-      if (lane < PL_BINS && qd < nq) {
-        put(qd, j, lane);
-        load += cost_of(s_sorted[qd * PL_QUAD]);                      // the quad's first tile is its costliest
+        for (int o = 0; o < PL_BINS; ++o) rank += __builtin_amdgcn_readlane(key, o) < key ? 1 : 0;
+        const int qd = j * PL_BINS + rank;                           // the bin with the rank-th lightest load takes the round's rank-th costliest quad
+        if (lane < PL_BINS && qd < nq) {
+          key += (int)s_bin[qd] << 5;
+          s_bin[qd] = (uint8_t)lane;
+        }
       }
     }
+    __syncthreads();
+    for (int qd = tid; qd < nq; qd += 1024) put(qd, qd / PL_BINS, s_bin[qd]);
   }
 }
 
@@ -594,7 +597,8 @@ __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ 
   __syncthreads();
   // quads of 4 consecutive tiles of the sorted list, dealt to the 32 CU bins in snake order (0 .. 31, 31 .. 0, ...); inside a bin the rounds
   // walk the four workgroups in snake order too.  One thread per quad.
-  plan_deal_quads(s_sorted, [&](int t) { return (int)s_cost[t]; }, nt, d.tile0[r], slots, out);
+  __shared__ uint8_t s_bin[PL_MAX_REGION_TILES / PL_QUAD];
+  plan_deal_quads(s_sorted, [&](int t) { return (int)s_cost[t]; }, nt, d.tile0[r], slots, out, s_bin);
 }
 
 // The whole plan of a table in ONE launch: the 8 regions are independent (own classes, own positions, own tiles, own waves), so one
@@ -758,7 +762,7 @@ __device__ __forceinline__ void plan_region_body(const PlanFusedArgs& a, const i
     if (live) s_sorted[s_cstart[c] + off + rank] = (uint16_t)t;
   }
   __syncthreads();
-  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, out);
+  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, out, reinterpret_cast<uint8_t*>(s_start));   // the class starts are dead: placement is over
 }
 
 // The same plan with a DETERMINISTIC order: inside a class the rows keep their table order, inside a cost bucket the tiles theirs, so a table has
@@ -910,7 +914,7 @@ __device__ __forceinline__ void plan_region_body_stable(const PlanFusedArgs& a, 
     if (live) s_sorted[s_cstart[c] + off + rank] = (uint16_t)t;
   }
   __syncthreads();
-  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, out);
+  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, out, reinterpret_cast<uint8_t*>(s_wc));      // the class counters are dead: placement is over
 }
 
 __device__ __forceinline__ void plan_region_dispatch(const PlanFusedArgs& a, const int r) {

@@ -58,12 +58,16 @@ def merged_branches(heads, x):
     branches = [(hi, name, getattr(head, name)) for hi, head in enumerate(heads) for name in head.sep_head_dict]
     if len(branches) < 2 or not x.is_cuda:
         return None
+    if not all(_plain(head) and type(head).forward is SeparateHead.forward for head in heads):
+        return None                                              # the merged form never calls head.forward: hooks on a head, or a subclass's forward, need the modules
     c = x.shape[1]
     for _, _, fc in branches:
         if len(fc) != 2 or not isinstance(fc[0], nn.Sequential) or len(fc[0]) != 3:
             return None
         conv1, bn, act, conv2 = fc[0][0], fc[0][1], fc[0][2], fc[1]
-        ok = (isinstance(conv1, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU) and isinstance(conv2, nn.Conv2d)
+        # exact types (as spconv/chain.py checks its blocks): a subclass -- a frozen BatchNorm with its own forward, say -- must run as itself
+        ok = (type(conv1) is nn.Conv2d and type(bn) is nn.BatchNorm2d and type(act) is nn.ReLU and type(conv2) is nn.Conv2d
+              and bn.momentum is not None                        # momentum None = cumulative average over num_batches_tracked: F.batch_norm has no such mode
               and conv1.in_channels == c and conv1.out_channels == c and conv2.in_channels == c and conv2.bias is not None
               and all(m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 for m in (conv1, conv2))
               and (conv1.bias is None) == (branches[0][2][0][0].bias is None)

@@ -99,6 +99,13 @@ def fps_bucketed(points, starts, cnt, batch, fixed_n, max_n, m, idx):
     lib = _lib.load()
     if not lib.sv_fps_bucket_applies(int(batch), int(max_n), int(m)):
         return False
+    if cnt is not None:
+        # the kernels size their scene slabs from the HOST's max_n: a scene longer than that (a stale points-per-scene bound) would be cut short without a
+        # word -- the exhaustive kernels had their error word for this.  Parked: raised at the stream's next host read, no read of its own.
+        def _check(v, max_n=int(max_n)):
+            if v > max_n:
+                raise _lib.SeevcnHipError(f"farthest_point_sampling: a scene has {v} points, the caller's max_n is {max_n}")
+        _lib.defer_check(cnt.max(), _check)
     scratch = torch.empty((int(lib.sv_fps_bucket_scratch_bytes(int(batch), int(max_n))),), dtype=torch.uint8, device=points.device)
     _lib.check(lib.sv_farthest_point_sampling_bucketed(_lib.ptr(points), _lib.ptr(starts), _lib.ptr(cnt), int(batch), int(fixed_n), int(max_n), int(m),
                                                        _lib.ptr(scratch), _lib.ptr(idx), _lib.stream()), "sv_farthest_point_sampling_bucketed")
@@ -144,9 +151,12 @@ class FpsHandle:
 
     def __init__(self, idx, err, stream, rerun):
         self.idx, self.err, self.stream, self._rerun = idx, err, stream, rerun
+        self.done = torch.cuda.Event()         # behind the sampling on its stream: what result() orders the caller's stream after when there is no error word to read
+        self.done.record(stream)
 
     def result(self):
         if self.err is None:                   # sampled by the one-workgroup bucket kernel: nothing that could have gone missing
+            torch.cuda.current_stream().wait_event(self.done)      # no host wait: the caller's stream goes behind the sampling stream
             return self.idx
         with torch.cuda.stream(self.stream):
             bad = int(self.err.item())
