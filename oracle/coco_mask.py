@@ -17,7 +17,9 @@ Shrinking (shrink_distance, ann_to_mask_shrunk): the reference moves every polyg
 (shared_utils.py:295-330: d = half diagonal of the bounding box x percentage / 100, Polygon.buffer(-d), exterior vertices truncated to int).  shapely /
 GEOS are not available here, and their vertex list (arcs as 16 chords per quadrant, noding, int truncation) is not restated: this file states the REGION
 a negative buffer describes -- the points of the polygon at least d from its boundary -- sampled at the pixel centres of the polygon's own mask.  Equal
-to the reference's mask except in a band of about one pixel along the shrunken boundary.  PARITY UNPINNED, and known to deviate in that band."""
+to the reference's mask except in a band of about one pixel along the shrunken boundary.  PARITY UNPINNED, and known to deviate in that band.
+Since round 6 the product's get_pts_in_mask follows the vertex-list form instead (oracle/polygon_buffer.py); this region form checks
+sv_polygons_to_masks_shrunk, which stays exported."""
 import math
 
 import numpy as np

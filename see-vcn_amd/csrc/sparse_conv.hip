@@ -480,6 +480,14 @@ extern "C" int sv_conv_table_rows(const int32_t* nbr, int64_t n_rows, int K, int
 #ifndef SEEVCN_PL_WAVES
 #define SEEVCN_PL_WAVES 4
 #endif
+// 1 (round 6): the G tiles a wave works on at a time are CONSECUTIVE in the cost-sorted list (units of G quads dealt together) instead of one tile from
+// each of G different rounds.  A wave walks the union of its tiles' offsets and issues every tile's gather and the offset's weight loads in each step,
+// whether the tile has the offset or not: with tiles of cost 27 / 12 / 8 / 5 the union is the 27 and a step carries 1.7 of 4 tiles on average
+// (32 -> 32 at 250 k rows), with four tiles of one cost -- neighbours in the sorted list, mostly one mask class -- 3.0; steps per launch 82 k -> 47 k
+// there, 67 k -> 52 k on the two-tile 64 -> 64 layers (an emulation of the plan on the bench's tables).  0: the round-2 deal (A/B builds).
+#ifndef SEEVCN_PL_ADJ
+#define SEEVCN_PL_ADJ 1
+#endif
 constexpr int PL_WAVES_PER_SIMD = SEEVCN_PL_WAVES;
 constexpr int PL_BINS = 32;                                         // CUs per XCD
 constexpr int PL_QUAD = 4;                                          // tiles dealt together: one per wave of a workgroup
@@ -503,9 +511,16 @@ static PlanDims plan_dims(int64_t n_rows, int G) {
     if (d.tiles[r] > max_tiles) max_tiles = d.tiles[r];
   }
   const int quads = (max_tiles + PL_QUAD - 1) / PL_QUAD;
+#if SEEVCN_PL_ADJ
+  // units of G consecutive quads (see plan_deal_quads): one unit per bin and round, PL_WAVES_PER_SIMD rounds per pass
+  const int units = (quads + G - 1) / G;
+  const int rounds = (units + PL_BINS - 1) / PL_BINS;
+  d.n_pass = rounds > 0 ? (rounds + PL_WAVES_PER_SIMD - 1) / PL_WAVES_PER_SIMD : 1;
+#else
   const int rounds = (quads + PL_BINS - 1) / PL_BINS;                            // quads per CU bin
   const int slots = (rounds + PL_WAVES_PER_SIMD - 1) / PL_WAVES_PER_SIMD;        // tiles per wave
   d.n_pass = slots > 0 ? (slots + G - 1) / G : 1;
+#endif
   return d;
 }
 
@@ -521,42 +536,50 @@ static PlanDims plan_dims(int64_t n_rows, int G) {
 #define SEEVCN_PL_LPT 1
 #endif
 template <typename CostOf>
-__device__ __forceinline__ void plan_deal_quads(const uint16_t* s_sorted, CostOf cost_of, int nt, int tile0, int slots, int32_t* __restrict__ out, uint8_t* s_bin) {
-  // s_bin: one byte of LDS per quad (the caller's: a table that is dead by now) -- the quad's cost, then its bin
+__device__ __forceinline__ void plan_deal_quads(const uint16_t* s_sorted, CostOf cost_of, int nt, int tile0, int slots, int G, int32_t* __restrict__ out, uint8_t* s_bin) {
+  // s_bin: one byte of LDS per unit (the caller's: a table that is dead by now) -- the unit's cost, then its bin
   const int tid = threadIdx.x;
   const int nq = (nt + PL_QUAD - 1) / PL_QUAD;
-  auto put = [&](int qd, int j, int bin) {
-    const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;       // inside a bin the rounds walk its workgroups in snake order
+  const int UG = SEEVCN_PL_ADJ ? G : 1;                              // quads per unit
+  const int nu = (nq + UG - 1) / UG;
+  // unit u of round j = u / 32 goes to `bin`; inside a bin the rounds walk its workgroups in snake order; the unit's quads fill the G slots of one pass
+  // (SEEVCN_PL_ADJ = 0: a unit is one quad and a round fills one SLOT of the bin's workgroups, as in rounds 2-5)
+  auto put = [&](int u, int j, int bin) {
+    const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;
+    const int slot0 = (j / PL_WAVES_PER_SIMD) * UG;
+    for (int g = 0; g < UG; ++g) {
+      const int qd = u * UG + g;
 #pragma unroll
-    for (int part = 0; part < PL_QUAD; ++part) {
-      const int p = qd * PL_QUAD + part;
-      if (p < nt) out[(int64_t)((bin + PL_BINS * wg) * 4 + part) * slots + j / PL_WAVES_PER_SIMD] = tile0 + s_sorted[p];
+      for (int part = 0; part < PL_QUAD; ++part) {
+        const int p = qd * PL_QUAD + part;
+        if (p < nt) out[(int64_t)((bin + PL_BINS * wg) * 4 + part) * slots + slot0 + g] = tile0 + s_sorted[p];
+      }
     }
   };
   if constexpr (SEEVCN_PL_LPT == 0) {
-    for (int qd = tid; qd < nq; qd += 1024) {
-      const int j = qd / PL_BINS, pos = qd % PL_BINS;                 // round of the bin, position in the round
-      put(qd, j, (j & 1) ? PL_BINS - 1 - pos : pos);
+    for (int u = tid; u < nu; u += 1024) {
+      const int j = u / PL_BINS, pos = u % PL_BINS;                   // round of the bin, position in the round
+      put(u, j, (j & 1) ? PL_BINS - 1 - pos : pos);
     }
   } else {
-    for (int qd = tid; qd < nq; qd += 1024) s_bin[qd] = (uint8_t)cost_of(s_sorted[qd * PL_QUAD]);      // the quad's first tile is its costliest
+    for (int u = tid; u < nu; u += 1024) s_bin[u] = (uint8_t)cost_of(s_sorted[u * UG * PL_QUAD]);      // the unit's first tile is its costliest (its quads cost about the same)
     __syncthreads();
     if (tid < 64) {                                                   // the serial part: one wave, nothing but the ranking and two LDS bytes per round
       const int lane = tid;
       int key = lane;                                                 // (load << 5) | bin: unique, so a bin's rank is the number of smaller keys
-      for (int j = 0; j * PL_BINS < nq; ++j) {
+      for (int j = 0; j * PL_BINS < nu; ++j) {
         int rank = 0;
 #pragma unroll
         for (int o = 0; o < PL_BINS; ++o) rank += __builtin_amdgcn_readlane(key, o) < key ? 1 : 0;
-        const int qd = j * PL_BINS + rank;                           // the bin with the rank-th lightest load takes the round's rank-th costliest quad
-        if (lane < PL_BINS && qd < nq) {
-          key += (int)s_bin[qd] << 5;
-          s_bin[qd] = (uint8_t)lane;
+        const int u = j * PL_BINS + rank;                            // the bin with the rank-th lightest load takes the round's rank-th costliest unit
+        if (lane < PL_BINS && u < nu) {
+          key += (int)s_bin[u] << 5;
+          s_bin[u] = (uint8_t)lane;
         }
       }
     }
     __syncthreads();
-    for (int qd = tid; qd < nq; qd += 1024) put(qd, qd / PL_BINS, s_bin[qd]);
+    for (int u = tid; u < nu; u += 1024) put(u, u / PL_BINS, s_bin[u]);
   }
 }
 
@@ -598,7 +621,7 @@ __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ 
   // quads of 4 consecutive tiles of the sorted list, dealt to the 32 CU bins in snake order (0 .. 31, 31 .. 0, ...); inside a bin the rounds
   // walk the four workgroups in snake order too.  One thread per quad.
   __shared__ uint8_t s_bin[PL_MAX_REGION_TILES / PL_QUAD];
-  plan_deal_quads(s_sorted, [&](int t) { return (int)s_cost[t]; }, nt, d.tile0[r], slots, out, s_bin);
+  plan_deal_quads(s_sorted, [&](int t) { return (int)s_cost[t]; }, nt, d.tile0[r], slots, d.G, out, s_bin);
 }
 
 // The whole plan of a table in ONE launch: the 8 regions are independent (own classes, own positions, own tiles, own waves), so one
@@ -762,7 +785,7 @@ __device__ __forceinline__ void plan_region_body(const PlanFusedArgs& a, const i
     if (live) s_sorted[s_cstart[c] + off + rank] = (uint16_t)t;
   }
   __syncthreads();
-  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, out, reinterpret_cast<uint8_t*>(s_start));   // the class starts are dead: placement is over
+  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, a.d.G, out, reinterpret_cast<uint8_t*>(s_start));   // the class starts are dead: placement is over
 }
 
 // The same plan with a DETERMINISTIC order: inside a class the rows keep their table order, inside a cost bucket the tiles theirs, so a table has
@@ -914,7 +937,7 @@ __device__ __forceinline__ void plan_region_body_stable(const PlanFusedArgs& a, 
     if (live) s_sorted[s_cstart[c] + off + rank] = (uint16_t)t;
   }
   __syncthreads();
-  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, out, reinterpret_cast<uint8_t*>(s_wc));      // the class counters are dead: placement is over
+  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, a.d.G, out, reinterpret_cast<uint8_t*>(s_wc));      // the class counters are dead: placement is over
 }
 
 __device__ __forceinline__ void plan_region_dispatch(const PlanFusedArgs& a, const int r) {

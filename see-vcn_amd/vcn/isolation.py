@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from . import polygon_buffer
 
 
 def _dev_points(points, device):
@@ -252,16 +253,16 @@ def instance_masks_device(instances, img_h, img_w, device='cuda', shrink_percent
     boundary arithmetic of cocoapi's rleFrPoly, union of an instance's parts); RLE dicts are decoded on the host and copied; an instance that
     already carries 'bin_mask' keeps it.
 
-    shrink_percentage != 0 (shrink_instance_masks, shared_utils.py:310-330; polygon instances only, like the reference): every part's boundary moves
-    inwards by d = half diagonal of its bounding box x percentage / 100 before the mask is made -- here as "the pixels of the part at least d from
-    its edges" (sv_polygons_to_masks_shrunk), which is the region shapely's buffer(-d) describes sampled at the pixel centres, not its vertex list:
-    equal masks except in a band of about one pixel along the shrunken boundary (oracle/coco_mask.py; shapely is not available to pin against).  An
-    instance with a part that shrinks to nothing keeps its unshrunken mask, as the reference returns the original polygons then."""
+    shrink_percentage != 0 (shrink_instance_masks, shared_utils.py:310-330; polygon instances only, like the reference): every polygon list goes
+    through polygon_buffer.shrink_instance_masks first -- the negative buffer's exterior ring(s) with int()-truncated vertices, the original list
+    when a part shrinks to nothing -- and the result is what is rasterised, as the reference rasterises its replaced instance['segmentation']
+    (vcn/polygon_buffer.py: a restatement of GEOS's construction, unpinned -- shapely is not available here).  Until round 6 this path kept the pixels
+    at least d from the part's edges (sv_polygons_to_masks_shrunk: the same region without the vertex list's int() shift; still exported)."""
     lib = _lib.load()
     dev = torch.device(device)
     n = len(instances)
     masks = torch.empty((n, img_h, img_w), dtype=torch.uint8, device=dev)
-    xy, off, inst_of, host, dist = [], [0], [], {}, []
+    xy, off, inst_of, host = [], [0], [], {}
     for i, inst in enumerate(instances):
         seg = inst.get('bin_mask')
         if seg is not None:
@@ -269,15 +270,16 @@ def instance_masks_device(instances, img_h, img_w, device='cuda', shrink_percent
         elif isinstance(inst['segmentation'], dict):
             host[i] = _rle_to_mask(inst['segmentation'])
         else:
-            for poly in inst['segmentation']:
+            polys = inst['segmentation']
+            if shrink_percentage:
+                polys = polygon_buffer.shrink_instance_masks(polys, shrink_percentage)
+            for poly in polys:
                 if len(poly) < 2:
                     continue
                 part = [float(t) for t in poly[:2 * (len(poly) // 2)]]
                 xy.extend(part)
                 off.append(len(xy) // 2)
                 inst_of.append(i)
-                xs, ys = part[0::2], part[1::2]
-                dist.append(0.5 * float(np.hypot(max(xs) - min(xs), max(ys) - min(ys))) * (shrink_percentage / 100.0))
     n_poly = len(inst_of)
     if n_poly:
         xy_t = torch.tensor(xy, dtype=torch.float64, device=dev)
@@ -288,21 +290,50 @@ def instance_masks_device(instances, img_h, img_w, device='cuda', shrink_percent
     else:
         xy_t = off_t = inst_t = scratch = None
         max_v = 0
-    if shrink_percentage and n_poly:
-        dist_t = torch.tensor(dist, dtype=torch.float64, device=dev)
-        kept = torch.empty((n_poly,), dtype=torch.int32, device=dev)
-        _lib.check(lib.sv_polygons_to_masks_shrunk(_lib.ptr(xy_t), _lib.ptr(off_t), _lib.ptr(inst_t), _lib.ptr(dist_t), n_poly, max_v, n, img_h, img_w,
-                                                   _lib.ptr(scratch), _lib.ptr(masks), _lib.ptr(kept), _lib.stream()), "sv_polygons_to_masks_shrunk")
-        empty = sorted({inst_of[p] for p in np.nonzero(kept.cpu().numpy() == 0)[0]})
-        if empty:                                                 # shared_utils.py:325-326: such an instance keeps its original polygons
-            redo = instance_masks_device([{'segmentation': instances[i]['segmentation']} for i in empty], img_h, img_w, dev, 0)
-            masks[torch.tensor(empty, device=dev)] = redo
-    else:
-        _lib.check(lib.sv_polygons_to_masks(_lib.ptr(xy_t), _lib.ptr(off_t), _lib.ptr(inst_t), n_poly, max_v, n, img_h, img_w, _lib.ptr(scratch),
-                                            _lib.ptr(masks), _lib.stream()), "sv_polygons_to_masks")
+    _lib.check(lib.sv_polygons_to_masks(_lib.ptr(xy_t), _lib.ptr(off_t), _lib.ptr(inst_t), n_poly, max_v, n, img_h, img_w, _lib.ptr(scratch),
+                                        _lib.ptr(masks), _lib.stream()), "sv_polygons_to_masks")
     for i, m in host.items():
         assert m.shape == (img_h, img_w), f"instance {i}: mask {m.shape} on a {(img_h, img_w)} image"
         masks[i].copy_(torch.from_numpy(np.ascontiguousarray(m)))
+    return masks
+
+
+def instance_masks_within_distance(instances, img_h, img_w, device='cuda', shrink_percentage=0):
+    """Round 5's form of the shrunken masks, kept for sv_polygons_to_masks_shrunk's callers: the pixels of every polygon part whose centre is at least
+    d (= half diagonal of the part's bounding box x percentage / 100) from the part's edges -- the REGION of the negative buffer without the vertex
+    list's int() truncation (get_pts_in_mask takes instance_masks_device / polygon_buffer instead).  An instance with a part that leaves no pixel
+    keeps its unshrunken mask.  Polygon instances only."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    n = len(instances)
+    masks = torch.zeros((n, img_h, img_w), dtype=torch.uint8, device=dev)
+    xy, off, inst_of, dist = [], [0], [], []
+    for i, inst in enumerate(instances):
+        for poly in inst['segmentation']:
+            if len(poly) < 2:
+                continue
+            part = [float(t) for t in poly[:2 * (len(poly) // 2)]]
+            xy.extend(part)
+            off.append(len(xy) // 2)
+            inst_of.append(i)
+            xs, ys = part[0::2], part[1::2]
+            dist.append(0.5 * float(np.hypot(max(xs) - min(xs), max(ys) - min(ys))) * (shrink_percentage / 100.0))
+    n_poly = len(inst_of)
+    if not n_poly:
+        return masks
+    xy_t = torch.tensor(xy, dtype=torch.float64, device=dev)
+    off_t = torch.tensor(off, dtype=torch.int32, device=dev)
+    inst_t = torch.tensor(inst_of, dtype=torch.int32, device=dev)
+    max_v = max(b - a for a, b in zip(off[:-1], off[1:]))
+    scratch = torch.empty((lib.sv_polygon_masks_scratch_bytes(n_poly, img_h, img_w),), dtype=torch.uint8, device=dev)
+    dist_t = torch.tensor(dist, dtype=torch.float64, device=dev)
+    kept = torch.empty((n_poly,), dtype=torch.int32, device=dev)
+    _lib.check(lib.sv_polygons_to_masks_shrunk(_lib.ptr(xy_t), _lib.ptr(off_t), _lib.ptr(inst_t), _lib.ptr(dist_t), n_poly, max_v, n, img_h, img_w,
+                                               _lib.ptr(scratch), _lib.ptr(masks), _lib.ptr(kept), _lib.stream()), "sv_polygons_to_masks_shrunk")
+    empty = sorted({inst_of[p] for p in np.nonzero(kept.cpu().numpy() == 0)[0]})
+    if empty:
+        redo = instance_masks_device([{'segmentation': instances[i]['segmentation']} for i in empty], img_h, img_w, dev, 0)
+        masks[torch.tensor(empty, device=dev)] = redo
     return masks
 
 
@@ -310,8 +341,8 @@ def get_pts_in_mask(dataset, instances, imgfov, shrink_percentage=0, use_bbox=Fa
     """shared_utils.py:36-106.  Instances may carry COCO polygons / RLE dicts under 'segmentation' (rasterised on the device: instance_masks_device,
     the role of `dataset.annToMask`; the image size comes from dataset.imgs when the COCO object is given, else from imgfov['img_shape']) or a ready
     'bin_mask'.  shrink_percentage != 0 (SHRINK_MASK_PERCENTAGE of the reference's cfgs; shapely's Polygon.buffer(-d) in shared_utils.py:295-330)
-    moves the polygons' boundaries inwards before the masks are made -- see instance_masks_device for what exactly is computed and where it
-    can differ from GEOS's output (a band of about one pixel).  Like the reference, shrinking applies to polygon segmentations."""
+    replaces every polygon list by its shrunken one before the masks are made (vcn/polygon_buffer.py: the negative buffer's exterior rings, vertices
+    truncated with int(); unpinned -- shapely is not available here).  Like the reference, shrinking applies to polygon segmentations."""
     pts, uv, fov = imgfov["_device"]
     kept = [dict(inst) for inst in instances if inst['segmentation']]
     out = {"img_uv": [], "cam_xyz": [], "lidar_xyz": [], "img_labels": []}
@@ -332,9 +363,14 @@ def get_pts_in_mask(dataset, instances, imgfov, shrink_percentage=0, use_bbox=Fa
         else:
             img = getattr(dataset, 'imgs', {}).get(kept[0].get('image_id')) if dataset is not None else None
             img_h, img_w = (img['height'], img['width']) if img else imgfov["img_shape"]
-            if shrink_percentage:                                   # the reference shrinks instance['segmentation'] and rasterises again
+            if shrink_percentage:
+                # shared_utils.py:63-64: the instance's polygon list is REPLACED by the shrunken one (the label that is returned carries it, and
+                # append_mask_info counts its parts), then rasterised again
                 kept = [{k: v for k, v in inst.items() if k != 'bin_mask' or not isinstance(inst['segmentation'], list)} for inst in kept]
-            masks = instance_masks_device(kept, int(img_h), int(img_w), uv.device, shrink_percentage)
+                for inst in kept:
+                    if isinstance(inst['segmentation'], list):
+                        inst['segmentation'] = polygon_buffer.shrink_instance_masks(inst['segmentation'], shrink_percentage)
+            masks = instance_masks_device(kept, int(img_h), int(img_w), uv.device, 0)
             masks_h = masks.cpu().numpy()
             for g, inst in enumerate(kept):                           # the reference keeps the binary mask with the label (shared_utils.py:69)
                 inst.setdefault('bin_mask', masks_h[g])

@@ -381,19 +381,128 @@ def test_oracle_shrunken_mask_known_answers():
 
 
 @pytest.mark.gpu
-def test_hip_shrunken_masks_equal_the_oracle_and_get_pts_in_mask_uses_them(inputs, cuda, hip_lib):
-    """sv_polygons_to_masks_shrunk == oracle/coco_mask.ann_to_mask_shrunk pixel for pixel: the hand cases (rectangle, L shape, a part that shrinks
-    away -> unshrunken instance), 40 random polygons and multi-part instances at 3 % and 10 %; get_pts_in_mask(shrink_percentage=3) selects the
-    points of those masks (SHRINK_MASK_PERCENTAGE of the reference's cfgs) and strictly fewer than without shrinking."""
+def test_hip_masks_within_distance_equal_the_oracle(cuda, hip_lib):
+    """sv_polygons_to_masks_shrunk (the REGION form of the shrunken masks, round 5; get_pts_in_mask now takes the vertex-list form below) ==
+    oracle/coco_mask.ann_to_mask_shrunk pixel for pixel: the hand cases (rectangle, L shape, a part that shrinks away -> unshrunken instance), 40 random
+    polygons and multi-part instances at 3 % and 10 %."""
     from oracle import coco_mask as cm
     from seevcn_amd.vcn import isolation as I
     rect, sliver, ell = [10, 20, 50, 20, 50, 50, 10, 50], [5, 5, 60, 5, 60, 7, 5, 7], [0, 0, 40, 0, 40, 20, 20, 20, 20, 40, 0, 40]
-    inst = [{"segmentation": [rect]}, {"segmentation": [ell]}, {"segmentation": [rect, sliver]}, {"segmentation": [sliver]},
-            {"segmentation": {"size": [64, 64], "counts": [100, 50, 64 * 64 - 150]}}]
+    inst = [{"segmentation": [rect]}, {"segmentation": [ell]}, {"segmentation": [rect, sliver]}, {"segmentation": [sliver]}]
     for pct in (10, 3):
-        got = I.instance_masks_device(inst, 64, 64, cuda, pct).cpu().numpy()
+        got = I.instance_masks_within_distance(inst, 64, 64, cuda, pct).cpu().numpy()
         for g, a in zip(got, inst):
             assert np.array_equal(g, cm.ann_to_mask_shrunk(a, 64, 64, pct)), (pct, a)
+    rng = np.random.default_rng(21)
+    h, w = 93, 131
+    polys = _random_polygons(rng, h, w, 52)
+    inst = [{"segmentation": [p]} for p in polys[:40]] + [{"segmentation": polys[40 + 4 * i:44 + 4 * i]} for i in range(3)]
+    for pct in (3, 10):
+        got = I.instance_masks_within_distance(inst, h, w, cuda, pct).cpu().numpy()
+        plain = I.instance_masks_device(inst, h, w, cuda).cpu().numpy()
+        for i, (g, a) in enumerate(zip(got, inst)):
+            want = cm.ann_to_mask_shrunk(a, h, w, pct)
+            assert np.array_equal(g, want), (pct, i, int((g != want).sum()))
+        assert got.sum() < plain.sum() and ((got == 1) <= (plain == 1)).all()
+
+
+def _canonical_rings(seg_list):
+    """int polygon lists -> sorted tuple of rings, each without its closing vertex and rotated to start at its smallest vertex (shapely's start vertex is
+    its own business; the rasterisation does not depend on it)"""
+    out = []
+    for l in seg_list:
+        pts = list(zip(l[0::2], l[1::2]))
+        if len(pts) > 1 and pts[0] == pts[-1]:
+            pts = pts[:-1]
+        k = pts.index(min(pts))
+        out.append(tuple(pts[k:] + pts[:k]))
+    return tuple(sorted(out))
+
+
+def test_oracle_polygon_buffer_known_answers():
+    """oracle/polygon_buffer (shapely's Polygon.buffer(-d) + exterior + int() as shrink_instance_masks uses them, shared_utils.py:295-330; PARITY
+    UNPINNED -- shapely / GEOS are not available) against answers derived by hand: a rectangle moves every edge inwards by d and truncates; an L
+    keeps its five convex corners and turns the reflex one into 16 chords of the circle of radius d around it (quad_segs 16: one chord per pi / 32);
+    a sliver thinner than 2 d is the empty polygon -> the function returns the list it was given (shared_utils.py:325-326), whatever the other
+    parts were; a dumb-bell whose neck is thinner than 2 d splits into a MultiPolygon -> two lists."""
+    from oracle import polygon_buffer as opb
+    rect = [10, 20, 50, 20, 50, 50, 10, 50]
+    assert abs(opb.shrink_distance(rect[0::2], rect[1::2], 10) - 2.5) < 1e-12
+    assert _canonical_rings(opb.shrink_instance_masks([rect], 10)) == (((12, 22), (47, 22), (47, 47), (12, 47)),)
+    got = opb.shrink_instance_masks([rect], 10)[0]
+    assert got[:2] == got[-2:] and len(got) == 10                                      # exterior.coords repeats the first vertex
+    ell = [0, 0, 40, 0, 40, 20, 20, 20, 20, 30, 0, 30]                                 # bounding box 40 x 30: half diagonal 25, 10 % = 2.5
+    arc = [(int(20 + 2.5 * np.cos(-np.pi / 2 - s * np.pi / 32)), int(20 + 2.5 * np.sin(-np.pi / 2 - s * np.pi / 32))) for s in range(1, 16)]
+    want = [(2, 2), (37, 2), (37, 17), (20, 17)] + arc + [(17, 20), (17, 27), (2, 27)]
+    assert _canonical_rings(opb.shrink_instance_masks([ell], 10)) == (tuple(want),)
+    sliver = [5, 5, 60, 5, 60, 7, 5, 7]                                                # half diagonal 27.5: 10 % = 2.75 > its half height
+    parts = [rect, sliver]
+    assert opb.shrink_instance_masks(parts, 10) is parts and opb.shrink_instance_masks([sliver], 10)[0] is sliver
+    bell = [0, 0, 40, 0, 40, 18, 60, 18, 60, 0, 100, 0, 100, 40, 60, 40, 60, 22, 40, 22, 40, 40, 0, 40]      # neck 4 high; 6 % of 53.85 = 3.23
+    two = opb.shrink_instance_masks([bell], 6)
+    assert len(two) == 2
+    boxes = sorted((min(l[0::2]), min(l[1::2]), max(l[0::2]), max(l[1::2])) for l in two)
+    assert boxes == [(3, 3, 37, 36), (62, 3, 96, 36)]                                  # the lobes, 3.23 in from their sides; the arcs reach 3.23 into the neck
+    assert opb.shrink_instance_masks([rect], 0) == [rect + rect[:2]]                   # buffer(0) of a valid ring: itself, closed
+
+
+def test_polygon_buffer_equals_the_oracle_and_covers_the_eroded_region():
+    """vcn/polygon_buffer.shrink_instance_masks (numpy, vectorised) == oracle/polygon_buffer (scalar restatement) ring for ring on random simple polygons
+    with real and with integer vertices, 3 ... 20 %; and the region property that pins the construction without GEOS: every pixel centre inside the ring
+    and more than d + 0.05 from it lies in the buffer's rings, no pixel centre nearer than d - 0.05 does (the arcs' chords sag 0.0012 d)."""
+    from oracle import coco_mask as cm
+    from oracle import polygon_buffer as opb
+    from seevcn_amd.vcn import polygon_buffer as pb
+    rng = np.random.default_rng(5)
+    done = 0
+    for trial in range(48):
+        n = int(rng.integers(4, 48))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        rad = 40 + 25 * rng.random(n) * (rng.random() < 0.8) + 10 * np.sin(3 * ang)
+        P = np.stack([80 + rad * np.cos(ang), 70 + rad * np.sin(ang)], 1)
+        if trial % 2:
+            P = np.round(P)
+        pc = pb._clean_ring(P)
+        if pc is None or len(pb._node(pc, 12)[0]) != len(pc):
+            continue                                                                   # the rounded star crosses itself: not a polygon
+        seg = [P.reshape(-1).tolist()]
+        pct = float(rng.choice([3, 6, 10, 20]))
+        a, b = pb.shrink_instance_masks(seg, pct), opb.shrink_instance_masks(seg, pct)
+        assert (a is seg) == (b is seg)
+        if a is not seg:
+            assert _canonical_rings(a) == _canonical_rings(b), trial
+        d = pb.shrink_distance(seg[0][0::2], seg[0][1::2], pct)
+        assert abs(d - opb.shrink_distance(seg[0][0::2], seg[0][1::2], pct)) < 1e-12
+        rings = pb.buffer_inward(P, d)
+        yy, xx = np.mgrid[0:150, 0:170].astype(np.float64)
+        px, py = xx.ravel(), yy.ravel()
+        inside = pb._winding(px, py, pc, np.roll(pc, -1, axis=0)) != 0
+        dist2 = cm._edge_distance2(px, py, seg[0])
+        got = np.zeros(len(px), bool)
+        for r in rings:
+            got |= pb._winding(px, py, r[:-1], r[1:]) != 0
+        assert not (inside & (dist2 >= (d + 0.05) ** 2) & ~got).any() and not ((~inside | (dist2 <= max(d - 0.05, 0.0) ** 2)) & got).any(), trial
+        done += 1
+    assert done >= 30
+
+
+@pytest.mark.gpu
+def test_hip_get_pts_in_mask_shrinks_like_the_reference(inputs, cuda, hip_lib):
+    """get_pts_in_mask(shrink_percentage=3) (SHRINK_MASK_PERCENTAGE of every IMG_DET cfg; shared_utils.py:62-69): the instance's polygon list is replaced by
+    the oracle's shrunken list (ring for ring), its mask is annToMask of THAT list pixel for pixel (oracle/coco_mask on oracle/polygon_buffer), the points
+    are the points of that mask and fewer than without shrinking; append_mask_info counts the SHRUNKEN parts (a dumb-bell that splits counts 2); an instance
+    with a part that vanishes keeps its original polygons and mask."""
+    from oracle import coco_mask as cm
+    from oracle import polygon_buffer as opb
+    from seevcn_amd.vcn import isolation as I
+    rect, sliver = [10, 20, 50, 20, 50, 50, 10, 50], [5, 5, 60, 5, 60, 7, 5, 7]
+    bell = [0, 0, 40, 0, 40, 18, 60, 18, 60, 0, 100, 0, 100, 40, 60, 40, 60, 22, 40, 22, 40, 40, 0, 40]
+    inst = [{"segmentation": [rect]}, {"segmentation": [bell]}, {"segmentation": [rect, sliver]}]
+    for pct in (10, 6, 3):
+        got = I.instance_masks_device(inst, 64, 110, cuda, pct).cpu().numpy()
+        for g, a in zip(got, inst):
+            want = cm.ann_to_mask({"segmentation": opb.shrink_instance_masks(a["segmentation"], pct)}, 64, 110)
+            assert np.array_equal(g, want), (pct, a)
     rng = np.random.default_rng(21)
     h, w = 93, 131
     polys = _random_polygons(rng, h, w, 52)
@@ -402,9 +511,9 @@ def test_hip_shrunken_masks_equal_the_oracle_and_get_pts_in_mask_uses_them(input
         got = I.instance_masks_device(inst, h, w, cuda, pct).cpu().numpy()
         plain = I.instance_masks_device(inst, h, w, cuda).cpu().numpy()
         for i, (g, a) in enumerate(zip(got, inst)):
-            want = cm.ann_to_mask_shrunk(a, h, w, pct)
+            want = cm.ann_to_mask({"segmentation": opb.shrink_instance_masks(a["segmentation"], pct)}, h, w)
             assert np.array_equal(g, want), (pct, i, int((g != want).sum()))
-        assert got.sum() < plain.sum() and ((got == 1) <= (plain == 1)).all()
+        assert got.sum() < plain.sum()
     calib = I.Calibration(inputs['calib'])
     imgfov = I.map_pointcloud_to_image(inputs['points'], calib, IMG_SHAPE, min_dist=1.0)
     polys = []
@@ -414,11 +523,14 @@ def test_hip_shrunken_masks_equal_the_oracle_and_get_pts_in_mask_uses_them(input
         pts = np.stack([x0 + bw / 2 + 0.7 * bw * np.cos(ang), y0 + bh / 2 + 0.7 * bh * np.sin(ang)], 1)
         polys.append([float(t) for t in pts.reshape(-1)])
     only_poly = [{"segmentation": [p], "bbox": i["bbox"], "category_id": 1, "box_id": i["box_id"]} for p, i in zip(polys, inputs['instances'])]
-    shrunk = I.get_pts_in_mask(None, only_poly, imgfov, shrink_percentage=3)
-    with_mask = [dict(a, bin_mask=cm.ann_to_mask_shrunk(a, *IMG_SHAPE, 3)) for a in only_poly]
-    ref = I.get_pts_in_mask(None, [{k: v for k, v in a.items()} for a in with_mask], imgfov)
+    shrunk = I.get_pts_in_mask(None, only_poly, imgfov, shrink_percentage=3, append_mask_info=True)
+    with_mask = [dict(a, segmentation=opb.shrink_instance_masks(a["segmentation"], 3)) for a in only_poly]
+    with_mask = [dict(a, bin_mask=cm.ann_to_mask(a, *IMG_SHAPE)) for a in with_mask]
+    ref = I.get_pts_in_mask(None, [dict(a) for a in with_mask], imgfov, append_mask_info=True)
     full = I.get_pts_in_mask(None, only_poly, imgfov)
     assert len(shrunk["lidar_xyz"]) == len(ref["lidar_xyz"]) > 0
-    for la, lb in zip(shrunk["lidar_xyz"], ref["lidar_xyz"]):
-        assert np.array_equal(la, lb)
+    for la, lb, ia, ib in zip(shrunk["lidar_xyz"], ref["lidar_xyz"], shrunk["img_labels"], ref["img_labels"]):
+        assert np.array_equal(la, lb) and np.array_equal(ia["bin_mask"], ib["bin_mask"])
+        assert _canonical_rings(ia["segmentation"]) == _canonical_rings(ib["segmentation"])
     assert sum(len(x) for x in shrunk["lidar_xyz"]) < sum(len(x) for x in full["lidar_xyz"])
+    assert all(a["segmentation"] == p["segmentation"] for a, p in zip(only_poly, [{"segmentation": [q]} for q in polys]))      # the caller's instances are not modified
