@@ -150,6 +150,86 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply_bwd(BnArgs a) {
   }
 }
 
+// Backward combine + elementwise pass in ONE launch (round 6; SEEVCN_BN_BWD_FUSED=1, OFF by default: measured SLOWER -- the step 3.56 / 3.58 ms with the
+// two launches, 3.63 / 3.64 ms with this one, two same-box alternations, profiles/r06_bnfused_ab.txt: 256 workgroups each pulling the 512 KB of partials out
+// of L2 beside the resident weight-gradient / data-gradient launches cost more than the small kernel and its boundary).  k_bn_finalize<true> is 64-128 small workgroups whose result every workgroup of
+// k_bn_apply_bwd needs: on the backward chain of the benchmarked step that pair cost 20.8 + 19.7 us per BatchNorm (12 of them, in-step durations,
+// profiles/r06_a_main_steady_kernels.csv; 5 + 13 us with the GPU otherwise idle) plus a kernel boundary.  Here every workgroup (one per CU, 1024 threads)
+// first combines ALL partial sums itself -- (wgs, 2, C) floats, 512 KB at C = 64 out of L2: thread (g, quad) adds the rows g, g + G, ... of its four
+// columns in fp64, the G group sums of a column are added in group order -- every workgroup the same values in the same order, so the coefficients are
+// identical everywhere and reproducible; workgroup 0 also writes dgamma / dbeta.  Then the elementwise pass with the coefficients in LDS.
+// (The combine's ORDER differs from k_bn_finalize<true>'s strided tree: both conv-side callers -- sv_batchnorm_relu_backward and _partial -- go through
+// this kernel, so the launch-list chain and the per-module path still agree bit for bit.)
+constexpr int BNF_THREADS = 1024;
+__global__ __launch_bounds__(BNF_THREADS) void k_bn_bwd_fused(BnArgs a) {
+  __shared__ double s_sum[BNF_THREADS * 4];                 // [group][2 C] column sums of a row group (G * 2 C = 4096 doubles whatever C is)
+  __shared__ __attribute__((aligned(16))) float s_coef[4 * BN_MAX_C];       // gamma * invstd | mean(dy) | mean(dy * xhat) | mean
+  const int tid = threadIdx.x, C = a.C, C2 = 2 * C, Q = C2 / 4, G = BNF_THREADS / Q;
+  {
+    const int q = tid % Q, g = tid / Q;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    if (g < G) {
+      for (int w = g; w < a.wgs; w += G) {
+        const float4 v = reinterpret_cast<const float4*>(a.partial + (size_t)w * C2)[q];
+        t0 += (double)v.x, t1 += (double)v.y, t2 += (double)v.z, t3 += (double)v.w;
+      }
+      double* d = s_sum + (size_t)g * C2 + 4 * q;
+      d[0] = t0, d[1] = t1, d[2] = t2, d[3] = t3;
+    }
+  }
+  __syncthreads();
+  if (tid < C) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int g = 0; g < G; ++g) t0 += s_sum[(size_t)g * C2 + tid], t1 += s_sum[(size_t)g * C2 + C + tid];
+    const float gm = a.gamma ? a.gamma[tid] : 1.f;
+    const float invstd = a.save_invstd[tid], m = a.save_mean[tid];
+    if (blockIdx.x == 0) a.dbeta[tid] = (float)t0, a.dgamma[tid] = (float)t1;
+    // dx = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat)),  xhat = (x - m) * invstd      (k_bn_finalize<true>'s coefficients)
+    s_coef[tid] = gm * invstd;
+    s_coef[C + tid] = (float)(t0 / (double)a.n);
+    s_coef[2 * C + tid] = (float)(t1 / (double)a.n);
+    s_coef[3 * C + tid] = m;
+  }
+  __syncthreads();
+  const int C4 = C >> 2;
+  const int64_t total = a.n * C4;
+  for (int64_t i = (int64_t)blockIdx.x * BNF_THREADS + tid; i < total; i += (int64_t)gridDim.x * BNF_THREADS) {
+    const int c4 = (int)(i % C4);
+    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
+    float4 d = reinterpret_cast<const float4*>(a.dy)[i];
+    const float4 k = reinterpret_cast<const float4*>(s_coef)[c4], md = reinterpret_cast<const float4*>(s_coef + C)[c4];
+    const float4 mx = reinterpret_cast<const float4*>(s_coef + 2 * C)[c4], m = reinterpret_cast<const float4*>(s_coef + 3 * C)[c4];
+    const float4 istd = reinterpret_cast<const float4*>(a.save_invstd)[c4];
+    const float4 xh = make_float4((v.x - m.x) * istd.x, (v.y - m.y) * istd.y, (v.z - m.z) * istd.z, (v.w - m.w) * istd.w);
+    if (a.relu) {
+      const float4 g = a.gamma ? reinterpret_cast<const float4*>(a.gamma)[c4] : make_float4(1, 1, 1, 1);
+      const float4 bt = a.beta ? reinterpret_cast<const float4*>(a.beta)[c4] : make_float4(0, 0, 0, 0);
+      const float4 sc = make_float4(istd.x * g.x, istd.y * g.y, istd.z * g.z, istd.w * g.w);       // the forward's scale / shift, bit for bit
+      const float4 sh = make_float4(bn_shift(m.x, sc.x, bt.x), bn_shift(m.y, sc.y, bt.y), bn_shift(m.z, sc.z, bt.z), bn_shift(m.w, sc.w, bt.w));
+      d.x = (bn_act(v.x, sc.x, sh.x) > 0.f) ? d.x : 0.f, d.y = (bn_act(v.y, sc.y, sh.y) > 0.f) ? d.y : 0.f;
+      d.z = (bn_act(v.z, sc.z, sh.z) > 0.f) ? d.z : 0.f, d.w = (bn_act(v.w, sc.w, sh.w) > 0.f) ? d.w : 0.f;
+    }
+    reinterpret_cast<float4*>(a.out)[i] = make_float4(k.x * (d.x - md.x - xh.x * mx.x), k.y * (d.y - md.y - xh.y * mx.y),
+                                                      k.z * (d.z - md.z - xh.z * mx.z), k.w * (d.w - md.w - xh.w * mx.w));
+  }
+}
+// combine + elementwise pass of a BatchNorm backward whose partial sums are in a.partial: k_bn_finalize<true> + k_bn_apply_bwd, or (SEEVCN_BN_BWD_FUSED=1)
+// the fused launch
+static void bn_backward_tail(const BnArgs& a, hipStream_t st) {
+  static const int fused = getenv("SEEVCN_BN_BWD_FUSED") ? atoi(getenv("SEEVCN_BN_BWD_FUSED")) : 0;
+  const int Q = a.C / 2;
+  if (fused && Q >= 1 && BNF_THREADS % Q == 0) {
+    const int64_t quads = a.n * (a.C / 4);
+    int wgs = (int)((quads + BNF_THREADS * 4 - 1) / (BNF_THREADS * 4));               // at least four sweeps per workgroup ...
+    if (wgs > 256) wgs = 256;                                                         // ... and at most one workgroup per CU: each pays the combine
+    if (wgs < 1) wgs = 1;
+    hipLaunchKernelGGL(k_bn_bwd_fused, dim3(wgs), dim3(BNF_THREADS), 0, st, a);
+    return;
+  }
+  hipLaunchKernelGGL(k_bn_finalize<true>, dim3(a.C), dim3(BN_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_bn_apply_bwd, dim3(sv_grid_1d(a.n * (a.C / 4), BN_THREADS)), dim3(BN_THREADS), 0, st, a);
+}
+
 // eval mode: per-channel scale/shift from the running statistics (one tiny launch), then the same apply kernel
 __global__ void k_bn_eval_coef(BnArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -279,8 +359,7 @@ extern "C" int sv_batchnorm_relu_backward(const float* x, const float* dy, int64
   bn_scratch(a, scratch);
   hipStream_t st = sv_stream(stream);
   hipLaunchKernelGGL(k_bn_reduce<true>, dim3(a.wgs), dim3(BN_THREADS), 0, st, a);
-  hipLaunchKernelGGL(k_bn_finalize<true>, dim3(channels), dim3(BN_THREADS), 0, st, a);
-  hipLaunchKernelGGL(k_bn_apply_bwd, dim3(sv_grid_1d(n * (channels / 4), BN_THREADS)), dim3(BN_THREADS), 0, st, a);
+  bn_backward_tail(a, st);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -301,8 +380,7 @@ extern "C" int sv_batchnorm_relu_backward_partial(const float* x, const float* d
   a.wgs = n_partials;
   bn_scratch(a, scratch);
   hipStream_t st = sv_stream(stream);
-  hipLaunchKernelGGL(k_bn_finalize<true>, dim3(channels), dim3(BN_THREADS), 0, st, a);
-  hipLaunchKernelGGL(k_bn_apply_bwd, dim3(sv_grid_1d(n * (channels / 4), BN_THREADS)), dim3(BN_THREADS), 0, st, a);
+  bn_backward_tail(a, st);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -480,11 +480,14 @@ extern "C" int sv_conv_table_rows(const int32_t* nbr, int64_t n_rows, int K, int
 #ifndef SEEVCN_PL_WAVES
 #define SEEVCN_PL_WAVES 4
 #endif
-// 1 (round 6): the G tiles a wave works on at a time are CONSECUTIVE in the cost-sorted list (units of G quads dealt together) instead of one tile from
-// each of G different rounds.  A wave walks the union of its tiles' offsets and issues every tile's gather and the offset's weight loads in each step,
+// 1 (round 6): on SUBMANIFOLD tables whose waves work on four tiles at a time (the 16- and 32-channel layers) those tiles are CONSECUTIVE in the
+// cost-sorted list (units of G quads dealt together) instead of one tile from each of G different rounds.  A wave walks the union of its tiles' offsets and issues every tile's gather and the offset's weight loads in each step,
 // whether the tile has the offset or not: with tiles of cost 27 / 12 / 8 / 5 the union is the 27 and a step carries 1.7 of 4 tiles on average
 // (32 -> 32 at 250 k rows), with four tiles of one cost -- neighbours in the sorted list, mostly one mask class -- 3.0; steps per launch 82 k -> 47 k
-// there, 67 k -> 52 k on the two-tile 64 -> 64 layers (an emulation of the plan on the bench's tables).  0: the round-2 deal (A/B builds).
+// there (an emulation of the plan on the bench's tables); measured 68.6 -> 59 us on that layer, 23.8 -> 22.1 us at 16 -> 16.  NOT for the others: a
+// wave of G costly tiles is also the launch's longest wave, and the strided tables' equal-cost tiles do not share masks -- 16 -> 32 strided 24.7 -> 28.1 us,
+// 32 -> 64 strided 44 -> 50 us, 64 -> 64 on two tiles 112 -> 116 us when every table was dealt this way (profiles/r06_adj_ab.txt).  A region takes its
+// table for submanifold when every row has the centre offset of a 27-offset kernel (bit 13 of every mask).  0: the round-2 deal everywhere (A/B builds).
 #ifndef SEEVCN_PL_ADJ
 #define SEEVCN_PL_ADJ 1
 #endif
@@ -511,16 +514,15 @@ static PlanDims plan_dims(int64_t n_rows, int G) {
     if (d.tiles[r] > max_tiles) max_tiles = d.tiles[r];
   }
   const int quads = (max_tiles + PL_QUAD - 1) / PL_QUAD;
-#if SEEVCN_PL_ADJ
-  // units of G consecutive quads (see plan_deal_quads): one unit per bin and round, PL_WAVES_PER_SIMD rounds per pass
-  const int units = (quads + G - 1) / G;
-  const int rounds = (units + PL_BINS - 1) / PL_BINS;
-  d.n_pass = rounds > 0 ? (rounds + PL_WAVES_PER_SIMD - 1) / PL_WAVES_PER_SIMD : 1;
-#else
+  // a region deals its tiles one quad per (bin, round) or -- submanifold tables on four tiles per wave, see plan_deal_quads -- in units of G consecutive
+  // quads; the slot count covers both
   const int rounds = (quads + PL_BINS - 1) / PL_BINS;                            // quads per CU bin
   const int slots = (rounds + PL_WAVES_PER_SIMD - 1) / PL_WAVES_PER_SIMD;        // tiles per wave
   d.n_pass = slots > 0 ? (slots + G - 1) / G : 1;
-#endif
+  const int units = (quads + G - 1) / G;
+  const int urounds = (units + PL_BINS - 1) / PL_BINS;
+  const int upass = (urounds + PL_WAVES_PER_SIMD - 1) / PL_WAVES_PER_SIMD;
+  if (SEEVCN_PL_ADJ && upass > d.n_pass) d.n_pass = upass;
   return d;
 }
 
@@ -535,15 +537,29 @@ static PlanDims plan_dims(int64_t n_rows, int G) {
 #ifndef SEEVCN_PL_LPT
 #define SEEVCN_PL_LPT 1
 #endif
+// AND of a region's masks: lanes hand in the AND of their rows' masks (all ones without a row), one LDS atomic per wave
+__device__ __forceinline__ void plan_and_masks(unsigned* s_and, unsigned mine) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine &= (unsigned)__shfl_xor((int)mine, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAnd(s_and, mine);
+}
+// ... and only with at least four rounds of units to deal (a bin takes one unit per round whatever it costs: with two or three rounds a unit of four
+// 27-offset tiles leaves its CU at 2-3x the mean; at the bench's four rounds the busiest CU of a region carries 1.0-1.2x (32 -> 32) / 1.4-1.8x (16 -> 16) the mean
+// and the launches are still 14 % / 7 % shorter -- these layers are bound by their steps, not by the matrix pipe)
+__device__ __forceinline__ bool plan_adjacent(int G, unsigned and_all, int nt) {
+  const int units = ((nt + PL_QUAD - 1) / PL_QUAD + G - 1) / G;
+  return G == 4 && ((and_all >> 13) & 1u) && (units + PL_BINS - 1) / PL_BINS >= 4;
+}
+
 template <typename CostOf>
-__device__ __forceinline__ void plan_deal_quads(const uint16_t* s_sorted, CostOf cost_of, int nt, int tile0, int slots, int G, int32_t* __restrict__ out, uint8_t* s_bin) {
+__device__ __forceinline__ void plan_deal_quads(const uint16_t* s_sorted, CostOf cost_of, int nt, int tile0, int slots, int G, bool adjacent, int32_t* __restrict__ out, uint8_t* s_bin) {
   // s_bin: one byte of LDS per unit (the caller's: a table that is dead by now) -- the unit's cost, then its bin
   const int tid = threadIdx.x;
   const int nq = (nt + PL_QUAD - 1) / PL_QUAD;
-  const int UG = SEEVCN_PL_ADJ ? G : 1;                              // quads per unit
+  const int UG = (SEEVCN_PL_ADJ && adjacent) ? G : 1;               // quads per unit
   const int nu = (nq + UG - 1) / UG;
   // unit u of round j = u / 32 goes to `bin`; inside a bin the rounds walk its workgroups in snake order; the unit's quads fill the G slots of one pass
-  // (SEEVCN_PL_ADJ = 0: a unit is one quad and a round fills one SLOT of the bin's workgroups, as in rounds 2-5)
+  // (not adjacent: a unit is one quad and a round fills one SLOT of the bin's workgroups, as in rounds 2-5)
   auto put = [&](int u, int j, int bin) {
     const int jm = j % PL_WAVES_PER_SIMD, wg = ((j / PL_WAVES_PER_SIMD) & 1) ? PL_WAVES_PER_SIMD - 1 - jm : jm;
     const int slot0 = (j / PL_WAVES_PER_SIMD) * UG;
@@ -587,12 +603,15 @@ __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ 
   __shared__ uint8_t s_cost[PL_MAX_REGION_TILES];
   __shared__ uint16_t s_sorted[PL_MAX_REGION_TILES];     // tiles of the region in descending cost order
   __shared__ int s_cnt[32], s_start[32];
+  __shared__ unsigned s_and_w;
   const int tid = threadIdx.x, r = blockIdx.x;
   const int nt = d.tiles[r], slots = d.n_pass * d.G;
   int32_t* out = tile_of + (int64_t)r * PL_REGION_WAVES * slots;
   for (int i = tid; i < PL_REGION_WAVES * slots; i += 1024) out[i] = -1;
   if (tid < 32) s_cnt[tid] = 0;
+  if (tid == 0) s_and_w = 0xFFFFFFFFu;
   __syncthreads();
+  unsigned andm = 0xFFFFFFFFu;
   for (int t = tid; t < nt; t += 1024) {
     const i32x4* mp = reinterpret_cast<const i32x4*>(masks_p + ((int64_t)d.tile0[r] + t) * 16);
     unsigned m = 0;
@@ -600,6 +619,7 @@ __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ 
     for (int q = 0; q < 4; ++q) {
       const i32x4 v = mp[q];
       m |= (unsigned)v.x | (unsigned)v.y | (unsigned)v.z | (unsigned)v.w;
+      andm &= (v.x ? (unsigned)v.x : ~0u) & (v.y ? (unsigned)v.y : ~0u) & (v.z ? (unsigned)v.z : ~0u) & (v.w ? (unsigned)v.w : ~0u);     // padding positions carry mask 0
     }
     const int c = __popc(m) > 31 ? 31 : __popc(m);
     s_cost[t] = (uint8_t)c;
@@ -617,11 +637,12 @@ __global__ __launch_bounds__(1024) void k_plan_deal(const int32_t* __restrict__ 
     const int c = s_cost[t];
     s_sorted[s_start[c] + atomicAdd(&s_cnt[c], 1)] = (uint16_t)t;
   }
+  plan_and_masks(&s_and_w, andm);
   __syncthreads();
-  // quads of 4 consecutive tiles of the sorted list, dealt to the 32 CU bins in snake order (0 .. 31, 31 .. 0, ...); inside a bin the rounds
-  // walk the four workgroups in snake order too.  One thread per quad.
+  const unsigned s_and = s_and_w;
+  // quads of 4 consecutive tiles of the sorted list, dealt to the 32 CU bins (plan_deal_quads)
   __shared__ uint8_t s_bin[PL_MAX_REGION_TILES / PL_QUAD];
-  plan_deal_quads(s_sorted, [&](int t) { return (int)s_cost[t]; }, nt, d.tile0[r], slots, d.G, out, s_bin);
+  plan_deal_quads(s_sorted, [&](int t) { return (int)s_cost[t]; }, nt, d.tile0[r], slots, d.G, plan_adjacent(d.G, s_and, nt), out, s_bin);
 }
 
 // The whole plan of a table in ONE launch: the 8 regions are independent (own classes, own positions, own tiles, own waves), so one
@@ -685,6 +706,9 @@ __device__ __forceinline__ void plan_region_body(const PlanFusedArgs& a, const i
   const int64_t n_pad = (a.n_rows + 15) / 16 * 16;
   const int nt = a.d.tiles[r], slots = a.d.n_pass * a.d.G;
   int32_t* out = a.tile_of + (int64_t)r * PL_REGION_WAVES * slots;
+  __shared__ unsigned s_and_w;
+  unsigned andm = 0xFFFFFFFFu;
+  if (tid == 0) s_and_w = 0xFFFFFFFFu;
   for (int i = tid; i < PL_CLASSES; i += 1024) s_start[i] = 0, s_cur[i] = 0;
   for (int i = tid; i < nt; i += 1024) s_tmask[i] = 0u;
   for (int i = tid; i < PL_REGION_WAVES * slots; i += 1024) out[i] = -1;
@@ -751,9 +775,12 @@ __device__ __forceinline__ void plan_region_body(const PlanFusedArgs& a, const i
         }
         if (live && m[u]) atomicOr(&s_tmask[(pos - row0) >> 4], m[u]);
       }
+      if (live && m[u]) andm &= m[u];
     }
   }
+  plan_and_masks(&s_and_w, andm);
   __syncthreads();
+  const unsigned s_and = s_and_w;
   if (a.debug & 4) return;
   // pass 4: tiles by descending cost, quads dealt to the 32 CU bins in snake order (k_plan_deal).  Neighbouring tiles are of neighbouring
   // classes and cost about the same: a wave's 64 tiles hit 2-4 of the 32 counters, so the wave groups its keys before the LDS atomic
@@ -785,7 +812,7 @@ __device__ __forceinline__ void plan_region_body(const PlanFusedArgs& a, const i
     if (live) s_sorted[s_cstart[c] + off + rank] = (uint16_t)t;
   }
   __syncthreads();
-  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, a.d.G, out, reinterpret_cast<uint8_t*>(s_start));   // the class starts are dead: placement is over
+  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, a.d.G, plan_adjacent(a.d.G, s_and, nt), out, reinterpret_cast<uint8_t*>(s_start));   // the class starts are dead: placement is over
 }
 
 // The same plan with a DETERMINISTIC order: inside a class the rows keep their table order, inside a cost bucket the tiles theirs, so a table has
@@ -808,6 +835,9 @@ __device__ __forceinline__ void plan_region_body_stable(const PlanFusedArgs& a, 
   const int64_t n_pad = (a.n_rows + 15) / 16 * 16;
   const int nt = a.d.tiles[r], slots = a.d.n_pass * a.d.G;
   int32_t* out = a.tile_of + (int64_t)r * PL_REGION_WAVES * slots;
+  __shared__ unsigned s_and_w;
+  unsigned andm = 0xFFFFFFFFu;
+  if (tid == 0) s_and_w = 0xFFFFFFFFu;
   for (int i = tid; i < 8 * PL_CLASSES; i += 1024) s_wc[i] = 0u;
   for (int i = tid; i < nt; i += 1024) s_tmask[i] = 0u;
   for (int i = tid; i < PL_REGION_WAVES * slots; i += 1024) out[i] = -1;
@@ -889,12 +919,14 @@ __device__ __forceinline__ void plan_region_body_stable(const PlanFusedArgs& a, 
         const int64_t pos = row0 + (int64_t)((old >> sh) & 0xffffu) + rank;
         a.perm[pos] = (int32_t)row;
         a.masks_p[pos] = (int32_t)m[u];
-        if (m[u]) atomicOr(&s_tmask[(pos - row0) >> 4], m[u]);
+        if (m[u]) atomicOr(&s_tmask[(pos - row0) >> 4], m[u]), andm &= m[u];
       }
     }
   }
+  plan_and_masks(&s_and_w, andm);
   if (r + 1 == PL_REGIONS && a.n_rows + tid < n_pad) a.perm[a.n_rows + tid] = -1, a.masks_p[a.n_rows + tid] = 0;    // padding of the last tile
   __syncthreads();
+  const unsigned s_and = s_and_w;
   // pass 4: tiles by descending cost (stable: ascending tile inside a cost), quads dealt to the 32 CU bins in snake order (k_plan_deal)
   const int tiles_per_wave = ((nt + 15) / 16 + 63) / 64 * 64;
   const int t0 = wid * tiles_per_wave, t1 = min(t0 + tiles_per_wave, nt);
@@ -937,7 +969,7 @@ __device__ __forceinline__ void plan_region_body_stable(const PlanFusedArgs& a, 
     if (live) s_sorted[s_cstart[c] + off + rank] = (uint16_t)t;
   }
   __syncthreads();
-  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, a.d.G, out, reinterpret_cast<uint8_t*>(s_wc));      // the class counters are dead: placement is over
+  plan_deal_quads(s_sorted, [&](int t) { return min(__popc(s_tmask[t]), 31); }, nt, a.d.tile0[r], slots, a.d.G, plan_adjacent(a.d.G, s_and, nt), out, reinterpret_cast<uint8_t*>(s_wc));      // the class counters are dead: placement is over
 }
 
 __device__ __forceinline__ void plan_region_dispatch(const PlanFusedArgs& a, const int r) {

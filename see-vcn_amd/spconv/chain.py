@@ -69,7 +69,8 @@ def _run_two_streams(rows, dev):
     wait for them; the current stream is ordered behind the side stream when the call returns."""
     side = _wgrad_stream.get(dev)
     if side is None:
-        side = _wgrad_stream[dev] = torch.cuda.Stream(dev)
+        # SEEVCN_WGRAD_STREAM_PRIORITY (A/B): priority of the weight gradients' stream (torch: lower number = served first; default 0 = the main stream's)
+        side = _wgrad_stream[dev] = torch.cuda.Stream(dev, priority=int(os.environ.get("SEEVCN_WGRAD_STREAM_PRIORITY", "0")))
     arr = np.array(rows, dtype=np.int64)
     _lib.check(_lib.load().sv_run_ops_two_streams(arr.ctypes.data, len(rows), _lib.stream(), side.cuda_stream), "sv_run_ops_two_streams (chain backward)")
 
