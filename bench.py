@@ -257,7 +257,9 @@ def run_step_prefetched(model, opt, params, pre, world, interleave=True):
     # before last (an event that has usually long completed): at most two trained steps are ever queued.
     inflight = pre.__dict__.setdefault("_done_events", [])
     if len(inflight) >= int(os.environ.get("SEEVCN_BENCH_MAX_INFLIGHT", "2")):
+        t_w = time.perf_counter()
         inflight.pop(0).synchronize()
+        pre.__dict__["_backpressure_s"] = pre.__dict__.get("_backpressure_s", 0.0) + (time.perf_counter() - t_w)      # host time blocked here: > 0 = the GPU is the slower side
     bd = pre.take()
     out = []
     gen = _compute_gen(model, opt, params, bd, world, out)
@@ -642,6 +644,8 @@ def main():
     import gc
     gc0 = [dict(g) for g in gc.get_stats()]
     dev_allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+    if pre is not None:
+        pre.__dict__["_backpressure_s"] = 0.0
     t0 = time.perf_counter()
     stamps = []                        # host clock after every step's enqueue (a pipelined step ends in a blocking read: stamps follow the steps): one
     for _ in range(args.steps):        # perf_counter call per step, reported as the slowest / median step interval so that a transient shows in the line
@@ -654,6 +658,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    backpressure_ms = pre.__dict__.get("_backpressure_s", 0.0) / args.steps * 1e3 if pre is not None else None
     if pre is not None:
         pre.close()
     main_ctx.__exit__(None, None, None)
@@ -686,7 +691,10 @@ def main():
             "completed_objects_per_sec": round(OBJECTS_PER_GPU * world * args.steps / elapsed, 1), "device_spinup_s": args.spinup,
             "step_interval_ms": {"median": round(float(np.median(gaps)), 3), "max": round(float(gaps.max()), 3), "first_10": [round(float(g), 2) for g in gaps[:10]],
                                  "slow_steps": int((gaps > 2 * np.median(gaps)).sum()),
-                                 "python_gc_runs_by_generation": gc_runs, "python_gc_objects_freed": gc_freed, "hipMalloc_calls_in_timed_steps": int(dev_allocs)},
+                                 "python_gc_runs_by_generation": gc_runs, "python_gc_objects_freed": gc_freed, "hipMalloc_calls_in_timed_steps": int(dev_allocs),
+                                 # host time per step spent BLOCKED on the trained side of the step before last (run_step_prefetched's back-pressure): the part of
+                                 # the step the one host thread has to spare -- ~0 would mean the host's enqueue time, not the GPU, sets the step
+                                 "host_blocked_on_gpu_ms": None if backpressure_ms is None else round(backpressure_ms, 3)},
             "ranks": ident, "backend": (backend if world > 1 else None),
         }
         if not args.no_kernel_rooflines:

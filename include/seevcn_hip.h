@@ -344,6 +344,13 @@ int sv_sparse_to_dense(const float* features, const int32_t* coords, int64_t n, 
 /* its backward: gather (B,C,D,H,W) at coords -> (N,C) */
 int sv_dense_to_sparse(const float* dense, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W,
                        float* out, void* stream);
+/* The same volume in channels-last memory for HeightCompression (height_compression.py:21-23: dense().view(N, C * D, H, W)) in front of a channels_last
+ * 2-D backbone: out[b][y][x][c * D + d] -- on the torch side a (B, C D, H, W) tensor with channels_last strides -- and its backward from a gradient
+ * in that order.  Scratch as sv_sparse_to_dense.  sv_sparse_to_dense_nhwc_applies: C % 4 == 0, D <= 8, H W % 16 == 0 (else use the pair above). */
+int sv_sparse_to_dense_nhwc_applies(int C, int D, int H, int W);
+int sv_sparse_to_dense_nhwc(const float* features, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W, void* scratch,
+                            float* out, void* stream);
+int sv_dense_to_sparse_nhwc(const float* dense, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PointNet++ stacked-batch primitives (detector3d/pcdet/ops/pointnet2/pointnet2_stack/src/ *.cu; pybind names in

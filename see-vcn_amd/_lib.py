@@ -100,6 +100,9 @@ SIGNATURES = {
     "sv_sparse_to_dense_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "sv_sparse_to_dense": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_dense_to_sparse": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "sv_sparse_to_dense_nhwc_applies": (c_i, [c_i, c_i, c_i, c_i]),
+    "sv_sparse_to_dense_nhwc": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "sv_dense_to_sparse_nhwc": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "sv_farthest_point_sampling": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_stack_farthest_point_sampling": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "sv_fps_multi_scratch_bytes": (c_sz, [c_i]),

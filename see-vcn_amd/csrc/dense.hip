@@ -193,6 +193,119 @@ extern "C" int sv_dense_to_sparse(const float* dense, const int32_t* coords, int
 
 
 // ------------------------------------------------------------------------------------------------
+// The same dense volume in CHANNELS-LAST memory, as the 2-D backbone behind HeightCompression wants it (round 6).  `.dense()` gives (B, C, D, H, W),
+// HeightCompression views it as (B, C D, H, W) -- channel c D + d -- and BaseBEVBackbone runs channels_last from 8 scenes per batch on, i.e. it first
+// copied the whole tensor into (B, H, W, C D) order: 706 + 219 us forward and 1 171 + 203 us backward of pure layout change per SECOND train step
+// (577 MB tensor; profiles/r05_d_second_step_sequence.txt).  Here the volume is WRITTEN in that order -- out[b][y][x][c D + d], a (B, C D, H, W)
+// tensor with channels_last strides on the torch side -- and its gradient is read in that order.  One workgroup per 16 consecutive (y, x) positions of
+// a scene: the D x 16 cell-map entries, the occupied rows into LDS, then every thread stores 16-byte pieces of the positions' 4 C D-byte pixel rows.
+constexpr int DH_POS = 16;
+extern "C" int sv_sparse_to_dense_nhwc_applies(int C, int D, int H, int W);
+__global__ __launch_bounds__(DN_THREADS) void k_dense_write_nhwc(const float* __restrict__ feat, const int32_t* __restrict__ cellmap, int C, int D,
+                                                                 int64_t hw, float* __restrict__ out) {
+  extern __shared__ float s_f[];                       // [slot][C + 1]
+  __shared__ int s_slot[DH_POS * 8];                   // [d][position]: slot of the cell's row in s_f, or -1 (D <= 8)
+  __shared__ int s_row[DH_POS * 8];
+  __shared__ int s_n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t pos0 = (int64_t)blockIdx.x * DH_POS;   // (b, y, x) flattened: b * hw + y * W + x
+  const int64_t b = pos0 / hw, s0 = pos0 - b * hw;
+  const int cells = DH_POS * D;
+  if (tid < 64) {
+    // cells of the workgroup in (d, position) order; at most 128 of them: two sweeps of the first wave
+    int n = 0;
+    for (int base = 0; base < cells; base += 64) {
+      const int e = base + lane;
+      int32_t row = -1;
+      if (e < cells) row = cellmap[(b * D + e / DH_POS) * hw + s0 + e % DH_POS];
+      const unsigned long long occ = __ballot(row >= 0);
+      const int slot = n + __popcll(occ & ((1ull << lane) - 1));
+      if (e < cells) s_slot[e] = row >= 0 ? slot : -1;
+      if (row >= 0) s_row[slot] = row;
+      n += __popcll(occ);
+    }
+    if (lane == 0) s_n = n;
+  }
+  __syncthreads();
+  const int n_occ = s_n, pitch = C + 1;
+  for (int slot = tid >> 5; slot < n_occ; slot += DN_THREADS / 32) {
+    const float* f = feat + (int64_t)s_row[slot] * C;
+    for (int c = (tid & 31) * 4; c < C; c += 128) {
+      const float4 v = *reinterpret_cast<const float4*>(f + c);
+      float* d = s_f + slot * pitch + c;
+      d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    }
+  }
+  if (n_occ) __syncthreads();
+  const int CD = C * D, q_per_pos = CD / 4;             // 16-byte pieces of a position's pixel row
+  float* o = out + pos0 * CD;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  for (int e = tid; e < DH_POS * q_per_pos; e += DN_THREADS) {
+    const int p = e / q_per_pos, ch0 = (e - p * q_per_pos) * 4;
+    f32x4_t v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch = ch0 + j, c = ch / D, d = ch - c * D;
+      const int slot = s_slot[d * DH_POS + p];
+      v[j] = slot >= 0 ? s_f[slot * pitch + c] : 0.f;
+    }
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(o + (int64_t)e * 4));
+  }
+}
+
+extern "C" int sv_sparse_to_dense_nhwc(const float* features, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W, void* scratch,
+                                       float* out, void* stream) {
+  SV_CHECK_ARG(n >= 0 && batch > 0 && C > 0 && D > 0 && H > 0 && W > 0 && out && scratch, "sparse_to_dense_nhwc: bad arguments");
+  SV_CHECK_ARG(n == 0 || (features && coords), "sparse_to_dense_nhwc: null pointer");
+  const int64_t hw = (int64_t)H * W;
+  SV_CHECK_ARG(sv_sparse_to_dense_nhwc_applies(C, D, H, W), "sparse_to_dense_nhwc: C %% 4 == 0, D <= 8, H W %% 16 == 0 and a workgroup's rows in 60 KB of LDS "
+               "(ask sv_sparse_to_dense_nhwc_applies; got C %d, D %d, H %d, W %d)", C, D, H, W);
+  SV_CHECK_ARG((uintptr_t)features % 16 == 0 && (uintptr_t)out % 16 == 0, "sparse_to_dense_nhwc: 16-byte alignment");
+  hipStream_t st = sv_stream(stream);
+  int32_t* cellmap = reinterpret_cast<int32_t*>(scratch);
+  SV_HIP(hipMemsetAsync(cellmap, 0xFF, (size_t)batch * D * hw * 4, st));
+  if (n > 0)
+    hipLaunchKernelGGL(k_cellmap_scatter, dim3(sv_grid_1d(n, DN_THREADS)), dim3(DN_THREADS), 0, st, reinterpret_cast<const int4*>(coords), n, batch, D, H, W,
+                       cellmap);
+  const size_t lds = (size_t)DH_POS * D * (C + 1) * sizeof(float);
+  hipLaunchKernelGGL(k_dense_write_nhwc, dim3((unsigned)(batch * hw / DH_POS)), dim3(DN_THREADS), lds, st, features, cellmap, C, D, hw, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+extern "C" int sv_sparse_to_dense_nhwc_applies(int C, int D, int H, int W) {
+  return (C > 0 && C % 4 == 0 && D >= 1 && D <= 8 && ((int64_t)H * W) % DH_POS == 0 && (size_t)DH_POS * D * (C + 1) * sizeof(float) <= 60 * 1024) ? 1 : 0;
+}
+
+// backward twin: grad_features[i][c] = grad[b][y][x][c D + d] for the voxel i at (b, d, y, x); a thread per (voxel, 4 channels): the lanes of a voxel walk
+// its 4 C D-byte pixel row (every D-th float of it is theirs)
+__global__ __launch_bounds__(DN_THREADS) void k_dense_gather_nhwc(const float* __restrict__ dense, const int4* __restrict__ coords, int64_t n, int B, int C,
+                                                                  int D, int H, int W, float* __restrict__ out) {
+  const int C4 = C / 4;
+  const int64_t total = n * C4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / C4;
+    const int c = (int)(idx - i * C4) * 4;
+    const int4 p = coords[i];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.x >= 0 && p.x < B && p.y >= 0 && p.y < D && p.z >= 0 && p.z < H && p.w >= 0 && p.w < W) {
+      const float* g = dense + (((int64_t)p.x * H + p.z) * W + p.w) * ((int64_t)C * D) + p.y;
+      v = make_float4(g[(int64_t)c * D], g[(int64_t)(c + 1) * D], g[(int64_t)(c + 2) * D], g[(int64_t)(c + 3) * D]);
+    }
+    *reinterpret_cast<float4*>(out + i * C + c) = v;
+  }
+}
+extern "C" int sv_dense_to_sparse_nhwc(const float* dense, const int32_t* coords, int64_t n, int batch, int C, int D, int H, int W, float* out, void* stream) {
+  SV_CHECK_ARG(n >= 0 && batch > 0 && C > 0 && C % 4 == 0 && D > 0 && H > 0 && W > 0, "dense_to_sparse_nhwc: bad arguments (C %% 4 == 0)");
+  if (n == 0) return SV_OK;
+  SV_CHECK_ARG(dense && coords && out && (uintptr_t)out % 16 == 0, "dense_to_sparse_nhwc: null or misaligned pointer");
+  hipLaunchKernelGGL(k_dense_gather_nhwc, dim3(sv_grid_1d(n * (C / 4), DN_THREADS, 256 * 16)), dim3(DN_THREADS), 0, sv_stream(stream), dense,
+                     reinterpret_cast<const int4*>(coords), n, batch, C, D, H, W, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // sum(x^2) and y = scale * x in ONE pass over x (n floats, n % 4 == 0): the forward of a mean-square loss over a dense BEV tensor that leaves the
 // loss's gradient (2 / n) x behind as it reads x -- one read + one write of the tensor instead of a reduction pass in the forward and a
 // read + write pass in the backward (bench.py's stand-in for the BEV backbone: 577 MB at the KITTI geometry, 16 scenes).  Deterministic: a fixed

@@ -2516,6 +2516,10 @@ static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
   static const int off32_env = getenv("SEEVCN_WGRAD_OFF32") ? atoi(getenv("SEEVCN_WGRAD_OFF32")) : 1;
   const bool off32 = off32_env && a.n_src > 0 && (uint64_t)a.n_src * (uint64_t)a.Cin * 4u < 0xffffffffull && (uint64_t)a.chunk_rows * a.Cout * 4u < 0xffffffffull;
   static const int wg_debug = getenv("SEEVCN_WGRAD_DEBUG") ? atoi(getenv("SEEVCN_WGRAD_DEBUG")) : 0;
+  // measurement only (gradients are then WRONG): 1 = the narrow layers' stage 1 is not launched at all, 2 = no chunked stage 1 at all -- what the step
+  // would gain if these launches were free (its sensitivity to the weight gradients' stream)
+  static const int wg_skip = getenv("SEEVCN_WGRAD_SKIP") ? atoi(getenv("SEEVCN_WGRAD_SKIP")) : 0;
+  if (wg_skip == 2 || (wg_skip == 1 && !(CT == 4 && NTL == 4))) return;
   if constexpr (CT == 4 && NTL == 4) {
     if (off32 && g_wgrad_trace) {
       WgradArgs t = a;

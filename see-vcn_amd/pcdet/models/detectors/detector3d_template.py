@@ -84,6 +84,9 @@ class Detector3DTemplate(nn.Module):
         if cfg is None:
             return None, model_info_dict
         m = backbones_2d.__all__[cfg_get(cfg, 'NAME')](model_cfg=cfg, input_channels=model_info_dict['num_bev_features'])
+        for prev in model_info_dict['module_list']:                     # seevcn: HeightCompression may write spatial_features in the backbone's memory format
+            if hasattr(prev, 'feeds_bev_backbone') and type(m).__name__ == 'BaseBEVBackbone':
+                prev.feeds_bev_backbone = True
         model_info_dict['module_list'].append(m)
         model_info_dict['num_bev_features'] = m.num_bev_features
         return m, model_info_dict

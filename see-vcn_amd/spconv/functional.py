@@ -831,3 +831,46 @@ class DenseFunction(torch.autograd.Function):
 
 def sparse_to_dense(features, indices, batch_size, spatial_shape):
     return DenseFunction.apply(features, indices, int(batch_size), list(spatial_shape))
+
+
+class DenseChannelsLastFunction(torch.autograd.Function):
+    """dense().view(N, C * D, H, W) written in channels_last memory (sv_sparse_to_dense_nhwc): the (N, C D, H, W) tensor a channels_last 2-D backbone
+    would otherwise make by copying the whole volume; the backward takes the gradient in that order too (any other layout is copied once)."""
+
+    @staticmethod
+    def forward(ctx, features, indices, batch_size, spatial_shape):
+        lib = _lib.load()
+        _lib.require_cuda(features, indices)
+        features = features.contiguous().float()
+        indices = indices.contiguous()
+        n, c = features.shape
+        d, h, w = (int(s) for s in spatial_shape)
+        dev = features.device
+        scratch = _lib.workspace.scratch("dense_map", lib.sv_sparse_to_dense_scratch_bytes(batch_size, d, h, w), dev)
+        out = torch.empty((batch_size, h, w, c * d), dtype=torch.float32, device=dev)
+        rc = lib.sv_sparse_to_dense_nhwc(_lib.ptr(features) if n else None, _lib.ptr(indices) if n else None, n, batch_size, c, d, h, w,
+                                         _lib.ptr(scratch), _lib.ptr(out), _lib.stream())
+        _lib.check(rc, "sv_sparse_to_dense_nhwc")
+        ctx.save_for_backward(indices)
+        ctx.dims = (batch_size, c, d, h, w)
+        return out.permute(0, 3, 1, 2)                                   # (N, C D, H, W), channels_last strides
+
+    @staticmethod
+    def backward(ctx, grad):
+        lib = _lib.load()
+        (indices,) = ctx.saved_tensors
+        b, c, d, h, w = ctx.dims
+        n = indices.shape[0]
+        grad = grad.float().permute(0, 2, 3, 1).contiguous()             # a view of a channels_last gradient
+        out = torch.empty((n, c), dtype=torch.float32, device=grad.device)
+        rc = lib.sv_dense_to_sparse_nhwc(_lib.ptr(grad), _lib.ptr(indices) if n else None, n, b, c, d, h, w, _lib.ptr(out) if n else None, _lib.stream())
+        _lib.check(rc, "sv_dense_to_sparse_nhwc")
+        return out, None, None, None
+
+
+def sparse_to_dense_channels_last(features, indices, batch_size, spatial_shape):
+    """(N, C * D, H, W) with channels_last strides, or None when the shape is not one sv_sparse_to_dense_nhwc takes (the caller then views dense())"""
+    d, h, w = (int(s) for s in spatial_shape)
+    if not features.is_cuda or not _lib.load().sv_sparse_to_dense_nhwc_applies(int(features.shape[1]), d, h, w):
+        return None
+    return DenseChannelsLastFunction.apply(features, indices, int(batch_size), [d, h, w])

@@ -401,6 +401,47 @@ def test_hip_dense_and_height_compression(cuda, hip_lib):
 
 
 @pytest.mark.gpu
+def test_hip_height_compression_in_channels_last_memory(cuda, hip_lib):
+    """HeightCompression in front of a channels_last BaseBEVBackbone (feeds_bev_backbone, >= 8 scenes): spatial_features is WRITTEN with channels_last
+    strides (sv_sparse_to_dense_nhwc) -- the same (N, C*D, H, W) values as the oracle's dense(), a tensor BaseBEVBackbone's
+    .contiguous(memory_format=channels_last) returns as it is -- and its backward takes the gradient in either layout; shapes the kernel does not take
+    (H W % 16 != 0, 6 channels) fall back to the contiguous view."""
+    import seevcn_amd.spconv as spconv
+    from seevcn_amd.pcdet.models.backbones_2d import map_to_bev
+    rng = np.random.default_rng(11)
+    for batch, shape, c, n, takes in [(8, (2, 32, 24), 128, 1500, True), (9, (2, 20, 16), 64, 900, True), (8, (1, 16, 16), 32, 300, True),
+                                      (8, (5, 16, 8), 16, 700, True), (8, (2, 25, 10), 64, 400, False), (8, (2, 16, 16), 6, 100, False)]:
+        coords = _rand_coords(rng, n, batch, shape, clustered=False)
+        feats = rng.normal(size=(len(coords), c)).astype(np.float32)
+        f = torch.from_numpy(feats).to(cuda).requires_grad_(True)
+        t = spconv.SparseConvTensor(f, torch.from_numpy(coords).to(cuda), shape, batch)
+        hc = map_to_bev.__all__["HeightCompression"]({"NUM_BEV_FEATURES": c * shape[0]})
+        hc.feeds_bev_backbone = True
+        sf = hc({"encoded_spconv_tensor": t, "encoded_spconv_tensor_stride": 8})["spatial_features"]
+        ref = osp.dense(feats, coords, batch, shape).reshape(batch, c * shape[0], shape[1], shape[2])
+        assert sf.shape == ref.shape and np.array_equal(sf.detach().cpu().numpy(), ref)
+        assert sf.is_contiguous(memory_format=torch.channels_last) == (takes or c * shape[0] == 1)
+        if takes:
+            assert sf.contiguous(memory_format=torch.channels_last).data_ptr() == sf.data_ptr()       # no copy in front of the NHWC convolutions
+        gd_full = rng.normal(size=ref.shape).astype(np.float32)
+        want = gd_full.reshape(batch, c, *shape)[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]]
+        for fmt in (torch.channels_last, torch.contiguous_format):                                      # the gradient in the backbone's layout, or in NCHW
+            f.grad = None
+            g = torch.from_numpy(gd_full).to(cuda).contiguous(memory_format=fmt)
+            sf.backward(g, retain_graph=True)
+            assert np.array_equal(f.grad.cpu().numpy(), want), (shape, c, fmt)
+    # below 8 scenes, or without a BaseBEVBackbone behind it: the reference's contiguous view
+    coords = _rand_coords(rng, 500, 4, (2, 32, 24), clustered=False)
+    t = spconv.SparseConvTensor(torch.from_numpy(rng.normal(size=(len(coords), 64)).astype(np.float32)).to(cuda), torch.from_numpy(coords).to(cuda), (2, 32, 24), 4)
+    hc = map_to_bev.__all__["HeightCompression"]({"NUM_BEV_FEATURES": 128})
+    hc.feeds_bev_backbone = True
+    assert hc({"encoded_spconv_tensor": t, "encoded_spconv_tensor_stride": 8})["spatial_features"].is_contiguous()
+    t8 = spconv.SparseConvTensor(t.features, t.indices, (2, 32, 24), 8)
+    hc.feeds_bev_backbone = False
+    assert hc({"encoded_spconv_tensor": t8, "encoded_spconv_tensor_stride": 8})["spatial_features"].is_contiguous()
+
+
+@pytest.mark.gpu
 def test_hip_backbone8x_vs_oracle(cuda, hip_lib):
     """DynMeanVFE -> VoxelBackBone8x (eval) on a small KITTI-geometry batch against the oracle chain."""
     import seevcn_amd.synth as synth

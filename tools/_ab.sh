@@ -1,7 +1,10 @@
 cd $GRAFT_REPO_ROOT
-TOP=40 TOPC=45 timeout 600 python3 tools/host_profile.py 2>&1 | grep -v amdgpu.ids | cut -c1-170 | head -130
-for v in "" "--prefetch-thread" "" "--prefetch-thread"; do
-  echo "=== bench $v"
-  timeout 600 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-side-modes $v 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['frac'])"
+timeout 900 python3 -m pytest tests/test_spconv.py tests/test_abi.py tests/test_head.py -x -q -m gpu 2>&1 | tail -8
+for v in auto nchw auto nchw; do
+  echo "=== second SEEVCN_BEV_FORMAT=$v"
+  SEEVCN_BEV_FORMAT=$v timeout 600 python3 bench.py --config second --steps 10 --warmup 5 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"
 done
-timeout 300 python3 tools/step_hosttime.py 2>&1 | grep -v amdgpu.ids | head -30
+for v in auto nchw; do
+  echo "=== centerpoint SEEVCN_BEV_FORMAT=$v"
+  SEEVCN_BEV_FORMAT=$v timeout 600 python3 bench.py --config centerpoint --steps 10 --warmup 5 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"
+done
