@@ -26,6 +26,7 @@ a straight run), the starting vertex and the direction of a ring (the rasterisat
 1e-6 d.  Input rings are taken to be simple (a self-intersecting annotation has no defined interior in shapely either: it raises or returns what
 GEOS's noder makes of it)."""
 import math
+import warnings
 
 import numpy as np
 
@@ -247,7 +248,13 @@ def shrink_instance_masks(seg_masks, shrink_percentage, quad_segs=QUAD_SEGS):
     for seg in seg_masks:
         u, v = list(seg[::2]), list(seg[1::2])
         k = min(len(u), len(v))
-        rings = buffer_inward(np.array([u[:k], v[:k]], np.float64).T, shrink_distance(u[:k], v[:k], shrink_percentage) if k else 0.0, quad_segs)
+        try:
+            rings = buffer_inward(np.array([u[:k], v[:k]], np.float64).T, shrink_distance(u[:k], v[:k], shrink_percentage) if k else 0.0, quad_segs)
+        except ArithmeticError:
+            # a ring that crosses itself has no interior to shrink (shapely raises on such input or returns whatever GEOS's noder makes of it): the
+            # instance keeps its polygons, like one whose part shrinks to nothing
+            warnings.warn("polygon_buffer: a segmentation ring crosses itself; the instance's mask is left unshrunken", RuntimeWarning, stacklevel=2)
+            return seg_masks
         if not rings:
             return seg_masks
         for r in rings:
