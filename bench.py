@@ -325,7 +325,9 @@ def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
     launches timed are the instances the step really uses (input-transform instances in the forward, plain ones in the data gradient).  Grouped by
     kernel instance k_spconv_rs3<NT, KQ, G> (NT = min(C_out, 64) / 16 column tiles per wave, KQ = C_in / 16).  Returns the instance group with the
     largest total time: (name, avg launch ms, algorithmic flop per launch = 2*pairs*Cin*Cout averaged over its launches, algorithmic bytes per launch,
-    launches per step, ms per step).  Pairs are counted from the rulebook table each launch used (outside the timed events)."""
+    launches per step, ms per step, extra) -- extra: the same four numbers for the equal-pieces weight gradient of the 64 -> 64 layers ("wgrad", or None) and
+    the 2 * pairs * C_in * C_out of every planned conv / data gradient / weight gradient of a step ("planned_flop_per_step").  Pairs are counted from the
+    rulebook table each launch used (outside the timed events)."""
     import ctypes
     from seevcn_amd import _lib
     from seevcn_amd.spconv import chain
@@ -404,9 +406,9 @@ def measure_spconv_kernel(model, opt, params, inputs, world, reps=3):
             g[3] += 1
             all_flop += 2.0 * pairs * kd * nc
     (nt, kq), (ms, flop, byt, n) = max(groups.items(), key=lambda kv: kv[1][0])
-    measure_spconv_kernel.extra = {"wgrad": (wg[0] / max(wg[3], 1), wg[1] / max(wg[3], 1), wg[2] / max(wg[3], 1), wg[3] // reps) if wg[3] else None,
-                                   "planned_flop_per_step": all_flop / reps}
-    return f"k_spconv_rs3<{nt}, {kq}, ", ms / n, flop / n, byt / n, n // reps, ms / reps
+    extra = {"wgrad": (wg[0] / max(wg[3], 1), wg[1] / max(wg[3], 1), wg[2] / max(wg[3], 1), wg[3] // reps) if wg[3] else None,
+             "planned_flop_per_step": all_flop / reps}
+    return f"k_spconv_rs3<{nt}, {kq}, ", ms / n, flop / n, byt / n, n // reps, ms / reps, extra
 
 
 def cpu_baseline(pts_np, objs_np, scene_np, n_objects=4, n_scenes=1, warmup=3, timed=10):
@@ -615,7 +617,7 @@ def main():
         for _ in range(max(args.warmup, 3)):
             run_step(model, opt, params, inputs, world)
         torch.cuda.synchronize()
-        name, c_ms, c_flop, c_bytes, c_launches, c_step_ms = measure_spconv_kernel(model, opt, params, inputs, 1, reps=args.roofline_only)
+        name, c_ms, c_flop, c_bytes, c_launches, c_step_ms, _ = measure_spconv_kernel(model, opt, params, inputs, 1, reps=args.roofline_only)
         if rank == 0:
             c_ach = c_flop / (c_ms * 1e-3) / 1e12
             print(json.dumps({"roofline_only": True, "reps": args.roofline_only, "kernel": f"{name}G>", "avg_launch_ms": round(c_ms, 4), "launches_per_step": c_launches,
@@ -789,7 +791,7 @@ def kernel_rooflines(out, model, opt, params, inputs):
                         "object is far below what SURVEY 8(d)'s 1.976 GFLOP/object implies; the algorithmic figure below is NOT a rate",
                 "algorithmic_flop_per_launch": algo_flop_per_launch, "algorithmic_tflops": round(achieved, 2)}
     # dominant kernel by time in the step: the register-stationary sparse-conv gather-GEMM (forward + data gradient)
-    name, c_ms, c_flop, c_bytes, c_launches, c_step_ms = measure_spconv_kernel(model, opt, params, inputs, 1)
+    name, c_ms, c_flop, c_bytes, c_launches, c_step_ms, extra = measure_spconv_kernel(model, opt, params, inputs, 1)
     c_ach = c_flop / (c_ms * 1e-3) / 1e12
     out["roofline"] = {"bound": "mfma", "kernel": f"{name}G> (sv_sparse_conv_gather_gemm_planned, v_mfma_f32_16x16x4_f32; G = tiles per wave, 1-4 by layer size)",
                        "achieved": round(c_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -797,7 +799,6 @@ def kernel_rooflines(out, model, opt, params, inputs):
                        "launches_per_step": c_launches, "avg_launch_ms": round(c_ms, 4), "ms_per_step": round(c_step_ms, 3),
                        "algorithmic_flop_per_launch": round(c_flop), "algorithmic_bytes_per_launch": round(c_bytes),
                        "algorithmic_GBps": round(c_bytes / (c_ms * 1e-3) / 1e9, 1)}
-    extra = getattr(measure_spconv_kernel, "extra", {})
     if extra.get("wgrad"):
         w_ms, w_flop, w_bytes, w_n = extra["wgrad"]
         w_ach = w_flop / (w_ms * 1e-3) / 1e12
